@@ -1,0 +1,274 @@
+"""ctypes front-end of the CPU oracle (TEST INFRASTRUCTURE ONLY).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; nothing under miniworld_amd/ does.  It deliberately shares no code with the
+product: scenes are plain dicts of numpy arrays (the "neutral scene" layout written by
+tools/gen_golden.py from the reference's own objects), textures are read straight from the
+asset pack.
+
+Neutral scene keys
+    polys_v f32[P,4,3]  polys_uv f32[P,4,2]  polys_n f32[P,3]  polys_nv i32[P]  polys_tex i32[P]
+    tex_names      list[str]            texture variant names, index = polys_tex value
+    ents_kind i32[E] (1 box, 2 mesh)   ents_mesh i32[E]   ents_pos f64[E,3]  ents_dir f64[E]
+    ents_size f64[E,3]  ents_color f64[E,3]  ents_scale f64[E]
+    ents_radius f64[E]  ents_height f64[E]  ents_static i32[E]
+    mesh_names     list[str]            e.g. "ball_red"
+    agent_pos f64[3] agent_dir f64  cam_height cam_fwd_disp cam_pitch cam_fov_y  (f64 scalars)
+    sky light_pos light_color light_ambient  f64[3]
+    wall_segs f64[S,2,2]
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "_build", "libmwo.so")
+_PACK = os.path.join(_HERE, "..", "miniworld_amd", "assets", "assets_v1.npz")
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (make); returns the library path."""
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.endswith((".c", ".h"))]
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE], check=True, capture_output=True)
+    return _LIB_PATH
+
+
+class _Poly(C.Structure):
+    _fields_ = [("v", C.c_float * 12), ("uv", C.c_float * 8), ("n", C.c_float * 3),
+                ("nv", C.c_int32), ("tex", C.c_int32)]
+
+
+class _Ent(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("mesh", C.c_int32), ("pos", C.c_double * 3),
+                ("dir", C.c_double), ("size", C.c_double * 3), ("color", C.c_double * 3),
+                ("scale", C.c_double)]
+
+
+class _Tex(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("nlevels", C.c_int32), ("pad", C.c_int32),
+                ("rgb", C.c_void_p)]
+
+
+class _Mesh(C.Structure):
+    _fields_ = [("ntris", C.c_int32), ("tex", C.c_int32), ("pos", C.c_void_p), ("nrm", C.c_void_p),
+                ("uv", C.c_void_p), ("rgb", C.c_void_p)]
+
+
+class _Scene(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("nsamples", C.c_int32), ("pad", C.c_int32),
+                ("agent_pos", C.c_double * 3), ("agent_dir", C.c_double),
+                ("cam_height", C.c_double), ("cam_fwd_disp", C.c_double),
+                ("cam_pitch", C.c_double), ("cam_fov_y", C.c_double),
+                ("sky", C.c_double * 3), ("light_pos", C.c_double * 3),
+                ("light_color", C.c_double * 3), ("light_ambient", C.c_double * 3),
+                ("n_polys", C.c_int32), ("n_ents", C.c_int32), ("n_tex", C.c_int32), ("n_mesh", C.c_int32),
+                ("polys", C.c_void_p), ("ents", C.c_void_p), ("tex", C.c_void_p), ("meshes", C.c_void_p)]
+
+
+class AgentState(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("dir", C.c_double), ("radius", C.c_double),
+                ("cam_height", C.c_double), ("carrying", C.c_int32), ("step_count", C.c_int32),
+                ("max_episode_steps", C.c_int32), ("task", C.c_int32), ("goal_ent", C.c_int32),
+                ("num_objs", C.c_int32), ("num_picked_up", C.c_int32), ("n_ents", C.c_int32),
+                ("max_forward_step", C.c_double)]
+
+
+class PhysEnt(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("dir", C.c_double), ("radius", C.c_double),
+                ("height", C.c_double), ("alive", C.c_int32), ("is_static", C.c_int32)]
+
+
+TASK_NONE, TASK_GOTO, TASK_PICKUP = 0, 1, 2
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        L.mwo_sincos.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+        L.mwo_mip_bytes.restype = C.c_int64
+        L.mwo_mip_bytes.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
+        L.mwo_build_mips.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.mwo_render_obs.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mwo_step.argtypes = [C.POINTER(AgentState), C.POINTER(PhysEnt), C.POINTER(PhysEnt), C.c_void_p,
+                               C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
+                               C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.mwo_intersect.argtypes = [C.POINTER(AgentState), C.POINTER(PhysEnt), C.c_int32, C.c_double,
+                                    C.c_double, C.c_double, C.c_void_p, C.c_int32]
+        _lib = L
+    return _lib
+
+
+def sincos(x: float):
+    s, c = C.c_double(), C.c_double()
+    lib().mwo_sincos(float(x), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+# ------------------------------------------------------------------ assets (own loader)
+
+_pack = None
+_mips = {}
+
+
+def _asset_pack():
+    global _pack
+    if _pack is None:
+        _pack = np.load(_PACK)
+    return _pack
+
+
+def texture_rgb_bottom_up(name: str) -> np.ndarray:
+    """RGB8 rows bottom-up, as pyglet hands them to glTexImage2D (opengl.py:156-171)."""
+    return np.ascontiguousarray(_asset_pack()["tex:" + name][::-1])
+
+
+def build_mips(rgb_bottom_up: np.ndarray):
+    h, w, _ = rgb_bottom_up.shape
+    n = C.c_int32()
+    nbytes = lib().mwo_mip_bytes(w, h, C.byref(n))
+    out = np.empty(nbytes, np.uint8)
+    src = np.ascontiguousarray(rgb_bottom_up, np.uint8)
+    lib().mwo_build_mips(src.ctypes.data, w, h, out.ctypes.data)
+    return out, n.value
+
+
+def mip_levels(rgb_bottom_up: np.ndarray):
+    """List of per-level uint8[h,w,3] arrays (for tests)."""
+    buf, n = build_mips(rgb_bottom_up)
+    h, w, _ = rgb_bottom_up.shape
+    out, off = [], 0
+    for _ in range(n):
+        out.append(buf[off:off + w * h * 3].reshape(h, w, 3))
+        off += w * h * 3
+        w, h = max(1, w // 2), max(1, h // 2)
+    return out
+
+
+def _mips_for(name, textures=None):
+    key = name if textures is None else (name, id(textures))
+    if key not in _mips:
+        rgb = textures[name] if textures is not None else texture_rgb_bottom_up(name)
+        _mips[key] = (build_mips(rgb), rgb.shape)
+    return _mips[key]
+
+
+# ------------------------------------------------------------------ render
+
+def render(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = None,
+           textures: dict | None = None, want_prim=False):
+    """Render a neutral scene.  Returns dict(rgb u8[H,W,3], z16 u16[H,W], depth f32[H,W,1])."""
+    L = lib()
+    P = int(len(scene["polys_nv"]))
+    polys = (_Poly * max(P, 1))()
+    pv = np.asarray(scene["polys_v"], np.float32).reshape(P, 12)
+    puv = np.asarray(scene["polys_uv"], np.float32).reshape(P, 8)
+    pn = np.asarray(scene["polys_n"], np.float32).reshape(P, 3)
+    for i in range(P):
+        polys[i].v[:] = pv[i].tolist()
+        polys[i].uv[:] = puv[i].tolist()
+        polys[i].n[:] = pn[i].tolist()
+        polys[i].nv = int(scene["polys_nv"][i])
+        polys[i].tex = int(scene["polys_tex"][i])
+    tex_names = [str(t) for t in scene["tex_names"]]
+    texs = (_Tex * max(len(tex_names), 1))()
+    keep = []
+    for i, name in enumerate(tex_names):
+        (buf, nl), shp = _mips_for(name, textures)
+        keep.append(buf)
+        texs[i].w, texs[i].h, texs[i].nlevels = shp[1], shp[0], nl
+        texs[i].rgb = buf.ctypes.data
+    E = int(len(scene["ents_kind"]))
+    ents = (_Ent * max(E, 1))()
+    for i in range(E):
+        ents[i].kind = int(scene["ents_kind"][i])
+        ents[i].mesh = int(scene["ents_mesh"][i])
+        ents[i].pos[:] = [float(x) for x in scene["ents_pos"][i]]
+        ents[i].dir = float(scene["ents_dir"][i])
+        ents[i].size[:] = [float(x) for x in scene["ents_size"][i]]
+        ents[i].color[:] = [float(x) for x in scene["ents_color"][i]]
+        ents[i].scale = float(scene["ents_scale"][i])
+    mesh_names = [str(m) for m in scene.get("mesh_names", [])]
+    mstructs = (_Mesh * max(len(mesh_names), 1))()
+    for i, name in enumerate(mesh_names):
+        m = meshes[name]
+        arrs = [np.ascontiguousarray(m[k], np.float32) for k in ("verts", "norms", "texcs", "colors")]
+        keep.extend(arrs)
+        mstructs[i].ntris = arrs[0].shape[0]
+        mstructs[i].tex = -1
+        mstructs[i].pos, mstructs[i].nrm, mstructs[i].uv, mstructs[i].rgb = (a.ctypes.data for a in arrs)
+    sc = _Scene()
+    sc.width, sc.height, sc.nsamples = width, height, nsamples
+    sc.agent_pos[:] = [float(x) for x in scene["agent_pos"]]
+    sc.agent_dir = float(scene["agent_dir"])
+    for k in ("cam_height", "cam_fwd_disp", "cam_pitch", "cam_fov_y"):
+        setattr(sc, k, float(scene[k]))
+    for k in ("sky", "light_pos", "light_color", "light_ambient"):
+        getattr(sc, k)[:] = [float(x) for x in scene[k]]
+    sc.n_polys, sc.n_ents, sc.n_tex, sc.n_mesh = P, E, len(tex_names), len(mesh_names)
+    sc.polys = C.addressof(polys)
+    sc.ents = C.addressof(ents)
+    sc.tex = C.addressof(texs)
+    sc.meshes = C.addressof(mstructs)
+    rgb = np.zeros((height, width, 3), np.uint8)
+    z16 = np.zeros((height, width), np.uint16)
+    depth = np.zeros((height, width, 1), np.float32)
+    prim = np.zeros((height, width, nsamples), np.int32) if want_prim else None
+    rc = L.mwo_render_obs(C.byref(sc), rgb.ctypes.data, z16.ctypes.data, depth.ctypes.data,
+                          prim.ctypes.data if want_prim else None)
+    if rc != 0:
+        raise RuntimeError(f"mwo_render_obs failed: {rc}")
+    out = {"rgb": rgb, "z16": z16, "depth": depth}
+    if want_prim:
+        out["prim"] = prim
+    return out
+
+
+# ------------------------------------------------------------------ dynamics
+
+class Dynamics:
+    """Thin stateful wrapper around mwo_step for one environment."""
+
+    def __init__(self, scene: dict, task: int, max_episode_steps: int, goal_ent: int = 0,
+                 num_objs: int = 0, max_forward_step: float = 0.17, agent_radius: float = 0.4):
+        E = int(len(scene["ents_kind"]))
+        self.ag = AgentState()
+        self.ag.pos[:] = [float(x) for x in scene["agent_pos"]]
+        self.ag.dir = float(scene["agent_dir"])
+        self.ag.radius = agent_radius
+        self.ag.cam_height = float(scene["cam_height"])
+        self.ag.carrying, self.ag.step_count = -1, 0
+        self.ag.max_episode_steps, self.ag.task, self.ag.goal_ent = max_episode_steps, task, goal_ent
+        self.ag.num_objs, self.ag.num_picked_up, self.ag.n_ents = num_objs, 0, E
+        self.ag.max_forward_step = max_forward_step
+        self.ents = (PhysEnt * max(E, 1))()
+        self.render_ents = (PhysEnt * max(E, 1))()
+        for i in range(E):
+            self.ents[i].pos[:] = [float(x) for x in scene["ents_pos"][i]]
+            self.ents[i].dir = float(scene["ents_dir"][i])
+            self.ents[i].radius = float(scene["ents_radius"][i])
+            self.ents[i].height = float(scene["ents_height"][i])
+            self.ents[i].alive = 1
+            self.ents[i].is_static = int(scene["ents_static"][i])
+        self.segs = np.ascontiguousarray(scene["wall_segs"], np.float64).reshape(-1, 4)
+
+    def step(self, action, fwd_step=0.15, fwd_drift=0.0, turn_step=15.0):
+        r, t, u = C.c_double(), C.c_int32(), C.c_int32()
+        lib().mwo_step(C.byref(self.ag), self.ents, self.render_ents, self.segs.ctypes.data,
+                       self.segs.shape[0], int(action), float(fwd_step), float(fwd_drift),
+                       float(turn_step), C.byref(r), C.byref(t), C.byref(u))
+        return r.value, bool(t.value), bool(u.value)
+
+    def intersect(self, self_idx, px, pz, radius):
+        return lib().mwo_intersect(C.byref(self.ag), self.ents, self_idx, px, pz, radius,
+                                   self.segs.ctypes.data, self.segs.shape[0])

@@ -1,0 +1,162 @@
+"""Generates tests/golden/*.npz from the reference itself (FIXTURE TOOLING).
+
+Runs the reference's own world generation and dynamics (under tools/refshim.py GL stubs)
+for the BASELINE configs, and stores per case:
+  * the neutral scene right after reset(seed)                    (keys "s0/<name>")
+  * a random-action trajectory of the reference                  (keys "tr/<name>")
+  * oracle renders (rgb, z16) of selected trajectory frames      (keys "obs/<k>/rgb|z16")
+plus tests/golden/meshes.npz with the per-face arrays produced by the reference's ObjMesh.
+
+The trajectory part pins the oracle's dynamics and the product's world generation to the
+reference; the obs part is produced by the CPU oracle (pixels are "parity unpinned", see
+oracle/mwo.h) and is what the HIP engine is compared with on the GPU box, where
+/root/reference does not exist.
+
+Usage (build container only):  python tools/gen_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", "oracle"))
+import pyoracle  # noqa: E402
+import refscene  # noqa: E402
+import refshim  # noqa: E402
+
+OUT = os.path.join(HERE, "..", "tests", "golden")
+
+# (case name, env class, kwargs, seed, n_actions, steps, frames to render)
+CASES = [
+    ("hallway_s0", "Hallway", {}, 0, 3, 120, [0, 7, 40, 119]),
+    ("hallway_s1", "Hallway", {}, 1, 3, 120, [0, 25]),
+    ("hallway_dr_s3", "Hallway", {"domain_rand": True}, 3, 3, 120, [0, 30, 60]),
+    ("oneroom_s0", "OneRoom", {}, 0, 3, 100, [0, 33, 99]),
+    ("oneroom_dr_s5", "OneRoom", {"domain_rand": True}, 5, 3, 60, [0, 20]),
+    ("mazes3_s0", "MazeS3", {}, 0, 3, 150, [0, 50, 149]),
+    ("maze_s0", "Maze", {}, 0, 3, 200, [0, 100, 199]),
+    ("maze_s2", "Maze", {}, 2, 3, 60, [0, 59]),
+    ("pickup_s0", "PickupObjects", {}, 0, 5, 200, [0, 60, 199]),
+    ("pickup_dr_s1", "PickupObjects", {"domain_rand": True}, 1, 5, 300, [0, 100, 299]),
+    ("pickup_dr_s4", "PickupObjects", {"domain_rand": True}, 4, 5, 300, [0, 150]),
+    # forward-biased policies so that termination / reward / pickup paths are exercised
+    ("hallway_fwd_s2", "Hallway", {}, 2, [0.1, 0.1, 0.8], 250, [0, 20]),
+    ("hallway_dr_fwd_s4", "Hallway", {"domain_rand": True}, 4, [0.1, 0.1, 0.8], 250, [0, 15]),
+    ("oneroom_fwd_s3", "OneRoom", {}, 3, [0.2, 0.1, 0.7], 180, [0, 40]),
+    ("oneroom_trunc_s7", "OneRoom", {}, 7, [0.5, 0.5, 0.0], 180, [0, 180]),
+    ("pickup_fwd_s2", "PickupObjects", {}, 2, [0.15, 0.1, 0.45, 0.05, 0.25], 400, [0, 80, 200]),
+    ("pickup_dr_fwd_s6", "PickupObjects", {"domain_rand": True}, 6, [0.15, 0.1, 0.45, 0.05, 0.25], 400, [0, 120]),
+]
+
+
+def run_case(name, cls, kwargs, seed, n_actions, steps, frames, meshes):
+    env = refshim.make_env(cls, **kwargs)
+    log = []
+    params = env.params.copy()
+    orig = params.sample
+
+    def sample(rng, pname):
+        v = orig(rng, pname)
+        log.append((pname, v))
+        return v
+    params.sample = sample
+    env.params = params
+    env.reset(seed=seed)
+    s0 = refscene.scene_from_ref_env(env)
+    ents0 = [e for e in env.entities if e is not env.agent]
+    for e in ents0:
+        if hasattr(e, "mesh"):
+            mname = refscene.mesh_name_of(e)
+            base = mname.split("_")[0]
+            if base not in meshes:
+                meshes[base] = refscene.ref_mesh_arrays(e.mesh)
+            meshes["kd:" + mname] = meshes.get("kd:" + mname, np.array(
+                refscene.ref_mesh_arrays(e.mesh)["colors"][0, 0], np.float64))
+    E = len(ents0)
+    rng = np.random.default_rng(1000 + seed)
+    tr = {k: [] for k in ("action", "pos", "dir", "carrying", "ents_pos", "ents_dir", "ents_alive",
+                          "reward", "term", "trunc", "fwd_step", "fwd_drift", "turn_step")}
+    scenes = {0: s0}
+    for t in range(steps):
+        if isinstance(n_actions, list):
+            a = int(rng.choice(len(n_actions), p=n_actions))
+        else:
+            a = int(rng.integers(0, n_actions))
+        del log[:]
+        obs, rew, term, trunc, info = env.step(a)
+        step_params = dict(log[:3])
+        tr["action"].append(a)
+        tr["pos"].append(np.array(env.agent.pos, np.float64))
+        tr["dir"].append(float(env.agent.dir))
+        tr["carrying"].append(ents0.index(env.agent.carrying) if env.agent.carrying is not None else -1)
+        tr["ents_pos"].append(np.array([e.pos for e in ents0], np.float64).reshape(E, 3))
+        tr["ents_dir"].append(np.array([e.dir for e in ents0], np.float64))
+        tr["ents_alive"].append(np.array([any(e is x for x in env.entities) for e in ents0], np.int32))
+        tr["reward"].append(float(rew))
+        tr["term"].append(bool(term))
+        tr["trunc"].append(bool(trunc))
+        tr["fwd_step"].append(float(step_params["forward_step"]))
+        tr["fwd_drift"].append(float(step_params["forward_drift"]))
+        tr["turn_step"].append(float(step_params["turn_step"]))
+        if (t + 1) in frames:
+            sc = refscene.scene_from_ref_env(env)
+            # keep the original entity indexing: dead entities get kind 0
+            full = dict(s0)
+            full.update({k: sc[k] for k in ("agent_pos", "agent_dir", "agent_carrying", "step_count")})
+            alive = tr["ents_alive"][-1]
+            full["ents_pos"] = tr["ents_pos"][-1]
+            full["ents_dir"] = tr["ents_dir"][-1]
+            full["ents_kind"] = np.where(alive > 0, s0["ents_kind"], 0).astype(np.int32)
+            scenes[t + 1] = full
+        if term or trunc:
+            break
+    out = {}
+    for k, v in s0.items():
+        out["s0/" + k] = v
+    for k, v in tr.items():
+        out["tr/" + k] = np.array(v)
+    out["meta/n_actions"] = np.int32(len(n_actions) if isinstance(n_actions, list) else n_actions)
+    out["meta/seed"] = np.int32(seed)
+    out["meta/domain_rand"] = np.int32(bool(kwargs.get("domain_rand", False)))
+    out["meta/env"] = np.array(cls)
+    mesh_arrays = {}
+    for mname in [str(m) for m in s0["mesh_names"]]:
+        base = mname.split("_")[0]
+        m = dict(meshes[base])
+        m["colors"] = np.broadcast_to(meshes["kd:" + mname].astype(np.float32), m["verts"].shape).copy()
+        mesh_arrays[mname] = m
+    for k, sc in scenes.items():
+        r = pyoracle.render(sc, meshes=mesh_arrays)
+        out[f"obs/{k}/rgb"] = r["rgb"]
+        out[f"obs/{k}/z16"] = r["z16"]
+        for key in ("agent_pos", "agent_dir", "ents_pos", "ents_dir", "ents_kind"):
+            out[f"obs/{k}/{key}"] = sc[key]
+    out["meta/frames"] = np.array(sorted(scenes.keys()), np.int32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print(f"{name}: steps={len(tr['action'])} ents={E} polys={len(s0['polys_nv'])} "
+          f"segs={len(s0['wall_segs'])} frames={sorted(scenes.keys())} "
+          f"reward_sum={sum(tr['reward']):.4f}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    meshes = {}
+    for case in CASES:
+        run_case(*case, meshes)
+    mout = {}
+    for k, v in meshes.items():
+        if k.startswith("kd:"):
+            mout[k] = v
+        else:
+            for kk, vv in v.items():
+                if kk != "colors":
+                    mout[f"{k}/{kk}"] = vv
+    np.savez_compressed(os.path.join(OUT, "meshes.npz"), **mout)
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,55 @@
+"""Builds miniworld_amd/assets/assets_v1.npz from the reference's data assets.
+
+The engine needs the same texture / mesh *data* the reference ships (Apache-2.0,
+/root/reference/miniworld/{textures,meshes}) to draw the same worlds; those files do not
+exist on the GPU box, so the subset used by the BASELINE configs is re-packed here into
+one engine-side container:
+    tex:<name>   uint8[h, w, 3]  decoded RGB, rows top-down as stored in the PNG
+                                 (alpha dropped exactly as glTexImage2D(GL_RGB) does,
+                                  opengl.py:161-171)
+    obj:<name>   uint8[...]      OBJ text (ball / key geometry is shared by all colours)
+    kd:<name>    float64[3]      diffuse colour of <name>.mtl (objmesh.py:234 looks the MTL
+                                 up by the OBJ's own name, not by its mtllib line)
+Run in the build container only:  python tools/pack_assets.py
+"""
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+REF = os.environ.get("MINIWORLD_REFERENCE_ROOT", "/root/reference")
+OUT = os.path.join(os.path.dirname(__file__), "..", "miniworld_amd", "assets", "assets_v1.npz")
+
+TEXTURES = [
+    "floor_tiles_bw_1", "concrete_1", "concrete_2", "concrete_3", "concrete_4",
+    "concrete_tiles_1", "brick_wall_1", "asphalt_1",
+]
+COLORS = ["blue", "green", "grey", "purple", "red", "yellow"]
+
+
+def main():
+    items = {}
+    for name in TEXTURES:
+        path = os.path.join(REF, "miniworld", "textures", name + ".png")
+        with Image.open(path) as im:
+            rgba = np.asarray(im.convert("RGBA"))
+        items["tex:" + name] = np.ascontiguousarray(rgba[:, :, :3])
+    for base in ("ball", "key"):
+        # geometry identical for every colour (checked with cmp); store it once
+        with open(os.path.join(REF, "miniworld", "meshes", f"{base}_red.obj"), "rb") as f:
+            items["obj:" + base] = np.frombuffer(f.read(), np.uint8)
+        for col in COLORS:
+            kd = None
+            with open(os.path.join(REF, "miniworld", "meshes", f"{base}_{col}.mtl")) as f:
+                for line in f:
+                    tok = line.split()
+                    if tok and tok[0] == "Kd":
+                        kd = np.array([float(t) for t in tok[1:4]])
+            items[f"kd:{base}_{col}"] = kd
+    np.savez_compressed(OUT, **items)
+    print("wrote", os.path.abspath(OUT), os.path.getsize(OUT) / 1e6, "MB")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
