@@ -1,0 +1,176 @@
+/* mwengine — C ABI of the MI355X-native batched Miniworld step+render engine.
+ *
+ * The reference (Farama-Foundation/Miniworld v2.1.0) has no FFI: its "backend" is the
+ * Python module miniworld/opengl.py (Texture, FrameBuffer, drawBox) plus raw GL calls in
+ * Entity.render(), driven once per MiniWorldEnv.step().  This header is the seam a
+ * maintainer binds instead of that module (ctypes stub: INTEGRATION.md).  Every entry
+ * point cites the reference interface it replaces.
+ *
+ * Conventions
+ *   - plain C, no exceptions: every call returns 0 on success or a negative MW_E_* code;
+ *     mw_last_error() gives the message (reference: Python assert / exception).
+ *   - the CALLER owns all output buffers (device pointers, e.g. torch tensors); the engine
+ *     owns the Structure-of-Arrays world state of its N environments.
+ *   - all device work is enqueued on the hipStream_t passed as `stream` (void* so that this
+ *     header needs no HIP include); nothing synchronises unless documented.
+ *   - one engine per device; an engine is not re-entrant (the reference is single-threaded:
+ *     one GL context per env, miniworld.py:1187), distinct engines are independent.
+ */
+#ifndef MWENGINE_H
+#define MWENGINE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MW_ABI_VERSION 1
+
+enum {
+    MW_OK = 0,
+    MW_E_INVALID = -1,      /* bad argument                                 */
+    MW_E_HIP = -2,          /* HIP runtime error (message has the hipError) */
+    MW_E_NOMEM = -3,
+    MW_E_CAPACITY = -4,     /* more polys / entities / textures than configured */
+    MW_E_DEVICE = -5,       /* no usable gfx950 device                      */
+    MW_E_OVERFLOW = -6      /* a kernel reported a per-env capacity overflow */
+};
+
+/* entity kinds (entity.py: Box :386, MeshEnt :124 / Ball :445 / Key :435) */
+enum { MW_ENT_NONE = 0, MW_ENT_BOX = 1, MW_ENT_MESH = 2 };
+
+/* env reward / termination rule applied after MiniWorldEnv.step (miniworld.py:670-730) */
+enum {
+    MW_TASK_NONE = 0,
+    MW_TASK_GOTO = 1,       /* hallway.py:67-74, oneroom.py:64-71, maze.py:155-162 */
+    MW_TASK_PICKUP = 2      /* pickupobjects.py:83-95                            */
+};
+
+/* device-side world generators for mw_reset / auto-reset (the env's _gen_world) */
+enum {
+    MW_GEN_NONE = 0,        /* worlds only come from mw_set_state             */
+    MW_GEN_HALLWAY = 1,     /* hallway.py:55-65                               */
+    MW_GEN_ONEROOM = 2,     /* oneroom.py:59-62                               */
+    MW_GEN_PICKUP = 3       /* pickupobjects.py:55-81                         */
+};
+
+enum { MW_AUTORESET_OFF = 0, MW_AUTORESET_SAME_STEP = 1 };
+
+typedef struct mw_engine mw_engine;
+
+/* Scalar simulation parameter with its domain-randomisation range (params.py:7-130). */
+typedef struct { double def, lo, hi; } mw_range;
+
+typedef struct {
+    int32_t abi_version;        /* MW_ABI_VERSION */
+    int32_t device_id;
+    int32_t num_envs;
+    int32_t obs_width, obs_height;  /* MiniWorldEnv(obs_width=80, obs_height=60) miniworld.py:473-474 */
+    int32_t msaa;               /* FrameBuffer(..., num_samples=8) miniworld.py:515; 8 only for now */
+    int32_t max_ents;           /* entity slots per env, agent excluded            */
+    int32_t max_polys;          /* room polygons per geometry set                  */
+    int32_t max_segs;           /* collision segments per geometry set             */
+    int32_t max_visible;        /* front-facing on-screen primitives kept per env  */
+    int32_t shared_geometry;    /* 1: one geometry set for all envs, 0: one per env */
+    int32_t task;               /* MW_TASK_*                                       */
+    int32_t goal_ent;           /* MW_TASK_GOTO: entity slot of the box            */
+    int32_t num_objs;           /* MW_TASK_PICKUP                                  */
+    int32_t max_episode_steps;  /* miniworld.py:472, per env class                 */
+    int32_t domain_rand;        /* miniworld.py:478                                */
+    int32_t generator;          /* MW_GEN_*                                        */
+    int32_t autoreset;          /* MW_AUTORESET_*                                  */
+    double agent_radius;        /* entity.py:470 (0.4)                             */
+    double max_forward_step;    /* params.get_max("forward_step") miniworld.py:581 */
+    mw_range forward_step, forward_drift, turn_step;   /* params.py:123-125, miniworld.py:678-680 */
+    /* per-episode parameters sampled by reset (miniworld.py:576-585, entity.py:405-407, 505-515) */
+    mw_range sky_color[3], light_pos[3], light_color[3], light_ambient[3];   /* params.py:116-121 */
+    mw_range obj_color_bias[3];                                               /* params.py:122     */
+    mw_range cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;                  /* params.py:127-130 */
+    /* generator parameters: [0..3] room min_x,max_x,min_z,max_z; [4] box min_x override;
+     * [5] agent max_x override; [6] agent |dir| range; [7] box size */
+    double gen_args[8];
+} mw_config;
+
+/* One room polygon exactly as Room._render feeds it to GL (miniworld.py:401-434). */
+typedef struct {
+    float v[4][3];              /* glVertex3f   */
+    float uv[4][2];             /* glTexCoord2f */
+    float n[3];                 /* glNormal3f   */
+    int32_t nv;                 /* 3 or 4       */
+    int32_t tex;                /* texture id from mw_upload_texture, -1 = untextured */
+} mw_poly;
+
+/* Host view of the world state of `count` consecutive envs; any pointer may be NULL
+ * (= leave / do not fetch).  Mirrors the Python attributes the reference keeps:
+ * agent.pos/dir/cam_* (entity.py:455-515), env.sky_color/light_* (miniworld.py:576-578),
+ * entities[*].pos/dir/size/color_vec/scale/radius/height (entity.py), step_count, carrying. */
+typedef struct {
+    double *agent_pos;          /* [count][3]                                        */
+    double *agent_dir;          /* [count]                                           */
+    double *cam;                /* [count][4] cam_height, cam_fwd_disp, cam_pitch(deg), cam_fov_y(deg) */
+    double *light;              /* [count][12] sky_color, light_pos, light_color, light_ambient */
+    int32_t *carrying;          /* [count] entity slot or -1                         */
+    int32_t *step_count;        /* [count]                                           */
+    int32_t *num_picked_up;     /* [count]                                           */
+    int32_t *ent_kind;          /* [count][max_ents] MW_ENT_* (NONE = empty / removed) */
+    int32_t *ent_mesh;          /* [count][max_ents] mesh id                         */
+    int32_t *ent_static;        /* [count][max_ents]                                 */
+    double *ent_pos;            /* [count][max_ents][3]                              */
+    double *ent_dir;            /* [count][max_ents]                                 */
+    double *ent_geom;           /* [count][max_ents][9] size xyz, color rgb, scale, radius, height */
+} mw_state_view;
+
+/* ---- lifetime --------------------------------------------------------------- */
+/* replaces MiniWorldEnv.__init__'s GL setup (shadow window, FrameBuffer) miniworld.py:504-518 */
+int mw_create(const mw_config *cfg, mw_engine **out);
+void mw_destroy(mw_engine *e);
+/* last error message of `e` (or of the failed mw_create when e == NULL) */
+const char *mw_last_error(const mw_engine *e);
+
+/* ---- assets ----------------------------------------------------------------- */
+/* replaces Texture.load (opengl.py:148-184): RGB8, rows bottom-up; builds the mip pyramid */
+int mw_upload_texture(mw_engine *e, int32_t tex_id, const uint8_t *rgb_bottom_up, int32_t w, int32_t h);
+/* replaces ObjMesh's vertex lists (objmesh.py:139-207): per-face-vertex arrays [ntris][3][k] */
+int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float *nrm, const float *uv,
+                   const float *rgb, int32_t ntris, int32_t tex_id);
+
+/* ---- world ------------------------------------------------------------------ */
+/* replaces Room._gen_static_data + _render_static's display list (miniworld.py:286-399,
+ * 1019-1062) and env.wall_segs (:998-999).  env = -1 for the shared set.
+ * segs: [n_segs][2][2] (x,z of both endpoints). */
+int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_polys,
+                    const double *segs, int32_t n_segs);
+/* state injection / inspection (synchronous) */
+int mw_set_state(mw_engine *e, int32_t first_env, int32_t count, const mw_state_view *host);
+/* Test hook: host double[num_envs][3] = forward_step, forward_drift, turn_step to use in
+ * the next steps instead of the defaults / device RNG draws (miniworld.py:678-680);
+ * NULL switches the override off. */
+int mw_set_step_params(mw_engine *e, const double *host_params);
+int mw_get_state(mw_engine *e, int32_t first_env, int32_t count, mw_state_view *host);
+/* device-side MiniWorldEnv.reset (miniworld.py:544-604) for the configured generator.
+ * mask: host uint8[num_envs] or NULL (= all); seeds: host uint64[num_envs] or NULL. */
+int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *stream);
+
+/* ---- the hot path ------------------------------------------------------------ */
+/* MiniWorldEnv.step (miniworld.py:670-730) + env rule + render_obs (:1177-1221) for all envs.
+ *   d_actions int32[N]            MiniWorldEnv.Actions (:451-468)
+ *   d_obs     uint8[N][H][W][3]   FrameBuffer.resolve() layout, row 0 = top (opengl.py:339-398)
+ *   d_depth   float[N][H][W][1]   FrameBuffer.get_depth_map(0.04, 100) (opengl.py:400-435); NULL = skip
+ *   d_reward  float[N], d_term uint8[N], d_trunc uint8[N]
+ * All device pointers; asynchronous on `stream`. */
+int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_depth,
+            float *d_reward, uint8_t *d_term, uint8_t *d_trunc, void *stream);
+/* render_obs / render_depth only (miniworld.py:1177-1236) */
+int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);
+/* checks the device-side status word (capacity overflows); synchronises `stream` */
+int mw_check(mw_engine *e, void *stream);
+
+/* ---- measurement ------------------------------------------------------------- */
+/* average duration (ms) of the dominant (raster) kernel over the launches since the last
+ * call, measured with HIP events on the stream the kernel ran on; enables timing on
+ * first use.  Returns <0 on error. */
+int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *setup_ms, int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

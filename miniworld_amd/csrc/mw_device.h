@@ -1,0 +1,70 @@
+// mwengine internal types shared by the host runtime (mw_engine.hip) and the kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/mwengine.h"
+
+#define MW_MAX_TEX 64
+#define MW_MAX_MESH 32
+#define MW_MAX_LEVELS 16
+#define MW_RASTER_REC 64     // dwords per raster record
+#define MW_SHADE_REC 16      // dwords per shade record
+#define MW_TILE_W 16
+#define MW_TILE_H 4
+#define MW_SKY_PID 0xFFFFu
+
+// status bits written by kernels, read by mw_check()
+#define MW_ST_VIS_OVERFLOW 1u
+#define MW_ST_PLACEMENT_FAIL 2u
+
+struct MwTexDesc {
+    uint32_t w, h, nlevels, pad;
+    uint32_t off[MW_MAX_LEVELS];   // first texel (dword index into the texel pool) of each level
+};
+
+struct MwMeshDesc {
+    uint32_t ntris;
+    int32_t tex;
+    uint32_t first;                // first triangle in the mesh pools
+    uint32_t pad;
+};
+
+// Everything the kernels need; passed by value (kernarg).
+struct MwArgs {
+    int32_t N, W, H, E;
+    int32_t max_polys, max_segs, max_vis, shared_geom;
+    int32_t task, goal_ent, num_objs, max_steps;
+    int32_t domain_rand, generator, autoreset, tiles_x;
+    int32_t tiles_y, n_tiles, pad0, pad1;
+    double agent_radius, max_forward_step;
+    mw_range fwd, drift, turn;
+    mw_range sky[3], light_pos[3], light_color[3], light_ambient[3], color_bias[3];
+    mw_range cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;
+    double gen_args[8];
+    // --- world state, SoA over envs -------------------------------------------------
+    double *ax, *ay, *az, *adir;
+    double *cam;        // [4][N]
+    double *light;      // [12][N]
+    int32_t *carry, *step, *picked;
+    int32_t *ekind, *emesh, *estatic;   // [E][N]
+    double *epos;       // [3][E][N]
+    double *edir;       // [E][N]
+    double *egeom;      // [9][E][N]
+    uint64_t *rng;      // [2][N]  seed, counter
+    const double *step_override;        // [N][3] or null
+    // --- geometry -------------------------------------------------------------------
+    const mw_poly *polys;   // [sets][max_polys]
+    const int32_t *npolys;  // [sets]
+    const double *segs;     // [sets][max_segs][4]
+    const int32_t *nsegs;   // [sets]
+    // --- assets ---------------------------------------------------------------------
+    const MwTexDesc *tex;
+    const uint32_t *texels; // RGBA8 pool
+    const MwMeshDesc *mesh;
+    // --- per-step scratch -----------------------------------------------------------
+    float *rec_raster;      // [N][max_vis][64]
+    float *rec_shade;       // [N][max_vis][16]
+    int32_t *nvis;          // [N]
+    float *envhdr;          // [N][4] sky rgb, pad
+    uint32_t *status;
+};

@@ -1,0 +1,518 @@
+// mwengine host runtime: the C ABI of include/mwengine.h on top of the HIP kernels.
+// Owns the device-resident Structure-of-Arrays world state of N environments, the texture /
+// mesh pools and the per-step scratch; never touches torch (the caller hands raw device
+// pointers and a hipStream_t).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mw_device.h"
+
+extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, const int32_t *actions, float *reward,
+                                                uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                            int waves_per_env, int tiles_per_wave, const float *rec_raster,
+                                            const float *rec_shade, const int32_t *nvis, const float *envhdr,
+                                            const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth);
+extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all);
+
+namespace {
+thread_local std::string g_create_error;
+}
+
+struct mw_engine {
+    mw_config cfg{};
+    MwArgs args{};
+    int n_sets = 1;
+    std::string err;
+    // device allocations (freed in destroy)
+    std::vector<void *> allocs;
+    // textures
+    std::vector<MwTexDesc> tex_desc;
+    std::vector<std::vector<uint32_t>> tex_data;   // RGBA8 pyramid per texture
+    uint32_t *d_texels = nullptr;
+    MwTexDesc *d_texdesc = nullptr;
+    MwMeshDesc *d_meshdesc = nullptr;
+    // scratch for the step outputs when the caller passes none
+    float *d_reward_scratch = nullptr;
+    uint8_t *d_flag_scratch = nullptr;
+    int32_t *d_action_scratch = nullptr;
+    uint8_t *d_mask = nullptr;
+    double *d_step_override = nullptr;
+    bool use_step_override = false;
+    // timing
+    bool timing = false;
+    struct Ev { hipEvent_t a, b, c; };
+    std::vector<Ev> ev_used, ev_free;
+    int waves_per_env = 0;
+};
+
+namespace {
+
+int fail(mw_engine *e, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (e) e->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(e, call)                                                                         \
+    do {                                                                                         \
+        hipError_t _st = (call);                                                                 \
+        if (_st != hipSuccess)                                                                   \
+            return fail(e, MW_E_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_st), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T>
+int dev_alloc(mw_engine *e, T **out, size_t count, bool zero = true)
+{
+    void *p = nullptr;
+    const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t st = hipMalloc(&p, bytes);
+    if (st != hipSuccess) return fail(e, MW_E_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(st));
+    if (zero) {
+        st = hipMemset(p, 0, bytes);
+        if (st != hipSuccess) return fail(e, MW_E_HIP, "hipMemset failed: %s", hipGetErrorString(st));
+    }
+    e->allocs.push_back(p);
+    *out = static_cast<T *>(p);
+    return MW_OK;
+}
+
+// R8: mip pyramid.  level k+1 dims max(1, floor(n/2)); even axis = 2-tap box, odd
+// axis n = 2d+1 = 3-tap polyphase box with weights (d-i, d, i+1); exact integers, round half up.
+struct Taps { int n; int idx[3]; int w[3]; int total; };
+Taps axis_taps(int n, int i)
+{
+    Taps t{};
+    if (n == 1) { t.n = 1; t.idx[0] = 0; t.w[0] = 1; t.total = 1; return t; }
+    if ((n & 1) == 0) { t.n = 2; t.idx[0] = 2 * i; t.idx[1] = 2 * i + 1; t.w[0] = t.w[1] = 1; t.total = 2; return t; }
+    const int d = n / 2;
+    t.n = 3;
+    for (int k = 0; k < 3; ++k) t.idx[k] = 2 * i + k;
+    t.w[0] = d - i; t.w[1] = d; t.w[2] = i + 1;
+    t.total = n;
+    return t;
+}
+
+void build_pyramid(const uint8_t *rgb, int w, int h, std::vector<uint32_t> &out, MwTexDesc &desc)
+{
+    std::vector<uint8_t> cur(rgb, rgb + (size_t)w * h * 3), nxt;
+    desc.w = (uint32_t)w; desc.h = (uint32_t)h; desc.nlevels = 0; desc.pad = 0;
+    out.clear();
+    for (;;) {
+        desc.off[desc.nlevels++] = (uint32_t)out.size();
+        for (size_t i = 0; i < (size_t)w * h; ++i)
+            out.push_back((uint32_t)cur[i * 3] | ((uint32_t)cur[i * 3 + 1] << 8) | ((uint32_t)cur[i * 3 + 2] << 16) | 0xFF000000u);
+        if ((w == 1 && h == 1) || desc.nlevels == MW_MAX_LEVELS) break;
+        const int nw = std::max(1, w / 2), nh = std::max(1, h / 2);
+        nxt.assign((size_t)nw * nh * 3, 0);
+        for (int j = 0; j < nh; ++j) {
+            const Taps ty = axis_taps(h, j);
+            for (int i = 0; i < nw; ++i) {
+                const Taps tx = axis_taps(w, i);
+                const long long tot = (long long)tx.total * ty.total;
+                for (int c = 0; c < 3; ++c) {
+                    long long acc = 0;
+                    for (int b = 0; b < ty.n; ++b)
+                        for (int a = 0; a < tx.n; ++a)
+                            acc += (long long)tx.w[a] * ty.w[b] * cur[((size_t)ty.idx[b] * w + tx.idx[a]) * 3 + c];
+                    nxt[((size_t)j * nw + i) * 3 + c] = (uint8_t)((2 * acc + tot) / (2 * tot));
+                }
+            }
+        }
+        cur.swap(nxt);
+        w = nw; h = nh;
+    }
+}
+
+int upload_textures(mw_engine *e)
+{
+    size_t total = 0;
+    std::vector<MwTexDesc> descs = e->tex_desc;
+    for (size_t i = 0; i < descs.size(); ++i) {
+        for (uint32_t l = 0; l < descs[i].nlevels; ++l) descs[i].off[l] += (uint32_t)total;
+        total += e->tex_data[i].size();
+    }
+    if (e->d_texels) { (void)hipFree(e->d_texels); e->d_texels = nullptr; }
+    HIP_TRY(e, hipMalloc((void **)&e->d_texels, std::max<size_t>(total, 1) * 4));
+    size_t off = 0;
+    for (size_t i = 0; i < descs.size(); ++i) {
+        if (!e->tex_data[i].empty())
+            HIP_TRY(e, hipMemcpy(e->d_texels + off, e->tex_data[i].data(), e->tex_data[i].size() * 4, hipMemcpyHostToDevice));
+        off += e->tex_data[i].size();
+    }
+    HIP_TRY(e, hipMemcpy(e->d_texdesc, descs.data(), descs.size() * sizeof(MwTexDesc), hipMemcpyHostToDevice));
+    e->args.texels = e->d_texels;
+    return MW_OK;
+}
+
+int pick_waves_per_env(const mw_engine *e)
+{
+    const int n_tiles = e->args.n_tiles;
+    if (const char *s = getenv("MW_WAVES_PER_ENV")) {
+        const int v = atoi(s);
+        if (v > 0 && v <= n_tiles) return v;
+    }
+    // enough wavefronts to fill 256 CUs x 4 SIMDs several times over, in divisors of n_tiles
+    int best = n_tiles;
+    for (int w = 1; w <= n_tiles; ++w) {
+        if (n_tiles % w) continue;
+        if ((long long)e->cfg.num_envs * w >= 16384) { best = w; break; }
+    }
+    return best;
+}
+
+// copy host [count][inner] <-> device SoA [inner][N] (component-major), element type T
+template <typename T>
+int xfer(mw_engine *e, T *dev, T *host, int first, int count, int inner, bool to_device)
+{
+    if (!host) return MW_OK;
+    const int N = e->cfg.num_envs;
+    std::vector<T> tmp((size_t)count);
+    for (int k = 0; k < inner; ++k) {
+        T *d = dev + (size_t)k * N + first;
+        if (to_device) {
+            for (int i = 0; i < count; ++i) tmp[i] = host[(size_t)i * inner + k];
+            HIP_TRY(e, hipMemcpy(d, tmp.data(), sizeof(T) * count, hipMemcpyHostToDevice));
+        } else {
+            HIP_TRY(e, hipMemcpy(tmp.data(), d, sizeof(T) * count, hipMemcpyDeviceToHost));
+            for (int i = 0; i < count; ++i) host[(size_t)i * inner + k] = tmp[i];
+        }
+    }
+    return MW_OK;
+}
+
+// host [count][E][inner] <-> device [inner][E][N]
+template <typename T>
+int xfer_ent(mw_engine *e, T *dev, T *host, int first, int count, int inner, bool to_device)
+{
+    if (!host) return MW_OK;
+    const int N = e->cfg.num_envs, E = e->cfg.max_ents;
+    std::vector<T> tmp((size_t)count);
+    for (int k = 0; k < inner; ++k)
+        for (int s = 0; s < E; ++s) {
+            T *d = dev + ((size_t)k * E + s) * N + first;
+            if (to_device) {
+                for (int i = 0; i < count; ++i) tmp[i] = host[((size_t)i * E + s) * inner + k];
+                HIP_TRY(e, hipMemcpy(d, tmp.data(), sizeof(T) * count, hipMemcpyHostToDevice));
+            } else {
+                HIP_TRY(e, hipMemcpy(tmp.data(), d, sizeof(T) * count, hipMemcpyDeviceToHost));
+                for (int i = 0; i < count; ++i) host[((size_t)i * E + s) * inner + k] = tmp[i];
+            }
+        }
+    return MW_OK;
+}
+
+int state_xfer(mw_engine *e, int first, int count, const mw_state_view *h, bool to_device)
+{
+    if (!e || !h) return fail(e, MW_E_INVALID, "null argument");
+    if (first < 0 || count < 0 || first + count > e->cfg.num_envs) return fail(e, MW_E_INVALID, "env range out of bounds");
+    MwArgs &a = e->args;
+    int rc;
+    // agent_pos is [count][3] on the host, three separate arrays on the device
+    if (h->agent_pos) {
+        std::vector<double> tmp((size_t)count);
+        double *dev[3] = {a.ax, a.ay, a.az};
+        for (int k = 0; k < 3; ++k) {
+            if (to_device) {
+                for (int i = 0; i < count; ++i) tmp[i] = h->agent_pos[(size_t)i * 3 + k];
+                HIP_TRY(e, hipMemcpy(dev[k] + first, tmp.data(), 8 * (size_t)count, hipMemcpyHostToDevice));
+            } else {
+                HIP_TRY(e, hipMemcpy(tmp.data(), dev[k] + first, 8 * (size_t)count, hipMemcpyDeviceToHost));
+                for (int i = 0; i < count; ++i) h->agent_pos[(size_t)i * 3 + k] = tmp[i];
+            }
+        }
+    }
+    if ((rc = xfer(e, a.adir, h->agent_dir, first, count, 1, to_device))) return rc;
+    if ((rc = xfer(e, a.cam, h->cam, first, count, 4, to_device))) return rc;
+    if ((rc = xfer(e, a.light, h->light, first, count, 12, to_device))) return rc;
+    if ((rc = xfer(e, a.carry, h->carrying, first, count, 1, to_device))) return rc;
+    if ((rc = xfer(e, a.step, h->step_count, first, count, 1, to_device))) return rc;
+    if ((rc = xfer(e, a.picked, h->num_picked_up, first, count, 1, to_device))) return rc;
+    if ((rc = xfer_ent(e, a.ekind, h->ent_kind, first, count, 1, to_device))) return rc;
+    if ((rc = xfer_ent(e, a.emesh, h->ent_mesh, first, count, 1, to_device))) return rc;
+    if ((rc = xfer_ent(e, a.estatic, h->ent_static, first, count, 1, to_device))) return rc;
+    if ((rc = xfer_ent(e, a.epos, h->ent_pos, first, count, 3, to_device))) return rc;
+    if ((rc = xfer_ent(e, a.edir, h->ent_dir, first, count, 1, to_device))) return rc;
+    if ((rc = xfer_ent(e, a.egeom, h->ent_geom, first, count, 9, to_device))) return rc;
+    return MW_OK;
+}
+
+mw_engine::Ev get_events(mw_engine *e)
+{
+    if (!e->ev_free.empty()) {
+        mw_engine::Ev ev = e->ev_free.back();
+        e->ev_free.pop_back();
+        return ev;
+    }
+    mw_engine::Ev ev{};
+    (void)hipEventCreate(&ev.a);
+    (void)hipEventCreate(&ev.b);
+    (void)hipEventCreate(&ev.c);
+    return ev;
+}
+
+int launch_frame(mw_engine *e, bool do_step, const int32_t *d_actions, uint8_t *d_obs, float *d_depth,
+                 float *d_reward, uint8_t *d_term, uint8_t *d_trunc, hipStream_t st)
+{
+    if (!d_obs) return fail(e, MW_E_INVALID, "d_obs is null");
+    MwArgs a = e->args;
+    a.step_override = e->use_step_override ? e->d_step_override : nullptr;
+    const int N = e->cfg.num_envs;
+    mw_engine::Ev ev{};
+    if (e->timing) {
+        ev = get_events(e);
+        (void)hipEventRecord(ev.a, st);
+    }
+    hipLaunchKernelGGL(mw_step_setup_kernel, dim3(N), dim3(64), 0, st, a, do_step ? 1 : 0, d_actions,
+                       d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
+                       d_trunc ? d_trunc : e->d_flag_scratch + N);
+    if (e->timing) (void)hipEventRecord(ev.b, st);
+    const int wpe = e->waves_per_env;
+    const int tpw = (a.n_tiles + wpe - 1) / wpe;
+    const int groups = (N + 7) / 8;
+    const size_t lds = (size_t)e->cfg.max_visible * MW_SHADE_REC * 4 + 192;
+    hipLaunchKernelGGL(mw_raster_kernel, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+                       a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const int32_t *)a.nvis,
+                       (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth);
+    if (e->timing) {
+        (void)hipEventRecord(ev.c, st);
+        e->ev_used.push_back(ev);
+    }
+    HIP_TRY(e, hipGetLastError());
+    return MW_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *mw_last_error(const mw_engine *e) { return e ? e->err.c_str() : g_create_error.c_str(); }
+
+int mw_create(const mw_config *cfg, mw_engine **out)
+{
+    if (!cfg || !out) return fail(nullptr, MW_E_INVALID, "null argument");
+    if (cfg->abi_version != MW_ABI_VERSION) return fail(nullptr, MW_E_INVALID, "ABI version mismatch: header %d, caller %d", MW_ABI_VERSION, cfg->abi_version);
+    if (cfg->num_envs <= 0 || cfg->max_ents < 0 || cfg->max_polys <= 0 || cfg->max_segs <= 0 || cfg->max_visible <= 0)
+        return fail(nullptr, MW_E_INVALID, "bad capacities");
+    if (cfg->msaa != 8) return fail(nullptr, MW_E_INVALID, "only msaa = 8 is implemented");
+    if (cfg->obs_width % MW_TILE_W || cfg->obs_height % MW_TILE_H || cfg->obs_width > 255 * MW_TILE_W || cfg->obs_height > 255 * MW_TILE_H)
+        return fail(nullptr, MW_E_INVALID, "obs size must be a multiple of %dx%d", MW_TILE_W, MW_TILE_H);
+    if (cfg->max_visible > 65000) return fail(nullptr, MW_E_CAPACITY, "max_visible too large");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, MW_E_DEVICE, "no HIP device available");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, MW_E_DEVICE, "device %d out of range (%d devices)", cfg->device_id, ndev);
+    hipError_t st = hipSetDevice(cfg->device_id);
+    if (st != hipSuccess) return fail(nullptr, MW_E_HIP, "hipSetDevice: %s", hipGetErrorString(st));
+
+    mw_engine *e = new mw_engine();
+    e->cfg = *cfg;
+    const int N = cfg->num_envs, E = std::max(cfg->max_ents, 1);
+    e->cfg.max_ents = E;
+    e->n_sets = cfg->shared_geometry ? 1 : N;
+    MwArgs &a = e->args;
+    a.N = N; a.W = cfg->obs_width; a.H = cfg->obs_height; a.E = E;
+    a.max_polys = cfg->max_polys; a.max_segs = cfg->max_segs; a.max_vis = cfg->max_visible;
+    a.shared_geom = cfg->shared_geometry ? 1 : 0;
+    a.task = cfg->task; a.goal_ent = cfg->goal_ent; a.num_objs = cfg->num_objs; a.max_steps = cfg->max_episode_steps;
+    a.domain_rand = cfg->domain_rand; a.generator = cfg->generator; a.autoreset = cfg->autoreset;
+    a.tiles_x = a.W / MW_TILE_W; a.tiles_y = a.H / MW_TILE_H; a.n_tiles = a.tiles_x * a.tiles_y;
+    a.agent_radius = cfg->agent_radius; a.max_forward_step = cfg->max_forward_step;
+    a.fwd = cfg->forward_step; a.drift = cfg->forward_drift; a.turn = cfg->turn_step;
+    memcpy(a.gen_args, cfg->gen_args, sizeof a.gen_args);
+    for (int i = 0; i < 3; ++i) {
+        a.sky[i] = cfg->sky_color[i]; a.light_pos[i] = cfg->light_pos[i]; a.light_color[i] = cfg->light_color[i];
+        a.light_ambient[i] = cfg->light_ambient[i]; a.color_bias[i] = cfg->obj_color_bias[i];
+    }
+    a.cam_height = cfg->cam_height; a.cam_fwd_disp = cfg->cam_fwd_disp; a.cam_pitch = cfg->cam_pitch; a.cam_fov_y = cfg->cam_fov_y;
+    int rc = MW_OK;
+#define ALLOC(ptr, count) if (rc == MW_OK) rc = dev_alloc(e, &ptr, (size_t)(count))
+    ALLOC(a.ax, N); ALLOC(a.ay, N); ALLOC(a.az, N); ALLOC(a.adir, N);
+    ALLOC(a.cam, 4 * (size_t)N); ALLOC(a.light, 12 * (size_t)N);
+    ALLOC(a.carry, N); ALLOC(a.step, N); ALLOC(a.picked, N);
+    ALLOC(a.ekind, (size_t)E * N); ALLOC(a.emesh, (size_t)E * N); ALLOC(a.estatic, (size_t)E * N);
+    ALLOC(a.epos, 3 * (size_t)E * N); ALLOC(a.edir, (size_t)E * N); ALLOC(a.egeom, 9 * (size_t)E * N);
+    ALLOC(a.rng, 2 * (size_t)N);
+    mw_poly *polys = nullptr; int32_t *npolys = nullptr; double *segs = nullptr; int32_t *nsegs = nullptr;
+    ALLOC(polys, (size_t)e->n_sets * cfg->max_polys); ALLOC(npolys, e->n_sets);
+    ALLOC(segs, (size_t)e->n_sets * cfg->max_segs * 4); ALLOC(nsegs, e->n_sets);
+    a.polys = polys; a.npolys = npolys; a.segs = segs; a.nsegs = nsegs;
+    ALLOC(e->d_texdesc, MW_MAX_TEX); ALLOC(e->d_meshdesc, MW_MAX_MESH);
+    a.tex = e->d_texdesc; a.mesh = e->d_meshdesc;
+    ALLOC(a.rec_raster, (size_t)N * cfg->max_visible * MW_RASTER_REC);
+    ALLOC(a.rec_shade, (size_t)N * cfg->max_visible * MW_SHADE_REC);
+    ALLOC(a.nvis, N); ALLOC(a.envhdr, 4 * (size_t)N); ALLOC(a.status, 1);
+    ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
+    ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
+#undef ALLOC
+    if (rc != MW_OK) { g_create_error = e->err; mw_destroy(e); return rc; }
+    // carrying = -1 everywhere; default seeds = env index
+    {
+        std::vector<int32_t> m1((size_t)N, -1);
+        (void)hipMemcpy(a.carry, m1.data(), 4 * (size_t)N, hipMemcpyHostToDevice);
+        std::vector<uint64_t> seeds(2 * (size_t)N, 0);
+        for (int i = 0; i < N; ++i) seeds[i] = (uint64_t)i;
+        (void)hipMemcpy(a.rng, seeds.data(), 16 * (size_t)N, hipMemcpyHostToDevice);
+    }
+    e->tex_desc.assign(MW_MAX_TEX, MwTexDesc{});
+    e->tex_data.assign(MW_MAX_TEX, {});
+    if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
+    e->waves_per_env = pick_waves_per_env(e);
+    *out = e;
+    return MW_OK;
+}
+
+void mw_destroy(mw_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device_id);
+    (void)hipDeviceSynchronize();
+    for (void *p : e->allocs) (void)hipFree(p);
+    if (e->d_texels) (void)hipFree(e->d_texels);
+    for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
+    for (auto &ev : e->ev_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
+    delete e;
+}
+
+int mw_upload_texture(mw_engine *e, int32_t tex_id, const uint8_t *rgb, int32_t w, int32_t h)
+{
+    if (!e || !rgb) return fail(e, MW_E_INVALID, "null argument");
+    if (tex_id < 0 || tex_id >= MW_MAX_TEX) return fail(e, MW_E_CAPACITY, "texture id %d out of range (max %d)", tex_id, MW_MAX_TEX);
+    if (w <= 0 || h <= 0 || w > 16384 || h > 16384) return fail(e, MW_E_INVALID, "bad texture size %dx%d", w, h);
+    build_pyramid(rgb, w, h, e->tex_data[tex_id], e->tex_desc[tex_id]);
+    return upload_textures(e);
+}
+
+int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float *nrm, const float *uv,
+                   const float *rgb, int32_t ntris, int32_t tex_id)
+{
+    (void)pos; (void)nrm; (void)uv; (void)rgb; (void)ntris; (void)tex_id;
+    if (!e) return MW_E_INVALID;
+    if (mesh_id < 0 || mesh_id >= MW_MAX_MESH) return fail(e, MW_E_CAPACITY, "mesh id out of range");
+    return fail(e, MW_E_INVALID, "mesh entities are not implemented yet");
+}
+
+int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_polys, const double *segs, int32_t n_segs)
+{
+    if (!e || (n_polys > 0 && !polys) || (n_segs > 0 && !segs)) return fail(e, MW_E_INVALID, "null argument");
+    if (n_polys < 0 || n_polys > e->cfg.max_polys) return fail(e, MW_E_CAPACITY, "%d polygons > max_polys %d", n_polys, e->cfg.max_polys);
+    if (n_segs < 0 || n_segs > e->cfg.max_segs) return fail(e, MW_E_CAPACITY, "%d segments > max_segs %d", n_segs, e->cfg.max_segs);
+    int set = 0;
+    if (e->cfg.shared_geometry) {
+        if (env != -1) return fail(e, MW_E_INVALID, "engine uses one shared geometry set: pass env = -1");
+    } else {
+        if (env < 0 || env >= e->cfg.num_envs) return fail(e, MW_E_INVALID, "env %d out of range", env);
+        set = env;
+    }
+    for (int i = 0; i < n_polys; ++i) {
+        if (polys[i].nv != 3 && polys[i].nv != 4) return fail(e, MW_E_INVALID, "polygon %d has %d vertices (3 or 4 supported)", i, polys[i].nv);
+        if (polys[i].tex >= MW_MAX_TEX) return fail(e, MW_E_INVALID, "polygon %d: bad texture id", i);
+        if (polys[i].tex >= 0 && e->tex_desc[polys[i].tex].nlevels == 0) return fail(e, MW_E_INVALID, "polygon %d uses texture %d which was never uploaded", i, polys[i].tex);
+    }
+    HIP_TRY(e, hipMemcpy(const_cast<mw_poly *>(e->args.polys) + (size_t)set * e->cfg.max_polys, polys, sizeof(mw_poly) * (size_t)n_polys, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(const_cast<int32_t *>(e->args.npolys) + set, &n_polys, 4, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(const_cast<double *>(e->args.segs) + (size_t)set * e->cfg.max_segs * 4, segs, 32 * (size_t)n_segs, hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(const_cast<int32_t *>(e->args.nsegs) + set, &n_segs, 4, hipMemcpyHostToDevice));
+    return MW_OK;
+}
+
+int mw_set_state(mw_engine *e, int32_t first_env, int32_t count, const mw_state_view *host)
+{
+    return state_xfer(e, first_env, count, host, true);
+}
+
+int mw_get_state(mw_engine *e, int32_t first_env, int32_t count, mw_state_view *host)
+{
+    if (e) (void)hipDeviceSynchronize();
+    return state_xfer(e, first_env, count, host, false);
+}
+
+int mw_set_step_params(mw_engine *e, const double *host_params)
+{
+    if (!e) return MW_E_INVALID;
+    if (!host_params) { e->use_step_override = false; return MW_OK; }
+    HIP_TRY(e, hipMemcpy(e->d_step_override, host_params, 24 * (size_t)e->cfg.num_envs, hipMemcpyHostToDevice));
+    e->use_step_override = true;
+    return MW_OK;
+}
+
+int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *stream)
+{
+    if (!e) return MW_E_INVALID;
+    if (e->cfg.generator == MW_GEN_NONE) return fail(e, MW_E_INVALID, "engine was created without a device-side generator");
+    const int N = e->cfg.num_envs;
+    hipStream_t st = (hipStream_t)stream;
+    if (seeds) {
+        std::vector<uint64_t> cur(2 * (size_t)N);
+        HIP_TRY(e, hipMemcpy(cur.data(), e->args.rng, 16 * (size_t)N, hipMemcpyDeviceToHost));
+        for (int i = 0; i < N; ++i)
+            if (!mask || mask[i]) { cur[i] = seeds[i]; cur[(size_t)N + i] = 0; }
+        HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 16 * (size_t)N, hipMemcpyHostToDevice));
+    }
+    if (mask) HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, N, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(mw_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, st, e->args, e->d_mask, mask ? 0 : 1);
+    HIP_TRY(e, hipGetLastError());
+    return MW_OK;
+}
+
+int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_depth, float *d_reward,
+            uint8_t *d_term, uint8_t *d_trunc, void *stream)
+{
+    if (!e) return MW_E_INVALID;
+    if (!d_actions) return fail(e, MW_E_INVALID, "d_actions is null");
+    return launch_frame(e, true, d_actions, d_obs, d_depth, d_reward, d_term, d_trunc, (hipStream_t)stream);
+}
+
+int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream)
+{
+    if (!e) return MW_E_INVALID;
+    return launch_frame(e, false, e->d_action_scratch, d_obs, d_depth, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int mw_check(mw_engine *e, void *stream)
+{
+    if (!e) return MW_E_INVALID;
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+    uint32_t st = 0;
+    HIP_TRY(e, hipMemcpy(&st, e->args.status, 4, hipMemcpyDeviceToHost));
+    if (st & MW_ST_VIS_OVERFLOW) return fail(e, MW_E_OVERFLOW, "more than max_visible=%d visible primitives in some env", e->cfg.max_visible);
+    if (st & MW_ST_PLACEMENT_FAIL) return fail(e, MW_E_OVERFLOW, "device-side placement did not converge in some env");
+    return MW_OK;
+}
+
+int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *setup_ms, int64_t *launches)
+{
+    if (!e) return MW_E_INVALID;
+    double r = 0, s = 0;
+    int64_t n = 0;
+    for (auto &ev : e->ev_used) {
+        (void)hipEventSynchronize(ev.c);
+        float t1 = 0, t2 = 0;
+        (void)hipEventElapsedTime(&t1, ev.a, ev.b);
+        (void)hipEventElapsedTime(&t2, ev.b, ev.c);
+        s += t1; r += t2; ++n;
+        e->ev_free.push_back(ev);
+    }
+    e->ev_used.clear();
+    if (raster_ms) *raster_ms = n ? r / n : 0.0;
+    if (setup_ms) *setup_ms = n ? s / n : 0.0;
+    if (launches) *launches = n;
+    e->timing = true;
+    if (reset < 0) e->timing = false;
+    return MW_OK;
+}
+
+int mw_abi_version(void) { return MW_ABI_VERSION; }
+
+}  // extern "C"

@@ -1,0 +1,10 @@
+// mw_reset_kernel — batched MiniWorldEnv.reset (miniworld.py:544-604): one thread per env.
+#include "mw_gen.h"
+
+extern "C" __global__ __launch_bounds__(64) void mw_reset_kernel(MwArgs a, const uint8_t *__restrict__ mask, int force_all)
+{
+    const int env = blockIdx.x * 64 + threadIdx.x;
+    if (env >= a.N) return;
+    if (!force_all && !mask[env]) return;
+    mw::generate_world(a, env);
+}

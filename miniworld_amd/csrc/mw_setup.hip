@@ -1,0 +1,569 @@
+// K1 — per-env step + primitive setup.  One 64-lane wavefront per environment.
+//
+// Replaces, per env and per step (reference file:line):
+//   MiniWorldEnv.step / move_agent / turn_agent / _get_carry_pos   miniworld.py:606-730
+//   MiniWorldEnv.intersect + intersect_circle_segs                 miniworld.py:937-963, math.py:30-62
+//   near / _reward + env rules                                     miniworld.py:965-975,1012-1017; hallway.py:67-74; pickupobjects.py:83-95
+//   Agent.cam_pos / cam_dir, gluLookAt, gluPerspective             entity.py:476-503; miniworld.py:1198-1219
+//   the fixed-function transform + lighting of every primitive     miniworld.py:401-434,1019-1077; entity.py:150-161,409-432
+// and leaves, for the raster kernel (K2), a draw-ordered list of front-facing on-screen
+// primitives per env: a 64-dword raster record (edge functions, per-sample thresholds,
+// depth plane) read by K2 through scalar loads, and a 16-dword shade record.
+//
+// Lanes cooperate: collision segments and entities are tested one per lane (ballot),
+// polygons are set up one per lane and compacted in draw order with ballot + popcount.
+// All double-precision dynamics follow numpy's evaluation order;
+// all float32 raster setup follows DESIGN.md section 3 rules R1-R11.
+#include "mw_device.h"
+#include "mw_math.h"
+#include "mw_rng.h"
+#include "mw_gen.h"
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+
+struct HV { float hx, hy, hw, cz; };
+
+struct Cam {
+    float m[3][4];
+    float p00, p11, p22, p23, halfw, halfh;
+    float L[3], amb[3], lcol[3];
+};
+
+// R5: D3D standard 8x pattern, offsets from the pixel centre in pixels
+__constant__ float kSampleDx[8] = {0.0625f, -0.0625f, 0.3125f, -0.1875f, -0.3125f, -0.4375f, 0.1875f, 0.4375f};
+__constant__ float kSampleDy[8] = {-0.1875f, 0.1875f, 0.0625f, -0.3125f, 0.3125f, -0.0625f, 0.4375f, -0.4375f};
+
+// drawBox vertex selectors and normals, in the order of opengl.py:460-503
+__constant__ unsigned char kBoxSel[6][4] = {
+    // bit0: x max, bit1: y max, bit2: z max
+    {7, 6, 4, 5}, {2, 3, 1, 0}, {6, 2, 0, 4}, {3, 7, 5, 1}, {7, 3, 2, 6}, {1, 5, 4, 0}};
+__constant__ float kBoxN[6][3] = {{0, 0, 1}, {0, 0, -1}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
+
+__device__ inline uint64_t ballot(bool p) { return __ballot(p); }
+
+// ---------------------------------------------------------------- dynamics (f64)
+
+struct StepCtx {
+    const MwArgs &a;
+    int env, lane, set;
+    double px, py, pz, dir;        // agent
+    double cam_height;
+    int carry;                     // slot the agent carries, -1 none
+    int live;                      // slot whose pos/dir live in cpos/cdir this step, -1 none
+    double cpos[3], cdir;
+};
+
+__device__ inline double ent_pos(const StepCtx &c, int slot, int comp)
+{
+    if (slot == c.live) return c.cpos[comp];
+    return c.a.epos[((size_t)comp * c.a.E + slot) * c.a.N + c.env];
+}
+
+__device__ inline double ent_geom(const MwArgs &a, int env, int slot, int k)
+{
+    return a.egeom[((size_t)k * a.E + slot) * a.N + env];
+}
+
+// MiniWorldEnv.intersect (miniworld.py:937-963): 0 none, -1 wall, 1+slot entity, 1+E agent.
+// Every lane passes the same arguments; segments / entities are spread over the lanes.
+__device__ int intersect(const StepCtx &c, int self_slot, double x, double z, double radius)
+{
+    const MwArgs &a = c.a;
+    const double *segs = a.segs + (size_t)c.set * a.max_segs * 4;
+    const int ns = a.nsegs[c.set];
+    bool hit = false;
+    for (int i = c.lane; i < ns; i += 64) {
+        const double sax = segs[i * 4 + 0], saz = segs[i * 4 + 1], sbx = segs[i * 4 + 2], sbz = segs[i * 4 + 3];
+        const double abx = sbx - sax, abz = sbz - saz;
+        const double apx = x - sax, apz = z - saz;
+        const double dap = apx * abx + apz * abz;
+        const double dab = abx * abx + abz * abz;
+        double t = dap / dab;
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double cx = sax + t * abx, cz = saz + t * abz;
+        const double dx = cx - x, dz = cz - z;
+        hit |= sqrt(dx * dx + dz * dz) < radius;
+    }
+    if (ballot(hit)) return -1;
+    for (int base = 0; base < a.E; base += 64) {
+        const int slot = base + c.lane;
+        bool h = false;
+        if (slot < a.E && slot != self_slot && a.ekind[(size_t)slot * a.N + c.env] != MW_ENT_NONE) {
+            const double dx = ent_pos(c, slot, 0) - x, dz = ent_pos(c, slot, 2) - z;
+            h = sqrt(dx * dx + dz * dz) < radius + ent_geom(a, c.env, slot, 7);
+        }
+        const uint64_t m = ballot(h);
+        if (m) return 1 + base + (__ffsll((unsigned long long)m) - 1);
+    }
+    if (self_slot >= 0) {
+        const double dx = c.px - x, dz = c.pz - z;
+        if (sqrt(dx * dx + dz * dz) < radius + a.agent_radius) return 1 + a.E;
+    }
+    return 0;
+}
+
+// _get_carry_pos (miniworld.py:606-618)
+__device__ inline void carry_pos(const StepCtx &c, int slot, double ax, double ay, double az, double dvx,
+                                 double dvz, double out[3])
+{
+    const double dist = c.a.agent_radius + ent_geom(c.a, c.env, slot, 7) + c.a.max_forward_step;
+    out[0] = ax + dvx * 1.05 * dist;
+    out[1] = ay + 0.0 * 1.05 * dist;
+    out[2] = az + dvz * 1.05 * dist;
+    const double y = c.cam_height - ent_geom(c.a, c.env, slot, 8) - 0.3;
+    out[1] = out[1] + 1.0 * (y > 0.0 ? y : 0.0);
+}
+
+__device__ void move_agent(StepCtx &c, double fwd_dist, double fwd_drift)
+{
+    const mw::SinCos sc = mw::sincos_det(c.dir);
+    const double dvx = sc.c, dvz = -sc.s, rvx = sc.s, rvz = sc.c;
+    const double nx = c.px + dvx * fwd_dist + rvx * fwd_drift;
+    const double ny = c.py + 0.0 * fwd_dist + 0.0 * fwd_drift;
+    const double nz = c.pz + dvz * fwd_dist + rvz * fwd_drift;
+    if (intersect(c, -1, nx, nz, c.a.agent_radius)) return;
+    if (c.carry >= 0) {
+        double cp[3];
+        carry_pos(c, c.carry, nx, ny, nz, dvx, dvz, cp);
+        if (intersect(c, c.carry, cp[0], cp[2], ent_geom(c.a, c.env, c.carry, 7))) return;
+        c.cpos[0] = cp[0]; c.cpos[1] = cp[1]; c.cpos[2] = cp[2];
+    }
+    c.px = nx; c.py = ny; c.pz = nz;
+}
+
+__device__ void turn_agent(StepCtx &c, double turn_deg)
+{
+    const double turn = turn_deg * (kPi / 180.0);
+    const double orig = c.dir;
+    c.dir = c.dir + turn;
+    if (c.carry >= 0) {
+        const mw::SinCos sc = mw::sincos_det(c.dir);
+        double cp[3];
+        carry_pos(c, c.carry, c.px, c.py, c.pz, sc.c, -sc.s, cp);
+        if (intersect(c, c.carry, cp[0], cp[2], ent_geom(c.a, c.env, c.carry, 7))) {
+            c.dir = orig;
+            return;
+        }
+        c.cpos[0] = cp[0]; c.cpos[1] = cp[1]; c.cpos[2] = cp[2];
+        c.cdir = c.dir;
+    }
+}
+
+// ---------------------------------------------------------------- camera (R1, R2, R10)
+
+__device__ void build_camera(const MwArgs &a, int env, double px, double py, double pz, double dir, Cam &cam,
+                             float sky[3])
+{
+    const double cam_height = a.cam[(size_t)0 * a.N + env], fwd_disp = a.cam[(size_t)1 * a.N + env];
+    const double pitch_deg = a.cam[(size_t)2 * a.N + env], fov_y = a.cam[(size_t)3 * a.N + env];
+    const mw::SinCos hd = mw::sincos_det(dir / 2.0);
+    const double ya = hd.c, yc = -1.0 * hd.s;
+    const double ry00 = ya * ya - yc * yc;
+    const double ry02 = 2.0 * (ya * yc);
+    const double ry11 = ya * ya + yc * yc;
+    const double pitch = pitch_deg * kPi / 180.0;
+    const mw::SinCos hp = mw::sincos_det(pitch / 2.0);
+    const double za = hp.c, zd = -1.0 * hp.s;
+    const double rz00 = za * za - zd * zd;
+    const double rz01 = 2.0 * (0.0 - za * zd);
+    const double eye[3] = {px + fwd_disp * ry00, py + cam_height * ry11, pz + fwd_disp * ry02};
+    const double cd[3] = {rz00 * ry00, rz01 * ry11, rz00 * ry02};
+    const double at[3] = {eye[0] + cd[0], eye[1] + cd[1], eye[2] + cd[2]};
+    double F[3] = {at[0] - eye[0], at[1] - eye[1], at[2] - eye[2]};
+    const double fl = sqrt(F[0] * F[0] + F[1] * F[1] + F[2] * F[2]);
+    F[0] /= fl; F[1] /= fl; F[2] /= fl;
+    double s[3] = {-F[2], 0.0, F[0]};
+    const double sl = sqrt(s[0] * s[0] + s[2] * s[2]);
+    s[0] /= sl; s[2] /= sl;
+    const double u[3] = {s[1] * F[2] - s[2] * F[1], s[2] * F[0] - s[0] * F[2], s[0] * F[1] - s[1] * F[0]};
+    const double R[3][3] = {{s[0], s[1], s[2]}, {u[0], u[1], u[2]}, {-F[0], -F[1], -F[2]}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        cam.m[i][0] = (float)R[i][0];
+        cam.m[i][1] = (float)R[i][1];
+        cam.m[i][2] = (float)R[i][2];
+        cam.m[i][3] = (float)(-(R[i][0] * eye[0] + R[i][1] * eye[1] + R[i][2] * eye[2]));
+    }
+    const double half = fov_y / 2.0 * kPi / 180.0;
+    const mw::SinCos hf = mw::sincos_det(half);
+    const double cot = hf.c / hf.s;
+    const double aspect = (double)a.W / (double)a.H;
+    const double zn = 0.04, zf = 100.0;
+    cam.p00 = (float)(cot / aspect);
+    cam.p11 = (float)cot;
+    cam.p22 = (float)(-(zf + zn) / (zf - zn));
+    cam.p23 = (float)(-2.0 * zn * zf / (zf - zn));
+    cam.halfw = (float)a.W * 0.5f;
+    cam.halfh = (float)a.H * 0.5f;
+    float lp[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) lp[i] = (float)(a.light[(size_t)(3 + i) * a.N + env] + 1.0);
+    const float ll = sqrtf(fmaf(lp[2], lp[2], fmaf(lp[1], lp[1], lp[0] * lp[0])));
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        cam.L[i] = lp[i] / ll;
+        cam.amb[i] = 0.2f + (float)a.light[(size_t)(9 + i) * a.N + env];
+        cam.lcol[i] = (float)a.light[(size_t)(6 + i) * a.N + env];
+        sky[i] = (float)a.light[(size_t)i * a.N + env];
+    }
+}
+
+__device__ inline HV xform(const Cam &c, float x, float y, float z)
+{
+    const float ex = fmaf(c.m[0][0], x, fmaf(c.m[0][1], y, fmaf(c.m[0][2], z, c.m[0][3])));
+    const float ey = fmaf(c.m[1][0], x, fmaf(c.m[1][1], y, fmaf(c.m[1][2], z, c.m[1][3])));
+    const float ez = fmaf(c.m[2][0], x, fmaf(c.m[2][1], y, fmaf(c.m[2][2], z, c.m[2][3])));
+    const float cx = c.p00 * ex, cy = c.p11 * ey, cw = -ez;
+    HV h;
+    h.cz = fmaf(c.p22, ez, c.p23);
+    h.hx = (cx + cw) * c.halfw;
+    h.hy = (cw - cy) * c.halfh;
+    h.hw = cw;
+    return h;
+}
+
+__device__ inline void light(const Cam &c, const float n[3], const float base[3], float out[3])
+{
+    const float ndl = fmaf(n[2], c.L[2], fmaf(n[1], c.L[1], n[0] * c.L[0]));
+    const float d = ndl > 0.0f ? ndl : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float k = fmaf(c.lcol[i], d, c.amb[i]);
+        const float v = base[i] * k;
+        out[i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    }
+}
+
+// edge function of a->b: the homogeneous cross product b x a (R4)
+__device__ inline void edge_coef(const HV &a, const HV &b, float &ea, float &eb, float &ec)
+{
+    ea = b.hy * a.hw - b.hw * a.hy;
+    eb = b.hw * a.hx - b.hx * a.hw;
+    ec = b.hx * a.hy - b.hy * a.hx;
+}
+
+// largest float strictly below x: E >= x  <=>  E > below(x)   (top-left tie rule folded in)
+__device__ inline float below(float x)
+{
+    if (x == 0.0f) return __uint_as_float(0x80000001u);
+    const uint32_t b = __float_as_uint(x);
+    return __uint_as_float(x > 0.0f ? b - 1u : b + 1u);
+}
+
+struct PrimOut {
+    float rr[MW_RASTER_REC];
+    float sr[MW_SHADE_REC];
+};
+
+// R4: setup of one flat-shaded polygon.  Returns false when culled.
+__device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float uv[3][2], const float col[3],
+                           int tex, PrimOut &o)
+{
+    float ga[3], gb[3], gc[3];
+    edge_coef(h[1], h[2], ga[0], gb[0], gc[0]);
+    edge_coef(h[2], h[0], ga[1], gb[1], gc[1]);
+    edge_coef(h[0], h[1], ga[2], gb[2], gc[2]);
+    const float D = fmaf(h[0].hx, ga[0], fmaf(h[0].hy, gb[0], h[0].hw * gc[0]));
+    if (!(D > 0.0f)) return false;
+    // conservative screen bounds -> tile range
+    bool allpos = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) allpos &= (k >= nv) || h[k].hw > 0.0f;
+    int tx0 = 0, ty0 = 0, tx1 = a.tiles_x - 1, ty1 = a.tiles_y - 1;
+    if (allpos) {
+        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (k < nv) {
+                const float X = h[k].hx / h[k].hw, Y = h[k].hy / h[k].hw;
+                xmin = fminf(xmin, X); xmax = fmaxf(xmax, X);
+                ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+            }
+        }
+        if (xmax < -1.0f || ymax < -1.0f || xmin > (float)a.W + 1.0f || ymin > (float)a.H + 1.0f) return false;
+        const float fx0 = fminf(fmaxf(floorf(xmin) - 1.0f, 0.0f), (float)(a.W - 1));
+        const float fx1 = fminf(fmaxf(floorf(xmax) + 1.0f, 0.0f), (float)(a.W - 1));
+        const float fy0 = fminf(fmaxf(floorf(ymin) - 1.0f, 0.0f), (float)(a.H - 1));
+        const float fy1 = fminf(fmaxf(floorf(ymax) + 1.0f, 0.0f), (float)(a.H - 1));
+        tx0 = (int)fx0 / MW_TILE_W; tx1 = (int)fx1 / MW_TILE_W;
+        ty0 = (int)fy0 / MW_TILE_H; ty1 = (int)fy1 / MW_TILE_H;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float ea = 0.0f, eb = 0.0f, ec = 1.0f;       // always-true edge for triangles
+        if (k < nv) {
+            const HV nxt = (k + 1 == nv || k == 3) ? h[0] : h[k < 3 ? k + 1 : 0];
+            edge_coef(h[k], nxt, ea, eb, ec);
+        }
+        const bool tl = (ea > 0.0f) || (ea == 0.0f && eb > 0.0f);
+        o.rr[k] = ea; o.rr[4 + k] = eb; o.rr[8 + k] = ec;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float thr = -fmaf(ea, kSampleDx[s], eb * kSampleDy[s]);
+            o.rr[16 + k * 8 + s] = (k < nv && tl) ? below(thr) : thr;
+        }
+    }
+    const float invD = 1.0f / D;
+    const float ta = fmaf(h[2].cz, ga[2], fmaf(h[1].cz, ga[1], h[0].cz * ga[0]));
+    const float tb = fmaf(h[2].cz, gb[2], fmaf(h[1].cz, gb[1], h[0].cz * gb[0]));
+    const float tc = fmaf(h[2].cz, gc[2], fmaf(h[1].cz, gc[1], h[0].cz * gc[0]));
+    const float zx = (ta * invD) * 0.5f, zy = (tb * invD) * 0.5f;
+    o.rr[12] = zx; o.rr[13] = zy; o.rr[14] = fmaf(tc * invD, 0.5f, 0.5f);
+    o.rr[15] = __uint_as_float((uint32_t)tx0 | ((uint32_t)tx1 << 8) | ((uint32_t)ty0 << 16) | ((uint32_t)ty1 << 24));
+#pragma unroll
+    for (int s = 0; s < 8; ++s) o.rr[48 + s] = fmaf(zx, kSampleDx[s], zy * kSampleDy[s]);
+#pragma unroll
+    for (int s = 56; s < 64; ++s) o.rr[s] = 0.0f;
+    // shade record
+    float U[3] = {0, 0, 0}, V[3] = {0, 0, 0};
+    if (tex >= 0) {
+        U[0] = fmaf(uv[2][0], ga[2], fmaf(uv[1][0], ga[1], uv[0][0] * ga[0]));
+        U[1] = fmaf(uv[2][0], gb[2], fmaf(uv[1][0], gb[1], uv[0][0] * gb[0]));
+        U[2] = fmaf(uv[2][0], gc[2], fmaf(uv[1][0], gc[1], uv[0][0] * gc[0]));
+        V[0] = fmaf(uv[2][1], ga[2], fmaf(uv[1][1], ga[1], uv[0][1] * ga[0]));
+        V[1] = fmaf(uv[2][1], gb[2], fmaf(uv[1][1], gb[1], uv[0][1] * gb[0]));
+        V[2] = fmaf(uv[2][1], gc[2], fmaf(uv[1][1], gc[1], uv[0][1] * gc[0]));
+    }
+    o.sr[0] = U[0]; o.sr[1] = U[1]; o.sr[2] = U[2];
+    o.sr[3] = V[0]; o.sr[4] = V[1]; o.sr[5] = V[2];
+    o.sr[6] = (ga[0] + ga[1]) + ga[2];
+    o.sr[7] = (gb[0] + gb[1]) + gb[2];
+    o.sr[8] = (gc[0] + gc[1]) + gc[2];
+    o.sr[9] = col[0]; o.sr[10] = col[1]; o.sr[11] = col[2];
+    o.sr[12] = __int_as_float(tex);
+    o.sr[13] = 0.0f; o.sr[14] = 0.0f; o.sr[15] = 0.0f;
+    return true;
+}
+
+// ordered append of the lanes' primitives to the env's visible list
+__device__ inline void emit(const MwArgs &a, int env, int lane, bool vis, const PrimOut &o, int &count)
+{
+    const uint64_t m = ballot(vis);
+    const int before = __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+    const int idx = count + before;
+    if (vis) {
+        if (idx < a.max_vis) {
+            float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
+            const float4 *src = reinterpret_cast<const float4 *>(o.rr);
+#pragma unroll
+            for (int i = 0; i < MW_RASTER_REC / 4; ++i) rr[i] = src[i];
+            float4 *sr = reinterpret_cast<float4 *>(a.rec_shade + ((size_t)env * a.max_vis + idx) * MW_SHADE_REC);
+            const float4 *ss = reinterpret_cast<const float4 *>(o.sr);
+#pragma unroll
+            for (int i = 0; i < MW_SHADE_REC / 4; ++i) sr[i] = ss[i];
+        } else {
+            atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+        }
+    }
+    count += __popcll((unsigned long long)m);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- the kernel
+
+extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
+    MwArgs a, int do_step, const int32_t *__restrict__ actions, float *__restrict__ reward,
+    uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
+{
+    const int env = blockIdx.x;
+    const int lane = threadIdx.x;
+    StepCtx c{a, env, lane, a.shared_geom ? 0 : env, 0, 0, 0, 0, 0, -1, -1, {0, 0, 0}, 0};
+    c.px = a.ax[env]; c.py = a.ay[env]; c.pz = a.az[env]; c.dir = a.adir[env];
+    c.cam_height = a.cam[env];
+    c.carry = a.carry[env];
+    c.live = -1;
+    c.cpos[0] = c.cpos[1] = c.cpos[2] = 0.0; c.cdir = 0.0;
+    if (c.carry >= 0) {
+        const int k = c.carry;
+        c.cpos[0] = ent_pos(c, k, 0); c.cpos[1] = ent_pos(c, k, 1); c.cpos[2] = ent_pos(c, k, 2);
+        c.cdir = a.edir[(size_t)k * a.N + env];
+        c.live = k;
+    }
+    int remove_slot = -1;
+    int tm = 0, tr = 0;             // terminated / truncated, uniform over the wave
+
+    if (do_step) {
+        int step_count = a.step[env] + 1;
+        int picked = a.picked[env];
+        // the three per-step parameters (miniworld.py:677-680)
+        double fwd_step = a.fwd.def, fwd_drift = a.drift.def, turn_step = a.turn.def;
+        if (a.step_override) {
+            fwd_step = a.step_override[(size_t)env * 3 + 0];
+            fwd_drift = a.step_override[(size_t)env * 3 + 1];
+            turn_step = a.step_override[(size_t)env * 3 + 2];
+        } else if (a.domain_rand) {
+            mw::Rng rng = mw::rng_load(a.rng, a.N, env);
+            fwd_step = mw::rng_uniform(rng, a.fwd.lo, a.fwd.hi);
+            fwd_drift = mw::rng_uniform(rng, a.drift.lo, a.drift.hi);
+            turn_step = mw::rng_uniform(rng, a.turn.lo, a.turn.hi);
+            if (lane == 0) mw::rng_store(a.rng, a.N, env, rng);
+        }
+        const int action = actions[env];
+        switch (action) {
+        case 2: move_agent(c, fwd_step, fwd_drift); break;
+        case 3: move_agent(c, -fwd_step, fwd_drift); break;
+        case 0: turn_agent(c, turn_step); break;
+        case 1: turn_agent(c, -turn_step); break;
+        case 4: {   // pickup (miniworld.py:695-702)
+            const mw::SinCos sc = mw::sincos_det(c.dir);
+            const double tx = c.px + sc.c * 1.5 * a.agent_radius;
+            const double tz = c.pz + (-sc.s) * 1.5 * a.agent_radius;
+            const int hit = intersect(c, -1, tx, tz, 1.2 * a.agent_radius);
+            if (c.carry < 0 && hit > 0 && hit <= a.E && !a.estatic[(size_t)(hit - 1) * a.N + env]) {
+                const int k = hit - 1;
+                c.cpos[0] = ent_pos(c, k, 0); c.cpos[1] = ent_pos(c, k, 1); c.cpos[2] = ent_pos(c, k, 2);
+                c.cdir = a.edir[(size_t)k * a.N + env];
+                c.carry = k;
+                c.live = k;
+            }
+            break;
+        }
+        case 5:     // drop (miniworld.py:705-708)
+            if (c.carry >= 0) {
+                c.cpos[1] = 0.0;
+                c.carry = -1;       // the live copy is written back at the end of the step
+            }
+            break;
+        default: break;
+        }
+        if (c.carry >= 0) {     // carried object follows (miniworld.py:711-714)
+            const mw::SinCos sc = mw::sincos_det(c.dir);
+            double cp[3];
+            carry_pos(c, c.carry, c.px, c.py, c.pz, sc.c, -sc.s, cp);
+            c.cpos[0] = cp[0]; c.cpos[1] = cp[1]; c.cpos[2] = cp[2];
+            c.cdir = c.dir;
+        }
+        // reward / termination (miniworld.py:720-730 + env rule)
+        double rew = 0.0;
+        tr = step_count >= a.max_steps ? 1 : 0;
+        if (a.task == MW_TASK_GOTO) {
+            const int g = a.goal_ent;
+            const double dx = ent_pos(c, g, 0) - c.px, dy = ent_pos(c, g, 1) - c.py, dz = ent_pos(c, g, 2) - c.pz;
+            const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+            if (dist < ent_geom(a, env, g, 7) + a.agent_radius + 1.1 * a.max_forward_step) {
+                rew += 1.0 - 0.2 * ((double)step_count / (double)a.max_steps);
+                tm = 1;
+            }
+        } else if (a.task == MW_TASK_PICKUP) {
+            if (c.carry >= 0) {
+                remove_slot = c.carry;      // still drawn this frame (pickupobjects.py:86-88 runs after :717)
+                picked += 1;
+                rew = 1.0;
+                if (picked == a.num_objs) tm = 1;
+            }
+        }
+        if (lane == 0) {
+            reward[env] = (float)rew;
+            term[env] = (uint8_t)tm;
+            trunc[env] = (uint8_t)tr;
+            a.step[env] = step_count;
+            a.picked[env] = picked;
+        }
+    }
+
+    // ---- state write-back (agent + carried entity) ------------------------------
+    bool regenerated = false;
+    if (do_step && lane == 0) {
+        a.ax[env] = c.px; a.ay[env] = c.py; a.az[env] = c.pz; a.adir[env] = c.dir;
+        if (c.live >= 0) {
+            a.epos[((size_t)0 * a.E + c.live) * a.N + env] = c.cpos[0];
+            a.epos[((size_t)1 * a.E + c.live) * a.N + env] = c.cpos[1];
+            a.epos[((size_t)2 * a.E + c.live) * a.N + env] = c.cpos[2];
+            a.edir[(size_t)c.live * a.N + env] = c.cdir;
+        }
+        a.carry[env] = remove_slot >= 0 ? -1 : c.carry;
+    }
+    if (do_step && a.autoreset == MW_AUTORESET_SAME_STEP && a.generator != MW_GEN_NONE) {
+        // same-step auto-reset: the observation returned with done=1 is the first one of the
+        // next episode (the reference leaves the reset to the caller, scripts/benchmark.py:36-37)
+        regenerated = (tm | tr) != 0;
+        if (regenerated) {
+            if (lane == 0) mw::generate_world(a, env);
+            __syncthreads();
+            c.px = a.ax[env]; c.py = a.ay[env]; c.pz = a.az[env]; c.dir = a.adir[env];
+            c.carry = -1; c.live = -1;
+            remove_slot = -1;
+        }
+    }
+
+    // ---- camera + primitive setup -----------------------------------------------
+    Cam cam;
+    float sky[3];
+    build_camera(a, env, c.px, c.py, c.pz, c.dir, cam, sky);
+    int count = 0;
+    const float white[3] = {1.0f, 1.0f, 1.0f};
+    const mw_poly *polys = a.polys + (size_t)c.set * a.max_polys;
+    const int np = a.npolys[c.set];
+    for (int base = 0; base < np; base += 64) {         // display list 1: rooms
+        const int i = base + lane;
+        PrimOut o;
+        bool vis = false;
+        if (i < np) {
+            const mw_poly q = polys[i];
+            HV h[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = xform(cam, q.v[k][0], q.v[k][1], q.v[k][2]);
+            float col[3];
+            light(cam, q.n, white, col);
+            const float uv[3][2] = {{q.uv[0][0], q.uv[0][1]}, {q.uv[1][0], q.uv[1][1]}, {q.uv[2][0], q.uv[2][1]}};
+            vis = setup_poly(a, h, q.nv, uv, col, q.tex, o);
+        }
+        emit(a, env, lane, vis, o, count);
+    }
+    // entities: two passes, static first then dynamic (miniworld.py:1058-1060, 1075-1077)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int nfaces = a.E * 6;
+        for (int base = 0; base < nfaces; base += 64) {
+            const int i = base + lane;
+            PrimOut o;
+            bool vis = false;
+            if (i < nfaces) {
+                const int slot = i / 6, f = i % 6;
+                const int kind = a.ekind[(size_t)slot * a.N + env];
+                const int is_static = a.estatic[(size_t)slot * a.N + env];
+                if (kind == MW_ENT_BOX && (is_static != 0) == (pass == 0)) {
+                    // Box.render (entity.py:409-432): T(pos) R_y(dir) drawBox(...)
+                    const double edir = (slot == c.live) ? c.cdir : a.edir[(size_t)slot * a.N + env];
+                    const mw::SinCos sc = mw::sincos_det(edir);
+                    const float cs = (float)sc.c, sn = (float)sc.s;
+                    const float ex = (float)ent_pos(c, slot, 0), ey = (float)ent_pos(c, slot, 1), ez = (float)ent_pos(c, slot, 2);
+                    const double sx = ent_geom(a, env, slot, 0), sy = ent_geom(a, env, slot, 1), sz = ent_geom(a, env, slot, 2);
+                    const float lo[3] = {(float)(-sx / 2), 0.0f, (float)(-sz / 2)};
+                    const float hi[3] = {(float)(sx / 2), (float)sy, (float)(sz / 2)};
+                    const float base_col[3] = {(float)ent_geom(a, env, slot, 3), (float)ent_geom(a, env, slot, 4),
+                                               (float)ent_geom(a, env, slot, 5)};
+                    HV h[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int sel = kBoxSel[f][k];
+                        const float lx = (sel & 1) ? hi[0] : lo[0];
+                        const float ly = (sel & 2) ? hi[1] : lo[1];
+                        const float lz = (sel & 4) ? hi[2] : lo[2];
+                        const float wx = fmaf(cs, lx, sn * lz) + ex;
+                        const float wy = ly + ey;
+                        const float wz = fmaf(cs, lz, -(sn * lx)) + ez;
+                        h[k] = xform(cam, wx, wy, wz);
+                    }
+                    const float n[3] = {fmaf(cs, kBoxN[f][0], sn * kBoxN[f][2]), kBoxN[f][1],
+                                        fmaf(cs, kBoxN[f][2], -(sn * kBoxN[f][0]))};
+                    float col[3];
+                    light(cam, n, base_col, col);
+                    const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+                    vis = setup_poly(a, h, 4, uv, col, -1, o);
+                }
+            }
+            emit(a, env, lane, vis, o, count);
+        }
+    }
+    if (lane == 0) {
+        a.nvis[env] = count < a.max_vis ? count : a.max_vis;
+        a.envhdr[(size_t)env * 4 + 0] = sky[0];
+        a.envhdr[(size_t)env * 4 + 1] = sky[1];
+        a.envhdr[(size_t)env * 4 + 2] = sky[2];
+        a.envhdr[(size_t)env * 4 + 3] = 0.0f;
+        if (remove_slot >= 0) a.ekind[(size_t)remove_slot * a.N + env] = MW_ENT_NONE;
+    }
+}

@@ -1,0 +1,277 @@
+"""ctypes binding of libmwengine.so (include/mwengine.h) — the only way the Python package
+reaches the GPU.  There is deliberately NO CPU fallback: if the HIP library is missing or no
+MI355X is visible, construction fails loudly.
+
+The binding passes raw device pointers (``tensor.data_ptr()``) and the current HIP stream;
+torch is used for memory and streams only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
+
+ABI_VERSION = 1
+ENT_NONE, ENT_BOX, ENT_MESH = 0, 1, 2
+TASK_NONE, TASK_GOTO, TASK_PICKUP = 0, 1, 2
+GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP = 0, 1, 2, 3
+AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
+
+EXPORTS = [
+    "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
+    "mw_set_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
+    "mw_step", "mw_render", "mw_check", "mw_kernel_time_ms",
+]
+
+
+class MwRange(C.Structure):
+    _fields_ = [("default", C.c_double), ("lo", C.c_double), ("hi", C.c_double)]
+
+    @classmethod
+    def of(cls, default, lo=None, hi=None):
+        return cls(float(default), float(default if lo is None else lo), float(default if hi is None else hi))
+
+
+class MwConfig(C.Structure):
+    _fields_ = [
+        ("abi_version", C.c_int32), ("device_id", C.c_int32), ("num_envs", C.c_int32),
+        ("obs_width", C.c_int32), ("obs_height", C.c_int32), ("msaa", C.c_int32),
+        ("max_ents", C.c_int32), ("max_polys", C.c_int32), ("max_segs", C.c_int32),
+        ("max_visible", C.c_int32), ("shared_geometry", C.c_int32), ("task", C.c_int32),
+        ("goal_ent", C.c_int32), ("num_objs", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("domain_rand", C.c_int32), ("generator", C.c_int32), ("autoreset", C.c_int32),
+        ("agent_radius", C.c_double), ("max_forward_step", C.c_double),
+        ("forward_step", MwRange), ("forward_drift", MwRange), ("turn_step", MwRange),
+        ("sky_color", MwRange * 3), ("light_pos", MwRange * 3), ("light_color", MwRange * 3),
+        ("light_ambient", MwRange * 3), ("obj_color_bias", MwRange * 3),
+        ("cam_height", MwRange), ("cam_fwd_disp", MwRange), ("cam_pitch", MwRange), ("cam_fov_y", MwRange),
+        ("gen_args", C.c_double * 8),
+    ]
+
+
+class MwPoly(C.Structure):
+    _fields_ = [("v", C.c_float * 12), ("uv", C.c_float * 8), ("n", C.c_float * 3),
+                ("nv", C.c_int32), ("tex", C.c_int32)]
+
+
+POLY_DTYPE = np.dtype([("v", np.float32, (4, 3)), ("uv", np.float32, (4, 2)), ("n", np.float32, (3,)),
+                       ("nv", np.int32), ("tex", np.int32)])
+assert POLY_DTYPE.itemsize == C.sizeof(MwPoly) == 100
+
+
+class MwStateView(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in (
+        "agent_pos", "agent_dir", "cam", "light", "carrying", "step_count", "num_picked_up",
+        "ent_kind", "ent_mesh", "ent_static", "ent_pos", "ent_dir", "ent_geom")]
+
+
+# name -> (dtype, per-env shape as a function of max_ents)
+STATE_FIELDS = {
+    "agent_pos": (np.float64, lambda E: (3,)),
+    "agent_dir": (np.float64, lambda E: ()),
+    "cam": (np.float64, lambda E: (4,)),
+    "light": (np.float64, lambda E: (12,)),
+    "carrying": (np.int32, lambda E: ()),
+    "step_count": (np.int32, lambda E: ()),
+    "num_picked_up": (np.int32, lambda E: ()),
+    "ent_kind": (np.int32, lambda E: (E,)),
+    "ent_mesh": (np.int32, lambda E: (E,)),
+    "ent_static": (np.int32, lambda E: (E,)),
+    "ent_pos": (np.float64, lambda E: (E, 3)),
+    "ent_dir": (np.float64, lambda E: (E,)),
+    "ent_geom": (np.float64, lambda E: (E, 9)),
+}
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def build_library(force: bool = False) -> str:
+    """Compile libmwengine.so for gfx950 with hipcc (in-tree); returns its path."""
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".h"))]
+    srcs.append(os.path.join(_CSRC, "..", "..", "include", "mwengine.h"))
+    stale = (not os.path.exists(LIB_PATH)) or any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs)
+    if force or stale:
+        r = subprocess.run([os.path.join(_CSRC, "build.sh")], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise EngineError("building libmwengine.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libmwengine.so and declare the C ABI.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"{LIB_PATH} not found: the HIP engine is not built (run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or miniworld_amd/csrc/build.sh).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32 = C.c_void_p, C.c_int32
+    L.mw_create.argtypes = [C.POINTER(MwConfig), C.POINTER(vp)]
+    L.mw_destroy.argtypes = [vp]
+    L.mw_destroy.restype = None
+    L.mw_last_error.argtypes = [vp]
+    L.mw_last_error.restype = C.c_char_p
+    L.mw_upload_texture.argtypes = [vp, i32, vp, i32, i32]
+    L.mw_upload_mesh.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32]
+    L.mw_set_geometry.argtypes = [vp, i32, vp, i32, vp, i32]
+    L.mw_set_state.argtypes = [vp, i32, i32, C.POINTER(MwStateView)]
+    L.mw_get_state.argtypes = [vp, i32, i32, C.POINTER(MwStateView)]
+    L.mw_set_step_params.argtypes = [vp, vp]
+    L.mw_reset.argtypes = [vp, vp, vp, vp]
+    L.mw_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    L.mw_render.argtypes = [vp, vp, vp, vp]
+    L.mw_check.argtypes = [vp, vp]
+    L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    _lib = L
+    return L
+
+
+def _stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class Engine:
+    """One mw_engine: N environments resident on one GPU."""
+
+    def __init__(self, cfg: MwConfig):
+        import torch
+        if not torch.cuda.is_available():
+            raise EngineError("no ROCm device visible: the mwengine HIP path cannot run (no CPU fallback exists)")
+        self.lib = load_library()
+        cfg.abi_version = ABI_VERSION
+        self.cfg = cfg
+        self.N = cfg.num_envs
+        self.E = max(cfg.max_ents, 1)
+        self.device = torch.device("cuda", cfg.device_id)
+        h = C.c_void_p()
+        rc = self.lib.mw_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise EngineError(f"mw_create failed ({rc}): {self.lib.mw_last_error(None).decode()}")
+        self.h = h
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise EngineError(f"{what} failed ({rc}): {self.lib.mw_last_error(self.h).decode()}")
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mw_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- assets / world -------------------------------------------------------------
+    def upload_texture(self, tex_id: int, rgb_bottom_up: np.ndarray):
+        a = np.ascontiguousarray(rgb_bottom_up, np.uint8)
+        assert a.ndim == 3 and a.shape[2] == 3
+        self._check(self.lib.mw_upload_texture(self.h, tex_id, a.ctypes.data, a.shape[1], a.shape[0]), "mw_upload_texture")
+
+    def set_geometry(self, env: int, polys: np.ndarray, segs: np.ndarray):
+        p = np.ascontiguousarray(polys, POLY_DTYPE)
+        s = np.ascontiguousarray(segs, np.float64).reshape(-1, 4)
+        self._check(self.lib.mw_set_geometry(self.h, env, p.ctypes.data, len(p), s.ctypes.data, len(s)), "mw_set_geometry")
+
+    def _view(self, arrays: dict, count: int, alloc: bool):
+        view, keep = MwStateView(), {}
+        for name, (dt, shp) in STATE_FIELDS.items():
+            if alloc:
+                arr = np.zeros((count,) + shp(self.E), dt)
+            elif name in arrays and arrays[name] is not None:
+                arr = np.ascontiguousarray(arrays[name], dt).reshape((count,) + shp(self.E))
+            else:
+                continue
+            keep[name] = arr
+            setattr(view, name, arr.ctypes.data)
+        return view, keep
+
+    def set_state(self, arrays: dict, first: int = 0, count: int | None = None):
+        count = self.N - first if count is None else count
+        view, keep = self._view(arrays, count, alloc=False)
+        self._check(self.lib.mw_set_state(self.h, first, count, C.byref(view)), "mw_set_state")
+
+    def get_state(self, first: int = 0, count: int | None = None) -> dict:
+        count = self.N - first if count is None else count
+        view, keep = self._view({}, count, alloc=True)
+        self._check(self.lib.mw_get_state(self.h, first, count, C.byref(view)), "mw_get_state")
+        return keep
+
+    def set_step_params(self, params: np.ndarray | None):
+        if params is None:
+            self._check(self.lib.mw_set_step_params(self.h, None), "mw_set_step_params")
+        else:
+            p = np.ascontiguousarray(params, np.float64).reshape(self.N, 3)
+            self._check(self.lib.mw_set_step_params(self.h, p.ctypes.data), "mw_set_step_params")
+
+    def reset(self, mask: np.ndarray | None = None, seeds: np.ndarray | None = None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
+        self._check(self.lib.mw_reset(self.h, None if m is None else m.ctypes.data,
+                                      None if s is None else s.ctypes.data, _stream_ptr()), "mw_reset")
+
+    # -- hot path ---------------------------------------------------------------------
+    def step(self, actions, obs, depth=None, reward=None, term=None, trunc=None):
+        """All arguments are torch tensors on this engine's device (depth may be None)."""
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self.lib.mw_step(self.h, ptr(actions), ptr(obs), ptr(depth), ptr(reward), ptr(term),
+                                     ptr(trunc), _stream_ptr()), "mw_step")
+
+    def render(self, obs, depth=None):
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self.lib.mw_render(self.h, ptr(obs), ptr(depth), _stream_ptr()), "mw_render")
+
+    def check(self):
+        self._check(self.lib.mw_check(self.h, _stream_ptr()), "mw_check")
+
+    def kernel_time_ms(self, reset=0):
+        r, s, n = C.c_double(), C.c_double(), C.c_int64()
+        self._check(self.lib.mw_kernel_time_ms(self.h, reset, C.byref(r), C.byref(s), C.byref(n)), "mw_kernel_time_ms")
+        return r.value, s.value, n.value
+
+
+# ------------------------------------------------------------------ DomainParams -> config
+
+def default_ranges() -> dict:
+    """The reference's DEFAULT_PARAMS table (params.py:115-130) as (default, min, max)."""
+    return {
+        "sky_color": ([0.25, 0.82, 1.0], [0.1, 0.1, 0.1], [1.0, 1.0, 1.0]),
+        "light_pos": ([0, 2.5, 0], [-40, 2.5, -40], [40, 5, 40]),
+        "light_color": ([0.7, 0.7, 0.7], [0.45, 0.45, 0.45], [0.8, 0.8, 0.8]),
+        "light_ambient": ([0.45, 0.45, 0.45], [0.35, 0.35, 0.35], [0.55, 0.55, 0.55]),
+        "obj_color_bias": ([0, 0, 0], [-0.2, -0.2, -0.2], [0.2, 0.2, 0.2]),
+        "forward_step": (0.15, 0.12, 0.17),
+        "forward_drift": (0.0, -0.05, 0.05),
+        "turn_step": (15.0, 10.0, 20.0),
+        "cam_pitch": (0.0, -5.0, 5.0),
+        "cam_fov_y": (60.0, 55.0, 65.0),
+        "cam_height": (1.5, 1.45, 1.55),
+        "cam_fwd_disp": (0.0, -0.05, 0.10),
+    }
+
+
+def fill_ranges(cfg: MwConfig, ranges: dict | None = None):
+    r = default_ranges() if ranges is None else ranges
+    for name in ("forward_step", "forward_drift", "turn_step", "cam_pitch", "cam_fov_y", "cam_height", "cam_fwd_disp"):
+        setattr(cfg, name, MwRange.of(*r[name]))
+    for name in ("sky_color", "light_pos", "light_color", "light_ambient", "obj_color_bias"):
+        d, lo, hi = r[name]
+        arr = getattr(cfg, name)
+        for k in range(3):
+            arr[k] = MwRange.of(d[k], lo[k], hi[k])
+    cfg.max_forward_step = float(r["forward_step"][2])

@@ -508,19 +508,27 @@ int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out, float *d
             }
         }
     }
-    /* R12: resolve (opengl.py:339-398): mean of the samples in float, groups of equal draw
-     * index accumulated in order of first appearance; 8-bit conversion round-half-up. */
+    /* R12: resolve (opengl.py:339-398): mean of the samples in float; the samples of one
+     * primitive carry one colour, and the groups are accumulated in ascending draw index,
+     * uncovered (sky) samples last; 8-bit conversion round-half-up. */
     for (int py = 0; py < tg.H; ++py)
         for (int px = 0; px < tg.W; ++px) {
             int64_t base = ((int64_t)py * tg.W + px) * tg.S;
             float acc[3] = {0.0f, 0.0f, 0.0f};
             int done[MAXS] = {0};
-            for (int s = 0; s < tg.S; ++s) {
-                if (done[s]) continue;
+            for (;;) {
+                int best = -1;
+                for (int s = 0; s < tg.S; ++s) {
+                    if (done[s]) continue;
+                    int64_t ks = tg.ibuf[base + s] < 0 ? 0x7fffffff : tg.ibuf[base + s];
+                    int64_t kb = best < 0 ? -1 : (tg.ibuf[base + best] < 0 ? 0x7fffffff : tg.ibuf[base + best]);
+                    if (best < 0 || ks < kb) best = s;
+                }
+                if (best < 0) break;
                 int cnt = 0;
-                for (int r = s; r < tg.S; ++r)
-                    if (!done[r] && tg.ibuf[base + r] == tg.ibuf[base + s]) { done[r] = 1; ++cnt; }
-                for (int c = 0; c < 3; ++c) acc[c] = fmaf((float)cnt, tg.cbuf[(base + s) * 3 + c], acc[c]);
+                for (int r = 0; r < tg.S; ++r)
+                    if (!done[r] && tg.ibuf[base + r] == tg.ibuf[base + best]) { done[r] = 1; ++cnt; }
+                for (int c = 0; c < 3; ++c) acc[c] = fmaf((float)cnt, tg.cbuf[(base + best) * 3 + c], acc[c]);
             }
             float inv = 1.0f / (float)tg.S;
             for (int c = 0; c < 3; ++c) {

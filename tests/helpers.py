@@ -1,0 +1,123 @@
+"""Shared test helpers: golden fixtures -> neutral scenes -> engine state."""
+import os
+
+import numpy as np
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_case(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    s0 = {k[3:]: d[k] for k in d.files if k.startswith("s0/")}
+    tr = {k[3:]: d[k] for k in d.files if k.startswith("tr/")}
+    meta = {k[5:]: d[k] for k in d.files if k.startswith("meta/")}
+    obs = {}
+    for k in d.files:
+        if k.startswith("obs/"):
+            _, fr, key = k.split("/")
+            obs.setdefault(int(fr), {})[key] = d[k]
+    return s0, tr, meta, obs
+
+
+def golden_meshes(scene):
+    """mesh name -> arrays dict for oracle.pyoracle.render, from tests/golden/meshes.npz."""
+    d = np.load(os.path.join(GOLDEN, "meshes.npz"))
+    out = {}
+    for name in [str(m) for m in scene.get("mesh_names", [])]:
+        base = name.split("_")[0]
+        m = {k: d[f"{base}/{k}"] for k in ("verts", "norms", "texcs")}
+        m["colors"] = np.broadcast_to(d["kd:" + name].astype(np.float32), m["verts"].shape).copy()
+        out[name] = m
+    return out
+
+
+def frame_scene(s0, frame):
+    """Scene s0 with the agent/entity state of a stored frame substituted."""
+    sc = dict(s0)
+    for k in ("agent_pos", "agent_dir", "ents_pos", "ents_dir", "ents_kind"):
+        sc[k] = frame[k]
+    return sc
+
+
+def task_of(meta):
+    return 2 if str(meta["env"]) == "PickupObjects" else 1
+
+
+# ------------------------------------------------------------------ engine glue (GPU tests)
+
+def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_rand=False, max_visible=None):
+    """Engine with the scene's shared geometry / textures uploaded (state not yet set)."""
+    from miniworld_amd import engine as eng
+    from miniworld_amd import assets
+    cfg = eng.MwConfig()
+    E = max(1, len(s0["ents_kind"]))
+    P, S = len(s0["polys_nv"]), len(s0["wall_segs"])
+    cfg.device_id = 0
+    cfg.num_envs = n_envs
+    cfg.obs_width, cfg.obs_height, cfg.msaa = 80, 60, 8
+    cfg.max_ents, cfg.max_polys, cfg.max_segs = E, P, S
+    cfg.max_visible = max_visible or min(max(64, P + 6 * E), 1024)
+    cfg.shared_geometry = 1
+    cfg.task = task
+    cfg.goal_ent = 0
+    cfg.num_objs = len(s0["ents_kind"])
+    cfg.max_episode_steps = int(max_episode_steps if max_episode_steps is not None else s0["max_episode_steps"])
+    cfg.domain_rand = int(domain_rand)
+    cfg.generator = eng.GEN_NONE
+    cfg.autoreset = eng.AUTORESET_OFF
+    cfg.agent_radius = 0.4
+    eng.fill_ranges(cfg)
+    cfg.max_forward_step = float(s0["max_forward_step"])
+    e = eng.Engine(cfg)
+    for i, name in enumerate([str(t) for t in s0["tex_names"]]):
+        e.upload_texture(i, assets.texture_rgb_bottom_up(name))
+    polys = np.zeros(P, eng.POLY_DTYPE)
+    polys["v"], polys["uv"], polys["n"] = s0["polys_v"], s0["polys_uv"], s0["polys_n"]
+    polys["nv"], polys["tex"] = s0["polys_nv"], s0["polys_tex"]
+    e.set_geometry(-1, polys, s0["wall_segs"])
+    return e
+
+
+def scene_state_arrays(scenes, E=None):
+    """Stack neutral scenes (same entity table layout) into mw_set_state arrays."""
+    n = len(scenes)
+    E = max(1, len(scenes[0]["ents_kind"])) if E is None else E
+    Es = len(scenes[0]["ents_kind"])
+    st = {
+        "agent_pos": np.array([s["agent_pos"] for s in scenes], np.float64),
+        "agent_dir": np.array([s["agent_dir"] for s in scenes], np.float64),
+        "cam": np.array([[s["cam_height"], s["cam_fwd_disp"], s["cam_pitch"], s["cam_fov_y"]] for s in scenes], np.float64),
+        "light": np.array([np.concatenate([s["sky"], s["light_pos"], s["light_color"], s["light_ambient"]]) for s in scenes], np.float64),
+        "carrying": np.array([int(s.get("agent_carrying", -1)) for s in scenes], np.int32),
+        "step_count": np.array([int(s.get("step_count", 0)) for s in scenes], np.int32),
+        "num_picked_up": np.zeros(n, np.int32),
+        "ent_kind": np.zeros((n, E), np.int32),
+        "ent_mesh": np.full((n, E), -1, np.int32),
+        "ent_static": np.zeros((n, E), np.int32),
+        "ent_pos": np.zeros((n, E, 3), np.float64),
+        "ent_dir": np.zeros((n, E), np.float64),
+        "ent_geom": np.zeros((n, E, 9), np.float64),
+    }
+    for i, s in enumerate(scenes):
+        if Es == 0:
+            continue
+        st["ent_kind"][i, :Es] = s["ents_kind"]
+        st["ent_mesh"][i, :Es] = s["ents_mesh"]
+        st["ent_static"][i, :Es] = s["ents_static"]
+        st["ent_pos"][i, :Es] = s["ents_pos"]
+        st["ent_dir"][i, :Es] = s["ents_dir"]
+        st["ent_geom"][i, :Es, 0:3] = s["ents_size"]
+        st["ent_geom"][i, :Es, 3:6] = s["ents_color"]
+        st["ent_geom"][i, :Es, 6] = s["ents_scale"]
+        st["ent_geom"][i, :Es, 7] = s["ents_radius"]
+        st["ent_geom"][i, :Es, 8] = s["ents_height"]
+    return st
+
+
+def depth_from_z16(z16):
+    """FrameBuffer.get_depth_map's own numpy expression (opengl.py:426-431) on a u16 map."""
+    z_near, z_far = 0.04, 100.0
+    depth_map = z16.astype(np.float32) / 65535
+    clip_z = (depth_map - 0.5) * 2.0
+    world_z = -2 * z_far * z_near / (clip_z * (z_far - z_near) - (z_far + z_near))
+    return world_z.astype(np.float32)

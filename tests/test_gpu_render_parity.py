@@ -1,0 +1,42 @@
+"""HIP render_obs vs the CPU oracle on the reference-derived golden scenes (GPU box).
+
+Bar (BASELINE.json north_star): depth buffer pixel-exact, RGB within +-1 LSB; the engine
+and the oracle implement the same pinned rules, so RGB is in fact
+expected to be bit-exact and the test records how many pixels differ at all.
+"""
+import numpy as np
+import pytest
+
+import helpers
+from conftest import golden_cases
+
+pytestmark = pytest.mark.gpu
+
+QUAD_CASES = [c for c in golden_cases() if not c.startswith("pickup")]
+
+
+@pytest.mark.parametrize("case", QUAD_CASES)
+def test_render_matches_golden_and_oracle(case):
+    import torch
+    import pyoracle
+    s0, tr, meta, obs = helpers.load_case(case)
+    frames = sorted(obs)
+    scenes = [helpers.frame_scene(s0, obs[f]) for f in frames]
+    eng = helpers.make_engine_for_scene(s0, len(scenes))
+    eng.set_state(helpers.scene_state_arrays(scenes))
+    rgb = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
+    depth = torch.zeros((len(scenes), 60, 80, 1), dtype=torch.float32, device="cuda")
+    eng.render(rgb, depth)
+    eng.check()
+    rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
+    for i, f in enumerate(frames):
+        want = pyoracle.render(scenes[i])
+        # the committed golden equals the live oracle (same machine-independent arithmetic)
+        assert np.array_equal(want["rgb"], obs[f]["rgb"]) and np.array_equal(want["z16"], obs[f]["z16"])
+        # depth: exact
+        assert np.array_equal(depth[i, :, :, 0], helpers.depth_from_z16(obs[f]["z16"])), f"{case} frame {f}: depth differs"
+        assert np.array_equal(depth[i], want["depth"])
+        diff = np.abs(rgb[i].astype(int) - obs[f]["rgb"].astype(int))
+        assert diff.max() <= 1, f"{case} frame {f}: max RGB diff {diff.max()}"
+        assert np.count_nonzero(diff) == 0, f"{case} frame {f}: {np.count_nonzero(diff)} channel values off by one"
+    eng.close()
