@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""bench.py — env-steps/s of the batched step+render hot path (BASELINE.json metric).
+
+Workload at N=1 (BASELINE.json configs[1]): MiniWorld-Hallway-v0, 4096 batched envs, 80x60 RGB
+on one MI355X; synthetic actions uniform{0,1,2}, pre-generated on the device; episodes
+auto-reset on the device (same-step).  One "step" = one pass of the hot path over the whole
+batch: physics + collision + reward/flags + auto-reset + one rendered observation per env.
+For N>1 the driver launches one rank per GPU (torch.distributed.run); envs shard trivially —
+every rank owns its own 4096 envs, no data-path collective (weak scaling).
+
+Prints ONE JSON line on rank 0 (see the task contract): value = total env-steps / wall time,
+plus `roofline` (algorithmic HBM bytes of the dominant kernel / its HIP-event duration) and, at
+N=1, `cpu_baseline` (the C oracle on the host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+ENV_ID = "MiniWorld-Hallway-v0"
+# algorithmic bytes per env-step, RGB, shared geometry:
+# obs 14400 + action 4 + agent/episode state r+w 64 + entity 64 + reward/flags 6 (+2 rounding)
+ALGO_BYTES_PER_ENV_STEP = 14540
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def cpu_baseline():
+    """The CPU oracle (oracle/, a port of the reference path) on the host: a bounded sample of
+    the same workload — one Hallway env stepped + rendered in a C loop on one core."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    from miniworld_amd import envs
+    from miniworld_amd.scene import scene_from_env
+    env = envs.Hallway(host_only=True)
+    env.reset(seed=0)
+    sc = scene_from_env(env)
+    pyoracle.bench_loop(sc, 1, 250, 3, 50)         # warm-up (page in textures, build mips)
+    steps = 4000                                   # ~10 s on one core
+    sec = pyoracle.bench_loop(sc, 1, 250, 3, steps)
+    return {"value": steps / sec, "unit": "env-steps/s", "cores": 1, "kind": "port",
+            "sample": f"{steps} steps of 1 Hallway env (step + 80x60x8spp render), C oracle, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+
+    from miniworld_amd.sharding import max_over_ranks, shard_plan
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n = args.envs_per_gpu
+    plan = shard_plan(rank, world, n)
+    vec = MiniWorldVecEnv(ENV_ID, n, device_id=local, seed=plan["first_seed"])
+    vec.reset()
+    total = args.steps + args.warmup
+    g = torch.Generator(device=f"cuda:{local}").manual_seed(1234 + rank)
+    actions = torch.randint(0, 3, (total, n), generator=g, device=f"cuda:{local}", dtype=torch.int32)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for t in range(args.warmup):
+        vec.step(actions[t])
+    vec.engine.kernel_time_ms()         # enable + clear the HIP-event timing of the kernels
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(args.warmup, total):
+        vec.step(actions[t])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    raster_ms, setup_ms, launches = vec.engine.kernel_time_ms()
+    vec.engine.check()
+    # sanity: the frames are real (a static or empty frame would be an invalid measurement)
+    m = float(vec.obs.float().mean())
+    assert 1.0 < m < 254.0, f"degenerate observation tensor (mean {m})"
+
+    if dist is not None:
+        elapsed = max_over_ranks(dist, elapsed, device=f"cuda:{local}")
+    if rank == 0:
+        steps_per_s = world * n * args.steps / elapsed
+        achieved = ALGO_BYTES_PER_ENV_STEP * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
+        out = {
+            "metric": "env-steps/s (batched, 80x60 RGB)",
+            "value": steps_per_s,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{ENV_ID}, {n} batched envs per GPU, 80x60 RGB, 8x MSAA, random actions, "
+                                   "device auto-reset", "envs_per_gpu": n, "parallelism": f"env-shard x{world}"},
+            "samples_per_s": steps_per_s * 80 * 60 * 8,
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "mw_raster_kernel",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                "traffic": None,
+                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
+                "kernel_ms": raster_ms,
+                "setup_kernel_ms": setup_ms,
+                "launches_timed": launches,
+                "note": "path is raster/texture VALU bound, not HBM bound (SURVEY.md section 8d)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

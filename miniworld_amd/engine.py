@@ -112,6 +112,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles its own HIP runtime (libamdhip64); loading it before our
+    # library makes both share ONE runtime instance (same soname), so device pointers and
+    # streams can be exchanged.  The other order yields two runtimes in one process.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise EngineError(
             f"{LIB_PATH} not found: the HIP engine is not built (run `python -c 'import __graft_entry__ as g; "

@@ -1,0 +1,31 @@
+"""Environment classes and their Gymnasium ids (the subset of envs/__init__.py:44-157 built so far)."""
+from ..gymshim import gym
+from .hallway import Hallway
+from .maze import Maze, MazeS2, MazeS3, MazeS3Fast
+from .oneroom import OneRoom, OneRoomS6, OneRoomS6Fast
+from .pickupobjects import PickupObjects
+
+__all__ = ["Hallway", "Maze", "MazeS2", "MazeS3", "MazeS3Fast", "OneRoom", "OneRoomS6", "OneRoomS6Fast",
+           "PickupObjects"]
+
+ENV_IDS = {
+    "MiniWorld-Hallway-v0": "Hallway",
+    "MiniWorld-Maze-v0": "Maze",
+    "MiniWorld-MazeS2-v0": "MazeS2",
+    "MiniWorld-MazeS3-v0": "MazeS3",
+    "MiniWorld-MazeS3Fast-v0": "MazeS3Fast",
+    "MiniWorld-OneRoom-v0": "OneRoom",
+    "MiniWorld-OneRoomS6-v0": "OneRoomS6",
+    "MiniWorld-OneRoomS6Fast-v0": "OneRoomS6Fast",
+    "MiniWorld-PickupObjects-v0": "PickupObjects",
+}
+
+_MODULE_OF = {"Hallway": "hallway", "Maze": "maze", "MazeS2": "maze", "MazeS3": "maze", "MazeS3Fast": "maze",
+              "OneRoom": "oneroom", "OneRoomS6": "oneroom", "OneRoomS6Fast": "oneroom",
+              "PickupObjects": "pickupobjects"}
+
+for _id, _cls in ENV_IDS.items():
+    try:
+        gym.register(id=_id, entry_point=f"miniworld_amd.envs.{_MODULE_OF[_cls]}:{_cls}")
+    except Exception:  # already registered (re-import)
+        pass

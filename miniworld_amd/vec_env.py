@@ -1,0 +1,138 @@
+"""MiniWorldVecEnv — N environments stepped and rendered in lockstep on one MI355X.
+
+This is the performance path: world state lives on the device as Structure-of-Arrays, one
+``step()`` is two kernel launches (step+setup, raster) that write the ``uint8[N,60,80,3]``
+observation tensor (and optionally ``float32[N,60,80,1]`` depth) straight into torch memory.
+Episodes auto-reset on the device (same-step semantics: the observation returned together
+with ``terminated|truncated`` is the first one of the next episode; the reference leaves the
+reset to the caller, scripts/benchmark.py:36-37).
+
+Envs whose generator is not on the device yet (Maze, PickupObjects) are generated on the host
+with the reference-compatible world generator and injected; their auto-reset is host-driven.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import engine as eng
+from . import envs as _envs
+from .scene import base_config, polys_array, scene_from_env, state_arrays
+
+_KIND = {
+    "MiniWorld-Hallway-v0": ("Hallway", eng.GEN_HALLWAY, eng.TASK_GOTO, 3),
+    "MiniWorld-OneRoom-v0": ("OneRoom", eng.GEN_ONEROOM, eng.TASK_GOTO, 3),
+    "MiniWorld-OneRoomS6-v0": ("OneRoomS6", eng.GEN_ONEROOM, eng.TASK_GOTO, 3),
+    "MiniWorld-Maze-v0": ("Maze", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-MazeS2-v0": ("MazeS2", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-MazeS3-v0": ("MazeS3", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-PickupObjects-v0": ("PickupObjects", eng.GEN_NONE, eng.TASK_PICKUP, 5),
+}
+
+
+class MiniWorldVecEnv:
+    def __init__(self, env_id: str, num_envs: int, device_id: int = 0, domain_rand: bool = False,
+                 want_depth: bool = False, seed: int = 0, autoreset: bool = True, **env_kwargs):
+        import torch
+        self.torch = torch
+        if env_id not in _KIND:
+            raise KeyError(f"{env_id!r} is not available in the batched engine yet; have {sorted(_KIND)}")
+        cls_name, generator, task, n_actions = _KIND[env_id]
+        self.env_id, self.num_envs, self.n_actions = env_id, num_envs, n_actions
+        self.domain_rand, self.want_depth = domain_rand, want_depth
+        self.generator = generator
+        cls = getattr(_envs, cls_name)
+        # template world: geometry, textures, capacities (host-side world generation only)
+        self.template = cls(domain_rand=False, host_only=True, **env_kwargs)
+        self.template.reset(seed=seed)
+        self._cls, self._env_kwargs = cls, env_kwargs
+        sc = scene_from_env(self.template)
+        shared = generator != eng.GEN_NONE or cls_name == "PickupObjects"
+        P, S, E = len(sc["polys_nv"]), len(sc["wall_segs"]), max(1, len(sc["ents_kind"]))
+        cfg = base_config(num_envs, self.template.obs_width, self.template.obs_height, E, P, S,
+                          max_visible=min(1024, max(64, P // 2 + 6 * E)),
+                          params_ranges=self.template.params.as_ranges(), device_id=device_id)
+        cfg.shared_geometry = int(shared)
+        cfg.task, cfg.goal_ent, cfg.num_objs = task, 0, len(sc["ents_kind"])
+        cfg.max_episode_steps = int(self.template.max_episode_steps)
+        cfg.domain_rand = int(domain_rand)
+        cfg.generator = generator
+        cfg.autoreset = eng.AUTORESET_SAME_STEP if (autoreset and generator != eng.GEN_NONE) else eng.AUTORESET_OFF
+        cfg.agent_radius = float(self.template.agent.radius)
+        if generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM):
+            room = self.template.rooms[0]
+            args = [room.min_x, room.max_x, room.min_z, room.max_z]
+            if generator == eng.GEN_HALLWAY:
+                args += [room.max_x - 2, room.max_x - 2, math.pi / 4, 0.8]
+            else:
+                args += [room.min_x, room.max_x, math.pi, 0.8]
+            for i, v in enumerate(args):
+                cfg.gen_args[i] = float(v)
+        self.engine = eng.Engine(cfg)
+        self.host_autoreset = autoreset and generator == eng.GEN_NONE
+        self._upload_assets(sc)
+        dev = self.engine.device
+        H, W = self.template.obs_height, self.template.obs_width
+        self.obs = torch.zeros((num_envs, H, W, 3), dtype=torch.uint8, device=dev)
+        self.depth = torch.zeros((num_envs, H, W, 1), dtype=torch.float32, device=dev) if want_depth else None
+        self.reward = torch.zeros(num_envs, dtype=torch.float32, device=dev)
+        self.terminated = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self.truncated = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
+        self._host_envs = None
+        self._next_seed = seed
+
+    # ------------------------------------------------------------------ assets / worlds
+    def _upload_assets(self, sc):
+        from . import assets
+        self.tex_ids = {}
+        for i, variant in enumerate([str(v) for v in sc["tex_names"]]):
+            self.tex_ids[variant] = i
+            self.engine.upload_texture(i, assets.texture_rgb_bottom_up(variant))
+        if self.engine.cfg.shared_geometry:
+            self.engine.set_geometry(-1, polys_array(sc), sc["wall_segs"])
+
+    def _host_generate(self, indices, seeds):
+        """Host world generation (reference-compatible stream) for envs without a device generator."""
+        if self._host_envs is None:
+            self._host_envs = [None] * self.num_envs
+        for i, s in zip(indices, seeds):
+            env = self._host_envs[i]
+            if env is None:
+                env = self._cls(domain_rand=self.domain_rand, host_only=True, **self._env_kwargs)
+                self._host_envs[i] = env
+            env.reset(seed=int(s))
+            sc = scene_from_env(env)
+            if not self.engine.cfg.shared_geometry:
+                tex_map = {k: self.tex_ids[str(v)] for k, v in enumerate(sc["tex_names"])}
+                self.engine.set_geometry(i, polys_array(sc, tex_map), sc["wall_segs"])
+            self.engine.set_state(state_arrays([sc], self.engine.E), first=i, count=1)
+
+    # ------------------------------------------------------------------ API
+    def reset(self, seed: int | None = None):
+        """Reset every env (env i is seeded with seed + i); returns the observation tensor."""
+        if seed is not None:
+            self._next_seed = seed
+        seeds = np.arange(self.num_envs, dtype=np.uint64) + np.uint64(self._next_seed)
+        self._next_seed += self.num_envs
+        if self.generator != eng.GEN_NONE:
+            self.engine.reset(None, seeds)
+        else:
+            self._host_generate(range(self.num_envs), seeds)
+        self.engine.render(self.obs, self.depth)
+        return self.obs
+
+    def step(self, actions):
+        """actions: int32 torch tensor [N] on the engine's device."""
+        self.engine.step(actions, self.obs, self.depth, self.reward, self.terminated, self.truncated)
+        if self.host_autoreset:
+            done = (self.terminated | self.truncated).nonzero().flatten().tolist()
+            if done:
+                seeds = np.arange(len(done), dtype=np.uint64) + np.uint64(self._next_seed)
+                self._next_seed += len(done)
+                self._host_generate(done, seeds)
+                self.engine.render(self.obs, self.depth)
+        return self.obs, self.reward, self.terminated, self.truncated
+
+    def close(self):
+        self.engine.close()

@@ -141,6 +141,10 @@ int mwo_step(mwo_agent_state *ag, mwo_phys_ent *ents, mwo_phys_ent *ents_at_rend
 int mwo_intersect(const mwo_agent_state *ag, const mwo_phys_ent *ents, int32_t self_idx,
                   double px, double pz, double radius, const double *segs, int32_t n_segs);
 
+/* bench.py cpu_baseline: timed loop of mwo_step + mwo_render_obs on one env; returns seconds */
+double mwo_bench_loop(mwo_scene *sc, mwo_agent_state *ag, mwo_phys_ent *ents, const double *segs,
+                      int32_t n_segs, int32_t n_actions, int32_t steps, uint8_t *rgb);
+
 #ifdef __cplusplus
 }
 #endif

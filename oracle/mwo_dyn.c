@@ -170,3 +170,29 @@ int mwo_step(mwo_agent_state *ag, mwo_phys_ent *ents, mwo_phys_ent *ents_at_rend
     *reward = rew; *terminated = term; *truncated = trunc;
     return 0;
 }
+
+/* cpu_baseline helper for bench.py: `steps` iterations of [mwo_step + mwo_render_obs] on one
+ * env with a deterministic action sequence (LCG), resetting the pose when the episode ends.
+ * Returns the elapsed wall-clock seconds (CLOCK_MONOTONIC) of the loop. */
+#include <time.h>
+double mwo_bench_loop(mwo_scene *sc, mwo_agent_state *ag, mwo_phys_ent *ents, const double *segs,
+                      int32_t n_segs, int32_t n_actions, int32_t steps, uint8_t *rgb)
+{
+    struct timespec t0, t1;
+    mwo_agent_state ag0 = *ag;
+    uint32_t lcg = 12345u;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (int i = 0; i < steps; ++i) {
+        lcg = lcg * 1664525u + 1013904223u;
+        int action = (int)((lcg >> 16) % (uint32_t)n_actions);
+        double rew;
+        int32_t te, tr;
+        mwo_step(ag, ents, 0, segs, n_segs, action, 0.15, 0.0, 15.0, &rew, &te, &tr);
+        if (te || tr) *ag = ag0;
+        sc->agent_pos[0] = ag->pos[0]; sc->agent_pos[1] = ag->pos[1]; sc->agent_pos[2] = ag->pos[2];
+        sc->agent_dir = ag->dir;
+        mwo_render_obs(sc, rgb, 0, 0, 0);
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}

@@ -105,6 +105,9 @@ def lib():
                                C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.mwo_intersect.argtypes = [C.POINTER(AgentState), C.POINTER(PhysEnt), C.c_int32, C.c_double,
                                     C.c_double, C.c_double, C.c_void_p, C.c_int32]
+        L.mwo_bench_loop.restype = C.c_double
+        L.mwo_bench_loop.argtypes = [C.POINTER(_Scene), C.POINTER(AgentState), C.POINTER(PhysEnt), C.c_void_p,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
 
@@ -165,10 +168,9 @@ def _mips_for(name, textures=None):
 
 # ------------------------------------------------------------------ render
 
-def render(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = None,
-           textures: dict | None = None, want_prim=False):
-    """Render a neutral scene.  Returns dict(rgb u8[H,W,3], z16 u16[H,W], depth f32[H,W,1])."""
-    L = lib()
+def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = None,
+               textures: dict | None = None):
+    """Neutral scene -> (mwo_scene struct, keep-alive list)."""
     P = int(len(scene["polys_nv"]))
     polys = (_Poly * max(P, 1))()
     pv = np.asarray(scene["polys_v"], np.float32).reshape(P, 12)
@@ -190,8 +192,11 @@ def render(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = N
         texs[i].rgb = buf.ctypes.data
     E = int(len(scene["ents_kind"]))
     ents = (_Ent * max(E, 1))()
-    for i in range(E):
-        ents[i].kind = int(scene["ents_kind"][i])
+    # draw order: static entities first, then dynamic ones (miniworld.py:1058-1060, 1075-1077)
+    stat = [int(x) for x in scene.get("ents_static", np.zeros(E, np.int32))]
+    order = [i for i in range(E) if stat[i]] + [i for i in range(E) if not stat[i]]
+    for j, i in enumerate(order):
+        ents[j].kind = int(scene["ents_kind"][i])
         ents[i].mesh = int(scene["ents_mesh"][i])
         ents[i].pos[:] = [float(x) for x in scene["ents_pos"][i]]
         ents[i].dir = float(scene["ents_dir"][i])
@@ -220,6 +225,15 @@ def render(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = N
     sc.ents = C.addressof(ents)
     sc.tex = C.addressof(texs)
     sc.meshes = C.addressof(mstructs)
+    keep.extend([polys, texs, ents, mstructs])
+    return sc, keep
+
+
+def render(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = None,
+           textures: dict | None = None, want_prim=False):
+    """Render a neutral scene.  Returns dict(rgb u8[H,W,3], z16 u16[H,W], depth f32[H,W,1])."""
+    L = lib()
+    sc, keep = pack_scene(scene, width, height, nsamples, meshes, textures)
     rgb = np.zeros((height, width, 3), np.uint8)
     z16 = np.zeros((height, width), np.uint16)
     depth = np.zeros((height, width, 1), np.float32)
@@ -272,3 +286,13 @@ class Dynamics:
     def intersect(self, self_idx, px, pz, radius):
         return lib().mwo_intersect(C.byref(self.ag), self.ents, self_idx, px, pz, radius,
                                    self.segs.ctypes.data, self.segs.shape[0])
+
+
+def bench_loop(scene: dict, task: int, max_episode_steps: int, n_actions: int, steps: int) -> float:
+    """Seconds the C oracle needs for `steps` x [MiniWorldEnv.step + render_obs] on one env."""
+    sc, keep = pack_scene(scene)
+    dyn = Dynamics(scene, task, max_episode_steps, num_objs=len(scene["ents_kind"]),
+                   max_forward_step=float(scene["max_forward_step"]))
+    rgb = np.zeros((60, 80, 3), np.uint8)
+    return lib().mwo_bench_loop(C.byref(sc), C.byref(dyn.ag), dyn.ents, dyn.segs.ctypes.data, dyn.segs.shape[0],
+                                n_actions, steps, rgb.ctypes.data)

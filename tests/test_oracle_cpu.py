@@ -1,0 +1,120 @@
+"""CPU tests of the oracle itself (no GPU): pinned against the reference-derived fixtures."""
+import math
+
+import numpy as np
+import pytest
+
+import helpers
+import pyoracle
+from conftest import golden_cases
+
+
+def test_sincos_within_one_ulp_of_libm():
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-600, 600, 20000), rng.uniform(-4, 4, 5000),
+                         np.arange(-200, 200) * math.pi / 12, [0.0, 1e-300, 1e-8]])
+    worst = 0.0
+    for x in xs:
+        s, c = pyoracle.sincos(float(x))
+        for got, want in ((s, math.sin(x)), (c, math.cos(x))):
+            if want != 0.0:
+                worst = max(worst, abs(got - want) / np.spacing(abs(want)))
+            else:
+                assert got == 0.0
+    assert worst <= 1.0
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_dynamics_match_reference_trajectory(case):
+    """mwo_step vs the reference's own miniworld.py run under GL stubs (tools/gen_golden.py)."""
+    s0, tr, meta, obs = helpers.load_case(case)
+    E = len(s0["ents_kind"])
+    dyn = pyoracle.Dynamics(s0, helpers.task_of(meta), int(s0["max_episode_steps"]), goal_ent=0,
+                            num_objs=E, max_forward_step=float(s0["max_forward_step"]))
+    worst = 0.0
+    for t in range(len(tr["action"])):
+        r, te, tu = dyn.step(tr["action"][t], tr["fwd_step"][t], tr["fwd_drift"][t], tr["turn_step"][t])
+        assert r == tr["reward"][t] and te == tr["term"][t] and tu == tr["trunc"][t], (case, t)
+        assert dyn.ag.carrying == tr["carrying"][t]
+        worst = max(worst, np.abs(np.array(dyn.ag.pos[:]) - tr["pos"][t]).max(), abs(dyn.ag.dir - tr["dir"][t]))
+        for i in range(E):
+            assert dyn.ents[i].alive == tr["ents_alive"][t][i]
+            if dyn.ents[i].alive:
+                worst = max(worst, np.abs(np.array(dyn.ents[i].pos[:]) - tr["ents_pos"][t][i]).max())
+    assert worst < 1e-12
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_render_reproduces_committed_golden(case):
+    s0, tr, meta, obs = helpers.load_case(case)
+    meshes = helpers.golden_meshes(s0)
+    for f, fr in obs.items():
+        out = pyoracle.render(helpers.frame_scene(s0, fr), meshes=meshes)
+        assert np.array_equal(out["rgb"], fr["rgb"]) and np.array_equal(out["z16"], fr["z16"])
+        # get_depth_map: the reference's own numpy expression applied to the resolved depth buffer
+        assert np.array_equal(out["depth"][:, :, 0], helpers.depth_from_z16(fr["z16"]))
+
+
+def _empty_scene():
+    s0, *_ = helpers.load_case("hallway_s0")
+    sc = dict(s0)
+    for k in ("polys_v", "polys_uv", "polys_n", "polys_nv", "polys_tex"):
+        sc[k] = s0[k][:0]
+    for k in [k for k in s0 if k.startswith("ents_")]:
+        sc[k] = s0[k][:0]
+    return sc, s0
+
+
+def test_sky_only_frame_is_sky_colour():
+    sc, _ = _empty_scene()
+    sc["sky"] = np.array([0.25, 0.82, 1.0])
+    out = pyoracle.render(sc)
+    assert (out["rgb"] == np.array([64, 209, 255], np.uint8)).all()
+    assert (out["z16"] == 65535).all()
+    assert np.allclose(out["depth"], 100.0, rtol=1e-3)                   # far plane
+
+
+def test_fronto_parallel_white_quad_is_lit_factor_times_255():
+    sc, s0 = _empty_scene()
+    # a huge untextured wall facing the camera 2 m ahead (+x), normal -x => ambient only: 0.65
+    sc["agent_pos"], sc["agent_dir"] = np.array([0.0, 0.0, 0.0]), np.float64(0.0)
+    v = np.array([[[2, -50, -50], [2, -50, 50], [2, 50, 50], [2, 50, -50]]], np.float32)
+    sc["polys_v"], sc["polys_uv"] = v, np.zeros((1, 4, 2), np.float32)
+    sc["polys_n"] = np.array([[-1, 0, 0]], np.float32)
+    sc["polys_nv"], sc["polys_tex"] = np.array([4], np.int32), np.array([-1], np.int32)
+    out = pyoracle.render(sc)
+    if (out["z16"] == 65535).all():       # winding the other way round -> culled; flip it
+        sc["polys_v"] = v[:, ::-1].copy()
+        out = pyoracle.render(sc)
+    assert (out["rgb"] == round(0.65 * 255)).all()
+    # depth of the centre pixel ~ 2 m (16-bit quantisation)
+    assert abs(out["depth"][30, 40, 0] - 2.0) < 0.01
+
+
+def test_default_light_direction_and_face_factors():
+    """Appendix A.3: directional light along light_pos + 1; floor 1.0, ceiling 0.65, walls 0.8354 / 0.65."""
+    s0, tr, meta, obs = helpers.load_case("hallway_s0")
+    lp = np.array([0, 2.5, 0]) + 1
+    L = lp / np.linalg.norm(lp)
+    assert np.allclose(L, [0.26490647, 0.92717265, 0.26490647])
+    # far-field pixel of the hallway's long walls in the frame looking down the hallway:
+    # concrete mean 152.9 * 0.65 ~ 99 / * 0.8354 ~ 128
+    sc = dict(s0)
+    sc["agent_pos"], sc["agent_dir"] = np.array([0.5, 0.0, 0.3]), np.float64(0.1)
+    out = pyoracle.render(sc)
+    assert abs(int(out["rgb"][30, 2, 0]) - 128) <= 4       # left wall, normal +z, lit
+    assert abs(int(out["rgb"][30, 77, 0]) - 99) <= 4       # right wall, ambient only
+
+
+def test_mip_chain_even_and_odd():
+    rgb = np.arange(6 * 4 * 3, dtype=np.uint8).reshape(4, 6, 3)       # h=4, w=6 -> 3x2 -> 1x1
+    lv = pyoracle.mip_levels(rgb)
+    assert [l.shape[:2] for l in lv] == [(4, 6), (2, 3), (1, 1)]
+    want = (rgb[0::2, 0::2].astype(int) + rgb[0::2, 1::2] + rgb[1::2, 0::2] + rgb[1::2, 1::2] + 2) >> 2
+    assert np.array_equal(lv[1], want)
+    # odd axis 3 -> 1: equal thirds; even axis 2 -> 1: halves
+    a = lv[1].astype(np.int64)
+    acc = (a[0] + a[1]).sum(axis=0)
+    assert np.array_equal(lv[2][0, 0], (2 * acc + 6) // 12)
+    big = pyoracle.mip_levels(pyoracle.texture_rgb_bottom_up("concrete_tiles_1"))    # 768: 768..3,1
+    assert [l.shape[0] for l in big] == [768, 384, 192, 96, 48, 24, 12, 6, 3, 1]
