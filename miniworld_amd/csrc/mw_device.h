@@ -8,7 +8,8 @@
 #define MW_MAX_MESH 32
 #define MW_MAX_LEVELS 16
 #define MW_RASTER_REC 64     // dwords per raster record
-#define MW_SHADE_REC 16      // dwords per shade record
+#define MW_SHADE_REC 32      // dwords per shade record (attribute planes, colour, tex, depth plane)
+#define MW_CULL_REC 24       // a[4] b[4] c[4] tmin[4] tmax[4] flags pad[3]
 #define MW_TILE_W 16
 #define MW_TILE_H 4
 #define MW_SKY_PID 0xFFFFu
@@ -64,6 +65,7 @@ struct MwArgs {
     // --- per-step scratch -----------------------------------------------------------
     float *rec_raster;      // [N][max_vis][64]
     float *rec_shade;       // [N][max_vis][16]
+    float *rec_cull;        // [N][max_vis][MW_CULL_REC] per-primitive tile classification data
     int32_t *nvis;          // [N]
     float *envhdr;          // [N][4] sky rgb, pad
     uint32_t *status;

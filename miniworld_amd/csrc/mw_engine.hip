@@ -18,8 +18,10 @@ extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, const int
                                                 uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                             int waves_per_env, int tiles_per_wave, const float *rec_raster,
-                                            const float *rec_shade, const int32_t *nvis, const float *envhdr,
-                                            const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth);
+                                            const float *rec_shade, const float *rec_cull, const int32_t *nvis,
+                                            const float *envhdr,
+                                            const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth, int dbg,
+                                            int texel_bytes);
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all);
 
 namespace {
@@ -51,6 +53,8 @@ struct mw_engine {
     struct Ev { hipEvent_t a, b, c; };
     std::vector<Ev> ev_used, ev_free;
     int waves_per_env = 0;
+    int texel_bytes = 4;
+    int dbg_flags = 0;       // MW_DEBUG_FLAGS: perf experiments only (bit0: flat shading)
 };
 
 namespace {
@@ -154,6 +158,7 @@ int upload_textures(mw_engine *e)
     }
     HIP_TRY(e, hipMemcpy(e->d_texdesc, descs.data(), descs.size() * sizeof(MwTexDesc), hipMemcpyHostToDevice));
     e->args.texels = e->d_texels;
+    e->texel_bytes = (int)(std::max<size_t>(total, 1) * 4);
     return MW_OK;
 }
 
@@ -164,11 +169,12 @@ int pick_waves_per_env(const mw_engine *e)
         const int v = atoi(s);
         if (v > 0 && v <= n_tiles) return v;
     }
-    // enough wavefronts to fill 256 CUs x 4 SIMDs several times over, in divisors of n_tiles
+    // enough wavefronts to fill 256 CUs x 4 SIMDs x 7 resident waves several times over (measured:
+    // 15-25 waves per env beat 5 by ~7 % at 4096 envs), in divisors of n_tiles
     int best = n_tiles;
     for (int w = 1; w <= n_tiles; ++w) {
         if (n_tiles % w) continue;
-        if ((long long)e->cfg.num_envs * w >= 16384) { best = w; break; }
+        if ((long long)e->cfg.num_envs * w >= 49152) { best = w; break; }
     }
     return best;
 }
@@ -282,10 +288,11 @@ int launch_frame(mw_engine *e, bool do_step, const int32_t *d_actions, uint8_t *
     const int wpe = e->waves_per_env;
     const int tpw = (a.n_tiles + wpe - 1) / wpe;
     const int groups = (N + 7) / 8;
-    const size_t lds = (size_t)e->cfg.max_visible * MW_SHADE_REC * 4 + 192;
+    const size_t lds = (size_t)e->cfg.max_visible * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
     hipLaunchKernelGGL(mw_raster_kernel, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
-                       a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const int32_t *)a.nvis,
-                       (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth);
+                       a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
+                       (const int32_t *)a.nvis,
+                       (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags, e->texel_bytes);
     if (e->timing) {
         (void)hipEventRecord(ev.c, st);
         e->ev_used.push_back(ev);
@@ -309,7 +316,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (cfg->msaa != 8) return fail(nullptr, MW_E_INVALID, "only msaa = 8 is implemented");
     if (cfg->obs_width % MW_TILE_W || cfg->obs_height % MW_TILE_H || cfg->obs_width > 255 * MW_TILE_W || cfg->obs_height > 255 * MW_TILE_H)
         return fail(nullptr, MW_E_INVALID, "obs size must be a multiple of %dx%d", MW_TILE_W, MW_TILE_H);
-    if (cfg->max_visible > 65000) return fail(nullptr, MW_E_CAPACITY, "max_visible too large");
+    if (cfg->max_visible > 384) return fail(nullptr, MW_E_CAPACITY, "max_visible > 384: the shade records of one env must fit the raster kernel's LDS");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, MW_E_DEVICE, "no HIP device available");
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, MW_E_DEVICE, "device %d out of range (%d devices)", cfg->device_id, ndev);
@@ -352,6 +359,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.tex = e->d_texdesc; a.mesh = e->d_meshdesc;
     ALLOC(a.rec_raster, (size_t)N * cfg->max_visible * MW_RASTER_REC);
     ALLOC(a.rec_shade, (size_t)N * cfg->max_visible * MW_SHADE_REC);
+    ALLOC(a.rec_cull, (size_t)N * cfg->max_visible * MW_CULL_REC);
     ALLOC(a.nvis, N); ALLOC(a.envhdr, 4 * (size_t)N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
@@ -369,6 +377,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     e->tex_data.assign(MW_MAX_TEX, {});
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
+    if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
     *out = e;
     return MW_OK;
 }

@@ -255,6 +255,7 @@ __device__ inline float below(float x)
 struct PrimOut {
     float rr[MW_RASTER_REC];
     float sr[MW_SHADE_REC];
+    float tmin[4];
 };
 
 // R4: setup of one flat-shaded polygon.  Returns false when culled.
@@ -267,26 +268,40 @@ __device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float u
     edge_coef(h[0], h[1], ga[2], gb[2], gc[2]);
     const float D = fmaf(h[0].hx, ga[0], fmaf(h[0].hy, gb[0], h[0].hw * gc[0]));
     if (!(D > 0.0f)) return false;
-    // conservative screen bounds -> tile range
-    bool allpos = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) allpos &= (k >= nv) || h[k].hw > 0.0f;
-    int tx0 = 0, ty0 = 0, tx1 = a.tiles_x - 1, ty1 = a.tiles_y - 1;
-    if (allpos) {
+    // conservative screen bounds -> tile range.  The polygon is clipped against w >= 0.01 (well in
+    // front of the 0.04 near plane) only to bound its projection; coverage itself never clips (R4).
+    int tx0, ty0, tx1, ty1;
+    {
+        const float wc = 0.01f;
         float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+        bool some = false;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             if (k < nv) {
-                const float X = h[k].hx / h[k].hw, Y = h[k].hy / h[k].hw;
-                xmin = fminf(xmin, X); xmax = fmaxf(xmax, X);
-                ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+                const HV p = h[k];
+                const HV q = (k + 1 == nv || k == 3) ? h[0] : h[k < 3 ? k + 1 : 0];
+                const bool pin = p.hw >= wc, qin = q.hw >= wc;
+                if (pin) {
+                    const float X = p.hx / p.hw, Y = p.hy / p.hw;
+                    xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+                    some = true;
+                }
+                if (pin != qin) {
+                    const float t = (wc - p.hw) / (q.hw - p.hw);
+                    const float X = fmaf(t, q.hx - p.hx, p.hx) / wc, Y = fmaf(t, q.hy - p.hy, p.hy) / wc;
+                    xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+                    some = true;
+                }
             }
         }
-        if (xmax < -1.0f || ymax < -1.0f || xmin > (float)a.W + 1.0f || ymin > (float)a.H + 1.0f) return false;
-        const float fx0 = fminf(fmaxf(floorf(xmin) - 1.0f, 0.0f), (float)(a.W - 1));
-        const float fx1 = fminf(fmaxf(floorf(xmax) + 1.0f, 0.0f), (float)(a.W - 1));
-        const float fy0 = fminf(fmaxf(floorf(ymin) - 1.0f, 0.0f), (float)(a.H - 1));
-        const float fy1 = fminf(fmaxf(floorf(ymax) + 1.0f, 0.0f), (float)(a.H - 1));
+        if (!some) return false;                         // entirely behind the eye
+        // generous margin: the clipped outline is computed in float and huge coordinates lose precision
+        const float mx = 1.0f + 1e-4f * fmaxf(fabsf(xmin), fabsf(xmax)), my = 1.0f + 1e-4f * fmaxf(fabsf(ymin), fabsf(ymax));
+        if (xmax + mx < 0.0f || ymax + my < 0.0f || xmin - mx > (float)a.W || ymin - my > (float)a.H) return false;
+        const float fx0 = fminf(fmaxf(floorf(xmin - mx), 0.0f), (float)(a.W - 1));
+        const float fx1 = fminf(fmaxf(floorf(xmax + mx), 0.0f), (float)(a.W - 1));
+        const float fy0 = fminf(fmaxf(floorf(ymin - my), 0.0f), (float)(a.H - 1));
+        const float fy1 = fminf(fmaxf(floorf(ymax + my), 0.0f), (float)(a.H - 1));
         tx0 = (int)fx0 / MW_TILE_W; tx1 = (int)fx1 / MW_TILE_W;
         ty0 = (int)fy0 / MW_TILE_H; ty1 = (int)fy1 / MW_TILE_H;
     }
@@ -299,11 +314,17 @@ __device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float u
         }
         const bool tl = (ea > 0.0f) || (ea == 0.0f && eb > 0.0f);
         o.rr[k] = ea; o.rr[4 + k] = eb; o.rr[8 + k] = ec;
+        float tmax = -1e30f, tmin = 1e30f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const float thr = -fmaf(ea, kSampleDx[s], eb * kSampleDy[s]);
-            o.rr[16 + k * 8 + s] = (k < nv && tl) ? below(thr) : thr;
+            const float adj = (k < nv && tl) ? below(thr) : thr;
+            o.rr[16 + k * 8 + s] = adj;
+            tmax = fmaxf(tmax, adj);
+            tmin = fminf(tmin, adj);
         }
+        o.rr[57 + k] = tmax;        // E > tmax  =>  every sample of the pixel is inside edge k
+        o.tmin[k] = tmin;           // E <= tmin =>  no sample of the pixel is inside edge k
     }
     const float invD = 1.0f / D;
     const float ta = fmaf(h[2].cz, ga[2], fmaf(h[1].cz, ga[1], h[0].cz * ga[0]));
@@ -314,8 +335,28 @@ __device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float u
     o.rr[15] = __uint_as_float((uint32_t)tx0 | ((uint32_t)tx1 << 8) | ((uint32_t)ty0 << 16) | ((uint32_t)ty1 << 24));
 #pragma unroll
     for (int s = 0; s < 8; ++s) o.rr[48 + s] = fmaf(zx, kSampleDx[s], zy * kSampleDy[s]);
+    // may_clip: can a sample inside this polygon fail the near / far test of R6?  Conservative:
+    // far  - some vertex in front of the eye is deeper than 99 m;
+    // near - some vertex is nearer than 5 cm AND the polygon's 1/w plane exceeds 1/0.05 at one of
+    //        the screen corners (1/w is linear on screen, so its maximum is at a corner).
+    bool may_clip = false;
+    {
+        float wmin = 1e30f, wmax = -1e30f;
 #pragma unroll
-    for (int s = 56; s < 64; ++s) o.rr[s] = 0.0f;
+        for (int k = 0; k < 4; ++k)
+            if (k < nv) { wmin = fminf(wmin, h[k].hw); wmax = fmaxf(wmax, h[k].hw); }
+        may_clip |= !(wmax <= 99.0f);
+        if (!(wmin >= 0.05f)) {
+            const float Wa = ((ga[0] + ga[1]) + ga[2]) * invD, Wb = ((gb[0] + gb[1]) + gb[2]) * invD,
+                        Wc = ((gc[0] + gc[1]) + gc[2]) * invD;
+            const float fw = (float)a.W, fh = (float)a.H;
+            const float c00 = Wc, c10 = fmaf(Wa, fw, Wc), c01 = fmaf(Wb, fh, Wc), c11 = fmaf(Wa, fw, fmaf(Wb, fh, Wc));
+            const float cmax = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11));
+            may_clip |= !(cmax <= 20.0f);
+        }
+    }
+    o.rr[56] = __uint_as_float(may_clip ? 1u : 0u);
+    o.rr[61] = 0.0f; o.rr[62] = 0.0f; o.rr[63] = 0.0f;
     // shade record
     float U[3] = {0, 0, 0}, V[3] = {0, 0, 0};
     if (tex >= 0) {
@@ -334,6 +375,11 @@ __device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float u
     o.sr[9] = col[0]; o.sr[10] = col[1]; o.sr[11] = col[2];
     o.sr[12] = __int_as_float(tex);
     o.sr[13] = 0.0f; o.sr[14] = 0.0f; o.sr[15] = 0.0f;
+    // depth plane again, for K2's lazy depth path (per-lane gather from LDS)
+    o.sr[16] = o.rr[12]; o.sr[17] = o.rr[13]; o.sr[18] = o.rr[14]; o.sr[19] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) o.sr[20 + s] = o.rr[48 + s];
+    o.sr[28] = 0.0f; o.sr[29] = 0.0f; o.sr[30] = 0.0f; o.sr[31] = 0.0f;
     return true;
 }
 
@@ -353,6 +399,14 @@ __device__ inline void emit(const MwArgs &a, int env, int lane, bool vis, const 
             const float4 *ss = reinterpret_cast<const float4 *>(o.sr);
 #pragma unroll
             for (int i = 0; i < MW_SHADE_REC / 4; ++i) sr[i] = ss[i];
+            // classification record: edge planes + extreme thresholds + flags (K2 reads one per lane)
+            float4 *cr = reinterpret_cast<float4 *>(a.rec_cull + ((size_t)env * a.max_vis + idx) * MW_CULL_REC);
+            cr[0] = make_float4(o.rr[0], o.rr[1], o.rr[2], o.rr[3]);
+            cr[1] = make_float4(o.rr[4], o.rr[5], o.rr[6], o.rr[7]);
+            cr[2] = make_float4(o.rr[8], o.rr[9], o.rr[10], o.rr[11]);
+            cr[3] = make_float4(o.tmin[0], o.tmin[1], o.tmin[2], o.tmin[3]);
+            cr[4] = make_float4(o.rr[57], o.rr[58], o.rr[59], o.rr[60]);
+            cr[5] = make_float4(o.rr[56], 0.0f, 0.0f, 0.0f);
         } else {
             atomicOr(a.status, MW_ST_VIS_OVERFLOW);
         }

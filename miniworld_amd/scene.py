@@ -189,7 +189,7 @@ class EngineBinding:
         self.close()
         caps = (max(16, need[0]), max(8, need[1]), max(8, need[2] + 2))
         cfg = base_config(1, env.obs_width, env.obs_height, caps[2], caps[0], caps[1],
-                          max_visible=min(65000, caps[0] + 6 * caps[2]), params_ranges=env.params.as_ranges(),
+                          max_visible=min(256, -(-(caps[0] + 6 * caps[2]) // 16) * 16), params_ranges=env.params.as_ranges(),
                           device_id=env.device_id)
         cfg.agent_radius = float(env.agent.radius)
         self.engine = eng.Engine(cfg)

@@ -51,7 +51,7 @@ class MiniWorldVecEnv:
         shared = generator != eng.GEN_NONE or cls_name == "PickupObjects"
         P, S, E = len(sc["polys_nv"]), len(sc["wall_segs"]), max(1, len(sc["ents_kind"]))
         cfg = base_config(num_envs, self.template.obs_width, self.template.obs_height, E, P, S,
-                          max_visible=min(1024, max(64, P // 2 + 6 * E)),
+                          max_visible=min(256, -(-(P + 6 * E) // 16) * 16),
                           params_ranges=self.template.params.as_ranges(), device_id=device_id)
         cfg.shared_geometry = int(shared)
         cfg.task, cfg.goal_ent, cfg.num_objs = task, 0, len(sc["ents_kind"])

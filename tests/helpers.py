@@ -56,7 +56,7 @@ def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_ran
     cfg.num_envs = n_envs
     cfg.obs_width, cfg.obs_height, cfg.msaa = 80, 60, 8
     cfg.max_ents, cfg.max_polys, cfg.max_segs = E, P, S
-    cfg.max_visible = max_visible or min(max(64, P + 6 * E), 1024)
+    cfg.max_visible = max_visible or min(-(-(P + 6 * E) // 16) * 16, 256)
     cfg.shared_geometry = 1
     cfg.task = task
     cfg.goal_ent = 0
