@@ -23,6 +23,13 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
 ENV_ID = "MiniWorld-Hallway-v0"
+# the other BASELINE.json configs, runnable with --config (not the headline line):
+#   name -> (env id, envs per GPU, depth, domain_rand, n_actions, algorithmic bytes per env-step)
+OTHER_CONFIGS = {
+    "oneroom_rgbd": ("MiniWorld-OneRoom-v0", 4096, True, False, 3, 33740),
+    "maze": ("MiniWorld-Maze-v0", 1024, False, False, 3, 30860),
+    "pickup_dr": ("MiniWorld-PickupObjects-v0", 2048, False, True, 5, 14800),
+}
 # algorithmic bytes per env-step, RGB, shared geometry:
 # obs 14400 + action 4 + agent/episode state r+w 64 + entity 64 + reward/flags 6 (+2 rounding)
 ALGO_BYTES_PER_ENV_STEP = 14540
@@ -53,7 +60,14 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="hallway", help="hallway (headline) | " + " | ".join(OTHER_CONFIGS))
     args = ap.parse_args()
+    env_id, want_depth, dr, n_act, algo_bytes = ENV_ID, False, False, 3, ALGO_BYTES_PER_ENV_STEP
+    if args.config != "hallway":
+        env_id, n_default, want_depth, dr, n_act, algo_bytes = OTHER_CONFIGS[args.config]
+        if args.envs_per_gpu == ENVS_PER_GPU:
+            args.envs_per_gpu = n_default
+        args.no_cpu_baseline = True
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -72,11 +86,11 @@ def main():
     from miniworld_amd.vec_env import MiniWorldVecEnv
     n = args.envs_per_gpu
     plan = shard_plan(rank, world, n)
-    vec = MiniWorldVecEnv(ENV_ID, n, device_id=local, seed=plan["first_seed"])
+    vec = MiniWorldVecEnv(env_id, n, device_id=local, seed=plan["first_seed"], want_depth=want_depth, domain_rand=dr)
     vec.reset()
     total = args.steps + args.warmup
     g = torch.Generator(device=f"cuda:{local}").manual_seed(1234 + rank)
-    actions = torch.randint(0, 3, (total, n), generator=g, device=f"cuda:{local}", dtype=torch.int32)
+    actions = torch.randint(0, n_act, (total, n), generator=g, device=f"cuda:{local}", dtype=torch.int32)
 
     def barrier():
         torch.cuda.synchronize()
@@ -103,7 +117,7 @@ def main():
         elapsed = max_over_ranks(dist, elapsed, device=f"cuda:{local}")
     if rank == 0:
         steps_per_s = world * n * args.steps / elapsed
-        achieved = ALGO_BYTES_PER_ENV_STEP * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
+        achieved = algo_bytes * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
         out = {
             "metric": "env-steps/s (batched, 80x60 RGB)",
             "value": steps_per_s,
@@ -117,18 +131,19 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{ENV_ID}, {n} batched envs per GPU, 80x60 RGB, 8x MSAA, random actions, "
-                                   "device auto-reset", "envs_per_gpu": n, "parallelism": f"env-shard x{world}"},
+            "config": {"workload": f"{env_id}, {n} batched envs per GPU, 80x60 RGB{'-D' if want_depth else ''}, 8x MSAA, "
+                                   f"random actions, {'domain_rand, ' if dr else ''}auto-reset",
+                       "envs_per_gpu": n, "parallelism": f"env-shard x{world}"},
             "samples_per_s": steps_per_s * 80 * 60 * 8,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "mw_raster_kernel",
+                "kernel": "mw_raster_mesh_kernel" if vec.mesh_ids else "mw_raster_kernel",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                 "traffic": None,
-                "algorithmic_bytes_per_launch": ALGO_BYTES_PER_ENV_STEP * n,
+                "algorithmic_bytes_per_launch": algo_bytes * n,
                 "kernel_ms": raster_ms,
                 "setup_kernel_ms": setup_ms,
                 "launches_timed": launches,

@@ -88,6 +88,11 @@ typedef struct {
     /* generator parameters: [0..3] room min_x,max_x,min_z,max_z; [4] box min_x override;
      * [5] agent max_x override; [6] agent |dir| range; [7] box size */
     double gen_args[8];
+    /* MW_GEN_PICKUP: per object kind (Ball, Box, Key — pickupobjects.py:65): radius, height, scale,
+     * first mesh id (mesh ids of one kind are consecutive in sorted colour order); and the RGB of the
+     * six colours in sorted name order (entity.py:30-43) */
+    double gen_tab[12];
+    double gen_colors[18];
 } mw_config;
 
 /* One room polygon exactly as Room._render feeds it to GL (miniworld.py:401-434). */

@@ -13,6 +13,9 @@
 #define MW_TILE_W 16
 #define MW_TILE_H 4
 #define MW_SKY_PID 0xFFFFu
+#define MW_ENVHDR 128         // floats per env: sky, camera, light, mesh-entity table (K1 -> K2/K3)
+#define MW_MAX_MESH_ENTS 8    // mesh entities drawn per env
+#define MW_HDR_MESH 32        // first float of the mesh-entity table; 12 floats per entry
 
 // status bits written by kernels, read by mw_check()
 #define MW_ST_VIS_OVERFLOW 1u
@@ -42,6 +45,8 @@ struct MwArgs {
     mw_range sky[3], light_pos[3], light_color[3], light_ambient[3], color_bias[3];
     mw_range cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;
     double gen_args[8];
+    double gen_tab[12];     // PICKUP: per kind (ball, box, key): radius, height, scale, first mesh id
+    double gen_colors[18];  // PICKUP: COLORS of the 6 sorted colour names (entity.py:30-40)
     // --- world state, SoA over envs -------------------------------------------------
     double *ax, *ay, *az, *adir;
     double *cam;        // [4][N]
@@ -62,11 +67,14 @@ struct MwArgs {
     const MwTexDesc *tex;
     const uint32_t *texels; // RGBA8 pool
     const MwMeshDesc *mesh;
+    const float *mesh_pos;  // [tris][3][3]
+    const float *mesh_nrm;  // [tris][3][3]
+    const float *mesh_rgb;  // [tris][3][3]
     // --- per-step scratch -----------------------------------------------------------
     float *rec_raster;      // [N][max_vis][64]
     float *rec_shade;       // [N][max_vis][16]
     float *rec_cull;        // [N][max_vis][MW_CULL_REC] per-primitive tile classification data
     int32_t *nvis;          // [N]
-    float *envhdr;          // [N][4] sky rgb, pad
+    float *envhdr;          // [N][MW_ENVHDR]
     uint32_t *status;
 };

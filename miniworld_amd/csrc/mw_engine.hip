@@ -22,7 +22,17 @@ extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, in
                                             const float *envhdr,
                                             const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth, int dbg,
                                             int texel_bytes);
+extern "C" __global__ void mw_raster_big_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                                int waves_per_env, int tiles_per_wave, const float *rec_raster,
+                                                const float *rec_shade, const float *rec_cull, const int32_t *nvis,
+                                                const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
+                                                uint8_t *obs, float *depth, int dbg, int texel_bytes);
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all);
+extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                                 const float *rec_raster, const float *rec_shade, const float *rec_cull,
+                                                 const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
+                                                 const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
+                                                 const float *mesh_rgb, uint8_t *obs, float *depth, int dbg, int texel_bytes);
 
 namespace {
 thread_local std::string g_create_error;
@@ -41,6 +51,11 @@ struct mw_engine {
     uint32_t *d_texels = nullptr;
     MwTexDesc *d_texdesc = nullptr;
     MwMeshDesc *d_meshdesc = nullptr;
+    std::vector<MwMeshDesc> mesh_desc;
+    std::vector<std::vector<float>> mesh_pos, mesh_nrm, mesh_rgb;   // per mesh id, [ntris][9]
+    float *d_mesh_pos = nullptr, *d_mesh_nrm = nullptr, *d_mesh_rgb = nullptr;
+    bool have_meshes = false;
+    bool mesh_lds_ready = false;
     // scratch for the step outputs when the caller passes none
     float *d_reward_scratch = nullptr;
     uint8_t *d_flag_scratch = nullptr;
@@ -285,14 +300,29 @@ int launch_frame(mw_engine *e, bool do_step, const int32_t *d_actions, uint8_t *
                        d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
                        d_trunc ? d_trunc : e->d_flag_scratch + N);
     if (e->timing) (void)hipEventRecord(ev.b, st);
-    const int wpe = e->waves_per_env;
-    const int tpw = (a.n_tiles + wpe - 1) / wpe;
-    const int groups = (N + 7) / 8;
-    const size_t lds = (size_t)e->cfg.max_visible * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
-    hipLaunchKernelGGL(mw_raster_kernel, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
-                       a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
-                       (const int32_t *)a.nvis,
-                       (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags, e->texel_bytes);
+    if (e->have_meshes) {
+        // envs may contain mesh entities: one 1024-thread workgroup per env, sample keys in LDS
+        const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * 192;
+        if (lds > 160 * 1024) return fail(e, MW_E_CAPACITY, "mesh entities need the env's sample keys in LDS: %dx%d is too large", a.W, a.H);
+        if (!e->mesh_lds_ready) {
+            HIP_TRY(e, hipFuncSetAttribute((const void *)mw_raster_mesh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            e->mesh_lds_ready = true;
+        }
+        hipLaunchKernelGGL(mw_raster_mesh_kernel, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
+                           (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
+                           (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
+                           a.mesh_rgb, d_obs, d_depth, e->dbg_flags, e->texel_bytes);
+    } else {
+        const int wpe = e->waves_per_env;
+        const int tpw = (a.n_tiles + wpe - 1) / wpe;
+        const int groups = (N + 7) / 8;
+        const bool big = e->cfg.max_visible > 64;      // records stay in global memory
+        const size_t lds = big ? 192 : (size_t)e->cfg.max_visible * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
+        hipLaunchKernelGGL(big ? mw_raster_big_kernel : mw_raster_kernel, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+                           a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
+                           (const int32_t *)a.nvis,
+                           (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags, e->texel_bytes);
+    }
     if (e->timing) {
         (void)hipEventRecord(ev.c, st);
         e->ev_used.push_back(ev);
@@ -316,7 +346,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (cfg->msaa != 8) return fail(nullptr, MW_E_INVALID, "only msaa = 8 is implemented");
     if (cfg->obs_width % MW_TILE_W || cfg->obs_height % MW_TILE_H || cfg->obs_width > 255 * MW_TILE_W || cfg->obs_height > 255 * MW_TILE_H)
         return fail(nullptr, MW_E_INVALID, "obs size must be a multiple of %dx%d", MW_TILE_W, MW_TILE_H);
-    if (cfg->max_visible > 384) return fail(nullptr, MW_E_CAPACITY, "max_visible > 384: the shade records of one env must fit the raster kernel's LDS");
+    if (cfg->max_visible > 60000) return fail(nullptr, MW_E_CAPACITY, "max_visible too large (16-bit draw ids)");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(nullptr, MW_E_DEVICE, "no HIP device available");
     if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(nullptr, MW_E_DEVICE, "device %d out of range (%d devices)", cfg->device_id, ndev);
@@ -338,6 +368,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.agent_radius = cfg->agent_radius; a.max_forward_step = cfg->max_forward_step;
     a.fwd = cfg->forward_step; a.drift = cfg->forward_drift; a.turn = cfg->turn_step;
     memcpy(a.gen_args, cfg->gen_args, sizeof a.gen_args);
+    memcpy(a.gen_tab, cfg->gen_tab, sizeof a.gen_tab);
+    memcpy(a.gen_colors, cfg->gen_colors, sizeof a.gen_colors);
     for (int i = 0; i < 3; ++i) {
         a.sky[i] = cfg->sky_color[i]; a.light_pos[i] = cfg->light_pos[i]; a.light_color[i] = cfg->light_color[i];
         a.light_ambient[i] = cfg->light_ambient[i]; a.color_bias[i] = cfg->obj_color_bias[i];
@@ -360,7 +392,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.rec_raster, (size_t)N * cfg->max_visible * MW_RASTER_REC);
     ALLOC(a.rec_shade, (size_t)N * cfg->max_visible * MW_SHADE_REC);
     ALLOC(a.rec_cull, (size_t)N * cfg->max_visible * MW_CULL_REC);
-    ALLOC(a.nvis, N); ALLOC(a.envhdr, 4 * (size_t)N); ALLOC(a.status, 1);
+    ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
 #undef ALLOC
@@ -373,6 +405,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
         for (int i = 0; i < N; ++i) seeds[i] = (uint64_t)i;
         (void)hipMemcpy(a.rng, seeds.data(), 16 * (size_t)N, hipMemcpyHostToDevice);
     }
+    e->mesh_desc.assign(MW_MAX_MESH, MwMeshDesc{});
+    e->mesh_pos.assign(MW_MAX_MESH, {}); e->mesh_nrm.assign(MW_MAX_MESH, {}); e->mesh_rgb.assign(MW_MAX_MESH, {});
     e->tex_desc.assign(MW_MAX_TEX, MwTexDesc{});
     e->tex_data.assign(MW_MAX_TEX, {});
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
@@ -389,6 +423,7 @@ void mw_destroy(mw_engine *e)
     (void)hipDeviceSynchronize();
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_texels) (void)hipFree(e->d_texels);
+    for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb}) if (p) (void)hipFree(p);
     for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     for (auto &ev : e->ev_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     delete e;
@@ -406,10 +441,35 @@ int mw_upload_texture(mw_engine *e, int32_t tex_id, const uint8_t *rgb, int32_t 
 int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float *nrm, const float *uv,
                    const float *rgb, int32_t ntris, int32_t tex_id)
 {
-    (void)pos; (void)nrm; (void)uv; (void)rgb; (void)ntris; (void)tex_id;
-    if (!e) return MW_E_INVALID;
-    if (mesh_id < 0 || mesh_id >= MW_MAX_MESH) return fail(e, MW_E_CAPACITY, "mesh id out of range");
-    return fail(e, MW_E_INVALID, "mesh entities are not implemented yet");
+    (void)uv;
+    if (!e || !pos || !nrm || !rgb) return fail(e, MW_E_INVALID, "null argument");
+    if (mesh_id < 0 || mesh_id >= MW_MAX_MESH) return fail(e, MW_E_CAPACITY, "mesh id %d out of range (max %d)", mesh_id, MW_MAX_MESH);
+    if (ntris <= 0 || ntris > 60000) return fail(e, MW_E_CAPACITY, "mesh with %d triangles (1..60000 supported: 16-bit draw ids)", ntris);
+    if (tex_id >= 0) return fail(e, MW_E_INVALID, "textured meshes are not implemented yet (tex_id must be -1)");
+    e->mesh_pos[mesh_id].assign(pos, pos + (size_t)ntris * 9);
+    e->mesh_nrm[mesh_id].assign(nrm, nrm + (size_t)ntris * 9);
+    e->mesh_rgb[mesh_id].assign(rgb, rgb + (size_t)ntris * 9);
+    e->mesh_desc[mesh_id].ntris = (uint32_t)ntris;
+    e->mesh_desc[mesh_id].tex = tex_id;
+    // repack all pools (uploads are rare)
+    size_t total = 0;
+    for (int i = 0; i < MW_MAX_MESH; ++i) { e->mesh_desc[i].first = (uint32_t)total; total += e->mesh_desc[i].ntris; }
+    for (float **p : {&e->d_mesh_pos, &e->d_mesh_nrm, &e->d_mesh_rgb})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_pos, total * 36));
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_nrm, total * 36));
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_rgb, total * 36));
+    for (int i = 0; i < MW_MAX_MESH; ++i) {
+        const size_t n = e->mesh_desc[i].ntris, off = (size_t)e->mesh_desc[i].first * 9;
+        if (!n) continue;
+        HIP_TRY(e, hipMemcpy(e->d_mesh_pos + off, e->mesh_pos[i].data(), n * 36, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->d_mesh_nrm + off, e->mesh_nrm[i].data(), n * 36, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->d_mesh_rgb + off, e->mesh_rgb[i].data(), n * 36, hipMemcpyHostToDevice));
+    }
+    HIP_TRY(e, hipMemcpy(e->d_meshdesc, e->mesh_desc.data(), sizeof(MwMeshDesc) * MW_MAX_MESH, hipMemcpyHostToDevice));
+    e->args.mesh_pos = e->d_mesh_pos; e->args.mesh_nrm = e->d_mesh_nrm; e->args.mesh_rgb = e->d_mesh_rgb;
+    e->have_meshes = true;
+    return MW_OK;
 }
 
 int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_polys, const double *segs, int32_t n_segs)

@@ -113,6 +113,51 @@ __device__ inline void generate_world(const MwArgs &a, int env)
         a.cam[(size_t)2 * N + env] = gen_param(r, a.cam_pitch, dr);
         a.cam[(size_t)3 * N + env] = gen_param(r, a.cam_fov_y, dr);
     }
+    if (a.generator == MW_GEN_PICKUP) {
+        // pickupobjects.py:55-81: num_objs objects of random kind (Ball, Box, Key) and colour, placed
+        // one after the other, then the agent; gen_tab holds the per-kind constants computed by the
+        // host from the meshes (radius, height, scale) and the first mesh id of each kind.
+        const int n = a.num_objs;
+        for (int s = 0; s < n && s < a.E; ++s) {
+            const int kind = (int)rng_below(r, 3);          // 0 ball, 1 box, 2 key (obj_types order)
+            const int color = (int)rng_below(r, 6);         // index into the sorted COLOR_NAMES
+            const double radius = a.gen_tab[kind * 4 + 0], height = a.gen_tab[kind * 4 + 1];
+            double x, z;
+            gen_place(a, env, set, r, radius, s, a.gen_args[0], a.gen_args[1], x, z);
+            const double dir = rng_uniform(r, -kGenPi, kGenPi);
+            const size_t E = a.E;
+            a.ekind[(size_t)s * N + env] = kind == 1 ? MW_ENT_BOX : MW_ENT_MESH;
+            a.emesh[(size_t)s * N + env] = kind == 1 ? -1 : (int)a.gen_tab[kind * 4 + 3] + color;
+            a.estatic[(size_t)s * N + env] = 0;
+            a.epos[((size_t)0 * E + s) * N + env] = x;
+            a.epos[((size_t)1 * E + s) * N + env] = 0.0;
+            a.epos[((size_t)2 * E + s) * N + env] = z;
+            a.edir[(size_t)s * N + env] = dir;
+            const double size = kind == 1 ? 0.9 : 0.0;
+            for (int k = 0; k < 3; ++k) a.egeom[((size_t)k * E + s) * N + env] = size;
+            for (int k = 0; k < 3; ++k) a.egeom[((size_t)(3 + k) * E + s) * N + env] = a.gen_colors[color * 3 + k];
+            a.egeom[((size_t)6 * E + s) * N + env] = a.gen_tab[kind * 4 + 2];
+            a.egeom[((size_t)7 * E + s) * N + env] = radius;
+            a.egeom[((size_t)8 * E + s) * N + env] = height;
+        }
+        gen_place(a, env, set, r, a.agent_radius, n < a.E ? n : a.E, a.gen_args[0], a.gen_args[1], ax, az);
+        adir = rng_uniform(r, -kGenPi, kGenPi);
+        for (int k = 0; k < 3; ++k) a.light[(size_t)(0 + k) * N + env] = gen_param(r, a.sky[k], dr);
+        for (int k = 0; k < 3; ++k) a.light[(size_t)(3 + k) * N + env] = gen_param(r, a.light_pos[k], dr);
+        for (int k = 0; k < 3; ++k) a.light[(size_t)(6 + k) * N + env] = gen_param(r, a.light_color[k], dr);
+        for (int k = 0; k < 3; ++k) a.light[(size_t)(9 + k) * N + env] = gen_param(r, a.light_ambient[k], dr);
+        for (int s = 0; s < n && s < a.E; ++s)               // Box.randomize: colour bias (entity.py:405-407)
+            if (a.ekind[(size_t)s * N + env] == MW_ENT_BOX)
+                for (int k = 0; k < 3; ++k) {
+                    const size_t gi = ((size_t)(3 + k) * a.E + s) * N + env;
+                    const double v = a.egeom[gi] + gen_param(r, a.color_bias[k], dr);
+                    a.egeom[gi] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+                }
+        a.cam[(size_t)0 * N + env] = gen_param(r, a.cam_height, dr);
+        a.cam[(size_t)1 * N + env] = gen_param(r, a.cam_fwd_disp, dr);
+        a.cam[(size_t)2 * N + env] = gen_param(r, a.cam_pitch, dr);
+        a.cam[(size_t)3 * N + env] = gen_param(r, a.cam_fov_y, dr);
+    }
     a.ax[env] = ax; a.ay[env] = 0.0; a.az[env] = az; a.adir[env] = adir;
     a.carry[env] = -1; a.step[env] = 0; a.picked[env] = 0;
     rng_store(a.rng, a.N, env, r);

@@ -1,0 +1,412 @@
+// Device functions shared by the raster kernels (mw_raster.hip, mw_raster_mesh.hip):
+// texture LOD + trilinear fetch (R7, R8), fragment shading (R9), resolve conversion (R12).
+#pragma once
+#include "mw_device.h"
+
+namespace {
+
+__device__ inline float lod_log2(float x)      // R7
+{
+    const uint32_t b = __float_as_uint(x);
+    const int e = (int)((b >> 23) & 255u) - 127;
+    const float m = __uint_as_float((b & 0x7fffffu) | 0x3f800000u);
+    const float f = m - 1.0f;
+    float p = -0.02528550662100315f;
+    p = fmaf(p, f, 0.12010025978088379f);
+    p = fmaf(p, f, -0.2759689688682556f);
+    p = fmaf(p, f, 0.45654040575027466f);
+    p = fmaf(p, f, -0.7179135084152222f);
+    p = fmaf(p, f, 1.4425272941589355f);
+    return fmaf(p, f, (float)e);
+}
+
+struct RGB { float r, g, b; };
+
+// Texel pool and descriptor table are read through raw buffer loads: 32-bit offsets (no 64-bit
+// address arithmetic per texel), hardware bounds check, descriptor in SGPRs.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+#define MW_RSRC_WORD3 0x00020000
+
+__device__ inline uint32_t ldw(rsrc_t r, uint32_t dword_index)
+{
+    return __builtin_amdgcn_raw_buffer_load_b32(r, dword_index << 2, 0, 0);
+}
+
+// R8: GL_LINEAR fetch on one mip level (first texel `off`, dims w x h), GL_REPEAT, centres at +0.5
+__device__ inline RGB bilinear(rsrc_t tx, uint32_t off, int w, int h, float u, float v)
+{
+    const float uu = u - floorf(u), vv = v - floorf(v);
+    const float x = fmaf(uu, (float)w, -0.5f), y = fmaf(vv, (float)h, -0.5f);
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    int i0 = (int)x0f, j0 = (int)y0f;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    if (i0 < 0) i0 += w;
+    if (i1 >= w) i1 -= w;
+    if (j0 < 0) j0 += h;
+    if (j1 >= h) j1 -= h;
+    const uint32_t r0 = off + __umul24((uint32_t)j0, (uint32_t)w), r1 = off + __umul24((uint32_t)j1, (uint32_t)w);
+    const uint32_t t00 = ldw(tx, r0 + i0), t10 = ldw(tx, r0 + i1);
+    const uint32_t t01 = ldw(tx, r1 + i0), t11 = ldw(tx, r1 + i1);
+    RGB o;
+    {
+        const float a = (float)(t00 & 255u), b = (float)(t10 & 255u), c = (float)(t01 & 255u), d = (float)(t11 & 255u);
+        const float r0f = fmaf(fx, b - a, a), r1f = fmaf(fx, d - c, c);
+        o.r = fmaf(fy, r1f - r0f, r0f);
+    }
+    {
+        const float a = (float)((t00 >> 8) & 255u), b = (float)((t10 >> 8) & 255u);
+        const float c = (float)((t01 >> 8) & 255u), d = (float)((t11 >> 8) & 255u);
+        const float r0f = fmaf(fx, b - a, a), r1f = fmaf(fx, d - c, c);
+        o.g = fmaf(fy, r1f - r0f, r0f);
+    }
+    {
+        const float a = (float)((t00 >> 16) & 255u), b = (float)((t10 >> 16) & 255u);
+        const float c = (float)((t01 >> 16) & 255u), d = (float)((t11 >> 16) & 255u);
+        const float r0f = fmaf(fx, b - a, a), r1f = fmaf(fx, d - c, c);
+        o.b = fmaf(fy, r1f - r0f, r0f);
+    }
+    return o;
+}
+
+__device__ inline int level_dim(int d, int l) { const int s = d >> l; return s > 0 ? s : 1; }
+
+// Textured fragment colour (R7-R9) for the lanes whose primitive uses texture `tex` (wave-uniform:
+// dims and level count live in SGPRs); the attribute planes come from the lane's shade record.
+__device__ inline RGB shade_tex(const float4 q0, const float4 q1, const float4 q2, rsrc_t td, rsrc_t tx, int tex,
+                                int tw, int th, int q, float Xc, float Yc)
+{
+    const float Ua = q0.x, Ub = q0.y, Uc = q0.z, Va = q0.w, Vb = q1.x, Vc = q1.y;
+    const float Wa = q1.z, Wb = q1.w, Wc = q2.x;
+    const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4) + 4u;     // &texd[tex].off[0], in dwords
+    const float Wq = fmaf(Wa, Xc, fmaf(Wb, Yc, Wc));
+    RGB texel;
+    // level selection first (all lanes), then at most two bilinear fetches
+    int l0 = q, l1 = -1;
+    float fr = 0.0f, u = 0.0f, v = 0.0f;
+    if (Wq > 0.0f) {
+        const float iw = 1.0f / Wq;
+        const float Uq = fmaf(Ua, Xc, fmaf(Ub, Yc, Uc));
+        const float Vq = fmaf(Va, Xc, fmaf(Vb, Yc, Vc));
+        u = Uq * iw; v = Vq * iw;
+        const float ux = (Ua - u * Wa) * iw, uy = (Ub - u * Wb) * iw;
+        const float vx = (Va - v * Wa) * iw, vy = (Vb - v * Wb) * iw;
+        const float ftw = (float)tw, fth = (float)th;
+        const float sx = ux * ftw, tx_ = vx * fth, sy = uy * ftw, ty_ = vy * fth;
+        const float r2x = fmaf(sx, sx, tx_ * tx_), r2y = fmaf(sy, sy, ty_ * ty_);
+        const float rho2 = r2x > r2y ? r2x : r2y;
+        if (!(rho2 > 1.0f)) {
+            l0 = 0;                                   // magnification: GL_LINEAR on level 0
+        } else if (rho2 < 1e30f) {
+            const float lam = 0.5f * lod_log2(rho2);
+            const float lf = floorf(lam);
+            const int li = (int)lf;
+            if (li < q) { l0 = li; l1 = li + 1; fr = lam - lf; }
+        }
+    }
+    const uint32_t off0 = ldw(td, desc + (uint32_t)l0);
+    const RGB c0 = bilinear(tx, off0, level_dim(tw, l0), level_dim(th, l0), u, v);
+    texel = c0;
+    if (l1 >= 0) {
+        const uint32_t off1 = ldw(td, desc + (uint32_t)l1);
+        const RGB c1 = bilinear(tx, off1, level_dim(tw, l1), level_dim(th, l1), u, v);
+        texel.r = fmaf(fr, c1.r - c0.r, c0.r);
+        texel.g = fmaf(fr, c1.g - c0.g, c0.g);
+        texel.b = fmaf(fr, c1.b - c0.b, c0.b);
+    }
+    RGB o;
+    o.r = (texel.r * (1.0f / 255.0f)) * q2.y;
+    o.g = (texel.g * (1.0f / 255.0f)) * q2.z;
+    o.b = (texel.b * (1.0f / 255.0f)) * q2.w;
+    return o;
+}
+
+__device__ inline uint32_t to_u8(float acc)     // R12: mean of 8, clamp, round half up
+{
+    float v = acc * 0.125f;
+    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    return (uint32_t)(int)fmaf(v, 255.0f, 0.5f);
+}
+
+}  // namespace
+
+
+// depth key of primitive `pid` at sample s of this lane's pixel, from the LDS copy of its plane
+namespace {
+__device__ inline uint32_t lazy_key(const float4 *s_shade, uint32_t pid, int s, float Xc, float Yc)
+{
+    const float4 pl = s_shade[pid * (MW_SHADE_REC / 4) + 4];                       // zx, zy, zc, -
+    const float zo = reinterpret_cast<const float *>(s_shade + pid * (MW_SHADE_REC / 4) + 5)[s];
+    const float zc = fmaf(pl.x, Xc, fmaf(pl.y, Yc, pl.z));
+    const float t = fmaf(zc + zo, 65535.0f, 0.5f);
+    return ((uint32_t)t << 16) | pid;
+}
+
+struct TexEnv {
+    rsrc_t td, tx;
+    const MwTexDesc *__restrict__ texd;
+    int flat;
+};
+
+// fragment colour of the primitive with LDS shade record `sr` at the pixel centre; executed by
+// the lanes that need it, textures handled by a waterfall over the distinct ids among them
+__device__ inline RGB shade_prim(const float4 *sr, const TexEnv &te, float Xc, float Yc)
+{
+    const float4 q2 = sr[2];
+    const int tex = te.flat ? -1 : __float_as_int(sr[3].x);
+    RGB c = {q2.y, q2.z, q2.w};                                 // untextured: the lit face colour
+    uint64_t pending = __ballot(tex >= 0);
+    if (pending) {
+        const float4 q0 = sr[0], q1 = sr[1];
+        while (pending) {
+            const int t0 = __builtin_amdgcn_readlane(tex, __ffsll((unsigned long long)pending) - 1);
+            const MwTexDesc *__restrict__ d = te.texd + t0;
+            const bool mine = tex == t0;
+            if (mine) c = shade_tex(q0, q1, q2, te.td, te.tx, t0, (int)d->w, (int)d->h, (int)d->nlevels - 1, Xc, Yc);
+            pending &= ~__ballot(mine);
+        }
+    }
+    return c;
+}
+
+struct TileCtx;
+__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc, float Yc);
+
+// Everything a wavefront needs to produce one 16x4 tile of one env.
+struct TileCtx {
+    const float4 *s_shade;          // [nvis][8]  shade records (LDS in K2, global in the mesh kernel)
+    const float4 *s_cull;           // [nvis][6]  classification records
+    const float *__restrict__ rr_env;   // [nvis][64] raster records (scalar loads)
+    uint8_t *s_pack;                // 192 B of LDS per wavefront
+    const float *hdr;               // env header (mesh kernel only)
+    const float *mesh_pos, *mesh_nrm, *mesh_rgb;
+    uint8_t *__restrict__ obs;
+    float *__restrict__ depth;
+    TexEnv te;
+    float sky_r, sky_g, sky_b;
+    int env, nvis, W, H, dbg, lane;
+};
+
+template <bool MESH>
+__device__ inline void raster_tile(const TileCtx &cx, int tx, int ty, const uint32_t *mesh_key)
+{
+    const int lane = cx.lane, nvis = cx.nvis, dbg = cx.dbg, env = cx.env, W = cx.W, H = cx.H;
+    const float4 *s_shade = cx.s_shade, *s_cull = cx.s_cull;
+    const float *__restrict__ rr_env = cx.rr_env;
+    uint8_t *s_pack = cx.s_pack;
+    uint8_t *__restrict__ obs = cx.obs;
+    float *__restrict__ depth = cx.depth;
+    const TexEnv &te = cx.te;
+    const float sky_r = cx.sky_r, sky_g = cx.sky_g, sky_b = cx.sky_b;
+    const int px = tx * MW_TILE_W + (lane & 15), py = ty * MW_TILE_H + (lane >> 4);
+    const float Xc = (float)px + 0.5f, Yc = (float)py + 0.5f;
+    const float Xlo = (float)(tx * MW_TILE_W) + 0.5f, Xhi = Xlo + (float)(MW_TILE_W - 1);
+    const float Ylo = (float)(ty * MW_TILE_H) + 0.5f, Yhi = Ylo + (float)(MW_TILE_H - 1);
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+    uint32_t z16 = 65535u;
+
+    // ============ pass A: "painter without overlap" ==================================
+    // As long as no sample is claimed by two primitives and no primitive can be near/far
+    // clipped, depth is irrelevant: every covered sample belongs to its only claimant, and
+    // visiting the primitives in ascending draw index IS the resolve order of R12.  Each
+    // visit shades immediately.  Any contention abandons the tile to pass B (exact keys).
+    bool exact = (dbg & 4) != 0;
+    if (MESH) {
+        bool m = false;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) m |= mesh_key[s] != 0xFFFFFFFFu;
+        exact |= __any(m) != 0;
+    }
+    if (!exact) {
+        bool cov[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) cov[s] = false;
+        uint32_t ncov = 0;                           // covered samples of this lane's pixel
+        for (int chunk = 0; chunk < ((dbg & 2) ? 0 : nvis) && !exact; chunk += 64) {
+            // Tile classification, one primitive per lane.  The edge function is monotone in X
+            // and Y (rounding included), so its extremes over the tile's pixel centres sit at
+            // corners:  touch = every edge's maximum exceeds its smallest sample threshold,
+            //           full  = every edge's minimum exceeds its largest sample threshold.
+            const int lp = chunk + lane;
+            bool touch = lp < nvis, full = touch, clipf = false;
+            if (touch) {
+                const float4 A = s_cull[lp * 6 + 0], B = s_cull[lp * 6 + 1], C = s_cull[lp * 6 + 2];
+                const float4 TMIN = s_cull[lp * 6 + 3], TMAX = s_cull[lp * 6 + 4];
+                const float ea[4] = {A.x, A.y, A.z, A.w}, eb[4] = {B.x, B.y, B.z, B.w}, ec[4] = {C.x, C.y, C.z, C.w};
+                const float tmn[4] = {TMIN.x, TMIN.y, TMIN.z, TMIN.w}, tmx[4] = {TMAX.x, TMAX.y, TMAX.z, TMAX.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float emax = fmaf(ea[k], ea[k] > 0.0f ? Xhi : Xlo, fmaf(eb[k], eb[k] > 0.0f ? Yhi : Ylo, ec[k]));
+                    const float emin = fmaf(ea[k], ea[k] > 0.0f ? Xlo : Xhi, fmaf(eb[k], eb[k] > 0.0f ? Ylo : Yhi, ec[k]));
+                    touch &= emax > tmn[k];
+                    full &= emin > tmx[k];
+                }
+                clipf = __float_as_uint(s_cull[lp * 6 + 5].x) != 0u;
+            }
+            uint64_t todo = __ballot(touch);
+            const uint64_t fullm = __ballot(full), clipm = __ballot(clipf);
+            if (todo & clipm) { exact = true; break; }
+            while (todo) {
+                const int bit = __ffsll((unsigned long long)todo) - 1;
+                const int p = chunk + bit;
+                todo &= todo - 1;
+                uint32_t cnt;
+                bool in0;
+                if ((fullm >> bit) & 1) {
+                    // the whole tile lies strictly inside primitive p
+                    if (__any(ncov != 0u)) { exact = true; break; }
+                    cnt = 8u; in0 = true;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) cov[s] = true;
+                } else {
+                    const float *__restrict__ rr = rr_env + (size_t)p * MW_RASTER_REC;
+                    bool in[8];
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) in[s] = true;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float E = fmaf(rr[k], Xc, fmaf(rr[4 + k], Yc, rr[8 + k]));
+                        if (__all(E > rr[57 + k])) continue;        // tile strictly inside edge k
+#pragma unroll
+                        for (int s = 0; s < 8; ++s) in[s] &= E > rr[16 + k * 8 + s];
+                    }
+                    bool clash = false;
+                    cnt = 0u;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        clash |= in[s] && cov[s];
+                        cnt += in[s] ? 1u : 0u;
+                    }
+                    if (__any(clash)) { exact = true; break; }
+                    if (!__any(cnt != 0u)) continue;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) cov[s] |= in[s];
+                    in0 = in[0];
+                }
+                ncov += cnt;
+                if (cnt != 0u) {
+                    const RGB c = shade_prim(s_shade + p * (MW_SHADE_REC / 4), te, Xc, Yc);
+                    const float fc = (float)cnt;
+                    acc_r = fmaf(fc, c.r, acc_r);
+                    acc_g = fmaf(fc, c.g, acc_g);
+                    acc_b = fmaf(fc, c.b, acc_b);
+                    if (depth && in0) z16 = lazy_key(s_shade, (uint32_t)p, 0, Xc, Yc) >> 16;
+                }
+            }
+        }
+        if (!exact) {
+            const float fs = (float)(8u - ncov);            // uncovered samples: sky, last (R12)
+            acc_r = fmaf(fs, sky_r, acc_r);
+            acc_g = fmaf(fs, sky_g, acc_g);
+            acc_b = fmaf(fs, sky_b, acc_b);
+        }
+    }
+
+    // ============ pass B: exact packed-key resolution =================================
+    if (exact) {
+        acc_r = acc_g = acc_b = 0.0f;
+        uint32_t key[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) key[s] = MESH ? mesh_key[s] : 0xFFFFFFFFu;
+        for (int chunk = 0; chunk < nvis; chunk += 64) {
+            const int lp = chunk + lane;
+            bool touch = lp < nvis;
+            if (touch) {
+                const float4 A = s_cull[lp * 6 + 0], B = s_cull[lp * 6 + 1], C = s_cull[lp * 6 + 2];
+                const float4 TMIN = s_cull[lp * 6 + 3];
+                const float ea[4] = {A.x, A.y, A.z, A.w}, eb[4] = {B.x, B.y, B.z, B.w}, ec[4] = {C.x, C.y, C.z, C.w};
+                const float tmn[4] = {TMIN.x, TMIN.y, TMIN.z, TMIN.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float emax = fmaf(ea[k], ea[k] > 0.0f ? Xhi : Xlo, fmaf(eb[k], eb[k] > 0.0f ? Yhi : Ylo, ec[k]));
+                    touch &= emax > tmn[k];
+                }
+            }
+            uint64_t todo = __ballot(touch);
+            while (todo) {
+                const int p = chunk + (__ffsll((unsigned long long)todo) - 1);
+                todo &= todo - 1;
+                const float *__restrict__ rr = rr_env + (size_t)p * MW_RASTER_REC;
+                bool in[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) in[s] = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float E = fmaf(rr[k], Xc, fmaf(rr[4 + k], Yc, rr[8 + k]));
+                    if (__all(E > rr[57 + k])) continue;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) in[s] &= E > rr[16 + k * 8 + s];
+                }
+                bool any = false;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) any |= in[s];
+                if (!__any(any)) continue;
+                const float zc = fmaf(rr[12], Xc, fmaf(rr[13], Yc, rr[14]));
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const float zs = zc + rr[48 + s];
+                    const float t = fmaf(zs, 65535.0f, 0.5f);
+                    const bool ok = in[s] && t >= 0.5f && t < 65536.0f;
+                    const uint32_t id = MESH ? __float_as_uint(rr[61]) : (uint32_t)p;     // draw id
+                    const uint32_t k = ((uint32_t)t << 16) | id;
+                    key[s] = ok ? min(key[s], k) : key[s];
+                }
+            }
+        }
+        z16 = key[0] >> 16;
+        uint32_t pid[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) pid[s] = key[s] & 0xFFFFu;
+        // deferred shading: each distinct winner once, ascending draw index, sky last (R9, R12)
+        for (;;) {
+            const uint32_t sel = min(min(min(pid[0], pid[1]), min(pid[2], pid[3])), min(min(pid[4], pid[5]), min(pid[6], pid[7])));
+            const bool active = sel != 0x10000u;
+            if (!__any(active)) break;
+            if (active) {
+                uint32_t cnt = 0;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    const bool eq = pid[s] == sel;
+                    cnt += eq ? 1u : 0u;
+                    pid[s] = eq ? 0x10000u : pid[s];
+                }
+                RGB c = {sky_r, sky_g, sky_b};
+                if (sel != MW_SKY_PID) {
+                    if (MESH) c = shade_by_draw_id(cx, sel, Xc, Yc);
+                    else c = shade_prim(s_shade + sel * (MW_SHADE_REC / 4), te, Xc, Yc);
+                }
+                const float fc = (float)cnt;
+                acc_r = fmaf(fc, c.r, acc_r);
+                acc_g = fmaf(fc, c.g, acc_g);
+                acc_b = fmaf(fc, c.b, acc_b);
+            }
+        }
+    }
+    const uint32_t R = to_u8(acc_r), G = to_u8(acc_g), B = to_u8(acc_b);
+
+    // ---- pack: tile rows of 16 px * 3 B = 48 B = 12 dwords; 4 rows -> 48 dword stores
+    const int row = lane >> 4, col = lane & 15;
+    s_pack[row * 48 + col * 3 + 0] = (uint8_t)R;
+    s_pack[row * 48 + col * 3 + 1] = (uint8_t)G;
+    s_pack[row * 48 + col * 3 + 2] = (uint8_t)B;
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (lane < 48) {
+        const int r = lane / 12, d = lane % 12;
+        const uint32_t w = reinterpret_cast<const uint32_t *>(s_pack)[r * 12 + d];
+        uint8_t *dst = obs + ((size_t)env * H + (ty * MW_TILE_H + r)) * W * 3 + (size_t)tx * (MW_TILE_W * 3) + d * 4;
+        *reinterpret_cast<uint32_t *>(dst) = w;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (depth) {
+        // R13 / R14: resolved depth = sample 0; get_depth_map in float32 as numpy evaluates it
+        const float z = (float)z16;
+        const float d = z / 65535.0f;
+        const float clip = (d - 0.5f) * 2.0f;
+        const float den = clip * (float)(100.0 - 0.04) - (float)(100.0 + 0.04);
+        depth[((size_t)env * H + py) * W + px] = (float)(-2.0 * 100.0 * 0.04) / den;
+    }
+}
+
+}  // namespace

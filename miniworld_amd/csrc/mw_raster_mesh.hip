@@ -1,0 +1,281 @@
+// K3 — raster kernel for envs that contain mesh entities (Ball / Key: entity.py:124-165, 435-452;
+// ObjMesh.render objmesh.py:280-292).  One 1024-thread workgroup per env.
+//
+// A ball is 5 192 sub-pixel triangles, so the pixel-per-lane scheme of K2 would waste 60+
+// lanes per triangle.  Here the whole env's sample-key buffer (80*60*8 dwords = 153 600 B)
+// lives in the CU's 160 KiB LDS and the mesh triangles are rasterised one per lane, scattering
+// packed keys (depth16 << 16 | draw id) with ds_min_u32 — GL_LESS / first-drawn-wins is an
+// unsigned min, hence order independent (R6).  After a barrier the 16 wavefronts walk the
+// tiles exactly like K2, starting from the mesh keys; winners whose draw id falls into a mesh
+// entity's range are shaded by re-deriving that triangle (Gouraud, R11).
+//
+// Per-triangle arithmetic (transform, unnormalised-normal lighting, edge / depth / colour
+// planes) follows DESIGN.md R3, R4, R6, R10, R11 exactly like the oracle's mesh path.
+#include "mw_raster_common.h"
+
+namespace {
+
+struct HV { float hx, hy, hw, cz; };
+
+struct MeshEnt {            // one entry of the env header's mesh table (written by K1)
+    int slot, start, ntris, first, tex;
+    float c, s, scale, px, py, pz;
+};
+
+__device__ inline MeshEnt load_ment(const float *hdr, int j)
+{
+    const float *m = hdr + MW_HDR_MESH + 12 * j;
+    MeshEnt e;
+    e.slot = __float_as_int(m[0]); e.start = __float_as_int(m[1]); e.ntris = __float_as_int(m[2]);
+    e.first = __float_as_int(m[3]);
+    e.c = m[4]; e.s = m[5]; e.scale = m[6]; e.px = m[7]; e.py = m[8]; e.pz = m[9];
+    e.tex = __float_as_int(m[10]);
+    return e;
+}
+
+__device__ inline HV xform_hdr(const float *hdr, float halfw, float halfh, float x, float y, float z)
+{
+    const float *m = hdr + 4;
+    const float ex = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
+    const float ey = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7])));
+    const float ez = fmaf(m[8], x, fmaf(m[9], y, fmaf(m[10], z, m[11])));
+    const float cx = hdr[16] * ex, cy = hdr[17] * ey, cw = -ez;
+    HV h;
+    h.cz = fmaf(hdr[18], ez, hdr[19]);
+    h.hx = (cx + cw) * halfw;
+    h.hy = (cw - cy) * halfh;
+    h.hw = cw;
+    return h;
+}
+
+__device__ inline void edge_coef(const HV &a, const HV &b, float &ea, float &eb, float &ec)
+{
+    ea = b.hy * a.hw - b.hw * a.hy;
+    eb = b.hw * a.hx - b.hx * a.hw;
+    ec = b.hx * a.hy - b.hy * a.hx;
+}
+
+__device__ inline float below(float x)
+{
+    if (x == 0.0f) return __uint_as_float(0x80000001u);
+    const uint32_t b = __float_as_uint(x);
+    return __uint_as_float(x > 0.0f ? b - 1u : b + 1u);
+}
+
+__constant__ float kDx[8] = {0.0625f, -0.0625f, 0.3125f, -0.1875f, -0.3125f, -0.4375f, 0.1875f, 0.4375f};
+__constant__ float kDy[8] = {-0.1875f, 0.1875f, 0.0625f, -0.3125f, 0.3125f, -0.0625f, 0.4375f, -0.4375f};
+
+// world-space vertices of triangle `tri` of mesh entity e (R11: pos + scale * R_y(dir) * v)
+__device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, int tri, float halfw, float halfh, HV h[3])
+{
+    const float *p = cx.mesh_pos + (size_t)(e.first + tri) * 9;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float lx = p[k * 3 + 0], ly = p[k * 3 + 1], lz = p[k * 3 + 2];
+        const float rx = fmaf(e.c, lx, e.s * lz), rz = fmaf(e.c, lz, -(e.s * lx));
+        const float wx = fmaf(e.scale, rx, e.px), wy = fmaf(e.scale, ly, e.py), wz = fmaf(e.scale, rz, e.pz);
+        h[k] = xform_hdr(cx.hdr, halfw, halfh, wx, wy, wz);
+    }
+}
+
+// Gouraud fragment colour of mesh triangle (e, tri) at the pixel centre (R9-R11)
+__device__ inline RGB shade_mesh_tri(const TileCtx &cx, const MeshEnt &e, int tri, float Xc, float Yc)
+{
+    const float halfw = (float)cx.W * 0.5f, halfh = (float)cx.H * 0.5f;
+    HV h[3];
+    tri_verts(cx, e, tri, halfw, halfh, h);
+    float ga[3], gb[3], gc[3];
+    edge_coef(h[1], h[2], ga[0], gb[0], gc[0]);
+    edge_coef(h[2], h[0], ga[1], gb[1], gc[1]);
+    edge_coef(h[0], h[1], ga[2], gb[2], gc[2]);
+    const float *L = cx.hdr + 20, *amb = cx.hdr + 24, *lcol = cx.hdr + 28;
+    const float *nrm = cx.mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = cx.mesh_rgb + (size_t)(e.first + tri) * 9;
+    float col[3][3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float nx0 = nrm[k * 3 + 0], ny0 = nrm[k * 3 + 1], nz0 = nrm[k * 3 + 2];
+        const float n[3] = {fmaf(e.c, nx0, e.s * nz0) / e.scale, ny0 / e.scale, fmaf(e.c, nz0, -(e.s * nx0)) / e.scale};
+        const float ndl = fmaf(n[2], L[2], fmaf(n[1], L[1], n[0] * L[0]));
+        const float d = ndl > 0.0f ? ndl : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float kk = fmaf(lcol[i], d, amb[i]);
+            const float v = rgb[k * 3 + i] * kk;
+            col[k][i] = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+        }
+    }
+    const float Wa = (ga[0] + ga[1]) + ga[2], Wb = (gb[0] + gb[1]) + gb[2], Wc = (gc[0] + gc[1]) + gc[2];
+    const float Wq = fmaf(Wa, Xc, fmaf(Wb, Yc, Wc));
+    RGB o;
+    if (Wq > 0.0f) {
+        const float iw = 1.0f / Wq;
+        float out[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float Ca = fmaf(col[2][i], ga[2], fmaf(col[1][i], ga[1], col[0][i] * ga[0]));
+            const float Cb = fmaf(col[2][i], gb[2], fmaf(col[1][i], gb[1], col[0][i] * gb[0]));
+            const float Cc = fmaf(col[2][i], gc[2], fmaf(col[1][i], gc[1], col[0][i] * gc[0]));
+            out[i] = fmaf(Ca, Xc, fmaf(Cb, Yc, Cc)) * iw;
+        }
+        o.r = out[0]; o.g = out[1]; o.b = out[2];
+    } else {
+        o.r = col[0][0]; o.g = col[0][1]; o.b = col[0][2];
+    }
+    return o;
+}
+
+// draw id -> record: ids inside a mesh entity's range are triangles, the others index the
+// visible-primitive list once the triangles drawn before them are subtracted
+__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc, float Yc)
+{
+    const int n_mesh = __float_as_int(cx.hdr[3]);
+    int vis = (int)id;
+    for (int j = 0; j < n_mesh; ++j) {
+        const int start = __float_as_int(cx.hdr[MW_HDR_MESH + 12 * j + 1]);
+        const int nt = __float_as_int(cx.hdr[MW_HDR_MESH + 12 * j + 2]);
+        if ((int)id >= start + nt) {
+            vis -= nt;
+        } else if ((int)id >= start) {
+            const MeshEnt e = load_ment(cx.hdr, j);
+            return shade_mesh_tri(cx, e, (int)id - start, Xc, Yc);
+        }
+    }
+    return shade_prim(cx.s_shade + vis * (MW_SHADE_REC / 4), cx.te, Xc, Yc);
+}
+
+// rasterise one mesh triangle into the LDS key buffer (one lane per triangle)
+__device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, uint32_t *keys)
+{
+    const int W = cx.W, H = cx.H;
+    const float halfw = (float)W * 0.5f, halfh = (float)H * 0.5f;
+    HV h[3];
+    tri_verts(cx, e, tri, halfw, halfh, h);
+    float ga[3], gb[3], gc[3];
+    edge_coef(h[1], h[2], ga[0], gb[0], gc[0]);
+    edge_coef(h[2], h[0], ga[1], gb[1], gc[1]);
+    edge_coef(h[0], h[1], ga[2], gb[2], gc[2]);
+    const float D = fmaf(h[0].hx, ga[0], fmaf(h[0].hy, gb[0], h[0].hw * gc[0]));
+    if (!(D > 0.0f)) return;                                  // back face (R4)
+    // pixel bounds of the part in front of w = 0.01 (conservative: coverage itself never clips, R4)
+    int x0, y0, x1, y1;
+    {
+        const float wc = 0.01f;
+        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+        bool some = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const HV p = h[k], q = h[k == 2 ? 0 : k + 1];
+            const bool pin = p.hw >= wc, qin = q.hw >= wc;
+            if (pin) {
+                const float X = p.hx / p.hw, Y = p.hy / p.hw;
+                xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+                some = true;
+            }
+            if (pin != qin) {
+                const float t = (wc - p.hw) / (q.hw - p.hw);
+                const float X = fmaf(t, q.hx - p.hx, p.hx) / wc, Y = fmaf(t, q.hy - p.hy, p.hy) / wc;
+                xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+                some = true;
+            }
+        }
+        if (!some) return;                                    // entirely behind the eye
+        const float mx = 1.0f + 1e-4f * fmaxf(fabsf(xmin), fabsf(xmax)), my = 1.0f + 1e-4f * fmaxf(fabsf(ymin), fabsf(ymax));
+        if (xmax + mx < 0.0f || ymax + my < 0.0f || xmin - mx > (float)W || ymin - my > (float)H) return;
+        x0 = (int)fminf(fmaxf(floorf(xmin - mx), 0.0f), (float)(W - 1));
+        x1 = (int)fminf(fmaxf(floorf(xmax + mx), 0.0f), (float)(W - 1));
+        y0 = (int)fminf(fmaxf(floorf(ymin - my), 0.0f), (float)(H - 1));
+        y1 = (int)fminf(fmaxf(floorf(ymax + my), 0.0f), (float)(H - 1));
+    }
+    // edges 0->1, 1->2, 2->0 in drawing order: coefficients = G2, G0, G1
+    const float ea[3] = {ga[2], ga[0], ga[1]}, eb[3] = {gb[2], gb[0], gb[1]}, ec[3] = {gc[2], gc[0], gc[1]};
+    float thr[3][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const bool tl = (ea[k] > 0.0f) || (ea[k] == 0.0f && eb[k] > 0.0f);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const float t = -fmaf(ea[k], kDx[s], eb[k] * kDy[s]);
+            thr[k][s] = tl ? below(t) : t;
+        }
+    }
+    const float invD = 1.0f / D;
+    const float ta = fmaf(h[2].cz, ga[2], fmaf(h[1].cz, ga[1], h[0].cz * ga[0]));
+    const float tb = fmaf(h[2].cz, gb[2], fmaf(h[1].cz, gb[1], h[0].cz * gb[0]));
+    const float tc = fmaf(h[2].cz, gc[2], fmaf(h[1].cz, gc[1], h[0].cz * gc[0]));
+    const float zx = (ta * invD) * 0.5f, zy = (tb * invD) * 0.5f, zcc = fmaf(tc * invD, 0.5f, 0.5f);
+    float zo[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) zo[s] = fmaf(zx, kDx[s], zy * kDy[s]);
+    const uint32_t id = (uint32_t)(e.start + tri);
+    for (int py = y0; py <= y1; ++py)
+        for (int px = x0; px <= x1; ++px) {
+            const float Xc = (float)px + 0.5f, Yc = (float)py + 0.5f;
+            const float E0 = fmaf(ea[0], Xc, fmaf(eb[0], Yc, ec[0]));
+            const float E1 = fmaf(ea[1], Xc, fmaf(eb[1], Yc, ec[1]));
+            const float E2 = fmaf(ea[2], Xc, fmaf(eb[2], Yc, ec[2]));
+            const float zc = fmaf(zx, Xc, fmaf(zy, Yc, zcc));
+            uint32_t *kp = keys + ((size_t)py * W + px) * 8;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (E0 > thr[0][s] && E1 > thr[1][s] && E2 > thr[2][s]) {
+                    const float t = fmaf(zc + zo[s], 65535.0f, 0.5f);
+                    if (t >= 0.5f && t < 65536.0f) atomicMin(kp + s, ((uint32_t)t << 16) | id);
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
+    int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+    const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
+    const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
+    const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
+    const float *__restrict__ mesh_rgb, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                     // [H][W][8]
+    const int nkeys = W * H * 8;
+    const int env = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint8_t *s_pack = smem + (size_t)nkeys * 4 + wave * 192;
+
+    for (int i = tid; i < nkeys; i += 1024) keys[i] = 0xFFFFFFFFu;
+    __syncthreads();
+
+    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
+    TileCtx cx;
+    cx.s_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
+    cx.s_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
+    cx.rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
+    cx.s_pack = s_pack;
+    cx.hdr = hdr;
+    cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb;
+    cx.obs = obs; cx.depth = depth;
+    cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
+    cx.te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);
+    cx.te.texd = texd;
+    cx.te.flat = dbg & 1;
+    cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
+    cx.env = env; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane;
+
+    // ---- phase 1: every mesh triangle -> LDS keys, one triangle per lane -------------------
+    const int n_mesh = __float_as_int(hdr[3]);
+    for (int j = 0; j < n_mesh; ++j) {
+        const MeshEnt e = load_ment(hdr, j);
+        for (int t = tid; t < e.ntris; t += 1024) raster_tri(cx, e, t, keys);
+    }
+    __syncthreads();
+
+    // ---- phase 2: tiles, 16 wavefronts round-robin --------------------------------------------
+    for (int tile = wave; tile < n_tiles; tile += 16) {
+        const int tx = tile % tiles_x, ty = tile / tiles_x;
+        const int px = tx * MW_TILE_W + (lane & 15), py = ty * MW_TILE_H + (lane >> 4);
+        uint32_t mk[8];
+        const uint4 k0 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8);
+        const uint4 k1 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8 + 4);
+        mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
+        raster_tile<true>(cx, tx, ty, mk);
+    }
+}

@@ -356,7 +356,8 @@ __device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float u
         }
     }
     o.rr[56] = __uint_as_float(may_clip ? 1u : 0u);
-    o.rr[61] = 0.0f; o.rr[62] = 0.0f; o.rr[63] = 0.0f;
+    o.rr[61] = 0.0f;            // draw id, filled in by emit()
+    o.rr[62] = 0.0f; o.rr[63] = 0.0f;
     // shade record
     float U[3] = {0, 0, 0}, V[3] = {0, 0, 0};
     if (tex >= 0) {
@@ -384,12 +385,13 @@ __device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float u
 }
 
 // ordered append of the lanes' primitives to the env's visible list
-__device__ inline void emit(const MwArgs &a, int env, int lane, bool vis, const PrimOut &o, int &count)
+__device__ inline void emit(const MwArgs &a, int env, int lane, bool vis, PrimOut &o, int &count, int id_offset)
 {
     const uint64_t m = ballot(vis);
     const int before = __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
     const int idx = count + before;
     if (vis) {
+        o.rr[61] = __uint_as_float((uint32_t)(idx + id_offset));   // draw id = list index + mesh triangles drawn before
         if (idx < a.max_vis) {
             float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
             const float4 *src = reinterpret_cast<const float4 *>(o.rr);
@@ -565,59 +567,106 @@ extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
             const float uv[3][2] = {{q.uv[0][0], q.uv[0][1]}, {q.uv[1][0], q.uv[1][1]}, {q.uv[2][0], q.uv[2][1]}};
             vis = setup_poly(a, h, q.nv, uv, col, q.tex, o);
         }
-        emit(a, env, lane, vis, o, count);
+        emit(a, env, lane, vis, o, count, 0);
     }
-    // entities: two passes, static first then dynamic (miniworld.py:1058-1060, 1075-1077)
+    // entities in draw order: static ones first, then dynamic (miniworld.py:1058-1060, 1075-1077).
+    // Boxes become 6 polygons each (runs of up to 10 consecutive boxes share one 64-lane batch);
+    // a mesh entity only reserves its range of draw ids and is described to the mesh raster kernel.
+    int mesh_tris = 0, n_mesh = 0;
+    float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
     for (int pass = 0; pass < 2; ++pass) {
-        const int nfaces = a.E * 6;
-        for (int base = 0; base < nfaces; base += 64) {
-            const int i = base + lane;
-            PrimOut o;
-            bool vis = false;
-            if (i < nfaces) {
-                const int slot = i / 6, f = i % 6;
-                const int kind = a.ekind[(size_t)slot * a.N + env];
-                const int is_static = a.estatic[(size_t)slot * a.N + env];
-                if (kind == MW_ENT_BOX && (is_static != 0) == (pass == 0)) {
-                    // Box.render (entity.py:409-432): T(pos) R_y(dir) drawBox(...)
-                    const double edir = (slot == c.live) ? c.cdir : a.edir[(size_t)slot * a.N + env];
+        int s0 = 0;
+        while (s0 < a.E) {
+            const int kind0 = a.ekind[(size_t)s0 * a.N + env];
+            const bool mine0 = (a.estatic[(size_t)s0 * a.N + env] != 0) == (pass == 0);
+            if (kind0 == MW_ENT_MESH && mine0) {
+                const int mid = a.emesh[(size_t)s0 * a.N + env];
+                const MwMeshDesc md = a.mesh[mid];
+                if (n_mesh < MW_MAX_MESH_ENTS && count + mesh_tris + (int)md.ntris < 0xFFF0) {
+                    const double edir = (s0 == c.live) ? c.cdir : a.edir[(size_t)s0 * a.N + env];
                     const mw::SinCos sc = mw::sincos_det(edir);
-                    const float cs = (float)sc.c, sn = (float)sc.s;
-                    const float ex = (float)ent_pos(c, slot, 0), ey = (float)ent_pos(c, slot, 1), ez = (float)ent_pos(c, slot, 2);
-                    const double sx = ent_geom(a, env, slot, 0), sy = ent_geom(a, env, slot, 1), sz = ent_geom(a, env, slot, 2);
-                    const float lo[3] = {(float)(-sx / 2), 0.0f, (float)(-sz / 2)};
-                    const float hi[3] = {(float)(sx / 2), (float)sy, (float)(sz / 2)};
-                    const float base_col[3] = {(float)ent_geom(a, env, slot, 3), (float)ent_geom(a, env, slot, 4),
-                                               (float)ent_geom(a, env, slot, 5)};
-                    HV h[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int sel = kBoxSel[f][k];
-                        const float lx = (sel & 1) ? hi[0] : lo[0];
-                        const float ly = (sel & 2) ? hi[1] : lo[1];
-                        const float lz = (sel & 4) ? hi[2] : lo[2];
-                        const float wx = fmaf(cs, lx, sn * lz) + ex;
-                        const float wy = ly + ey;
-                        const float wz = fmaf(cs, lz, -(sn * lx)) + ez;
-                        h[k] = xform(cam, wx, wy, wz);
+                    if (lane == 0) {
+                        float *m = hdr + MW_HDR_MESH + 12 * n_mesh;
+                        m[0] = __int_as_float(s0);
+                        m[1] = __int_as_float(count + mesh_tris);
+                        m[2] = __int_as_float((int)md.ntris);
+                        m[3] = __int_as_float((int)md.first);
+                        m[4] = (float)sc.c; m[5] = (float)sc.s;
+                        m[6] = (float)ent_geom(a, env, s0, 6);
+                        m[7] = (float)ent_pos(c, s0, 0); m[8] = (float)ent_pos(c, s0, 1); m[9] = (float)ent_pos(c, s0, 2);
+                        m[10] = __int_as_float(md.tex);
+                        m[11] = 0.0f;
                     }
-                    const float n[3] = {fmaf(cs, kBoxN[f][0], sn * kBoxN[f][2]), kBoxN[f][1],
-                                        fmaf(cs, kBoxN[f][2], -(sn * kBoxN[f][0]))};
-                    float col[3];
-                    light(cam, n, base_col, col);
-                    const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-                    vis = setup_poly(a, h, 4, uv, col, -1, o);
+                    mesh_tris += (int)md.ntris;
+                    ++n_mesh;
+                } else {
+                    atomicOr(a.status, MW_ST_VIS_OVERFLOW);
                 }
+                ++s0;
+                continue;
             }
-            emit(a, env, lane, vis, o, count);
+            int s1 = s0;
+            while (s1 < a.E && s1 - s0 < 10) {
+                const int k1 = a.ekind[(size_t)s1 * a.N + env];
+                const bool m1 = (a.estatic[(size_t)s1 * a.N + env] != 0) == (pass == 0);
+                if (k1 == MW_ENT_MESH && m1) break;
+                ++s1;
+            }
+            {
+                const int i = lane;
+                PrimOut o;
+                bool vis = false;
+                const int slot = s0 + i / 6, f = i % 6;
+                if (i < (s1 - s0) * 6) {
+                    const int kind = a.ekind[(size_t)slot * a.N + env];
+                    const int is_static = a.estatic[(size_t)slot * a.N + env];
+                    if (kind == MW_ENT_BOX && (is_static != 0) == (pass == 0)) {
+                        // Box.render (entity.py:409-432): T(pos) R_y(dir) drawBox(...)
+                        const double edir = (slot == c.live) ? c.cdir : a.edir[(size_t)slot * a.N + env];
+                        const mw::SinCos sc = mw::sincos_det(edir);
+                        const float cs = (float)sc.c, sn = (float)sc.s;
+                        const float ex = (float)ent_pos(c, slot, 0), ey = (float)ent_pos(c, slot, 1), ez = (float)ent_pos(c, slot, 2);
+                        const double sx = ent_geom(a, env, slot, 0), sy = ent_geom(a, env, slot, 1), sz = ent_geom(a, env, slot, 2);
+                        const float lo[3] = {(float)(-sx / 2), 0.0f, (float)(-sz / 2)};
+                        const float hi[3] = {(float)(sx / 2), (float)sy, (float)(sz / 2)};
+                        const float base_col[3] = {(float)ent_geom(a, env, slot, 3), (float)ent_geom(a, env, slot, 4),
+                                                   (float)ent_geom(a, env, slot, 5)};
+                        HV h[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int sel = kBoxSel[f][k];
+                            const float lx = (sel & 1) ? hi[0] : lo[0];
+                            const float ly = (sel & 2) ? hi[1] : lo[1];
+                            const float lz = (sel & 4) ? hi[2] : lo[2];
+                            const float wx = fmaf(cs, lx, sn * lz) + ex;
+                            const float wy = ly + ey;
+                            const float wz = fmaf(cs, lz, -(sn * lx)) + ez;
+                            h[k] = xform(cam, wx, wy, wz);
+                        }
+                        const float n[3] = {fmaf(cs, kBoxN[f][0], sn * kBoxN[f][2]), kBoxN[f][1],
+                                            fmaf(cs, kBoxN[f][2], -(sn * kBoxN[f][0]))};
+                        float col[3];
+                        light(cam, n, base_col, col);
+                        const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+                        vis = setup_poly(a, h, 4, uv, col, -1, o);
+                    }
+                }
+                emit(a, env, lane, vis, o, count, mesh_tris);
+            }
+            s0 = s1;
         }
     }
     if (lane == 0) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
-        a.envhdr[(size_t)env * 4 + 0] = sky[0];
-        a.envhdr[(size_t)env * 4 + 1] = sky[1];
-        a.envhdr[(size_t)env * 4 + 2] = sky[2];
-        a.envhdr[(size_t)env * 4 + 3] = 0.0f;
+        hdr[0] = sky[0]; hdr[1] = sky[1]; hdr[2] = sky[2];
+        hdr[3] = __int_as_float(n_mesh);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            hdr[4 + 4 * i + 0] = cam.m[i][0]; hdr[4 + 4 * i + 1] = cam.m[i][1];
+            hdr[4 + 4 * i + 2] = cam.m[i][2]; hdr[4 + 4 * i + 3] = cam.m[i][3];
+            hdr[20 + i] = cam.L[i]; hdr[24 + i] = cam.amb[i]; hdr[28 + i] = cam.lcol[i];
+        }
+        hdr[16] = cam.p00; hdr[17] = cam.p11; hdr[18] = cam.p22; hdr[19] = cam.p23;
         if (remove_slot >= 0) a.ekind[(size_t)remove_slot * a.N + env] = MW_ENT_NONE;
     }
 }

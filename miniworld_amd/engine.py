@@ -51,6 +51,8 @@ class MwConfig(C.Structure):
         ("light_ambient", MwRange * 3), ("obj_color_bias", MwRange * 3),
         ("cam_height", MwRange), ("cam_fwd_disp", MwRange), ("cam_pitch", MwRange), ("cam_fov_y", MwRange),
         ("gen_args", C.c_double * 8),
+        ("gen_tab", C.c_double * 12),
+        ("gen_colors", C.c_double * 18),
     ]
 
 
@@ -186,6 +188,14 @@ class Engine:
         a = np.ascontiguousarray(rgb_bottom_up, np.uint8)
         assert a.ndim == 3 and a.shape[2] == 3
         self._check(self.lib.mw_upload_texture(self.h, tex_id, a.ctypes.data, a.shape[1], a.shape[0]), "mw_upload_texture")
+
+    def upload_mesh(self, mesh_id: int, verts, norms, texcs, colors, tex_id: int = -1):
+        """Per-face-vertex arrays [ntris][3][k] as built by miniworld_amd.objmesh.ObjMesh."""
+        arrs = [np.ascontiguousarray(a, np.float32) for a in (verts, norms, texcs, colors)]
+        n = arrs[0].shape[0]
+        assert arrs[0].shape == (n, 3, 3) and arrs[1].shape == (n, 3, 3) and arrs[3].shape == (n, 3, 3)
+        self._check(self.lib.mw_upload_mesh(self.h, mesh_id, arrs[0].ctypes.data, arrs[1].ctypes.data,
+                                            arrs[2].ctypes.data, arrs[3].ctypes.data, n, tex_id), "mw_upload_mesh")
 
     def set_geometry(self, env: int, polys: np.ndarray, segs: np.ndarray):
         p = np.ascontiguousarray(polys, POLY_DTYPE)

@@ -101,6 +101,19 @@ def scene_from_env(env) -> dict:
     }
 
 
+def upload_scene_meshes(engine, scene: dict, mesh_ids: dict) -> dict:
+    """Make sure every mesh named by the scene is resident; returns scene-index -> engine mesh id."""
+    from .objmesh import ObjMesh
+    out = {}
+    for i, name in enumerate([str(m) for m in scene.get("mesh_names", [])]):
+        if name not in mesh_ids:
+            mesh_ids[name] = len(mesh_ids)
+            m = ObjMesh.get(name)
+            engine.upload_mesh(mesh_ids[name], m.verts, m.norms, m.texcs, m.colors)
+        out[i] = mesh_ids[name]
+    return out
+
+
 def polys_array(scene: dict, tex_map=None) -> np.ndarray:
     P = len(scene["polys_nv"])
     polys = np.zeros(P, eng.POLY_DTYPE)
@@ -110,8 +123,9 @@ def polys_array(scene: dict, tex_map=None) -> np.ndarray:
     return polys
 
 
-def state_arrays(scenes: list, E: int) -> dict:
-    """mw_set_state arrays for a list of neutral scenes (entity tables padded to E slots)."""
+def state_arrays(scenes: list, E: int, mesh_maps: list | None = None) -> dict:
+    """mw_set_state arrays for a list of neutral scenes (entity tables padded to E slots).
+    mesh_maps[i] translates scene i's mesh indices into engine mesh ids."""
     n = len(scenes)
     st = {
         "agent_pos": np.array([s["agent_pos"] for s in scenes], np.float64),
@@ -134,7 +148,8 @@ def state_arrays(scenes: list, E: int) -> dict:
         if k == 0:
             continue
         st["ent_kind"][i, :k] = s["ents_kind"]
-        st["ent_mesh"][i, :k] = s["ents_mesh"]
+        mm = mesh_maps[i] if mesh_maps else None
+        st["ent_mesh"][i, :k] = [(-1 if m < 0 else (mm[int(m)] if mm else int(m))) for m in s["ents_mesh"]]
         st["ent_static"][i, :k] = s["ents_static"]
         st["ent_pos"][i, :k] = s["ents_pos"]
         st["ent_dir"][i, :k] = s["ents_dir"]
@@ -189,7 +204,7 @@ class EngineBinding:
         self.close()
         caps = (max(16, need[0]), max(8, need[1]), max(8, need[2] + 2))
         cfg = base_config(1, env.obs_width, env.obs_height, caps[2], caps[0], caps[1],
-                          max_visible=min(256, -(-(caps[0] + 6 * caps[2]) // 16) * 16), params_ranges=env.params.as_ranges(),
+                          max_visible=-(-(caps[0] + 6 * caps[2]) // 16) * 16, params_ranges=env.params.as_ranges(),
                           device_id=env.device_id)
         cfg.agent_radius = float(env.agent.radius)
         self.engine = eng.Engine(cfg)
@@ -218,7 +233,8 @@ class EngineBinding:
 
     def push_state(self, env, scene=None):
         scene = scene_from_env(env) if scene is None else scene
-        self.engine.set_state(state_arrays([scene], self.engine.E))
+        mm = upload_scene_meshes(self.engine, scene, self.mesh_ids)
+        self.engine.set_state(state_arrays([scene], self.engine.E, [mm]))
         self._ents = [e for e in env.entities if e is not env.agent]
 
     def _pull_state(self, env):

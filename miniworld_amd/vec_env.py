@@ -18,7 +18,7 @@ import numpy as np
 
 from . import engine as eng
 from . import envs as _envs
-from .scene import base_config, polys_array, scene_from_env, state_arrays
+from .scene import base_config, polys_array, scene_from_env, state_arrays, upload_scene_meshes
 
 _KIND = {
     "MiniWorld-Hallway-v0": ("Hallway", eng.GEN_HALLWAY, eng.TASK_GOTO, 3),
@@ -27,7 +27,7 @@ _KIND = {
     "MiniWorld-Maze-v0": ("Maze", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-MazeS2-v0": ("MazeS2", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-MazeS3-v0": ("MazeS3", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-PickupObjects-v0": ("PickupObjects", eng.GEN_NONE, eng.TASK_PICKUP, 5),
+    "MiniWorld-PickupObjects-v0": ("PickupObjects", eng.GEN_PICKUP, eng.TASK_PICKUP, 5),
 }
 
 
@@ -48,10 +48,19 @@ class MiniWorldVecEnv:
         self.template.reset(seed=seed)
         self._cls, self._env_kwargs = cls, env_kwargs
         sc = scene_from_env(self.template)
-        shared = generator != eng.GEN_NONE or cls_name == "PickupObjects"
+        shared = generator != eng.GEN_NONE
         P, S, E = len(sc["polys_nv"]), len(sc["wall_segs"]), max(1, len(sc["ents_kind"]))
+        pickup_meshes = None
+        if cls_name == "PickupObjects":
+            # any mix of kinds can be generated on the device: all 12 ball / key meshes are resident,
+            # ids ball_<colour> = 0..5, key_<colour> = 6..11 in sorted colour order
+            from .entity import COLOR_NAMES, COLORS, Ball, Box, Key
+            E = max(E, self.template.num_objs)
+            pickup_meshes = [f"ball_{c}" for c in COLOR_NAMES] + [f"key_{c}" for c in COLOR_NAMES]
+            protos = (Ball(COLOR_NAMES[0], size=0.9), Box(COLOR_NAMES[0], size=0.9), Key(COLOR_NAMES[0]))
+            first_mesh = (0, -1, 6)
         cfg = base_config(num_envs, self.template.obs_width, self.template.obs_height, E, P, S,
-                          max_visible=min(256, -(-(P + 6 * E) // 16) * 16),
+                          max_visible=-(-(P + 6 * E) // 16) * 16,
                           params_ranges=self.template.params.as_ranges(), device_id=device_id)
         cfg.shared_geometry = int(shared)
         cfg.task, cfg.goal_ent, cfg.num_objs = task, 0, len(sc["ents_kind"])
@@ -69,9 +78,26 @@ class MiniWorldVecEnv:
                 args += [room.min_x, room.max_x, math.pi, 0.8]
             for i, v in enumerate(args):
                 cfg.gen_args[i] = float(v)
+        if generator == eng.GEN_PICKUP:
+            room = self.template.rooms[0]
+            for i, v in enumerate([room.min_x, room.max_x, room.min_z, room.max_z]):
+                cfg.gen_args[i] = float(v)
+            for k, (proto, fm) in enumerate(zip(protos, first_mesh)):
+                scale = float(getattr(proto, "scale", 1.0))
+                for j, v in enumerate([float(proto.radius), float(proto.height), scale, float(fm)]):
+                    cfg.gen_tab[k * 4 + j] = v
+            for ci, cname in enumerate(COLOR_NAMES):
+                for j in range(3):
+                    cfg.gen_colors[ci * 3 + j] = float(COLORS[cname][j])
         self.engine = eng.Engine(cfg)
         self.host_autoreset = autoreset and generator == eng.GEN_NONE
         self._upload_assets(sc)
+        if pickup_meshes:
+            from .objmesh import ObjMesh
+            for name in pickup_meshes:
+                self.mesh_ids[name] = len(self.mesh_ids)
+                m = ObjMesh.get(name)
+                self.engine.upload_mesh(self.mesh_ids[name], m.verts, m.norms, m.texcs, m.colors)
         dev = self.engine.device
         H, W = self.template.obs_height, self.template.obs_width
         self.obs = torch.zeros((num_envs, H, W, 3), dtype=torch.uint8, device=dev)
@@ -85,7 +111,7 @@ class MiniWorldVecEnv:
     # ------------------------------------------------------------------ assets / worlds
     def _upload_assets(self, sc):
         from . import assets
-        self.tex_ids = {}
+        self.tex_ids, self.mesh_ids = {}, {}
         for i, variant in enumerate([str(v) for v in sc["tex_names"]]):
             self.tex_ids[variant] = i
             self.engine.upload_texture(i, assets.texture_rgb_bottom_up(variant))
@@ -106,7 +132,8 @@ class MiniWorldVecEnv:
             if not self.engine.cfg.shared_geometry:
                 tex_map = {k: self.tex_ids[str(v)] for k, v in enumerate(sc["tex_names"])}
                 self.engine.set_geometry(i, polys_array(sc, tex_map), sc["wall_segs"])
-            self.engine.set_state(state_arrays([sc], self.engine.E), first=i, count=1)
+            mm = upload_scene_meshes(self.engine, sc, self.mesh_ids)
+            self.engine.set_state(state_arrays([sc], self.engine.E, [mm]), first=i, count=1)
 
     # ------------------------------------------------------------------ API
     def reset(self, seed: int | None = None):

@@ -56,7 +56,7 @@ def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_ran
     cfg.num_envs = n_envs
     cfg.obs_width, cfg.obs_height, cfg.msaa = 80, 60, 8
     cfg.max_ents, cfg.max_polys, cfg.max_segs = E, P, S
-    cfg.max_visible = max_visible or min(-(-(P + 6 * E) // 16) * 16, 256)
+    cfg.max_visible = max_visible or -(-(P + 6 * E) // 16) * 16
     cfg.shared_geometry = 1
     cfg.task = task
     cfg.goal_ent = 0
@@ -75,6 +75,8 @@ def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_ran
     polys["v"], polys["uv"], polys["n"] = s0["polys_v"], s0["polys_uv"], s0["polys_n"]
     polys["nv"], polys["tex"] = s0["polys_nv"], s0["polys_tex"]
     e.set_geometry(-1, polys, s0["wall_segs"])
+    from miniworld_amd.scene import upload_scene_meshes
+    e._test_mesh_map = upload_scene_meshes(e, s0, {})
     return e
 
 
@@ -102,7 +104,7 @@ def scene_state_arrays(scenes, E=None):
         if Es == 0:
             continue
         st["ent_kind"][i, :Es] = s["ents_kind"]
-        st["ent_mesh"][i, :Es] = s["ents_mesh"]
+        st["ent_mesh"][i, :Es] = s["ents_mesh"]       # scene mesh index == engine mesh id (upload order)
         st["ent_static"][i, :Es] = s["ents_static"]
         st["ent_pos"][i, :Es] = s["ents_pos"]
         st["ent_dir"][i, :Es] = s["ents_dir"]

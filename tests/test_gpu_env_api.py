@@ -7,10 +7,10 @@ from conftest import golden_cases
 
 pytestmark = pytest.mark.gpu
 
-QUAD_CASES = [c for c in golden_cases() if not c.startswith("pickup")]
+ALL_CASES = golden_cases()
 
 
-@pytest.mark.parametrize("case", QUAD_CASES)
+@pytest.mark.parametrize("case", ALL_CASES)
 def test_single_env_reset_and_trajectory_match_reference(case):
     """envs.X(...).reset(seed) -> first observation == oracle render of the reference's world;
     then the reference's action sequence reproduces its rewards / flags / poses and the stored
@@ -122,3 +122,86 @@ def test_vec_env_full_size_properties():
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     m = outs[0][0].float().mean(dim=(1, 2, 3))
     assert (m > 20).all() and (m < 235).all()
+
+
+def _scene_of_env(vec, st, i):
+    """Neutral scene of env i of a VecEnv from the engine's state arrays (for the oracle)."""
+    from miniworld_amd.scene import scene_from_env
+    sc = scene_from_env(vec.template)
+    E = st["ent_kind"].shape[1]
+    names = sorted(vec.mesh_ids, key=vec.mesh_ids.get)
+    sc["agent_pos"], sc["agent_dir"] = st["agent_pos"][i], st["agent_dir"][i]
+    sc["cam_height"], sc["cam_fwd_disp"], sc["cam_pitch"], sc["cam_fov_y"] = st["cam"][i]
+    sc["sky"], sc["light_pos"] = st["light"][i, 0:3], st["light"][i, 3:6]
+    sc["light_color"], sc["light_ambient"] = st["light"][i, 6:9], st["light"][i, 9:12]
+    sc["ents_kind"], sc["ents_mesh"] = st["ent_kind"][i], st["ent_mesh"][i]
+    sc["ents_pos"], sc["ents_dir"] = st["ent_pos"][i], st["ent_dir"][i]
+    sc["ents_size"], sc["ents_color"] = st["ent_geom"][i, :, 0:3], st["ent_geom"][i, :, 3:6]
+    sc["ents_scale"], sc["ents_radius"], sc["ents_height"] = st["ent_geom"][i, :, 6], st["ent_geom"][i, :, 7], st["ent_geom"][i, :, 8]
+    sc["ents_static"] = st["ent_static"][i]
+    sc["mesh_names"] = np.array(names)
+    return sc
+
+
+def test_vec_env_pickup_device_generator_and_mesh_frames():
+    """PickupObjects with domain randomisation, generated and auto-reset on the device: valid
+    placements, all three kinds appear, pickups happen, frames (ball / key meshes) equal the oracle."""
+    import torch
+    import pyoracle
+    from miniworld_amd.objmesh import ObjMesh
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 128
+    vec = MiniWorldVecEnv("MiniWorld-PickupObjects-v0", n, domain_rand=True, want_depth=True, seed=9)
+    vec.reset()
+    st = vec.engine.get_state()
+    assert (st["ent_kind"][:, :5] != 0).all()
+    kinds = {(int(k), int(m) // 6 if k == 2 else -1) for k, m in zip(st["ent_kind"][:, :5].ravel(), st["ent_mesh"][:, :5].ravel())}
+    assert kinds == {(1, -1), (2, 0), (2, 1)}            # boxes, balls, keys
+    # no two objects (nor the agent) intersect: the reference's own invariant (test_miniworld.py:112)
+    for i in range(n):
+        p = np.concatenate([st["ent_pos"][i, :5][:, [0, 2]], st["agent_pos"][i][None, [0, 2]]])
+        r = np.concatenate([st["ent_geom"][i, :5, 7], [0.4]])
+        d = np.hypot(p[:, None, 0] - p[None, :, 0], p[:, None, 1] - p[None, :, 1]) + np.eye(6) * 1e9
+        assert (d >= r[:, None] + r[None, :] - 1e-12).all()
+        assert (p > r[:, None] - 1e-12).all() and (p < 12 - r[:, None] + 1e-12).all()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    total_reward = 0.0
+    for t in range(300):
+        act = torch.randint(0, 5, (n,), generator=g, device="cuda", dtype=torch.int32)
+        act[torch.rand(n, generator=g, device="cuda") < 0.5] = 2
+        obs, rew, term, trunc = vec.step(act)
+        total_reward += float(rew.sum())
+    vec.engine.check()
+    assert total_reward > 0                                  # something was picked up
+    st = vec.engine.get_state()
+    meshes = {}
+    for name in vec.mesh_ids:
+        m = ObjMesh.get(name)
+        meshes[name] = {"verts": m.verts, "norms": m.norms, "texcs": m.texcs, "colors": m.colors}
+    for i in (0, 17, n - 1):
+        want = pyoracle.render(_scene_of_env(vec, st, i), meshes=meshes)
+        assert np.array_equal(vec.obs[i].cpu().numpy(), want["rgb"]), f"env {i}"
+        assert np.array_equal(vec.depth[i].cpu().numpy(), want["depth"]), f"env {i}"
+    vec.close()
+
+
+def test_vec_env_maze_host_generated_per_env_geometry():
+    """Maze: per-env geometry (510 polygons, 256 segments each), host world generation, frames == oracle."""
+    import torch
+    import pyoracle
+    from miniworld_amd.scene import scene_from_env
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 8
+    vec = MiniWorldVecEnv("MiniWorld-Maze-v0", n, seed=0)
+    vec.reset()
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for t in range(40):
+        vec.step(torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32))
+    vec.engine.check()
+    st = vec.engine.get_state()
+    for i in (0, 3, n - 1):
+        sc = scene_from_env(vec._host_envs[i])
+        sc["agent_pos"], sc["agent_dir"] = st["agent_pos"][i], st["agent_dir"][i]
+        want = pyoracle.render(sc)
+        assert np.array_equal(vec.obs[i].cpu().numpy(), want["rgb"]), f"env {i}"
+    vec.close()

@@ -12,10 +12,10 @@ from conftest import golden_cases
 
 pytestmark = pytest.mark.gpu
 
-QUAD_CASES = [c for c in golden_cases() if not c.startswith("pickup")]
+ALL_CASES = golden_cases()          # Hallway / OneRoom / Maze (quads) and PickupObjects (ball / key meshes)
 
 
-@pytest.mark.parametrize("case", QUAD_CASES)
+@pytest.mark.parametrize("case", ALL_CASES)
 def test_render_matches_golden_and_oracle(case):
     import torch
     import pyoracle
@@ -30,7 +30,7 @@ def test_render_matches_golden_and_oracle(case):
     eng.check()
     rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
     for i, f in enumerate(frames):
-        want = pyoracle.render(scenes[i])
+        want = pyoracle.render(scenes[i], meshes=helpers.golden_meshes(s0))
         # the committed golden equals the live oracle (same machine-independent arithmetic)
         assert np.array_equal(want["rgb"], obs[f]["rgb"]) and np.array_equal(want["z16"], obs[f]["z16"])
         # depth: exact

@@ -13,7 +13,7 @@ from PIL import Image  # noqa: E402
 
 out = os.path.join(ROOT, "gpurun_out", "debug")
 os.makedirs(out, exist_ok=True)
-cases = sys.argv[1:] or ["hallway_s0", "oneroom_s0", "mazes3_s0", "maze_s0"]
+cases = sys.argv[1:] or ["hallway_s0", "oneroom_s0", "mazes3_s0", "maze_s0", "pickup_s0", "pickup_dr_s1"]
 for case in cases:
     s0, tr, meta, obs = helpers.load_case(case)
     frames = sorted(obs)
