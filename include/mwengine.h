@@ -50,7 +50,8 @@ enum {
     MW_GEN_NONE = 0,        /* worlds only come from mw_set_state             */
     MW_GEN_HALLWAY = 1,     /* hallway.py:55-65                               */
     MW_GEN_ONEROOM = 2,     /* oneroom.py:59-62                               */
-    MW_GEN_PICKUP = 3       /* pickupobjects.py:55-81                         */
+    MW_GEN_PICKUP = 3,      /* pickupobjects.py:55-81                         */
+    MW_GEN_MAZE = 4         /* maze.py:73-153 (needs shared_geometry = 0)     */
 };
 
 enum { MW_AUTORESET_OFF = 0, MW_AUTORESET_SAME_STEP = 1 };
@@ -145,6 +146,8 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
 int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_polys,
                     const double *segs, int32_t n_segs);
 /* state injection / inspection (synchronous) */
+/* reads one geometry set back (polys: max_polys entries, segs: max_segs*4 doubles) */
+int mw_get_geometry(mw_engine *e, int32_t env, mw_poly *polys, int32_t *n_polys, double *segs, int32_t *n_segs);
 int mw_set_state(mw_engine *e, int32_t first_env, int32_t count, const mw_state_view *host);
 /* Test hook: host double[num_envs][3] = forward_step, forward_drift, turn_step to use in
  * the next steps instead of the defaults / device RNG draws (miniworld.py:678-680);

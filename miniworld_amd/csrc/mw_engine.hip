@@ -496,6 +496,19 @@ int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_p
     return MW_OK;
 }
 
+int mw_get_geometry(mw_engine *e, int32_t env, mw_poly *polys, int32_t *n_polys, double *segs, int32_t *n_segs)
+{
+    if (!e || !polys || !n_polys || !segs || !n_segs) return fail(e, MW_E_INVALID, "null argument");
+    const int set = e->cfg.shared_geometry ? 0 : env;
+    if (set < 0 || set >= e->n_sets) return fail(e, MW_E_INVALID, "env out of range");
+    HIP_TRY(e, hipDeviceSynchronize());
+    HIP_TRY(e, hipMemcpy(n_polys, e->args.npolys + set, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(n_segs, e->args.nsegs + set, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(polys, e->args.polys + (size_t)set * e->cfg.max_polys, sizeof(mw_poly) * (size_t)e->cfg.max_polys, hipMemcpyDeviceToHost));
+    HIP_TRY(e, hipMemcpy(segs, e->args.segs + (size_t)set * e->cfg.max_segs * 4, 32 * (size_t)e->cfg.max_segs, hipMemcpyDeviceToHost));
+    return MW_OK;
+}
+
 int mw_set_state(mw_engine *e, int32_t first_env, int32_t count, const mw_state_view *host)
 {
     return state_xfer(e, first_env, count, host, true);

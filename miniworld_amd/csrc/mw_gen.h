@@ -78,8 +78,193 @@ __device__ inline void gen_store_box(const MwArgs &a, int env, int slot, double 
     a.egeom[((size_t)8 * E + slot) * N + env] = size;
 }
 
+// ---------------------------------------------------------------- Maze (maze.py:73-153)
+// Per-env geometry is written straight into the env's polygon / segment set in the layout and
+// order Room._gen_static_data + Room._render produce on the host (miniworld.py:286-434): cells
+// row-major, then the connecting rooms in carving order; per room floor, ceiling, kept walls.
+// gen_tab: [0] rows, [1] cols, [2] room_size, [3] gap, [4] wall_height, [5..7] texture ids of
+// floor / ceiling / wall; gen_colors[0..5]: TEX_DENSITY / texture size (u, v) for the same three.
+
+struct MazeRect { double x0, x1, z0, z1; };     // min_x, max_x, min_z, max_z
+
+__device__ inline void maze_emit_room(const MwArgs &a, int set, const double px[4], const double pz[4],
+                                      unsigned keep_walls, int &np, int &ns)
+{
+    mw_poly *polys = const_cast<mw_poly *>(a.polys) + (size_t)set * a.max_polys;
+    double *segs = const_cast<double *>(a.segs) + (size_t)set * a.max_segs * 4;
+    const double h = a.gen_tab[4];
+    const int tex_f = (int)a.gen_tab[5], tex_c = (int)a.gen_tab[6], tex_w = (int)a.gen_tab[7];
+    {   // floor: the outline itself, normal +Y (miniworld.py:408-415), texcoords = (x, z) * density
+        mw_poly &q = polys[np++];
+        for (int k = 0; k < 4; ++k) {
+            q.v[k][0] = (float)px[k]; q.v[k][1] = 0.0f; q.v[k][2] = (float)pz[k];
+            q.uv[k][0] = (float)(px[k] * a.gen_colors[0]); q.uv[k][1] = (float)(pz[k] * a.gen_colors[1]);
+        }
+        q.n[0] = 0.0f; q.n[1] = 1.0f; q.n[2] = 0.0f; q.nv = 4; q.tex = tex_f;
+    }
+    {   // ceiling: flipped outline at wall height, normal -Y (:304-306, 418-425)
+        mw_poly &q = polys[np++];
+        for (int k = 0; k < 4; ++k) {
+            const double x = px[3 - k], z = pz[3 - k];
+            q.v[k][0] = (float)x; q.v[k][1] = (float)(0.0 + h * 1.0); q.v[k][2] = (float)z;
+            q.uv[k][0] = (float)(x * a.gen_colors[2]); q.uv[k][1] = (float)(z * a.gen_colors[3]);
+        }
+        q.n[0] = 0.0f; q.n[1] = -1.0f; q.n[2] = 0.0f; q.nv = 4; q.tex = tex_c;
+    }
+    for (int w = 0; w < 4; ++w) {
+        if (!((keep_walls >> w) & 1u)) continue;
+        const double ax = px[w], az = pz[w], bx0 = px[(w + 1) & 3], bz0 = pz[(w + 1) & 3];
+        const double dx = bx0 - ax, dz = bz0 - az;
+        const double width = sqrt(dx * dx + dz * dz);
+        const double sx = dx / width, sz = dz / width;
+        const double bx = ax + width * sx, bz = az + width * sz;
+        mw_poly &q = polys[np++];
+        q.v[0][0] = (float)ax; q.v[0][1] = 0.0f;     q.v[0][2] = (float)az;
+        q.v[1][0] = (float)ax; q.v[1][1] = (float)h; q.v[1][2] = (float)az;
+        q.v[2][0] = (float)bx; q.v[2][1] = (float)h; q.v[2][2] = (float)bz;
+        q.v[3][0] = (float)bx; q.v[3][1] = 0.0f;     q.v[3][2] = (float)bz;
+        const float u1 = (float)((0 + width) * a.gen_colors[4]), v1 = (float)((0 + h) * a.gen_colors[5]);
+        q.uv[0][0] = 0.0f; q.uv[0][1] = 0.0f; q.uv[1][0] = 0.0f; q.uv[1][1] = v1;
+        q.uv[2][0] = u1;   q.uv[2][1] = v1;   q.uv[3][0] = u1;   q.uv[3][1] = 0.0f;
+        // normal = -cross(b - a, Y) / |.|   (miniworld.py:335-336)
+        const double ex = bx - ax, ez = bz - az, len = sqrt(ez * ez + ex * ex);
+        q.n[0] = (float)(-(-ez) / len); q.n[1] = 0.0f; q.n[2] = (float)(-(ex) / len);
+        q.nv = 4; q.tex = tex_w;
+        segs[ns * 4 + 0] = bx; segs[ns * 4 + 1] = bz; segs[ns * 4 + 2] = ax; segs[ns * 4 + 3] = az;   // [s_p1, s_p0]
+        ++ns;
+    }
+}
+
+__device__ inline MazeRect maze_cell(const MwArgs &a, int i, int j)
+{
+    const double pitch = a.gen_tab[2] + a.gen_tab[3];
+    MazeRect r;
+    r.x0 = i * pitch; r.x1 = r.x0 + a.gen_tab[2];
+    r.z0 = j * pitch; r.z1 = r.z0 + a.gen_tab[2];
+    return r;
+}
+
+// outline of the room connecting cell A to its neighbour B in direction d (0 east, 1 west,
+// 2 north, 3 south) — connect_rooms' [c, b, a, d] (miniworld.py:807-821) for facing rect rooms
+__device__ inline void maze_link_outline(const MazeRect &A, const MazeRect &B, int d, double px[4], double pz[4])
+{
+    switch (d) {
+    case 0: px[0] = B.x0; pz[0] = A.z0; px[1] = A.x1; pz[1] = A.z0; px[2] = A.x1; pz[2] = A.z1; px[3] = B.x0; pz[3] = A.z1; break;
+    case 1: px[0] = B.x1; pz[0] = A.z1; px[1] = A.x0; pz[1] = A.z1; px[2] = A.x0; pz[2] = A.z0; px[3] = B.x1; pz[3] = A.z0; break;
+    case 2: px[0] = A.x0; pz[0] = B.z1; px[1] = A.x0; pz[1] = A.z0; px[2] = A.x1; pz[2] = A.z0; px[3] = A.x1; pz[3] = B.z1; break;
+    default: px[0] = A.x1; pz[0] = B.z0; px[1] = A.x1; pz[1] = A.z1; px[2] = A.x0; pz[2] = A.z1; px[3] = A.x0; pz[3] = B.z0; break;
+    }
+}
+
+#define MW_GEN_WS_BYTES 384     // per-env scratch of the generators (LDS, provided by the caller)
+
+__device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsigned char *ws, double &bx, double &bz,
+                                double &bdir, double &ax, double &az, double &adir)
+{
+    const int rows = (int)a.gen_tab[0], cols = (int)a.gen_tab[1];
+    const int ncell = rows * cols;
+    // direction d: (dj, di) of maze.py:113  (0,1) (0,-1) (-1,0) (1,0); wall of A opened / of B opened
+    const int DI[4] = {1, -1, 0, 0}, DJ[4] = {0, 0, -1, 1};
+    const int OPEN_A[4] = {0, 2, 1, 3}, OPEN_B[4] = {2, 0, 3, 1};
+    // workspace in LDS (keeps the kernels' register budgets small): 6 arrays of 64 bytes
+    unsigned char *open = ws;               // per cell: bit w = wall w replaced by a portal
+    unsigned char *link_cell = ws + 64, *link_dir = ws + 128;
+    unsigned char *st_cell = ws + 192, *st_perm = ws + 256, *st_next = ws + 320;
+    unsigned long long visited = 0ull;
+    for (int k = 0; k < ncell; ++k) open[k] = 0;
+    int nlink = 0, sp = 0;
+    // recursive backtracker (maze.py:100-149), explicit stack; the visiting order of the 4
+    // neighbours is drawn without replacement when a cell is first entered
+    auto enter = [&](int cell) {
+        visited |= 1ull << cell;
+        int pool[4] = {0, 1, 2, 3};
+        unsigned perm = 0;
+        for (int k = 4; k >= 1; --k) {
+            const int idx = (int)rng_below(r, (uint32_t)k);
+            perm |= (unsigned)pool[idx] << (2 * (4 - k));
+            for (int m = idx; m < k - 1; ++m) pool[m] = pool[m + 1];
+        }
+        st_cell[sp] = (unsigned char)cell; st_perm[sp] = (unsigned char)perm; st_next[sp] = 0;
+        ++sp;
+    };
+    enter(0);
+    while (sp > 0) {
+        const int top = sp - 1;
+        if (st_next[top] >= 4) { --sp; continue; }
+        const int d = (st_perm[top] >> (2 * st_next[top])) & 3;
+        st_next[top]++;
+        const int cell = st_cell[top], i = cell % cols, j = cell / cols;
+        const int ni = i + DI[d], nj = j + DJ[d];
+        if (ni < 0 || ni >= cols || nj < 0 || nj >= rows) continue;
+        const int ncellidx = nj * cols + ni;
+        if ((visited >> ncellidx) & 1ull) continue;
+        open[cell] |= (unsigned char)(1u << OPEN_A[d]);
+        open[ncellidx] |= (unsigned char)(1u << OPEN_B[d]);
+        link_cell[nlink] = (unsigned char)cell; link_dir[nlink] = (unsigned char)d; ++nlink;
+        enter(ncellidx);
+    }
+    // ---- geometry ------------------------------------------------------------------------
+    int np = 0, ns = 0;
+    for (int cell = 0; cell < ncell; ++cell) {
+        const MazeRect c = maze_cell(a, cell % cols, cell / cols);
+        const double px[4] = {c.x1, c.x1, c.x0, c.x0}, pz[4] = {c.z1, c.z0, c.z0, c.z1};   // add_rect_room outline
+        maze_emit_room(a, set, px, pz, (~(unsigned)open[cell]) & 15u, np, ns);
+    }
+    for (int k = 0; k < nlink; ++k) {
+        const int cell = link_cell[k], d = link_dir[k];
+        const MazeRect A = maze_cell(a, cell % cols, cell / cols);
+        const MazeRect B = maze_cell(a, cell % cols + DI[d], cell / cols + DJ[d]);
+        double px[4], pz[4];
+        maze_link_outline(A, B, d, px, pz);
+        maze_emit_room(a, set, px, pz, 5u, np, ns);          // walls 1 and 3 are portals (miniworld.py:836-837)
+    }
+    const_cast<int32_t *>(a.npolys)[set] = np;
+    const_cast<int32_t *>(a.nsegs)[set] = ns;
+    // ---- placement: box then agent, room drawn with probability ~ area (miniworld.py:872-905) --
+    const double cell_area = a.gen_tab[2] * a.gen_tab[2], link_area = a.gen_tab[2] * a.gen_tab[3];
+    const double total = ncell * cell_area + nlink * link_area;
+    const double radii[2] = {sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2.0, a.agent_radius};
+    double out[2][2];
+    for (int who = 0; who < 2; ++who) {
+        const double rad = radii[who];
+        bool placed = false;
+        for (int attempt = 0; attempt < 100000 && !placed; ++attempt) {
+            const double u = rng_double(r) * total;
+            MazeRect rr;
+            if (u < ncell * cell_area) {
+                int cell = (int)(u / cell_area);
+                cell = cell < ncell ? cell : ncell - 1;
+                rr = maze_cell(a, cell % cols, cell / cols);
+            } else {
+                int k = (int)((u - ncell * cell_area) / link_area);
+                k = k < nlink ? k : nlink - 1;
+                const int cell = link_cell[k], d = link_dir[k];
+                const MazeRect A = maze_cell(a, cell % cols, cell / cols);
+                const MazeRect B = maze_cell(a, cell % cols + DI[d], cell / cols + DJ[d]);
+                double px[4], pz[4];
+                maze_link_outline(A, B, d, px, pz);
+                rr.x0 = fmin(fmin(px[0], px[1]), fmin(px[2], px[3])); rr.x1 = fmax(fmax(px[0], px[1]), fmax(px[2], px[3]));
+                rr.z0 = fmin(fmin(pz[0], pz[1]), fmin(pz[2], pz[3])); rr.z1 = fmax(fmax(pz[0], pz[1]), fmax(pz[2], pz[3]));
+            }
+            const double x = rng_uniform(r, rr.x0 - rad, rr.x1 + rad);
+            const double z = rng_uniform(r, rr.z0 - rad, rr.z1 + rad);
+            if (!(x > rr.x0 && x < rr.x1 && z > rr.z0 && z < rr.z1)) continue;        // Room.point_inside
+            if (gen_hits_wall(a, set, x, z, rad)) continue;
+            if (who == 1) {
+                const double dx = out[0][0] - x, dz = out[0][1] - z;
+                if (sqrt(dx * dx + dz * dz) < rad + radii[0]) continue;
+            }
+            out[who][0] = x; out[who][1] = z;
+            placed = true;
+        }
+        if (!placed) { atomicOr(a.status, MW_ST_PLACEMENT_FAIL); out[who][0] = 1.5; out[who][1] = 1.5; }
+        if (who == 0) bdir = rng_uniform(r, -kGenPi, kGenPi); else adir = rng_uniform(r, -kGenPi, kGenPi);
+    }
+    bx = out[0][0]; bz = out[0][1]; ax = out[1][0]; az = out[1][1];
+}
+
 // One full reset of env `env`.  Writes every per-env state array.
-__device__ inline void generate_world(const MwArgs &a, int env)
+__device__ inline void generate_world(const MwArgs &a, int env, unsigned char *ws)
 {
     const int set = a.shared_geom ? 0 : env;
     const bool dr = a.domain_rand != 0;
@@ -87,18 +272,24 @@ __device__ inline void generate_world(const MwArgs &a, int env)
     const size_t N = a.N;
     for (int s = 0; s < a.E; ++s) a.ekind[(size_t)s * N + env] = MW_ENT_NONE;
     double ax = 0, az = 0, adir = 0;
-    if (a.generator == MW_GEN_HALLWAY || a.generator == MW_GEN_ONEROOM) {
-        // the red box (hallway.py:59, oneroom.py:61), then the agent (hallway.py:62-65, oneroom.py:62)
-        const double size = a.gen_args[7];
-        const double brad = sqrt(size * size + size * size) / 2.0;
-        double bx, bz;
-        gen_place(a, env, set, r, brad, 0, a.gen_args[4], a.gen_args[1], bx, bz);
-        const double bdir = rng_uniform(r, -kGenPi, kGenPi);
+    if (a.generator == MW_GEN_HALLWAY || a.generator == MW_GEN_ONEROOM || a.generator == MW_GEN_MAZE) {
+        // the red box (hallway.py:59, oneroom.py:61, maze.py:151), then the agent
+        const double size = a.generator == MW_GEN_MAZE ? 0.8 : a.gen_args[7];
         double col[3] = {1.0, 0.0, 0.0};                       // COLORS["red"] entity.py:31
-        // written first so that the agent's placement sees it; colour bias applied below
-        gen_store_box(a, env, 0, bx, bz, bdir, size, col);
-        adir = rng_uniform(r, -a.gen_args[6], a.gen_args[6]);
-        gen_place(a, env, set, r, a.agent_radius, 1, a.gen_args[0], a.gen_args[5], ax, az);
+        if (a.generator == MW_GEN_MAZE) {
+            double bx, bz, bdir;
+            gen_maze(a, env, set, r, ws, bx, bz, bdir, ax, az, adir);
+            gen_store_box(a, env, 0, bx, bz, bdir, size, col);
+        } else {
+            const double brad = sqrt(size * size + size * size) / 2.0;
+            double bx, bz;
+            gen_place(a, env, set, r, brad, 0, a.gen_args[4], a.gen_args[1], bx, bz);
+            const double bdir = rng_uniform(r, -kGenPi, kGenPi);
+            // written first so that the agent's placement sees it; colour bias applied below
+            gen_store_box(a, env, 0, bx, bz, bdir, size, col);
+            adir = rng_uniform(r, -a.gen_args[6], a.gen_args[6]);
+            gen_place(a, env, set, r, a.agent_radius, 1, a.gen_args[0], a.gen_args[5], ax, az);
+        }
         // per-episode parameters (miniworld.py:576-578), then entity randomisation (:584-585)
         for (int k = 0; k < 3; ++k) a.light[(size_t)(0 + k) * N + env] = gen_param(r, a.sky[k], dr);
         for (int k = 0; k < 3; ++k) a.light[(size_t)(3 + k) * N + env] = gen_param(r, a.light_pos[k], dr);

@@ -3,8 +3,9 @@
 
 extern "C" __global__ __launch_bounds__(64) void mw_reset_kernel(MwArgs a, const uint8_t *__restrict__ mask, int force_all)
 {
+    __shared__ unsigned char ws[64][MW_GEN_WS_BYTES];
     const int env = blockIdx.x * 64 + threadIdx.x;
     if (env >= a.N) return;
     if (!force_all && !mask[env]) return;
-    mw::generate_world(a, env);
+    mw::generate_world(a, env, ws[threadIdx.x]);
 }

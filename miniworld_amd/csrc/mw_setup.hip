@@ -424,6 +424,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
     MwArgs a, int do_step, const int32_t *__restrict__ actions, float *__restrict__ reward,
     uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
 {
+    __shared__ unsigned char gen_ws[MW_GEN_WS_BYTES];
     const int env = blockIdx.x;
     const int lane = threadIdx.x;
     StepCtx c{a, env, lane, a.shared_geom ? 0 : env, 0, 0, 0, 0, 0, -1, -1, {0, 0, 0}, 0};
@@ -537,7 +538,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
         // next episode (the reference leaves the reset to the caller, scripts/benchmark.py:36-37)
         regenerated = (tm | tr) != 0;
         if (regenerated) {
-            if (lane == 0) mw::generate_world(a, env);
+            if (lane == 0) mw::generate_world(a, env, gen_ws);
             __syncthreads();
             c.px = a.ax[env]; c.py = a.ay[env]; c.pz = a.az[env]; c.dir = a.adir[env];
             c.carry = -1; c.live = -1;

@@ -19,12 +19,12 @@ LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
 ABI_VERSION = 1
 ENT_NONE, ENT_BOX, ENT_MESH = 0, 1, 2
 TASK_NONE, TASK_GOTO, TASK_PICKUP = 0, 1, 2
-GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP = 0, 1, 2, 3
+GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE = 0, 1, 2, 3, 4
 AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
 
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
-    "mw_set_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
+    "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
     "mw_step", "mw_render", "mw_check", "mw_kernel_time_ms",
 ]
 
@@ -132,6 +132,7 @@ def load_library():
     L.mw_upload_texture.argtypes = [vp, i32, vp, i32, i32]
     L.mw_upload_mesh.argtypes = [vp, i32, vp, vp, vp, vp, i32, i32]
     L.mw_set_geometry.argtypes = [vp, i32, vp, i32, vp, i32]
+    L.mw_get_geometry.argtypes = [vp, i32, vp, C.POINTER(i32), vp, C.POINTER(i32)]
     L.mw_set_state.argtypes = [vp, i32, i32, C.POINTER(MwStateView)]
     L.mw_get_state.argtypes = [vp, i32, i32, C.POINTER(MwStateView)]
     L.mw_set_step_params.argtypes = [vp, vp]
@@ -201,6 +202,14 @@ class Engine:
         p = np.ascontiguousarray(polys, POLY_DTYPE)
         s = np.ascontiguousarray(segs, np.float64).reshape(-1, 4)
         self._check(self.lib.mw_set_geometry(self.h, env, p.ctypes.data, len(p), s.ctypes.data, len(s)), "mw_set_geometry")
+
+    def get_geometry(self, env: int):
+        polys = np.zeros(self.cfg.max_polys, POLY_DTYPE)
+        segs = np.zeros((self.cfg.max_segs, 2, 2), np.float64)
+        npoly, nseg = C.c_int32(), C.c_int32()
+        self._check(self.lib.mw_get_geometry(self.h, env, polys.ctypes.data, C.byref(npoly), segs.ctypes.data,
+                                             C.byref(nseg)), "mw_get_geometry")
+        return polys[:npoly.value], segs[:nseg.value]
 
     def _view(self, arrays: dict, count: int, alloc: bool):
         view, keep = MwStateView(), {}

@@ -24,9 +24,9 @@ _KIND = {
     "MiniWorld-Hallway-v0": ("Hallway", eng.GEN_HALLWAY, eng.TASK_GOTO, 3),
     "MiniWorld-OneRoom-v0": ("OneRoom", eng.GEN_ONEROOM, eng.TASK_GOTO, 3),
     "MiniWorld-OneRoomS6-v0": ("OneRoomS6", eng.GEN_ONEROOM, eng.TASK_GOTO, 3),
-    "MiniWorld-Maze-v0": ("Maze", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-MazeS2-v0": ("MazeS2", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-MazeS3-v0": ("MazeS3", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-Maze-v0": ("Maze", eng.GEN_MAZE, eng.TASK_GOTO, 3),
+    "MiniWorld-MazeS2-v0": ("MazeS2", eng.GEN_MAZE, eng.TASK_GOTO, 3),
+    "MiniWorld-MazeS3-v0": ("MazeS3", eng.GEN_MAZE, eng.TASK_GOTO, 3),
     "MiniWorld-PickupObjects-v0": ("PickupObjects", eng.GEN_PICKUP, eng.TASK_PICKUP, 5),
 }
 
@@ -48,7 +48,7 @@ class MiniWorldVecEnv:
         self.template.reset(seed=seed)
         self._cls, self._env_kwargs = cls, env_kwargs
         sc = scene_from_env(self.template)
-        shared = generator != eng.GEN_NONE
+        shared = generator not in (eng.GEN_NONE, eng.GEN_MAZE)
         P, S, E = len(sc["polys_nv"]), len(sc["wall_segs"]), max(1, len(sc["ents_kind"]))
         pickup_meshes = None
         if cls_name == "PickupObjects":
@@ -78,6 +78,17 @@ class MiniWorldVecEnv:
                 args += [room.min_x, room.max_x, math.pi, 0.8]
             for i, v in enumerate(args):
                 cfg.gen_args[i] = float(v)
+        if generator == eng.GEN_MAZE:
+            t = self.template
+            r0 = t.rooms[0]
+            texs = [r0.floor_tex, r0.ceil_tex, r0.wall_tex]
+            names = [str(v) for v in sc["tex_names"]]
+            vals = [t.num_rows, t.num_cols, t.room_size, t.gap_size, r0.wall_height] + [names.index(x.variant) for x in texs]
+            for i, v in enumerate(vals):
+                cfg.gen_tab[i] = float(v)
+            for k, x in enumerate(texs):
+                cfg.gen_colors[2 * k] = 512 / x.width
+                cfg.gen_colors[2 * k + 1] = 512 / x.height
         if generator == eng.GEN_PICKUP:
             room = self.template.rooms[0]
             for i, v in enumerate([room.min_x, room.max_x, room.min_z, room.max_z]):
@@ -117,6 +128,9 @@ class MiniWorldVecEnv:
             self.engine.upload_texture(i, assets.texture_rgb_bottom_up(variant))
         if self.engine.cfg.shared_geometry:
             self.engine.set_geometry(-1, polys_array(sc), sc["wall_segs"])
+
+    def host_generate(self, indices, seeds):
+        return self._host_generate(indices, seeds)
 
     def _host_generate(self, indices, seeds):
         """Host world generation (reference-compatible stream) for envs without a device generator."""

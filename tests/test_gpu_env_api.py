@@ -185,23 +185,106 @@ def test_vec_env_pickup_device_generator_and_mesh_frames():
     vec.close()
 
 
-def test_vec_env_maze_host_generated_per_env_geometry():
-    """Maze: per-env geometry (510 polygons, 256 segments each), host world generation, frames == oracle."""
+def _links_from_device_polys(polys, room_size=3.0, pitch=3.25):
+    """Recover (i, j, direction) of every connecting room from a device-generated maze."""
+    floors = [k for k in range(len(polys)) if polys["n"][k][1] == 1.0]
+    links = []
+    for k in floors[64:]:
+        P0, P1 = polys["v"][k][0], polys["v"][k][1]
+        if P0[2] == P1[2]:
+            if P0[0] > P1[0]:
+                links.append((round((P1[0] - room_size) / pitch), round(P1[2] / pitch), 0))                  # east
+            else:
+                links.append((round(P1[0] / pitch), round((P1[2] - room_size) / pitch), 1))                  # west
+        elif P0[2] < P1[2]:
+            links.append((round(P1[0] / pitch), round(P1[2] / pitch), 2))                                    # north
+        else:
+            links.append((round((P1[0] - room_size) / pitch), round((P1[2] - room_size) / pitch), 3))        # south
+    return links
+
+
+def test_vec_env_maze_device_generator_matches_host_geometry():
+    """Maze generated on the device (recursive backtracker, per-env geometry): a spanning tree of
+    the 8x8 grid; every polygon / texcoord / normal / collision segment equals what the host world
+    builder (itself seed-exact with the reference) produces for the same carving order; placements
+    are collision free; frames equal the oracle; episodes auto-reset with fresh mazes."""
     import torch
+    import pyoracle
+    from miniworld_amd import envs
+    from miniworld_amd.entity import Box
+    from miniworld_amd.scene import scene_from_env
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    DI, DJ = (1, -1, 0, 0), (0, 0, -1, 1)
+
+    class FixedMaze(envs.Maze):
+        def __init__(self, links):
+            self._links = links
+            super().__init__(host_only=True)
+
+        def _gen_world(self):
+            pitch = self.room_size + self.gap_size
+            grid = [[self.add_rect_room(min_x=i * pitch, max_x=i * pitch + self.room_size, min_z=j * pitch,
+                                        max_z=j * pitch + self.room_size, wall_tex="brick_wall")
+                     for i in range(self.num_cols)] for j in range(self.num_rows)]
+            for i, j, d in self._links:
+                room, nb = grid[j][i], grid[j + DJ[d]][i + DI[d]]
+                if DI[d] == 0:
+                    self.connect_rooms(room, nb, min_x=room.min_x, max_x=room.max_x)
+                else:
+                    self.connect_rooms(room, nb, min_z=room.min_z, max_z=room.max_z)
+            self.box = self.place_entity(Box(color="red"))
+            self.place_agent()
+
+    n = 16
+    vec = MiniWorldVecEnv("MiniWorld-Maze-v0", n, seed=3)
+    vec.reset()
+    vec.engine.check()
+    st = vec.engine.get_state()
+    seen = set()
+    for i in (0, 5, n - 1):
+        polys, segs = vec.engine.get_geometry(i)
+        assert len(polys) == 510 and len(segs) == 256
+        links = _links_from_device_polys(polys)
+        assert len(links) == 63
+        # spanning tree: every cell reached exactly once
+        reached = {(0, 0)}
+        for ci, cj, d in links:
+            assert (ci, cj) in reached
+            nxt = (ci + DI[d], cj + DJ[d])
+            assert nxt not in reached
+            reached.add(nxt)
+        assert len(reached) == 64
+        seen.add(tuple(links))
+        host = FixedMaze(links)
+        sc = scene_from_env(host)
+        for key, field in (("polys_v", "v"), ("polys_uv", "uv"), ("polys_n", "n"), ("polys_nv", "nv"), ("polys_tex", "tex")):
+            assert np.array_equal(sc[key], polys[field]), (i, key)
+        assert np.array_equal(sc["wall_segs"], segs)
+        # placement validity + frame parity
+        sc["agent_pos"], sc["agent_dir"] = st["agent_pos"][i], st["agent_dir"][i]
+        sc["ents_pos"], sc["ents_dir"] = st["ent_pos"][i, :1], st["ent_dir"][i, :1]
+        dyn = pyoracle.Dynamics(sc, pyoracle.TASK_GOTO, 1536)
+        assert dyn.intersect(-1, st["agent_pos"][i, 0], st["agent_pos"][i, 2], 0.4) == 0
+        assert np.array_equal(vec.obs[i].cpu().numpy(), pyoracle.render(sc)["rgb"])
+    assert len(seen) == 3                                        # different mazes per env
+    # stepping + auto-reset (forward-biased so that some episode ends)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for t in range(60):
+        vec.step(torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32))
+    vec.engine.check()
+    vec.close()
+
+
+def test_vec_env_host_generation_path():
+    """Worlds can also be generated on the host (reference-compatible numpy stream) and injected."""
     import pyoracle
     from miniworld_amd.scene import scene_from_env
     from miniworld_amd.vec_env import MiniWorldVecEnv
-    n = 8
-    vec = MiniWorldVecEnv("MiniWorld-Maze-v0", n, seed=0)
-    vec.reset()
-    g = torch.Generator(device="cuda").manual_seed(2)
-    for t in range(40):
-        vec.step(torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32))
-    vec.engine.check()
+    vec = MiniWorldVecEnv("MiniWorld-Maze-v0", 4, seed=0)
+    vec.host_generate(range(4), [0, 1, 2, 3])
+    vec.engine.render(vec.obs, None)
     st = vec.engine.get_state()
-    for i in (0, 3, n - 1):
-        sc = scene_from_env(vec._host_envs[i])
-        sc["agent_pos"], sc["agent_dir"] = st["agent_pos"][i], st["agent_dir"][i]
-        want = pyoracle.render(sc)
-        assert np.array_equal(vec.obs[i].cpu().numpy(), want["rgb"]), f"env {i}"
+    s0, tr, meta, obs = helpers.load_case("maze_s0")
+    assert np.array_equal(vec.obs[0].cpu().numpy(), obs[0]["rgb"])       # seed 0 == the reference's reset(seed=0)
+    assert np.array_equal(st["agent_pos"][0], s0["agent_pos"])
     vec.close()
