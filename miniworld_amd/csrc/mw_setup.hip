@@ -252,93 +252,101 @@ __device__ inline float below(float x)
     return __uint_as_float(x > 0.0f ? b - 1u : b + 1u);
 }
 
-struct PrimOut {
-    float rr[MW_RASTER_REC];
-    float sr[MW_SHADE_REC];
-    float tmin[4];
+// R4 is split in two so that nothing big stays live across the ordered compaction: cull_poly()
+// decides visibility (orientation + conservative tile bounds), write_poly() derives the records of
+// a visible polygon and stores them straight into the env's lists.
+struct PolyGeom {
+    float ga[3], gb[3], gc[3];      // interpolation basis G0 = edge(1->2), G1 = edge(2->0), G2 = edge(0->1)
+    float D;
+    uint32_t bbox;                  // tile bounds tx0 | tx1<<8 | ty0<<16 | ty1<<24
 };
 
-// R4: setup of one flat-shaded polygon.  Returns false when culled.
-__device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float uv[3][2], const float col[3],
-                           int tex, PrimOut &o)
+__device__ bool cull_poly(const MwArgs &a, const HV h[4], int nv, PolyGeom &g)
 {
-    float ga[3], gb[3], gc[3];
-    edge_coef(h[1], h[2], ga[0], gb[0], gc[0]);
-    edge_coef(h[2], h[0], ga[1], gb[1], gc[1]);
-    edge_coef(h[0], h[1], ga[2], gb[2], gc[2]);
-    const float D = fmaf(h[0].hx, ga[0], fmaf(h[0].hy, gb[0], h[0].hw * gc[0]));
-    if (!(D > 0.0f)) return false;
+    edge_coef(h[1], h[2], g.ga[0], g.gb[0], g.gc[0]);
+    edge_coef(h[2], h[0], g.ga[1], g.gb[1], g.gc[1]);
+    edge_coef(h[0], h[1], g.ga[2], g.gb[2], g.gc[2]);
+    g.D = fmaf(h[0].hx, g.ga[0], fmaf(h[0].hy, g.gb[0], h[0].hw * g.gc[0]));
+    if (!(g.D > 0.0f)) return false;          // back-face cull (miniworld.py:512)
     // conservative screen bounds -> tile range.  The polygon is clipped against w >= 0.01 (well in
     // front of the 0.04 near plane) only to bound its projection; coverage itself never clips (R4).
-    int tx0, ty0, tx1, ty1;
-    {
-        const float wc = 0.01f;
-        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
-        bool some = false;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (k < nv) {
-                const HV p = h[k];
-                const HV q = (k + 1 == nv || k == 3) ? h[0] : h[k < 3 ? k + 1 : 0];
-                const bool pin = p.hw >= wc, qin = q.hw >= wc;
-                if (pin) {
-                    const float X = p.hx / p.hw, Y = p.hy / p.hw;
-                    xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
-                    some = true;
-                }
-                if (pin != qin) {
-                    const float t = (wc - p.hw) / (q.hw - p.hw);
-                    const float X = fmaf(t, q.hx - p.hx, p.hx) / wc, Y = fmaf(t, q.hy - p.hy, p.hy) / wc;
-                    xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
-                    some = true;
-                }
-            }
-        }
-        if (!some) return false;                         // entirely behind the eye
-        // generous margin: the clipped outline is computed in float and huge coordinates lose precision
-        const float mx = 1.0f + 1e-4f * fmaxf(fabsf(xmin), fabsf(xmax)), my = 1.0f + 1e-4f * fmaxf(fabsf(ymin), fabsf(ymax));
-        if (xmax + mx < 0.0f || ymax + my < 0.0f || xmin - mx > (float)a.W || ymin - my > (float)a.H) return false;
-        const float fx0 = fminf(fmaxf(floorf(xmin - mx), 0.0f), (float)(a.W - 1));
-        const float fx1 = fminf(fmaxf(floorf(xmax + mx), 0.0f), (float)(a.W - 1));
-        const float fy0 = fminf(fmaxf(floorf(ymin - my), 0.0f), (float)(a.H - 1));
-        const float fy1 = fminf(fmaxf(floorf(ymax + my), 0.0f), (float)(a.H - 1));
-        tx0 = (int)fx0 / MW_TILE_W; tx1 = (int)fx1 / MW_TILE_W;
-        ty0 = (int)fy0 / MW_TILE_H; ty1 = (int)fy1 / MW_TILE_H;
-    }
+    const float wc = 0.01f;
+    float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+    bool some = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        float ea = 0.0f, eb = 0.0f, ec = 1.0f;       // always-true edge for triangles
+        if (k < nv) {
+            const HV p = h[k];
+            const HV q = (k + 1 == nv || k == 3) ? h[0] : h[k < 3 ? k + 1 : 0];
+            const bool pin = p.hw >= wc, qin = q.hw >= wc;
+            if (pin) {
+                const float X = p.hx / p.hw, Y = p.hy / p.hw;
+                xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+                some = true;
+            }
+            if (pin != qin) {
+                const float t = (wc - p.hw) / (q.hw - p.hw);
+                const float X = fmaf(t, q.hx - p.hx, p.hx) / wc, Y = fmaf(t, q.hy - p.hy, p.hy) / wc;
+                xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+                some = true;
+            }
+        }
+    }
+    if (!some) return false;                         // entirely behind the eye
+    // generous margin: the clipped outline is computed in float and huge coordinates lose precision
+    const float mx = 1.0f + 1e-4f * fmaxf(fabsf(xmin), fabsf(xmax)), my = 1.0f + 1e-4f * fmaxf(fabsf(ymin), fabsf(ymax));
+    if (xmax + mx < 0.0f || ymax + my < 0.0f || xmin - mx > (float)a.W || ymin - my > (float)a.H) return false;
+    const float fx0 = fminf(fmaxf(floorf(xmin - mx), 0.0f), (float)(a.W - 1));
+    const float fx1 = fminf(fmaxf(floorf(xmax + mx), 0.0f), (float)(a.W - 1));
+    const float fy0 = fminf(fmaxf(floorf(ymin - my), 0.0f), (float)(a.H - 1));
+    const float fy1 = fminf(fmaxf(floorf(ymax + my), 0.0f), (float)(a.H - 1));
+    g.bbox = (uint32_t)((int)fx0 / MW_TILE_W) | ((uint32_t)((int)fx1 / MW_TILE_W) << 8) |
+             ((uint32_t)((int)fy0 / MW_TILE_H) << 16) | ((uint32_t)((int)fy1 / MW_TILE_H) << 24);
+    return true;
+}
+
+__device__ void write_poly(const MwArgs &a, int env, int idx, uint32_t draw_id, const HV h[4], int nv,
+                           const PolyGeom &g, const float uv[3][2], const float col[3], int tex)
+{
+    float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
+    float4 *sr = reinterpret_cast<float4 *>(a.rec_shade + ((size_t)env * a.max_vis + idx) * MW_SHADE_REC);
+    float4 *cr = reinterpret_cast<float4 *>(a.rec_cull + ((size_t)env * a.max_vis + idx) * MW_CULL_REC);
+    float ea[4], eb[4], ec[4], tmaxv[4], tminv[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ea[k] = 0.0f; eb[k] = 0.0f; ec[k] = 1.0f;       // always-true edge for triangles
         if (k < nv) {
             const HV nxt = (k + 1 == nv || k == 3) ? h[0] : h[k < 3 ? k + 1 : 0];
-            edge_coef(h[k], nxt, ea, eb, ec);
+            edge_coef(h[k], nxt, ea[k], eb[k], ec[k]);
         }
-        const bool tl = (ea > 0.0f) || (ea == 0.0f && eb > 0.0f);
-        o.rr[k] = ea; o.rr[4 + k] = eb; o.rr[8 + k] = ec;
+        const bool tl = (ea[k] > 0.0f) || (ea[k] == 0.0f && eb[k] > 0.0f);
+        float thr[8];
         float tmax = -1e30f, tmin = 1e30f;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const float thr = -fmaf(ea, kSampleDx[s], eb * kSampleDy[s]);
-            const float adj = (k < nv && tl) ? below(thr) : thr;
-            o.rr[16 + k * 8 + s] = adj;
-            tmax = fmaxf(tmax, adj);
-            tmin = fminf(tmin, adj);
+            const float t = -fmaf(ea[k], kSampleDx[s], eb[k] * kSampleDy[s]);
+            thr[s] = (k < nv && tl) ? below(t) : t;      // top-left tie rule folded into the threshold
+            tmax = fmaxf(tmax, thr[s]);
+            tmin = fminf(tmin, thr[s]);
         }
-        o.rr[57 + k] = tmax;        // E > tmax  =>  every sample of the pixel is inside edge k
-        o.tmin[k] = tmin;           // E <= tmin =>  no sample of the pixel is inside edge k
+        rr[4 + 2 * k] = make_float4(thr[0], thr[1], thr[2], thr[3]);
+        rr[5 + 2 * k] = make_float4(thr[4], thr[5], thr[6], thr[7]);
+        tmaxv[k] = tmax;            // E > tmax  =>  every sample of the pixel is inside edge k
+        tminv[k] = tmin;            // E <= tmin =>  no sample of the pixel is inside edge k
     }
-    const float invD = 1.0f / D;
-    const float ta = fmaf(h[2].cz, ga[2], fmaf(h[1].cz, ga[1], h[0].cz * ga[0]));
-    const float tb = fmaf(h[2].cz, gb[2], fmaf(h[1].cz, gb[1], h[0].cz * gb[0]));
-    const float tc = fmaf(h[2].cz, gc[2], fmaf(h[1].cz, gc[1], h[0].cz * gc[0]));
-    const float zx = (ta * invD) * 0.5f, zy = (tb * invD) * 0.5f;
-    o.rr[12] = zx; o.rr[13] = zy; o.rr[14] = fmaf(tc * invD, 0.5f, 0.5f);
-    o.rr[15] = __uint_as_float((uint32_t)tx0 | ((uint32_t)tx1 << 8) | ((uint32_t)ty0 << 16) | ((uint32_t)ty1 << 24));
+    const float invD = 1.0f / g.D;
+    const float ta = fmaf(h[2].cz, g.ga[2], fmaf(h[1].cz, g.ga[1], h[0].cz * g.ga[0]));
+    const float tb = fmaf(h[2].cz, g.gb[2], fmaf(h[1].cz, g.gb[1], h[0].cz * g.gb[0]));
+    const float tc = fmaf(h[2].cz, g.gc[2], fmaf(h[1].cz, g.gc[1], h[0].cz * g.gc[0]));
+    const float zx = (ta * invD) * 0.5f, zy = (tb * invD) * 0.5f, zc = fmaf(tc * invD, 0.5f, 0.5f);
+    float zo[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) o.rr[48 + s] = fmaf(zx, kSampleDx[s], zy * kSampleDy[s]);
+    for (int s = 0; s < 8; ++s) zo[s] = fmaf(zx, kSampleDx[s], zy * kSampleDy[s]);
     // may_clip: can a sample inside this polygon fail the near / far test of R6?  Conservative:
     // far  - some vertex in front of the eye is deeper than 99 m;
     // near - some vertex is nearer than 5 cm AND the polygon's 1/w plane exceeds 1/0.05 at one of
     //        the screen corners (1/w is linear on screen, so its maximum is at a corner).
+    const float Wa = (g.ga[0] + g.ga[1]) + g.ga[2], Wb = (g.gb[0] + g.gb[1]) + g.gb[2], Wc = (g.gc[0] + g.gc[1]) + g.gc[2];
     bool may_clip = false;
     {
         float wmin = 1e30f, wmax = -1e30f;
@@ -347,80 +355,59 @@ __device__ bool setup_poly(const MwArgs &a, const HV h[4], int nv, const float u
             if (k < nv) { wmin = fminf(wmin, h[k].hw); wmax = fmaxf(wmax, h[k].hw); }
         may_clip |= !(wmax <= 99.0f);
         if (!(wmin >= 0.05f)) {
-            const float Wa = ((ga[0] + ga[1]) + ga[2]) * invD, Wb = ((gb[0] + gb[1]) + gb[2]) * invD,
-                        Wc = ((gc[0] + gc[1]) + gc[2]) * invD;
+            const float na = Wa * invD, nb = Wb * invD, nc = Wc * invD;
             const float fw = (float)a.W, fh = (float)a.H;
-            const float c00 = Wc, c10 = fmaf(Wa, fw, Wc), c01 = fmaf(Wb, fh, Wc), c11 = fmaf(Wa, fw, fmaf(Wb, fh, Wc));
-            const float cmax = fmaxf(fmaxf(c00, c10), fmaxf(c01, c11));
-            may_clip |= !(cmax <= 20.0f);
+            const float c00 = nc, c10 = fmaf(na, fw, nc), c01 = fmaf(nb, fh, nc), c11 = fmaf(na, fw, fmaf(nb, fh, nc));
+            may_clip |= !(fmaxf(fmaxf(c00, c10), fmaxf(c01, c11)) <= 20.0f);
         }
     }
-    o.rr[56] = __uint_as_float(may_clip ? 1u : 0u);
-    o.rr[61] = 0.0f;            // draw id, filled in by emit()
-    o.rr[62] = 0.0f; o.rr[63] = 0.0f;
-    // shade record
+    const float flag = __uint_as_float(may_clip ? 1u : 0u);
+    rr[0] = make_float4(ea[0], ea[1], ea[2], ea[3]);
+    rr[1] = make_float4(eb[0], eb[1], eb[2], eb[3]);
+    rr[2] = make_float4(ec[0], ec[1], ec[2], ec[3]);
+    rr[3] = make_float4(zx, zy, zc, __uint_as_float(g.bbox));
+    rr[12] = make_float4(zo[0], zo[1], zo[2], zo[3]);
+    rr[13] = make_float4(zo[4], zo[5], zo[6], zo[7]);
+    rr[14] = make_float4(flag, tmaxv[0], tmaxv[1], tmaxv[2]);
+    rr[15] = make_float4(tmaxv[3], __uint_as_float(draw_id), 0.0f, 0.0f);       // draw id = list index + mesh triangles drawn before
+    cr[0] = rr[0]; cr[1] = rr[1]; cr[2] = rr[2];
+    cr[3] = make_float4(tminv[0], tminv[1], tminv[2], tminv[3]);
+    cr[4] = make_float4(tmaxv[0], tmaxv[1], tmaxv[2], tmaxv[3]);
+    cr[5] = make_float4(flag, 0.0f, 0.0f, 0.0f);
+    // shade record: attribute planes (unnormalised), face colour, texture, depth plane again
     float U[3] = {0, 0, 0}, V[3] = {0, 0, 0};
     if (tex >= 0) {
-        U[0] = fmaf(uv[2][0], ga[2], fmaf(uv[1][0], ga[1], uv[0][0] * ga[0]));
-        U[1] = fmaf(uv[2][0], gb[2], fmaf(uv[1][0], gb[1], uv[0][0] * gb[0]));
-        U[2] = fmaf(uv[2][0], gc[2], fmaf(uv[1][0], gc[1], uv[0][0] * gc[0]));
-        V[0] = fmaf(uv[2][1], ga[2], fmaf(uv[1][1], ga[1], uv[0][1] * ga[0]));
-        V[1] = fmaf(uv[2][1], gb[2], fmaf(uv[1][1], gb[1], uv[0][1] * gb[0]));
-        V[2] = fmaf(uv[2][1], gc[2], fmaf(uv[1][1], gc[1], uv[0][1] * gc[0]));
+        U[0] = fmaf(uv[2][0], g.ga[2], fmaf(uv[1][0], g.ga[1], uv[0][0] * g.ga[0]));
+        U[1] = fmaf(uv[2][0], g.gb[2], fmaf(uv[1][0], g.gb[1], uv[0][0] * g.gb[0]));
+        U[2] = fmaf(uv[2][0], g.gc[2], fmaf(uv[1][0], g.gc[1], uv[0][0] * g.gc[0]));
+        V[0] = fmaf(uv[2][1], g.ga[2], fmaf(uv[1][1], g.ga[1], uv[0][1] * g.ga[0]));
+        V[1] = fmaf(uv[2][1], g.gb[2], fmaf(uv[1][1], g.gb[1], uv[0][1] * g.gb[0]));
+        V[2] = fmaf(uv[2][1], g.gc[2], fmaf(uv[1][1], g.gc[1], uv[0][1] * g.gc[0]));
     }
-    o.sr[0] = U[0]; o.sr[1] = U[1]; o.sr[2] = U[2];
-    o.sr[3] = V[0]; o.sr[4] = V[1]; o.sr[5] = V[2];
-    o.sr[6] = (ga[0] + ga[1]) + ga[2];
-    o.sr[7] = (gb[0] + gb[1]) + gb[2];
-    o.sr[8] = (gc[0] + gc[1]) + gc[2];
-    o.sr[9] = col[0]; o.sr[10] = col[1]; o.sr[11] = col[2];
-    o.sr[12] = __int_as_float(tex);
-    o.sr[13] = 0.0f; o.sr[14] = 0.0f; o.sr[15] = 0.0f;
-    // depth plane again, for K2's lazy depth path (per-lane gather from LDS)
-    o.sr[16] = o.rr[12]; o.sr[17] = o.rr[13]; o.sr[18] = o.rr[14]; o.sr[19] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < 8; ++s) o.sr[20 + s] = o.rr[48 + s];
-    o.sr[28] = 0.0f; o.sr[29] = 0.0f; o.sr[30] = 0.0f; o.sr[31] = 0.0f;
-    return true;
+    sr[0] = make_float4(U[0], U[1], U[2], V[0]);
+    sr[1] = make_float4(V[1], V[2], Wa, Wb);
+    sr[2] = make_float4(Wc, col[0], col[1], col[2]);
+    sr[3] = make_float4(__int_as_float(tex), 0.0f, 0.0f, 0.0f);
+    sr[4] = make_float4(zx, zy, zc, 0.0f);
+    sr[5] = make_float4(zo[0], zo[1], zo[2], zo[3]);
+    sr[6] = make_float4(zo[4], zo[5], zo[6], zo[7]);
+    sr[7] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
-// ordered append of the lanes' primitives to the env's visible list
-__device__ inline void emit(const MwArgs &a, int env, int lane, bool vis, PrimOut &o, int &count, int id_offset)
+// ordered compaction: list index of this lane's primitive (valid if vis); advances count
+__device__ inline int compact(int lane, bool vis, int &count)
 {
     const uint64_t m = ballot(vis);
-    const int before = __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-    const int idx = count + before;
-    if (vis) {
-        o.rr[61] = __uint_as_float((uint32_t)(idx + id_offset));   // draw id = list index + mesh triangles drawn before
-        if (idx < a.max_vis) {
-            float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
-            const float4 *src = reinterpret_cast<const float4 *>(o.rr);
-#pragma unroll
-            for (int i = 0; i < MW_RASTER_REC / 4; ++i) rr[i] = src[i];
-            float4 *sr = reinterpret_cast<float4 *>(a.rec_shade + ((size_t)env * a.max_vis + idx) * MW_SHADE_REC);
-            const float4 *ss = reinterpret_cast<const float4 *>(o.sr);
-#pragma unroll
-            for (int i = 0; i < MW_SHADE_REC / 4; ++i) sr[i] = ss[i];
-            // classification record: edge planes + extreme thresholds + flags (K2 reads one per lane)
-            float4 *cr = reinterpret_cast<float4 *>(a.rec_cull + ((size_t)env * a.max_vis + idx) * MW_CULL_REC);
-            cr[0] = make_float4(o.rr[0], o.rr[1], o.rr[2], o.rr[3]);
-            cr[1] = make_float4(o.rr[4], o.rr[5], o.rr[6], o.rr[7]);
-            cr[2] = make_float4(o.rr[8], o.rr[9], o.rr[10], o.rr[11]);
-            cr[3] = make_float4(o.tmin[0], o.tmin[1], o.tmin[2], o.tmin[3]);
-            cr[4] = make_float4(o.rr[57], o.rr[58], o.rr[59], o.rr[60]);
-            cr[5] = make_float4(o.rr[56], 0.0f, 0.0f, 0.0f);
-        } else {
-            atomicOr(a.status, MW_ST_VIS_OVERFLOW);
-        }
-    }
+    const int idx = count + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
     count += __popcll((unsigned long long)m);
+    return idx;
 }
 
 }  // namespace
 
 // ---------------------------------------------------------------- the kernel
 
-extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void mw_step_setup_kernel(
     MwArgs a, int do_step, const int32_t *__restrict__ actions, float *__restrict__ reward,
     uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
 {
@@ -556,19 +543,27 @@ extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
     const int np = a.npolys[c.set];
     for (int base = 0; base < np; base += 64) {         // display list 1: rooms
         const int i = base + lane;
-        PrimOut o;
         bool vis = false;
+        HV h[4];
+        PolyGeom g;
+        mw_poly q;
         if (i < np) {
-            const mw_poly q = polys[i];
-            HV h[4];
+            q = polys[i];
 #pragma unroll
             for (int k = 0; k < 4; ++k) h[k] = xform(cam, q.v[k][0], q.v[k][1], q.v[k][2]);
-            float col[3];
-            light(cam, q.n, white, col);
-            const float uv[3][2] = {{q.uv[0][0], q.uv[0][1]}, {q.uv[1][0], q.uv[1][1]}, {q.uv[2][0], q.uv[2][1]}};
-            vis = setup_poly(a, h, q.nv, uv, col, q.tex, o);
+            vis = cull_poly(a, h, q.nv, g);
         }
-        emit(a, env, lane, vis, o, count, 0);
+        const int idx = compact(lane, vis, count);
+        if (vis) {
+            if (idx < a.max_vis) {
+                float col[3];
+                light(cam, q.n, white, col);
+                const float uv[3][2] = {{q.uv[0][0], q.uv[0][1]}, {q.uv[1][0], q.uv[1][1]}, {q.uv[2][0], q.uv[2][1]}};
+                write_poly(a, env, idx, (uint32_t)idx, h, q.nv, g, uv, col, q.tex);
+            } else {
+                atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+            }
+        }
     }
     // entities in draw order: static ones first, then dynamic (miniworld.py:1058-1060, 1075-1077).
     // Boxes become 6 polygons each (runs of up to 10 consecutive boxes share one 64-lane batch);
@@ -615,8 +610,10 @@ extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
             }
             {
                 const int i = lane;
-                PrimOut o;
                 bool vis = false;
+                HV h[4];
+                PolyGeom g;
+                float col[3] = {0.0f, 0.0f, 0.0f};
                 const int slot = s0 + i / 6, f = i % 6;
                 if (i < (s1 - s0) * 6) {
                     const int kind = a.ekind[(size_t)slot * a.N + env];
@@ -632,7 +629,6 @@ extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
                         const float hi[3] = {(float)(sx / 2), (float)sy, (float)(sz / 2)};
                         const float base_col[3] = {(float)ent_geom(a, env, slot, 3), (float)ent_geom(a, env, slot, 4),
                                                    (float)ent_geom(a, env, slot, 5)};
-                        HV h[4];
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const int sel = kBoxSel[f][k];
@@ -646,13 +642,19 @@ extern "C" __global__ __launch_bounds__(64) void mw_step_setup_kernel(
                         }
                         const float n[3] = {fmaf(cs, kBoxN[f][0], sn * kBoxN[f][2]), kBoxN[f][1],
                                             fmaf(cs, kBoxN[f][2], -(sn * kBoxN[f][0]))};
-                        float col[3];
                         light(cam, n, base_col, col);
-                        const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-                        vis = setup_poly(a, h, 4, uv, col, -1, o);
+                        vis = cull_poly(a, h, 4, g);
                     }
                 }
-                emit(a, env, lane, vis, o, count, mesh_tris);
+                const int idx = compact(lane, vis, count);
+                if (vis) {
+                    if (idx < a.max_vis) {
+                        const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+                        write_poly(a, env, idx, (uint32_t)(idx + mesh_tris), h, 4, g, uv, col, -1);
+                    } else {
+                        atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+                    }
+                }
             }
             s0 = s1;
         }

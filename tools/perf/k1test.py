@@ -1,0 +1,16 @@
+import sys, torch, time
+sys.path.insert(0, "/root/repo")
+from miniworld_amd.vec_env import MiniWorldVecEnv
+for ar in (True, False):
+    vec = MiniWorldVecEnv("MiniWorld-Hallway-v0", 4096, autoreset=ar)
+    vec.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = torch.randint(0, 3, (220, 4096), generator=g, device="cuda", dtype=torch.int32)
+    for t in range(20): vec.step(acts[t])
+    vec.engine.kernel_time_ms()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for t in range(20, 220): vec.step(acts[t])
+    torch.cuda.synchronize(); el = time.perf_counter() - t0
+    r, s, n = vec.engine.kernel_time_ms()
+    print("autoreset", ar, "steps/s %.3g" % (4096 * 200 / el), "raster ms %.4f setup ms %.4f" % (r, s))
+    vec.close()
