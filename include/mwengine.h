@@ -42,7 +42,8 @@ enum { MW_ENT_NONE = 0, MW_ENT_BOX = 1, MW_ENT_MESH = 2 };
 enum {
     MW_TASK_NONE = 0,
     MW_TASK_GOTO = 1,       /* hallway.py:67-74, oneroom.py:64-71, maze.py:155-162 */
-    MW_TASK_PICKUP = 2      /* pickupobjects.py:83-95                            */
+    MW_TASK_PICKUP = 2,     /* pickupobjects.py:83-95                            */
+    MW_TASK_PUTNEXT = 3     /* putnext.py:71-80: goal_ent next to goal_ent2, not carrying */
 };
 
 /* device-side world generators for mw_reset / auto-reset (the env's _gen_world) */
@@ -74,6 +75,7 @@ typedef struct {
     int32_t shared_geometry;    /* 1: one geometry set for all envs, 0: one per env */
     int32_t task;               /* MW_TASK_*                                       */
     int32_t goal_ent;           /* MW_TASK_GOTO: entity slot of the box            */
+    int32_t goal_ent2;          /* MW_TASK_PUTNEXT: slot of the second entity      */
     int32_t num_objs;           /* MW_TASK_PICKUP                                  */
     int32_t max_episode_steps;  /* miniworld.py:472, per env class                 */
     int32_t domain_rand;        /* miniworld.py:478                                */

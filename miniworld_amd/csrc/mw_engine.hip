@@ -362,7 +362,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.N = N; a.W = cfg->obs_width; a.H = cfg->obs_height; a.E = E;
     a.max_polys = cfg->max_polys; a.max_segs = cfg->max_segs; a.max_vis = cfg->max_visible;
     a.shared_geom = cfg->shared_geometry ? 1 : 0;
-    a.task = cfg->task; a.goal_ent = cfg->goal_ent; a.num_objs = cfg->num_objs; a.max_steps = cfg->max_episode_steps;
+    a.task = cfg->task; a.goal_ent = cfg->goal_ent; a.goal_ent2 = cfg->goal_ent2; a.num_objs = cfg->num_objs; a.max_steps = cfg->max_episode_steps;
     a.domain_rand = cfg->domain_rand; a.generator = cfg->generator; a.autoreset = cfg->autoreset;
     a.tiles_x = a.W / MW_TILE_W; a.tiles_y = a.H / MW_TILE_H; a.n_tiles = a.tiles_x * a.tiles_y;
     a.agent_radius = cfg->agent_radius; a.max_forward_step = cfg->max_forward_step;

@@ -491,6 +491,17 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                 rew += 1.0 - 0.2 * ((double)step_count / (double)a.max_steps);
                 tm = 1;
             }
+        } else if (a.task == MW_TASK_PUTNEXT) {
+            if (c.carry < 0) {      // putnext.py:74-78
+                const int g0 = a.goal_ent, g1 = a.goal_ent2;
+                const double dx = ent_pos(c, g0, 0) - ent_pos(c, g1, 0), dy = ent_pos(c, g0, 1) - ent_pos(c, g1, 1),
+                             dz = ent_pos(c, g0, 2) - ent_pos(c, g1, 2);
+                const double dist = sqrt(dx * dx + dy * dy + dz * dz);
+                if (dist < ent_geom(a, env, g0, 7) + ent_geom(a, env, g1, 7) + 1.1 * a.max_forward_step) {
+                    rew += 1.0 - 0.2 * ((double)step_count / (double)a.max_steps);
+                    tm = 1;
+                }
+            }
         } else if (a.task == MW_TASK_PICKUP) {
             if (c.carry >= 0) {
                 remove_slot = c.carry;      // still drawn this frame (pickupobjects.py:86-88 runs after :717)

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
 
 ABI_VERSION = 1
 ENT_NONE, ENT_BOX, ENT_MESH = 0, 1, 2
-TASK_NONE, TASK_GOTO, TASK_PICKUP = 0, 1, 2
+TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT = 0, 1, 2, 3
 GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE = 0, 1, 2, 3, 4
 AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
 
@@ -43,7 +43,7 @@ class MwConfig(C.Structure):
         ("obs_width", C.c_int32), ("obs_height", C.c_int32), ("msaa", C.c_int32),
         ("max_ents", C.c_int32), ("max_polys", C.c_int32), ("max_segs", C.c_int32),
         ("max_visible", C.c_int32), ("shared_geometry", C.c_int32), ("task", C.c_int32),
-        ("goal_ent", C.c_int32), ("num_objs", C.c_int32), ("max_episode_steps", C.c_int32),
+        ("goal_ent", C.c_int32), ("goal_ent2", C.c_int32), ("num_objs", C.c_int32), ("max_episode_steps", C.c_int32),
         ("domain_rand", C.c_int32), ("generator", C.c_int32), ("autoreset", C.c_int32),
         ("agent_radius", C.c_double), ("max_forward_step", C.c_double),
         ("forward_step", MwRange), ("forward_drift", MwRange), ("turn_step", MwRange),

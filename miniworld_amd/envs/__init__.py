@@ -1,14 +1,24 @@
 """Environment classes and their Gymnasium ids (the subset of envs/__init__.py:44-157 built so far)."""
 from ..gymshim import gym
+from .fourrooms import FourRooms
 from .hallway import Hallway
 from .maze import Maze, MazeS2, MazeS3, MazeS3Fast
 from .oneroom import OneRoom, OneRoomS6, OneRoomS6Fast
 from .pickupobjects import PickupObjects
+from .putnext import PutNext
+from .roomobjects import RoomObjects
+from .tmaze import TMaze, TMazeLeft, TMazeRight
 
-__all__ = ["Hallway", "Maze", "MazeS2", "MazeS3", "MazeS3Fast", "OneRoom", "OneRoomS6", "OneRoomS6Fast",
+__all__ = ["FourRooms", "PutNext", "RoomObjects", "TMaze", "TMazeLeft", "TMazeRight", "Hallway", "Maze", "MazeS2", "MazeS3", "MazeS3Fast", "OneRoom", "OneRoomS6", "OneRoomS6Fast",
            "PickupObjects"]
 
 ENV_IDS = {
+    "MiniWorld-FourRooms-v0": "FourRooms",
+    "MiniWorld-PutNext-v0": "PutNext",
+    "MiniWorld-RoomObjects-v0": "RoomObjects",
+    "MiniWorld-TMaze-v0": "TMaze",
+    "MiniWorld-TMazeLeft-v0": "TMazeLeft",
+    "MiniWorld-TMazeRight-v0": "TMazeRight",
     "MiniWorld-Hallway-v0": "Hallway",
     "MiniWorld-Maze-v0": "Maze",
     "MiniWorld-MazeS2-v0": "MazeS2",
@@ -20,7 +30,8 @@ ENV_IDS = {
     "MiniWorld-PickupObjects-v0": "PickupObjects",
 }
 
-_MODULE_OF = {"Hallway": "hallway", "Maze": "maze", "MazeS2": "maze", "MazeS3": "maze", "MazeS3Fast": "maze",
+_MODULE_OF = {"FourRooms": "fourrooms", "PutNext": "putnext", "RoomObjects": "roomobjects", "TMaze": "tmaze",
+              "TMazeLeft": "tmaze", "TMazeRight": "tmaze","Hallway": "hallway", "Maze": "maze", "MazeS2": "maze", "MazeS3": "maze", "MazeS3Fast": "maze",
               "OneRoom": "oneroom", "OneRoomS6": "oneroom", "OneRoomS6Fast": "oneroom",
               "PickupObjects": "pickupobjects"}
 

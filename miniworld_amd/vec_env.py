@@ -28,6 +28,13 @@ _KIND = {
     "MiniWorld-MazeS2-v0": ("MazeS2", eng.GEN_MAZE, eng.TASK_GOTO, 3),
     "MiniWorld-MazeS3-v0": ("MazeS3", eng.GEN_MAZE, eng.TASK_GOTO, 3),
     "MiniWorld-PickupObjects-v0": ("PickupObjects", eng.GEN_PICKUP, eng.TASK_PICKUP, 5),
+    # host-generated worlds (reference-compatible numpy stream), device stepping / rendering
+    "MiniWorld-FourRooms-v0": ("FourRooms", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-TMaze-v0": ("TMaze", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-TMazeLeft-v0": ("TMazeLeft", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-TMazeRight-v0": ("TMazeRight", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-PutNext-v0": ("PutNext", eng.GEN_NONE, eng.TASK_PUTNEXT, 8),
+    "MiniWorld-RoomObjects-v0": ("RoomObjects", eng.GEN_NONE, eng.TASK_NONE, 8),
 }
 
 
@@ -64,7 +71,10 @@ class MiniWorldVecEnv:
                           params_ranges=self.template.params.as_ranges(), device_id=device_id)
         cfg.shared_geometry = int(shared)
         cfg.task, cfg.goal_ent, cfg.num_objs = task, 0, len(sc["ents_kind"])
-        cfg.max_episode_steps = int(self.template.max_episode_steps)
+        if task == eng.TASK_PUTNEXT:
+            ents = [e for e in self.template.entities if e is not self.template.agent]
+            cfg.goal_ent, cfg.goal_ent2 = ents.index(self.template.red_box), ents.index(self.template.yellow_box)
+        cfg.max_episode_steps = int(min(float(self.template.max_episode_steps), 2 ** 30))
         cfg.domain_rand = int(domain_rand)
         cfg.generator = generator
         cfg.autoreset = eng.AUTORESET_SAME_STEP if (autoreset and generator != eng.GEN_NONE) else eng.AUTORESET_OFF

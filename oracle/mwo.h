@@ -93,7 +93,7 @@ void mwo_build_mips(const uint8_t *rgb, int32_t w, int32_t h, uint8_t *out);
 int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16, float *depth, int32_t *prim);
 
 /* ---- dynamics (MiniWorldEnv.step and friends) --------------------------------- */
-enum { MWO_TASK_NONE = 0, MWO_TASK_GOTO = 1, MWO_TASK_PICKUP = 2 };
+enum { MWO_TASK_NONE = 0, MWO_TASK_GOTO = 1, MWO_TASK_PICKUP = 2, MWO_TASK_PUTNEXT = 3 };
 
 typedef struct {
     /* agent */
@@ -111,6 +111,8 @@ typedef struct {
     int32_t num_picked_up;
     int32_t n_ents;
     double max_forward_step;/* params.get_max("forward_step") (miniworld.py:581) */
+    int32_t goal_ent2;      /* PUTNEXT: the entity goal_ent has to be put next to (putnext.py:74-78) */
+    int32_t pad;
 } mwo_agent_state;
 
 typedef struct {            /* physical part of an entity (miniworld.py:951-961) */

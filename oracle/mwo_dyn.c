@@ -158,6 +158,17 @@ int mwo_step(mwo_agent_state *ag, mwo_phys_ent *ents, mwo_phys_ent *ents_at_rend
             rew += 1.0 - 0.2 * ((double)ag->step_count / (double)ag->max_episode_steps);
             term = 1;
         }
+    } else if (ag->task == MWO_TASK_PUTNEXT) {
+        /* putnext.py:74-78: not carrying and near(red_box, yellow_box) */
+        if (ag->carrying < 0) {
+            const mwo_phys_ent *e0 = &ents[ag->goal_ent], *e1 = &ents[ag->goal_ent2];
+            double dx = e0->pos[0] - e1->pos[0], dy = e0->pos[1] - e1->pos[1], dz = e0->pos[2] - e1->pos[2];
+            double dist = sqrt(dx * dx + dy * dy + dz * dz);
+            if (dist < e0->radius + e1->radius + 1.1 * ag->max_forward_step) {
+                rew += 1.0 - 0.2 * ((double)ag->step_count / (double)ag->max_episode_steps);
+                term = 1;
+            }
+        }
     } else if (ag->task == MWO_TASK_PICKUP) {
         if (ag->carrying >= 0) {                                              /* pickupobjects.py:86-93 */
             ents[ag->carrying].alive = 0;

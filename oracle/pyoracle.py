@@ -77,7 +77,7 @@ class AgentState(C.Structure):
                 ("cam_height", C.c_double), ("carrying", C.c_int32), ("step_count", C.c_int32),
                 ("max_episode_steps", C.c_int32), ("task", C.c_int32), ("goal_ent", C.c_int32),
                 ("num_objs", C.c_int32), ("num_picked_up", C.c_int32), ("n_ents", C.c_int32),
-                ("max_forward_step", C.c_double)]
+                ("max_forward_step", C.c_double), ("goal_ent2", C.c_int32), ("pad", C.c_int32)]
 
 
 class PhysEnt(C.Structure):
@@ -85,7 +85,7 @@ class PhysEnt(C.Structure):
                 ("height", C.c_double), ("alive", C.c_int32), ("is_static", C.c_int32)]
 
 
-TASK_NONE, TASK_GOTO, TASK_PICKUP = 0, 1, 2
+TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT = 0, 1, 2, 3
 
 _lib = None
 
@@ -254,7 +254,7 @@ class Dynamics:
     """Thin stateful wrapper around mwo_step for one environment."""
 
     def __init__(self, scene: dict, task: int, max_episode_steps: int, goal_ent: int = 0,
-                 num_objs: int = 0, max_forward_step: float = 0.17, agent_radius: float = 0.4):
+                 num_objs: int = 0, max_forward_step: float = 0.17, agent_radius: float = 0.4, goal_ent2: int = -1):
         E = int(len(scene["ents_kind"]))
         self.ag = AgentState()
         self.ag.pos[:] = [float(x) for x in scene["agent_pos"]]
@@ -265,6 +265,7 @@ class Dynamics:
         self.ag.max_episode_steps, self.ag.task, self.ag.goal_ent = max_episode_steps, task, goal_ent
         self.ag.num_objs, self.ag.num_picked_up, self.ag.n_ents = num_objs, 0, E
         self.ag.max_forward_step = max_forward_step
+        self.ag.goal_ent2 = goal_ent2
         self.ents = (PhysEnt * max(E, 1))()
         self.render_ents = (PhysEnt * max(E, 1))()
         for i in range(E):

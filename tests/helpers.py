@@ -40,12 +40,17 @@ def frame_scene(s0, frame):
 
 
 def task_of(meta):
-    return 2 if str(meta["env"]) == "PickupObjects" else 1
+    return {"PickupObjects": 2, "PutNext": 3, "RoomObjects": 0}.get(str(meta["env"]), 1)
+
+
+def goals_of(meta):
+    return int(meta.get("goal_ent", 0)), int(meta.get("goal_ent2", -1))
 
 
 # ------------------------------------------------------------------ engine glue (GPU tests)
 
-def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_rand=False, max_visible=None):
+def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_rand=False, max_visible=None,
+                          goal_ent=0, goal_ent2=-1, agent_radius=0.4):
     """Engine with the scene's shared geometry / textures uploaded (state not yet set)."""
     from miniworld_amd import engine as eng
     from miniworld_amd import assets
@@ -59,13 +64,14 @@ def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_ran
     cfg.max_visible = max_visible or -(-(P + 6 * E) // 16) * 16
     cfg.shared_geometry = 1
     cfg.task = task
-    cfg.goal_ent = 0
+    cfg.goal_ent, cfg.goal_ent2 = goal_ent, goal_ent2
     cfg.num_objs = len(s0["ents_kind"])
-    cfg.max_episode_steps = int(max_episode_steps if max_episode_steps is not None else s0["max_episode_steps"])
+    mes = max_episode_steps if max_episode_steps is not None else s0["max_episode_steps"]
+    cfg.max_episode_steps = int(min(float(mes), 2 ** 30))
     cfg.domain_rand = int(domain_rand)
     cfg.generator = eng.GEN_NONE
     cfg.autoreset = eng.AUTORESET_OFF
-    cfg.agent_radius = 0.4
+    cfg.agent_radius = agent_radius
     eng.fill_ranges(cfg)
     cfg.max_forward_step = float(s0["max_forward_step"])
     e = eng.Engine(cfg)

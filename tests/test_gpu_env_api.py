@@ -21,7 +21,11 @@ def test_single_env_reset_and_trajectory_match_reference(case):
     o, info = env.reset(seed=int(meta["seed"]))
     assert o.shape == env.observation_space.shape and o.dtype == np.uint8
     assert np.array_equal(o, obs[0]["rgb"])
+    poke = meta.get("poke", np.array([-1.0]))
+    ents = [e for e in env.entities if e is not env.agent]
     for t in range(len(tr["action"])):
+        if int(poke[0]) == t:
+            ents[int(poke[1])].pos = np.array(poke[2:5])
         o, r, te, tu, info = env.step(int(tr["action"][t]))
         assert r == tr["reward"][t] and te == bool(tr["term"][t]) and tu == bool(tr["trunc"][t]), (case, t)
         assert np.abs(env.agent.pos - tr["pos"][t]).max() < 1e-12 and abs(env.agent.dir - tr["dir"][t]) < 1e-12

@@ -19,7 +19,9 @@ def test_step_matches_reference_trajectory(case):
     import torch
     s0, tr, meta, obs = helpers.load_case(case)
     task = helpers.task_of(meta)
-    eng = helpers.make_engine_for_scene(s0, 1, task=task)
+    g0, g1 = helpers.goals_of(meta)
+    eng = helpers.make_engine_for_scene(s0, 1, task=task, goal_ent=g0, goal_ent2=g1,
+                                        agent_radius=float(meta.get("agent_radius", 0.4)))
     eng.set_state(helpers.scene_state_arrays([s0]))
     E = len(s0["ents_kind"])
     T = len(tr["action"])
@@ -29,7 +31,12 @@ def test_step_matches_reference_trajectory(case):
     term = torch.zeros(1, dtype=torch.uint8, device="cuda")
     trunc = torch.zeros(1, dtype=torch.uint8, device="cuda")
     maxerr = 0.0
+    poke = meta.get("poke", np.array([-1.0]))
     for t in range(T):
+        if int(poke[0]) == t:
+            st = eng.get_state()
+            st["ent_pos"][0, int(poke[1])] = poke[2:5]
+            eng.set_state({"ent_pos": st["ent_pos"]})
         eng.set_step_params(np.array([[tr["fwd_step"][t], tr["fwd_drift"][t], tr["turn_step"][t]]]))
         act[0] = int(tr["action"][t])
         eng.step(act, rgb, None, rew, term, trunc)

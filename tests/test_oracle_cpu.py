@@ -29,10 +29,15 @@ def test_dynamics_match_reference_trajectory(case):
     """mwo_step vs the reference's own miniworld.py run under GL stubs (tools/gen_golden.py)."""
     s0, tr, meta, obs = helpers.load_case(case)
     E = len(s0["ents_kind"])
-    dyn = pyoracle.Dynamics(s0, helpers.task_of(meta), int(s0["max_episode_steps"]), goal_ent=0,
-                            num_objs=E, max_forward_step=float(s0["max_forward_step"]))
+    g0, g1 = helpers.goals_of(meta)
+    dyn = pyoracle.Dynamics(s0, helpers.task_of(meta), int(min(float(s0["max_episode_steps"]), 2 ** 30)), goal_ent=g0,
+                            goal_ent2=g1, num_objs=E, max_forward_step=float(s0["max_forward_step"]),
+                            agent_radius=float(meta.get("agent_radius", 0.4)))
     worst = 0.0
+    poke = meta.get("poke", np.array([-1.0]))
     for t in range(len(tr["action"])):
+        if int(poke[0]) == t:
+            dyn.ents[int(poke[1])].pos[:] = [float(x) for x in poke[2:5]]
         r, te, tu = dyn.step(tr["action"][t], tr["fwd_step"][t], tr["fwd_drift"][t], tr["turn_step"][t])
         assert r == tr["reward"][t] and te == tr["term"][t] and tu == tr["trunc"][t], (case, t)
         assert dyn.ag.carrying == tr["carrying"][t]

@@ -48,6 +48,17 @@ CASES = [
     ("oneroom_trunc_s7", "OneRoom", {}, 7, [0.5, 0.5, 0.0], 180, [0, 180]),
     ("pickup_fwd_s2", "PickupObjects", {}, 2, [0.15, 0.1, 0.45, 0.05, 0.25], 400, [0, 80, 200]),
     ("pickup_dr_fwd_s6", "PickupObjects", {"domain_rand": True}, 6, [0.15, 0.1, 0.45, 0.05, 0.25], 400, [0, 120]),
+    # section 8(f) rank 4: more env families on the same primitives
+    ("fourrooms_s0", "FourRooms", {}, 0, [0.15, 0.15, 0.7], 250, [0, 60, 150]),
+    ("fourrooms_dr_s2", "FourRooms", {"domain_rand": True}, 2, 3, 120, [0, 119]),
+    ("tmaze_s1", "TMaze", {}, 1, [0.1, 0.1, 0.8], 280, [0, 40]),
+    ("tmazeleft_s0", "TMazeLeft", {}, 0, [0.12, 0.08, 0.8], 280, [0, 70]),
+    ("putnext_s0", "PutNext", {}, 0, [0.12, 0.1, 0.38, 0.05, 0.2, 0.15, 0.0, 0.0], 250, [0, 100, 249]),
+    # "poke": before step 40 the red box is teleported 1 m from the yellow one, so that the
+    # reference's success rule (putnext.py:74-78) fires and is pinned
+    ("putnext_poke_s1", "PutNext", {}, 1, [0.12, 0.1, 0.38, 0.05, 0.2, 0.15, 0.0, 0.0], 250, [0, 40]),
+    ("putnext_dr_s3", "PutNext", {"domain_rand": True}, 3, [0.12, 0.1, 0.38, 0.05, 0.2, 0.15, 0.0, 0.0], 250, [0, 125]),
+    ("roomobjects_s0", "RoomObjects", {}, 0, [0.15, 0.1, 0.4, 0.05, 0.2, 0.1, 0.0, 0.0], 150, [0, 75, 149]),
 ]
 
 
@@ -79,7 +90,11 @@ def run_case(name, cls, kwargs, seed, n_actions, steps, frames, meshes):
     tr = {k: [] for k in ("action", "pos", "dir", "carrying", "ents_pos", "ents_dir", "ents_alive",
                           "reward", "term", "trunc", "fwd_step", "fwd_drift", "turn_step")}
     scenes = {0: s0}
+    poke = np.array([-1, 0, 0, 0, 0], np.float64)
     for t in range(steps):
+        if name.startswith("putnext_poke") and t == 40:
+            env.red_box.pos = env.yellow_box.pos + np.array([1.0, 0.0, 0.0])
+            poke = np.array([t, ents0.index(env.red_box), *env.red_box.pos], np.float64)
         if isinstance(n_actions, list):
             a = int(rng.choice(len(n_actions), p=n_actions))
         else:
@@ -121,6 +136,12 @@ def run_case(name, cls, kwargs, seed, n_actions, steps, frames, meshes):
     out["meta/seed"] = np.int32(seed)
     out["meta/domain_rand"] = np.int32(bool(kwargs.get("domain_rand", False)))
     out["meta/env"] = np.array(cls)
+    out["meta/poke"] = poke
+    goal, goal2 = 0, -1
+    if cls == "PutNext":
+        goal, goal2 = ents0.index(env.red_box), ents0.index(env.yellow_box)
+    out["meta/goal_ent"], out["meta/goal_ent2"] = np.int32(goal), np.int32(goal2)
+    out["meta/agent_radius"] = np.float64(env.agent.radius)
     mesh_arrays = {}
     for mname in [str(m) for m in s0["mesh_names"]]:
         base = mname.split("_")[0]

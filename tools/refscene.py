@@ -101,7 +101,7 @@ def scene_from_ref_env(env):
         "light_ambient": np.array(env.light_ambient, np.float64),
         "wall_segs": np.ascontiguousarray(np.asarray(env.wall_segs, np.float64)[:, :, [0, 2]]),
         "max_forward_step": np.float64(env.max_forward_step),
-        "max_episode_steps": np.int32(env.max_episode_steps),
+        "max_episode_steps": np.float64(env.max_episode_steps),
         "step_count": np.int32(env.step_count),
     }
 
