@@ -96,6 +96,16 @@ typedef struct {
      * six colours in sorted name order (entity.py:30-43) */
     double gen_tab[12];
     double gen_colors[18];
+    /* Texture domain randomisation for generated single-room worlds (Texture.get with an rng,
+     * opengl.py:124-140; Room._gen_static_data :295-297): per slot (0 wall, 1 floor, 2 ceiling —
+     * the reference's draw order of rng.integers) the number of variants, their texture ids and
+     * TEX_DENSITY / size (u, v).  n = 0 disables (geometry stays the shared set). */
+    int32_t tex_nvar[3];
+    int32_t tex_var_id[3][9];
+    double tex_var_scale[3][9][2];
+    double room_wall_height;    /* Room.wall_height of the generated room (2.74) */
+    int32_t room_no_ceiling;    /* Room(no_ceiling=True) */
+    int32_t pad_;
 } mw_config;
 
 /* One room polygon exactly as Room._render feeds it to GL (miniworld.py:401-434). */

@@ -47,6 +47,11 @@ struct MwArgs {
     double gen_args[8];
     double gen_tab[12];     // PICKUP: per kind (ball, box, key): radius, height, scale, first mesh id
     double gen_colors[18];  // PICKUP: COLORS of the 6 sorted colour names (entity.py:30-40)
+    int32_t tex_nvar[3];    // texture domain randomisation of generated rooms: wall, floor, ceiling
+    int32_t tex_var_id[3][9];
+    double tex_var_scale[3][9][2];
+    double room_wall_height;
+    int32_t room_no_ceiling, pad2;
     // --- world state, SoA over envs -------------------------------------------------
     double *ax, *ay, *az, *adir;
     double *cam;        // [4][N]

@@ -370,6 +370,10 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     memcpy(a.gen_args, cfg->gen_args, sizeof a.gen_args);
     memcpy(a.gen_tab, cfg->gen_tab, sizeof a.gen_tab);
     memcpy(a.gen_colors, cfg->gen_colors, sizeof a.gen_colors);
+    memcpy(a.tex_nvar, cfg->tex_nvar, sizeof a.tex_nvar);
+    memcpy(a.tex_var_id, cfg->tex_var_id, sizeof a.tex_var_id);
+    memcpy(a.tex_var_scale, cfg->tex_var_scale, sizeof a.tex_var_scale);
+    a.room_wall_height = cfg->room_wall_height; a.room_no_ceiling = cfg->room_no_ceiling;
     for (int i = 0; i < 3; ++i) {
         a.sky[i] = cfg->sky_color[i]; a.light_pos[i] = cfg->light_pos[i]; a.light_color[i] = cfg->light_color[i];
         a.light_ambient[i] = cfg->light_ambient[i]; a.color_bias[i] = cfg->obj_color_bias[i];

@@ -87,27 +87,34 @@ __device__ inline void gen_store_box(const MwArgs &a, int env, int slot, double 
 
 struct MazeRect { double x0, x1, z0, z1; };     // min_x, max_x, min_z, max_z
 
-__device__ inline void maze_emit_room(const MwArgs &a, int set, const double px[4], const double pz[4],
-                                      unsigned keep_walls, int &np, int &ns)
+struct RoomTex {            // textures of one emitted room: ids and TEX_DENSITY / size per axis
+    int floor, ceil, wall;
+    double fu, fv, cu, cv, wu, wv;
+    double height;
+    bool ceiling;
+};
+
+__device__ inline void emit_room(const MwArgs &a, int set, const RoomTex &rt, const double px[4], const double pz[4],
+                                 unsigned keep_walls, int &np, int &ns)
 {
     mw_poly *polys = const_cast<mw_poly *>(a.polys) + (size_t)set * a.max_polys;
     double *segs = const_cast<double *>(a.segs) + (size_t)set * a.max_segs * 4;
-    const double h = a.gen_tab[4];
-    const int tex_f = (int)a.gen_tab[5], tex_c = (int)a.gen_tab[6], tex_w = (int)a.gen_tab[7];
+    const double h = rt.height;
+    const int tex_f = rt.floor, tex_c = rt.ceil, tex_w = rt.wall;
     {   // floor: the outline itself, normal +Y (miniworld.py:408-415), texcoords = (x, z) * density
         mw_poly &q = polys[np++];
         for (int k = 0; k < 4; ++k) {
             q.v[k][0] = (float)px[k]; q.v[k][1] = 0.0f; q.v[k][2] = (float)pz[k];
-            q.uv[k][0] = (float)(px[k] * a.gen_colors[0]); q.uv[k][1] = (float)(pz[k] * a.gen_colors[1]);
+            q.uv[k][0] = (float)(px[k] * rt.fu); q.uv[k][1] = (float)(pz[k] * rt.fv);
         }
         q.n[0] = 0.0f; q.n[1] = 1.0f; q.n[2] = 0.0f; q.nv = 4; q.tex = tex_f;
     }
-    {   // ceiling: flipped outline at wall height, normal -Y (:304-306, 418-425)
+    if (rt.ceiling) {   // ceiling: flipped outline at wall height, normal -Y (:304-306, 418-425)
         mw_poly &q = polys[np++];
         for (int k = 0; k < 4; ++k) {
             const double x = px[3 - k], z = pz[3 - k];
             q.v[k][0] = (float)x; q.v[k][1] = (float)(0.0 + h * 1.0); q.v[k][2] = (float)z;
-            q.uv[k][0] = (float)(x * a.gen_colors[2]); q.uv[k][1] = (float)(z * a.gen_colors[3]);
+            q.uv[k][0] = (float)(x * rt.cu); q.uv[k][1] = (float)(z * rt.cv);
         }
         q.n[0] = 0.0f; q.n[1] = -1.0f; q.n[2] = 0.0f; q.nv = 4; q.tex = tex_c;
     }
@@ -123,7 +130,7 @@ __device__ inline void maze_emit_room(const MwArgs &a, int set, const double px[
         q.v[1][0] = (float)ax; q.v[1][1] = (float)h; q.v[1][2] = (float)az;
         q.v[2][0] = (float)bx; q.v[2][1] = (float)h; q.v[2][2] = (float)bz;
         q.v[3][0] = (float)bx; q.v[3][1] = 0.0f;     q.v[3][2] = (float)bz;
-        const float u1 = (float)((0 + width) * a.gen_colors[4]), v1 = (float)((0 + h) * a.gen_colors[5]);
+        const float u1 = (float)((0 + width) * rt.wu), v1 = (float)((0 + h) * rt.wv);
         q.uv[0][0] = 0.0f; q.uv[0][1] = 0.0f; q.uv[1][0] = 0.0f; q.uv[1][1] = v1;
         q.uv[2][0] = u1;   q.uv[2][1] = v1;   q.uv[3][0] = u1;   q.uv[3][1] = 0.0f;
         // normal = -cross(b - a, Y) / |.|   (miniworld.py:335-336)
@@ -204,11 +211,16 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
         enter(ncellidx);
     }
     // ---- geometry ------------------------------------------------------------------------
+    RoomTex rt;
+    rt.floor = (int)a.gen_tab[5]; rt.ceil = (int)a.gen_tab[6]; rt.wall = (int)a.gen_tab[7];
+    rt.fu = a.gen_colors[0]; rt.fv = a.gen_colors[1]; rt.cu = a.gen_colors[2]; rt.cv = a.gen_colors[3];
+    rt.wu = a.gen_colors[4]; rt.wv = a.gen_colors[5];
+    rt.height = a.gen_tab[4]; rt.ceiling = true;
     int np = 0, ns = 0;
     for (int cell = 0; cell < ncell; ++cell) {
         const MazeRect c = maze_cell(a, cell % cols, cell / cols);
         const double px[4] = {c.x1, c.x1, c.x0, c.x0}, pz[4] = {c.z1, c.z0, c.z0, c.z1};   // add_rect_room outline
-        maze_emit_room(a, set, px, pz, (~(unsigned)open[cell]) & 15u, np, ns);
+        emit_room(a, set, rt, px, pz, (~(unsigned)open[cell]) & 15u, np, ns);
     }
     for (int k = 0; k < nlink; ++k) {
         const int cell = link_cell[k], d = link_dir[k];
@@ -216,7 +228,7 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
         const MazeRect B = maze_cell(a, cell % cols + DI[d], cell / cols + DJ[d]);
         double px[4], pz[4];
         maze_link_outline(A, B, d, px, pz);
-        maze_emit_room(a, set, px, pz, 5u, np, ns);          // walls 1 and 3 are portals (miniworld.py:836-837)
+        emit_room(a, set, rt, px, pz, 5u, np, ns);          // walls 1 and 3 are portals (miniworld.py:836-837)
     }
     const_cast<int32_t *>(a.npolys)[set] = np;
     const_cast<int32_t *>(a.nsegs)[set] = ns;
@@ -272,6 +284,23 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     const size_t N = a.N;
     for (int s = 0; s < a.E; ++s) a.ekind[(size_t)s * N + env] = MW_ENT_NONE;
     double ax = 0, az = 0, adir = 0;
+    if (a.tex_nvar[0] > 0 && !a.shared_geom && a.generator != MW_GEN_MAZE) {
+        // Room._gen_static_data with an rng (miniworld.py:295-297): wall, floor, ceiling variant
+        // drawn in that order (opengl.py:136-138); the room is re-emitted into this env's own set
+        int pick[3];
+        for (int k = 0; k < 3; ++k) pick[k] = a.tex_nvar[k] > 1 ? (int)rng_below(r, (uint32_t)a.tex_nvar[k]) : 0;
+        RoomTex rt;
+        rt.wall = a.tex_var_id[0][pick[0]]; rt.wu = a.tex_var_scale[0][pick[0]][0]; rt.wv = a.tex_var_scale[0][pick[0]][1];
+        rt.floor = a.tex_var_id[1][pick[1]]; rt.fu = a.tex_var_scale[1][pick[1]][0]; rt.fv = a.tex_var_scale[1][pick[1]][1];
+        rt.ceil = a.tex_var_id[2][pick[2]]; rt.cu = a.tex_var_scale[2][pick[2]][0]; rt.cv = a.tex_var_scale[2][pick[2]][1];
+        rt.height = a.room_wall_height; rt.ceiling = !a.room_no_ceiling;
+        const double px[4] = {a.gen_args[1], a.gen_args[1], a.gen_args[0], a.gen_args[0]};
+        const double pz[4] = {a.gen_args[3], a.gen_args[2], a.gen_args[2], a.gen_args[3]};
+        int np = 0, ns = 0;
+        emit_room(a, set, rt, px, pz, 15u, np, ns);
+        const_cast<int32_t *>(a.npolys)[set] = np;
+        const_cast<int32_t *>(a.nsegs)[set] = ns;
+    }
     if (a.generator == MW_GEN_HALLWAY || a.generator == MW_GEN_ONEROOM || a.generator == MW_GEN_MAZE) {
         // the red box (hallway.py:59, oneroom.py:61, maze.py:151), then the agent
         const double size = a.generator == MW_GEN_MAZE ? 0.8 : a.gen_args[7];

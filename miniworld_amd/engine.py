@@ -53,6 +53,9 @@ class MwConfig(C.Structure):
         ("gen_args", C.c_double * 8),
         ("gen_tab", C.c_double * 12),
         ("gen_colors", C.c_double * 18),
+        ("tex_nvar", C.c_int32 * 3), ("tex_var_id", (C.c_int32 * 9) * 3),
+        ("tex_var_scale", ((C.c_double * 2) * 9) * 3),
+        ("room_wall_height", C.c_double), ("room_no_ceiling", C.c_int32), ("pad_", C.c_int32),
     ]
 
 

@@ -55,7 +55,13 @@ class MiniWorldVecEnv:
         self.template.reset(seed=seed)
         self._cls, self._env_kwargs = cls, env_kwargs
         sc = scene_from_env(self.template)
-        shared = generator not in (eng.GEN_NONE, eng.GEN_MAZE)
+        # texture domain randomisation needs one geometry set per env (texcoords depend on the variant)
+        from . import assets as _assets
+        room0 = self.template.rooms[0]
+        tex_slots = [room0.wall_tex_name, room0.floor_tex_name, room0.ceil_tex_name]
+        variants = [_assets.texture_variants(t) for t in tex_slots]
+        tex_dr = bool(domain_rand) and generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM, eng.GEN_PICKUP) and any(len(v) > 1 for v in variants)
+        shared = generator not in (eng.GEN_NONE, eng.GEN_MAZE) and not tex_dr
         P, S, E = len(sc["polys_nv"]), len(sc["wall_segs"]), max(1, len(sc["ents_kind"]))
         pickup_meshes = None
         if cls_name == "PickupObjects":
@@ -110,6 +116,21 @@ class MiniWorldVecEnv:
             for ci, cname in enumerate(COLOR_NAMES):
                 for j in range(3):
                     cfg.gen_colors[ci * 3 + j] = float(COLORS[cname][j])
+        self._tex_dr_variants = None
+        if tex_dr:
+            order, nid = [], len(sc["tex_names"])
+            names = [str(v) for v in sc["tex_names"]]
+            for k, vs in enumerate(variants):
+                cfg.tex_nvar[k] = len(vs)
+                for j, v in enumerate(vs):
+                    if v not in names:
+                        names.append(v)
+                    cfg.tex_var_id[k][j] = names.index(v)
+                    w, h = _assets.texture_size(v)
+                    cfg.tex_var_scale[k][j][0], cfg.tex_var_scale[k][j][1] = 512 / w, 512 / h
+            self._tex_dr_variants = names
+            cfg.room_wall_height = float(room0.wall_height)
+            cfg.room_no_ceiling = int(bool(room0.no_ceiling))
         self.engine = eng.Engine(cfg)
         self.host_autoreset = autoreset and generator == eng.GEN_NONE
         self._upload_assets(sc)
@@ -133,7 +154,7 @@ class MiniWorldVecEnv:
     def _upload_assets(self, sc):
         from . import assets
         self.tex_ids, self.mesh_ids = {}, {}
-        for i, variant in enumerate([str(v) for v in sc["tex_names"]]):
+        for i, variant in enumerate(self._tex_dr_variants or [str(v) for v in sc["tex_names"]]):
             self.tex_ids[variant] = i
             self.engine.upload_texture(i, assets.texture_rgb_bottom_up(variant))
         if self.engine.cfg.shared_geometry:

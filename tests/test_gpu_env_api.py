@@ -292,3 +292,45 @@ def test_vec_env_host_generation_path():
     assert np.array_equal(vec.obs[0].cpu().numpy(), obs[0]["rgb"])       # seed 0 == the reference's reset(seed=0)
     assert np.array_equal(st["agent_pos"][0], s0["agent_pos"])
     vec.close()
+
+
+def test_vec_env_texture_domain_randomisation_on_device():
+    """Hallway with domain_rand: every env draws its own wall texture variant (concrete_1..4, one of
+    them 768^2 so the texcoords change too), sky / light / camera parameters; frames == oracle."""
+    import torch
+    import pyoracle
+    from miniworld_amd import assets
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 64
+    vec = MiniWorldVecEnv("MiniWorld-Hallway-v0", n, domain_rand=True, want_depth=True, seed=4)
+    vec.reset()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    for _ in range(12):
+        vec.step(torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32))
+    vec.engine.check()
+    st = vec.engine.get_state()
+    names = vec._tex_dr_variants
+    walls = set()
+    for i in range(n):
+        polys, segs = vec.engine.get_geometry(i)
+        assert len(polys) == 6 and len(segs) == 4
+        wall_variant = names[int(polys["tex"][2])]
+        walls.add(wall_variant)
+        w, h = assets.texture_size(wall_variant)
+        # east wall of the 12 x 4 hallway: 4 m wide, 2.74 m high (gen_texcs_wall, miniworld.py:82-103)
+        assert np.allclose(polys["uv"][2][2], [4 * 512 / w, 2.74 * 512 / h], rtol=1e-6)
+    assert walls == {"concrete_1", "concrete_2", "concrete_3", "concrete_4"}
+    assert len(np.unique(st["light"][:, 0])) > n // 2 and (np.abs(st["cam"][:, 2]) <= 5).all()
+    for i in (0, 9, n - 1):
+        polys, segs = vec.engine.get_geometry(i)
+        sc = _scene_of_env(vec, st, i)
+        sc["polys_v"], sc["polys_uv"], sc["polys_n"] = polys["v"], polys["uv"], polys["n"]
+        sc["polys_nv"], sc["polys_tex"] = polys["nv"], polys["tex"]
+        sc["tex_names"] = np.array(names)
+        sc["ents_kind"], sc["ents_mesh"] = st["ent_kind"][i, :1], st["ent_mesh"][i, :1]
+        for k in ("ents_pos", "ents_dir", "ents_size", "ents_color", "ents_scale", "ents_radius", "ents_height", "ents_static"):
+            sc[k] = sc[k][:1]
+        want = pyoracle.render(sc)
+        assert np.array_equal(vec.obs[i].cpu().numpy(), want["rgb"]), f"env {i}"
+        assert np.array_equal(vec.depth[i].cpu().numpy(), want["depth"]), f"env {i}"
+    vec.close()
