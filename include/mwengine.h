@@ -82,6 +82,7 @@ typedef struct {
     int32_t generator;          /* MW_GEN_*                                        */
     int32_t autoreset;          /* MW_AUTORESET_*                                  */
     double agent_radius;        /* entity.py:470 (0.4)                             */
+    double agent_height;        /* entity.py:471 (1.6): height of the top-view marker */
     double max_forward_step;    /* params.get_max("forward_step") miniworld.py:581 */
     mw_range forward_step, forward_drift, turn_step;   /* params.py:123-125, miniworld.py:678-680 */
     /* per-episode parameters sampled by reset (miniworld.py:576-585, entity.py:405-407, 505-515) */
@@ -135,6 +136,7 @@ typedef struct {
     double *ent_pos;            /* [count][max_ents][3]                              */
     double *ent_dir;            /* [count][max_ents]                                 */
     double *ent_geom;           /* [count][max_ents][9] size xyz, color rgb, scale, radius, height */
+    double *extent;             /* [count][4] env.min_x, max_x, min_z, max_z (miniworld.py:588-591); top view only */
 } mw_state_view;
 
 /* ---- lifetime --------------------------------------------------------------- */
@@ -181,6 +183,9 @@ int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_dep
             float *d_reward, uint8_t *d_term, uint8_t *d_trunc, void *stream);
 /* render_obs / render_depth only (miniworld.py:1177-1236) */
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);
+/* render_top_view (miniworld.py:1088-1175): orthographic map of the whole floorplan into the same
+ * kind of buffers; render_agent != 0 also draws Agent.render's marker (entity.py:518-539) */
+int mw_render_top(mw_engine *e, uint8_t *d_obs, float *d_depth, int32_t render_agent, void *stream);
 /* checks the device-side status word (capacity overflows); synchronises `stream` */
 int mw_check(mw_engine *e, void *stream);
 

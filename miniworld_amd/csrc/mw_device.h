@@ -40,7 +40,7 @@ struct MwArgs {
     int32_t task, goal_ent, num_objs, max_steps;
     int32_t domain_rand, generator, autoreset, tiles_x;
     int32_t tiles_y, n_tiles, goal_ent2, pad1;
-    double agent_radius, max_forward_step;
+    double agent_radius, max_forward_step, agent_height;
     mw_range fwd, drift, turn;
     mw_range sky[3], light_pos[3], light_color[3], light_ambient[3], color_bias[3];
     mw_range cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;
@@ -61,6 +61,7 @@ struct MwArgs {
     double *epos;       // [3][E][N]
     double *edir;       // [E][N]
     double *egeom;      // [9][E][N]
+    double *extent;     // [4][N] world extents min_x, max_x, min_z, max_z (top view)
     uint64_t *rng;      // [2][N]  seed, counter
     const double *step_override;        // [N][3] or null
     // --- geometry -------------------------------------------------------------------

@@ -14,8 +14,8 @@
 
 #include "mw_device.h"
 
-extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, const int32_t *actions, float *reward,
-                                                uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
+                                                float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                             int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                             const float *rec_shade, const float *rec_cull, const int32_t *nvis,
@@ -267,6 +267,7 @@ int state_xfer(mw_engine *e, int first, int count, const mw_state_view *h, bool 
     if ((rc = xfer_ent(e, a.epos, h->ent_pos, first, count, 3, to_device))) return rc;
     if ((rc = xfer_ent(e, a.edir, h->ent_dir, first, count, 1, to_device))) return rc;
     if ((rc = xfer_ent(e, a.egeom, h->ent_geom, first, count, 9, to_device))) return rc;
+    if ((rc = xfer(e, a.extent, h->extent, first, count, 4, to_device))) return rc;
     return MW_OK;
 }
 
@@ -284,7 +285,7 @@ mw_engine::Ev get_events(mw_engine *e)
     return ev;
 }
 
-int launch_frame(mw_engine *e, bool do_step, const int32_t *d_actions, uint8_t *d_obs, float *d_depth,
+int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_actions, uint8_t *d_obs, float *d_depth,
                  float *d_reward, uint8_t *d_term, uint8_t *d_trunc, hipStream_t st)
 {
     if (!d_obs) return fail(e, MW_E_INVALID, "d_obs is null");
@@ -296,7 +297,7 @@ int launch_frame(mw_engine *e, bool do_step, const int32_t *d_actions, uint8_t *
         ev = get_events(e);
         (void)hipEventRecord(ev.a, st);
     }
-    hipLaunchKernelGGL(mw_step_setup_kernel, dim3(N), dim3(64), 0, st, a, do_step ? 1 : 0, d_actions,
+    hipLaunchKernelGGL(mw_step_setup_kernel, dim3(N), dim3(64), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
                        d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
                        d_trunc ? d_trunc : e->d_flag_scratch + N);
     if (e->timing) (void)hipEventRecord(ev.b, st);
@@ -366,6 +367,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.domain_rand = cfg->domain_rand; a.generator = cfg->generator; a.autoreset = cfg->autoreset;
     a.tiles_x = a.W / MW_TILE_W; a.tiles_y = a.H / MW_TILE_H; a.n_tiles = a.tiles_x * a.tiles_y;
     a.agent_radius = cfg->agent_radius; a.max_forward_step = cfg->max_forward_step;
+    a.agent_height = cfg->agent_height > 0.0 ? cfg->agent_height : 1.6;
     a.fwd = cfg->forward_step; a.drift = cfg->forward_drift; a.turn = cfg->turn_step;
     memcpy(a.gen_args, cfg->gen_args, sizeof a.gen_args);
     memcpy(a.gen_tab, cfg->gen_tab, sizeof a.gen_tab);
@@ -386,7 +388,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.carry, N); ALLOC(a.step, N); ALLOC(a.picked, N);
     ALLOC(a.ekind, (size_t)E * N); ALLOC(a.emesh, (size_t)E * N); ALLOC(a.estatic, (size_t)E * N);
     ALLOC(a.epos, 3 * (size_t)E * N); ALLOC(a.edir, (size_t)E * N); ALLOC(a.egeom, 9 * (size_t)E * N);
-    ALLOC(a.rng, 2 * (size_t)N);
+    ALLOC(a.rng, 2 * (size_t)N); ALLOC(a.extent, 4 * (size_t)N);
     mw_poly *polys = nullptr; int32_t *npolys = nullptr; double *segs = nullptr; int32_t *nsegs = nullptr;
     ALLOC(polys, (size_t)e->n_sets * cfg->max_polys); ALLOC(npolys, e->n_sets);
     ALLOC(segs, (size_t)e->n_sets * cfg->max_segs * 4); ALLOC(nsegs, e->n_sets);
@@ -557,13 +559,20 @@ int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_dep
 {
     if (!e) return MW_E_INVALID;
     if (!d_actions) return fail(e, MW_E_INVALID, "d_actions is null");
-    return launch_frame(e, true, d_actions, d_obs, d_depth, d_reward, d_term, d_trunc, (hipStream_t)stream);
+    return launch_frame(e, true, 0, d_actions, d_obs, d_depth, d_reward, d_term, d_trunc, (hipStream_t)stream);
 }
 
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream)
 {
     if (!e) return MW_E_INVALID;
-    return launch_frame(e, false, e->d_action_scratch, d_obs, d_depth, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    return launch_frame(e, false, 0, e->d_action_scratch, d_obs, d_depth, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int mw_render_top(mw_engine *e, uint8_t *d_obs, float *d_depth, int32_t render_agent, void *stream)
+{
+    if (!e) return MW_E_INVALID;
+    return launch_frame(e, false, 1 | (render_agent ? 2 : 0), e->d_action_scratch, d_obs, d_depth, nullptr, nullptr, nullptr,
+                        (hipStream_t)stream);
 }
 
 int mw_check(mw_engine *e, void *stream)

@@ -380,6 +380,13 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     }
     a.ax[env] = ax; a.ay[env] = 0.0; a.az[env] = az; a.adir[env] = adir;
     a.carry[env] = -1; a.step[env] = 0; a.picked[env] = 0;
+    if (a.generator == MW_GEN_MAZE) {
+        const double pitch = a.gen_tab[2] + a.gen_tab[3];
+        a.extent[(size_t)0 * N + env] = 0.0; a.extent[(size_t)1 * N + env] = ((int)a.gen_tab[1] - 1) * pitch + a.gen_tab[2];
+        a.extent[(size_t)2 * N + env] = 0.0; a.extent[(size_t)3 * N + env] = ((int)a.gen_tab[0] - 1) * pitch + a.gen_tab[2];
+    } else {
+        for (int k = 0; k < 4; ++k) a.extent[(size_t)k * N + env] = a.gen_args[k];
+    }
     rng_store(a.rng, a.N, env, r);
 }
 

@@ -39,7 +39,12 @@ __device__ inline HV xform_hdr(const float *hdr, float halfw, float halfh, float
     const float ex = fmaf(m[0], x, fmaf(m[1], y, fmaf(m[2], z, m[3])));
     const float ey = fmaf(m[4], x, fmaf(m[5], y, fmaf(m[6], z, m[7])));
     const float ez = fmaf(m[8], x, fmaf(m[9], y, fmaf(m[10], z, m[11])));
-    const float cx = hdr[16] * ex, cy = hdr[17] * ey, cw = -ez;
+    float cx = hdr[16] * ex, cy = hdr[17] * ey, cw = -ez;
+    if (__float_as_int(hdr[23])) {      // top view: glOrtho (translation terms, w = 1)
+        cx = fmaf(hdr[16], ex, hdr[27]);
+        cy = fmaf(hdr[17], ey, hdr[31]);
+        cw = 1.0f;
+    }
     HV h;
     h.cz = fmaf(hdr[18], ez, hdr[19]);
     h.hx = (cx + cw) * halfw;

@@ -28,6 +28,8 @@ struct HV { float hx, hy, hw, cz; };
 struct Cam {
     float m[3][4];
     float p00, p11, p22, p23, halfw, halfh;
+    float p03, p13;         // orthographic (top view) only
+    int ortho;
     float L[3], amb[3], lcol[3];
 };
 
@@ -154,8 +156,34 @@ __device__ void turn_agent(StepCtx &c, double turn_deg)
 // ---------------------------------------------------------------- camera (R1, R2, R10)
 
 __device__ void build_camera(const MwArgs &a, int env, double px, double py, double pz, double dir, Cam &cam,
-                             float sky[3])
+                             float sky[3], bool top_view)
 {
+    cam.ortho = 0; cam.p03 = 0.0f; cam.p13 = 0.0f;
+    cam.halfw = (float)a.W * 0.5f;
+    cam.halfh = (float)a.H * 0.5f;
+    if (top_view) {
+        // render_top_view (miniworld.py:1108-1160): extents +-1 m widened to the buffer's aspect,
+        // glOrtho(min_x, max_x, -max_z, -min_z, -100, 100), modelview (x, y, z) -> (x, -z, y)
+        double min_x = a.extent[(size_t)0 * a.N + env] - 1, max_x = a.extent[(size_t)1 * a.N + env] + 1;
+        double min_z = a.extent[(size_t)2 * a.N + env] - 1, max_z = a.extent[(size_t)3 * a.N + env] + 1;
+        const double width = max_x - min_x, height = max_z - min_z;
+        const double aspect = width / height, fb_aspect = (double)a.W / (double)a.H;
+        if (aspect > fb_aspect) {
+            const double new_h = width / fb_aspect, h_diff = new_h - height;
+            min_z -= h_diff / 2; max_z += h_diff / 2;
+        } else if (aspect < fb_aspect) {
+            const double new_w = height * fb_aspect, w_diff = new_w - width;
+            min_x -= w_diff / 2; max_x += w_diff / 2;
+        }
+        const double l = min_x, r = max_x, b = -max_z, t = -min_z, n = -100.0, f = 100.0;
+        cam.ortho = 1;
+        cam.p00 = (float)(2.0 / (r - l)); cam.p03 = (float)(-(r + l) / (r - l));
+        cam.p11 = (float)(2.0 / (t - b)); cam.p13 = (float)(-(t + b) / (t - b));
+        cam.p22 = (float)(-2.0 / (f - n)); cam.p23 = (float)(-(f + n) / (f - n));
+        cam.m[0][0] = 1; cam.m[0][1] = 0; cam.m[0][2] = 0; cam.m[0][3] = 0;
+        cam.m[1][0] = 0; cam.m[1][1] = 0; cam.m[1][2] = -1; cam.m[1][3] = 0;
+        cam.m[2][0] = 0; cam.m[2][1] = 1; cam.m[2][2] = 0; cam.m[2][3] = 0;
+    } else {
     const double cam_height = a.cam[(size_t)0 * a.N + env], fwd_disp = a.cam[(size_t)1 * a.N + env];
     const double pitch_deg = a.cam[(size_t)2 * a.N + env], fov_y = a.cam[(size_t)3 * a.N + env];
     const mw::SinCos hd = mw::sincos_det(dir / 2.0);
@@ -195,8 +223,7 @@ __device__ void build_camera(const MwArgs &a, int env, double px, double py, dou
     cam.p11 = (float)cot;
     cam.p22 = (float)(-(zf + zn) / (zf - zn));
     cam.p23 = (float)(-2.0 * zn * zf / (zf - zn));
-    cam.halfw = (float)a.W * 0.5f;
-    cam.halfh = (float)a.H * 0.5f;
+    }
     float lp[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) lp[i] = (float)(a.light[(size_t)(3 + i) * a.N + env] + 1.0);
@@ -215,7 +242,12 @@ __device__ inline HV xform(const Cam &c, float x, float y, float z)
     const float ex = fmaf(c.m[0][0], x, fmaf(c.m[0][1], y, fmaf(c.m[0][2], z, c.m[0][3])));
     const float ey = fmaf(c.m[1][0], x, fmaf(c.m[1][1], y, fmaf(c.m[1][2], z, c.m[1][3])));
     const float ez = fmaf(c.m[2][0], x, fmaf(c.m[2][1], y, fmaf(c.m[2][2], z, c.m[2][3])));
-    const float cx = c.p00 * ex, cy = c.p11 * ey, cw = -ez;
+    float cx = c.p00 * ex, cy = c.p11 * ey, cw = -ez;
+    if (c.ortho) {              // glOrtho: translation terms, w = 1
+        cx = fmaf(c.p00, ex, c.p03);
+        cy = fmaf(c.p11, ey, c.p13);
+        cw = 1.0f;
+    }
     HV h;
     h.cz = fmaf(c.p22, ez, c.p23);
     h.hx = (cx + cw) * c.halfw;
@@ -408,7 +440,7 @@ __device__ inline int compact(int lane, bool vis, int &count)
 // ---------------------------------------------------------------- the kernel
 
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void mw_step_setup_kernel(
-    MwArgs a, int do_step, const int32_t *__restrict__ actions, float *__restrict__ reward,
+    MwArgs a, int do_step, int view_flags, const int32_t *__restrict__ actions, float *__restrict__ reward,
     uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
 {
     __shared__ unsigned char gen_ws[MW_GEN_WS_BYTES];
@@ -547,7 +579,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
     // ---- camera + primitive setup -----------------------------------------------
     Cam cam;
     float sky[3];
-    build_camera(a, env, c.px, c.py, c.pz, c.dir, cam, sky);
+    build_camera(a, env, c.px, c.py, c.pz, c.dir, cam, sky, (view_flags & 1) != 0);
+    float stale_n[3] = {0.0f, 1.0f, 0.0f};       // GL's current normal after the last draw (top-view agent marker)
     int count = 0;
     const float white[3] = {1.0f, 1.0f, 1.0f};
     const mw_poly *polys = a.polys + (size_t)c.set * a.max_polys;
@@ -575,6 +608,10 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                 atomicOr(a.status, MW_ST_VIS_OVERFLOW);
             }
         }
+    }
+    if (np > 0) {
+        const mw_poly &lastq = polys[np - 1];
+        stale_n[0] = lastq.n[0]; stale_n[1] = lastq.n[1]; stale_n[2] = lastq.n[2];
     }
     // entities in draw order: static ones first, then dynamic (miniworld.py:1058-1060, 1075-1077).
     // Boxes become 6 polygons each (runs of up to 10 consecutive boxes share one 64-lane batch);
@@ -606,6 +643,10 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                     }
                     mesh_tris += (int)md.ntris;
                     ++n_mesh;
+                    if (md.ntris > 0) {     // the mesh's last vertex normal stays current
+                        const float *ln = a.mesh_nrm + ((size_t)(md.first + md.ntris - 1) * 3 + 2) * 3;
+                        stale_n[0] = ln[0]; stale_n[1] = ln[1]; stale_n[2] = ln[2];
+                    }
                 } else {
                     atomicOr(a.status, MW_ST_VIS_OVERFLOW);
                 }
@@ -667,7 +708,49 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                     }
                 }
             }
+            // drawBox ends with glNormal3f(0, -1, 0) (opengl.py:495): current after the last box of the run
+            for (int sb = s0; sb < s1; ++sb) {
+                const int kb = a.ekind[(size_t)sb * a.N + env];
+                const bool mb = (a.estatic[(size_t)sb * a.N + env] != 0) == (pass == 0);
+                if (kb == MW_ENT_BOX && mb) { stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f; }
+            }
             s0 = s1;
+        }
+    }
+    if (view_flags & 2) {
+        // Agent.render (entity.py:518-539): red triangle on top of the agent's cylinder, no glNormal3f
+        // => lit with the stale current normal.  Last in draw order.
+        bool vis = false;
+        HV h[4];
+        PolyGeom g;
+        float col[3] = {0.0f, 0.0f, 0.0f};
+        if (lane == 0) {
+            const mw::SinCos sc = mw::sincos_det(c.dir);
+            const double rad = a.agent_radius, hgt = a.agent_height;
+            const double p[3] = {c.px + 0 * hgt, c.py + 1 * hgt, c.pz + 0 * hgt};
+            const double dv[3] = {sc.c * rad, 0 * rad, -sc.s * rad}, rv[3] = {sc.s * rad, 0 * rad, sc.c * rad};
+            double q0[3], q1[3], q2[3];
+            for (int i = 0; i < 3; ++i) {
+                q0[i] = p[i] + dv[i];
+                q1[i] = p[i] + 0.75 * (rv[i] - dv[i]);
+                q2[i] = p[i] + 0.75 * (-rv[i] - dv[i]);
+            }
+            h[0] = xform(cam, (float)q0[0], (float)q0[1], (float)q0[2]);
+            h[1] = xform(cam, (float)q2[0], (float)q2[1], (float)q2[2]);
+            h[2] = xform(cam, (float)q1[0], (float)q1[1], (float)q1[2]);
+            h[3] = h[0];
+            const float red[3] = {1.0f, 0.0f, 0.0f};
+            light(cam, stale_n, red, col);
+            vis = cull_poly(a, h, 3, g);
+        }
+        const int idx = compact(lane, vis, count);
+        if (vis) {
+            if (idx < a.max_vis) {
+                const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
+                write_poly(a, env, idx, (uint32_t)(idx + mesh_tris), h, 3, g, uv, col, -1);
+            } else {
+                atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+            }
         }
     }
     if (lane == 0) {
@@ -681,6 +764,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
             hdr[20 + i] = cam.L[i]; hdr[24 + i] = cam.amb[i]; hdr[28 + i] = cam.lcol[i];
         }
         hdr[16] = cam.p00; hdr[17] = cam.p11; hdr[18] = cam.p22; hdr[19] = cam.p23;
+        hdr[23] = __int_as_float(cam.ortho); hdr[27] = cam.p03; hdr[31] = cam.p13;
         if (remove_slot >= 0) a.ekind[(size_t)remove_slot * a.N + env] = MW_ENT_NONE;
     }
 }

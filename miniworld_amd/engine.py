@@ -25,7 +25,7 @@ AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_check", "mw_kernel_time_ms",
+    "mw_step", "mw_render", "mw_render_top", "mw_check", "mw_kernel_time_ms",
 ]
 
 
@@ -45,7 +45,7 @@ class MwConfig(C.Structure):
         ("max_visible", C.c_int32), ("shared_geometry", C.c_int32), ("task", C.c_int32),
         ("goal_ent", C.c_int32), ("goal_ent2", C.c_int32), ("num_objs", C.c_int32), ("max_episode_steps", C.c_int32),
         ("domain_rand", C.c_int32), ("generator", C.c_int32), ("autoreset", C.c_int32),
-        ("agent_radius", C.c_double), ("max_forward_step", C.c_double),
+        ("agent_radius", C.c_double), ("agent_height", C.c_double), ("max_forward_step", C.c_double),
         ("forward_step", MwRange), ("forward_drift", MwRange), ("turn_step", MwRange),
         ("sky_color", MwRange * 3), ("light_pos", MwRange * 3), ("light_color", MwRange * 3),
         ("light_ambient", MwRange * 3), ("obj_color_bias", MwRange * 3),
@@ -72,7 +72,7 @@ assert POLY_DTYPE.itemsize == C.sizeof(MwPoly) == 100
 class MwStateView(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in (
         "agent_pos", "agent_dir", "cam", "light", "carrying", "step_count", "num_picked_up",
-        "ent_kind", "ent_mesh", "ent_static", "ent_pos", "ent_dir", "ent_geom")]
+        "ent_kind", "ent_mesh", "ent_static", "ent_pos", "ent_dir", "ent_geom", "extent")]
 
 
 # name -> (dtype, per-env shape as a function of max_ents)
@@ -90,6 +90,7 @@ STATE_FIELDS = {
     "ent_pos": (np.float64, lambda E: (E, 3)),
     "ent_dir": (np.float64, lambda E: (E,)),
     "ent_geom": (np.float64, lambda E: (E, 9)),
+    "extent": (np.float64, lambda E: (4,)),
 }
 
 
@@ -142,6 +143,7 @@ def load_library():
     L.mw_reset.argtypes = [vp, vp, vp, vp]
     L.mw_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.mw_render.argtypes = [vp, vp, vp, vp]
+    L.mw_render_top.argtypes = [vp, vp, vp, i32, vp]
     L.mw_check.argtypes = [vp, vp]
     L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = L
@@ -261,6 +263,10 @@ class Engine:
     def render(self, obs, depth=None):
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         self._check(self.lib.mw_render(self.h, ptr(obs), ptr(depth), _stream_ptr()), "mw_render")
+
+    def render_top(self, obs, depth=None, render_agent=True):
+        ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+        self._check(self.lib.mw_render_top(self.h, ptr(obs), ptr(depth), int(render_agent), _stream_ptr()), "mw_render_top")
 
     def check(self):
         self._check(self.lib.mw_check(self.h, _stream_ptr()), "mw_check")

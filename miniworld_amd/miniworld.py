@@ -357,6 +357,24 @@ class MiniWorldEnv(gym.Env):
     def render_obs(self, frame_buffer=None):
         return self._engine.render(self)["rgb"]
 
+    def render_top_view(self, frame_buffer=None, render_agent=True, return_scale=False):
+        """Orthographic map of the whole floorplan at the observation resolution (the reference's
+        default frame buffer for this call is obs_fb, miniworld.py:1093-1094)."""
+        img = self._engine.render(self, top_view=True, render_agent=render_agent)["rgb"]
+        if not return_scale:
+            return img
+        min_x, max_x, min_z, max_z = self.min_x - 1, self.max_x + 1, self.min_z - 1, self.max_z + 1
+        width, height = max_x - min_x, max_z - min_z
+        aspect, fb_aspect = width / height, self.obs_width / self.obs_height
+        if aspect > fb_aspect:
+            diff = width / fb_aspect - height
+            min_z, max_z = min_z - diff / 2, max_z + diff / 2
+        elif aspect < fb_aspect:
+            diff = height * fb_aspect - width
+            min_x, max_x = min_x - diff / 2, max_x + diff / 2
+        xs, zs = self.obs_width / (max_x - min_x), self.obs_height / (max_z - min_z)
+        return img, {"x_scale": xs, "z_scale": zs, "x_offset": int(0 - min_x * xs), "z_offset": int(0 - min_z * zs)}
+
     def render_depth(self, frame_buffer=None):
         return self._engine.render(self, want_depth=True)["depth"]
 
@@ -364,7 +382,7 @@ class MiniWorldEnv(gym.Env):
         if self.render_mode is None:
             gym.logger.warn("You are calling render method without specifying any render mode.")
             return None
-        return self.render_obs()
+        return self.render_top_view() if self.view == "top" else self.render_obs()
 
     def close(self):
         if self._engine is not None:

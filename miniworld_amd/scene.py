@@ -98,6 +98,9 @@ def scene_from_env(env) -> dict:
         "max_forward_step": np.float64(env.max_forward_step),
         "max_episode_steps": np.float64(env.max_episode_steps),
         "step_count": np.int32(env.step_count),
+        "extent": np.array([env.min_x, env.max_x, env.min_z, env.max_z], np.float64),
+        "agent_radius": np.float64(env.agent.radius),
+        "agent_height": np.float64(env.agent.height),
     }
 
 
@@ -142,6 +145,7 @@ def state_arrays(scenes: list, E: int, mesh_maps: list | None = None) -> dict:
         "ent_pos": np.zeros((n, E, 3), np.float64),
         "ent_dir": np.zeros((n, E), np.float64),
         "ent_geom": np.zeros((n, E, 9), np.float64),
+        "extent": np.array([s.get("extent", np.zeros(4)) for s in scenes], np.float64),
     }
     for i, s in enumerate(scenes):
         k = len(s["ents_kind"])
@@ -174,6 +178,7 @@ def base_config(num_envs, width, height, max_ents, max_polys, max_segs, max_visi
     cfg.generator = eng.GEN_NONE
     cfg.autoreset = eng.AUTORESET_OFF
     cfg.agent_radius = 0.4
+    cfg.agent_height = 1.6
     r = eng.default_ranges()
     if params_ranges:
         r.update({k: v for k, v in params_ranges.items() if k in r})
@@ -255,9 +260,12 @@ class EngineBinding:
         self._pull_state(env)
         return self.obs[0].cpu().numpy()
 
-    def render(self, env, want_depth=False):
+    def render(self, env, want_depth=False, top_view=False, render_agent=True):
         self.push_state(env)
-        self.engine.render(self.obs, self.depth if want_depth else None)
+        if top_view:
+            self.engine.render_top(self.obs, self.depth if want_depth else None, render_agent)
+        else:
+            self.engine.render(self.obs, self.depth if want_depth else None)
         out = {"rgb": self.obs[0].cpu().numpy()}
         if want_depth:
             out["depth"] = self.depth[0].cpu().numpy()

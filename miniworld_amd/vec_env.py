@@ -206,5 +206,11 @@ class MiniWorldVecEnv:
                 self.engine.render(self.obs, self.depth)
         return self.obs, self.reward, self.terminated, self.truncated
 
+    def render_top_view(self, render_agent=True):
+        """uint8[N,H,W,3] map views (render_top_view, miniworld.py:1088-1175) of every env."""
+        out = self.torch.zeros_like(self.obs)
+        self.engine.render_top(out, None, render_agent)
+        return out
+
     def close(self):
         self.engine.close()

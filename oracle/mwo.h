@@ -74,6 +74,11 @@ typedef struct {
     const mwo_ent *ents;    /* in draw order: static first, then dynamic (miniworld.py:1058-1077) */
     const mwo_tex *tex;
     const mwo_mesh *meshes;
+    /* render_top_view (miniworld.py:1088-1175): view = 1 selects the orthographic map view over the
+     * world extents (+-1 m, aspect-fitted); render_agent draws Agent.render's marker (entity.py:518-539) */
+    int32_t view, render_agent;
+    double extent[4];       /* env.min_x, max_x, min_z, max_z (miniworld.py:588-591) */
+    double agent_radius, agent_height;
 } mwo_scene;
 
 /* ---- math --------------------------------------------------------------------- */

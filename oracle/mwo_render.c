@@ -43,6 +43,8 @@ typedef struct { float hx, hy, hw, cz; } hvert;
 typedef struct {
     float m[3][4];          /* modelview rows (f32)                */
     float p00, p11, p22, p23;
+    float p03, p13;         /* orthographic only (R3o)             */
+    int ortho;
     float halfw, halfh;
     float L[3];             /* unit light direction, world space   */
     float amb[3];           /* 0.2 + light_ambient                 */
@@ -81,6 +83,31 @@ static void build_camera(const mwo_scene *sc, camera *cam)
     double az = cp, dz = -1.0 * sp;            /* b = c = 0 for the Z axis          */
     double rz00 = az * az - dz * dz;           /* cos(pitch)                        */
     double rz01 = 2.0 * (0.0 - az * dz);       /* sin(pitch)                        */
+    cam->ortho = 0; cam->p03 = 0.0f; cam->p13 = 0.0f;
+    cam->halfw = (float)sc->width * 0.5f;
+    cam->halfh = (float)sc->height * 0.5f;
+    if (sc->view == 1) {
+        /* R1o / R2o: render_top_view (miniworld.py:1108-1160).  Extents +-1 m, widened to the frame
+         * buffer's aspect; glOrtho(min_x, max_x, -max_z, -min_z, -100, 100); modelview maps
+         * (x, y, z) -> (x, -z, y).  All in double, then float32. */
+        double min_x = sc->extent[0] - 1, max_x = sc->extent[1] + 1, min_z = sc->extent[2] - 1, max_z = sc->extent[3] + 1;
+        double width = max_x - min_x, height = max_z - min_z;
+        double aspect = width / height, fb_aspect = (double)sc->width / (double)sc->height;
+        if (aspect > fb_aspect) {
+            double new_h = width / fb_aspect, h_diff = new_h - height;
+            min_z -= h_diff / 2; max_z += h_diff / 2;
+        } else if (aspect < fb_aspect) {
+            double new_w = height * fb_aspect, w_diff = new_w - width;
+            min_x -= w_diff / 2; max_x += w_diff / 2;
+        }
+        double l = min_x, r = max_x, b = -max_z, t = -min_z, n = -100.0, f = 100.0;
+        cam->ortho = 1;
+        cam->p00 = (float)(2.0 / (r - l)); cam->p03 = (float)(-(r + l) / (r - l));
+        cam->p11 = (float)(2.0 / (t - b)); cam->p13 = (float)(-(t + b) / (t - b));
+        cam->p22 = (float)(-2.0 / (f - n)); cam->p23 = (float)(-(f + n) / (f - n));
+        const float M[3][4] = {{1, 0, 0, 0}, {0, 0, -1, 0}, {0, 1, 0, 0}};
+        memcpy(cam->m, M, sizeof M);
+    } else {
     double eye[3], dir[3];
     eye[0] = sc->agent_pos[0] + sc->cam_fwd_disp * ry00;
     eye[1] = sc->agent_pos[1] + sc->cam_height * ry11;
@@ -116,8 +143,7 @@ static void build_camera(const mwo_scene *sc, camera *cam)
     cam->p11 = (float)cot;
     cam->p22 = (float)(-(zf + zn) / (zf - zn));
     cam->p23 = (float)(-2.0 * zn * zf / (zf - zn));
-    cam->halfw = (float)sc->width * 0.5f;
-    cam->halfh = (float)sc->height * 0.5f;
+    }
 
     /* R10: light.  (GLfloat*4)(*light_pos + [1]) (miniworld.py:1031): ndarray + [1] adds
      * 1 to every component and leaves w = 0 => directional light along light_pos + 1. */
@@ -140,6 +166,11 @@ static hvert xform(const camera *cam, float x, float y, float z)
     float ez = fmaf(cam->m[2][0], x, fmaf(cam->m[2][1], y, fmaf(cam->m[2][2], z, cam->m[2][3])));
     float cx = cam->p00 * ex, cy = cam->p11 * ey;
     float cw = -ez;
+    if (cam->ortho) {           /* R3o: glOrtho has translation terms and w = 1 */
+        cx = fmaf(cam->p00, ex, cam->p03);
+        cy = fmaf(cam->p11, ey, cam->p13);
+        cw = 1.0f;
+    }
     hvert h;
     h.cz = fmaf(cam->p22, ez, cam->p23);
     h.hx = (cx + cw) * cam->halfw;
@@ -451,10 +482,12 @@ int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out, float *d
     }
     int draw = 0;
     static const float white[3] = {1.0f, 1.0f, 1.0f};
+    float stale_n[3] = {0.0f, 1.0f, 0.0f};      /* the GL "current normal" left behind by the last draw */
     /* display list 1: rooms (miniworld.py:1053-1055) */
     for (int i = 0; i < sc->n_polys; ++i, ++draw) {
         const mwo_poly *q = &sc->polys[i];
         draw_poly(sc, &cam, &tg, q->v, q->uv, q->n, white, q->nv, q->tex, draw);
+        memcpy(stale_n, q->n, sizeof stale_n);
     }
     /* entities, already in draw order */
     for (int e = 0; e < sc->n_ents; ++e) {
@@ -484,6 +517,7 @@ int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out, float *d
                 n[2] = fmaf(c, BOXN[f][2], -(s * BOXN[f][0]));
                 draw_poly(sc, &cam, &tg, (const float (*)[3])v, NULL, n, base, 4, -1, draw);
             }
+            stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f;      /* drawBox ends with glNormal3f(0,-1,0) */
         } else if (en->kind == MWO_ENT_MESH) {
             /* MeshEnt.render (entity.py:150-161): T(pos) * S(scale) * R_y(dir); normals through
              * the inverse transpose WITHOUT renormalisation => R_y(dir) n / scale (R11) */
@@ -506,7 +540,29 @@ int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out, float *d
                 if (setup_prim(sc, h, 3, (const float (*)[2])uv, (const float (*)[3])vcol, 1, m->tex, &p))
                     draw_prim(sc, &tg, &p, draw);
             }
+            if (m->ntris > 0) memcpy(stale_n, &m->nrm[((size_t)(m->ntris - 1) * 3 + 2) * 3], sizeof stale_n);
         }
+    }
+    if (sc->render_agent) {
+        /* Agent.render (entity.py:518-539): a red triangle at the top of the agent's cylinder, drawn
+         * without any glNormal3f => lit with the normal the previous draw left behind, under the
+         * camera modelview only (no renormalisation, no model scale).  Pinned untextured. */
+        double sd, cd;
+        mwo_sincos(sc->agent_dir, &sd, &cd);
+        double rad = sc->agent_radius, hgt = sc->agent_height;
+        double p[3] = {sc->agent_pos[0] + 0 * hgt, sc->agent_pos[1] + 1 * hgt, sc->agent_pos[2] + 0 * hgt};
+        double dv[3] = {cd * rad, 0 * rad, -sd * rad}, rv[3] = {sd * rad, 0 * rad, cd * rad};
+        double p0[3], p1[3], p2[3];
+        for (int i = 0; i < 3; ++i) {
+            p0[i] = p[i] + dv[i];
+            p1[i] = p[i] + 0.75 * (rv[i] - dv[i]);
+            p2[i] = p[i] + 0.75 * (-rv[i] - dv[i]);
+        }
+        float v[4][3] = {{(float)p0[0], (float)p0[1], (float)p0[2]}, {(float)p2[0], (float)p2[1], (float)p2[2]},
+                         {(float)p1[0], (float)p1[1], (float)p1[2]}, {0, 0, 0}};
+        static const float red[3] = {1.0f, 0.0f, 0.0f};
+        draw_poly(sc, &cam, &tg, (const float (*)[3])v, NULL, stale_n, red, 3, -1, draw);
+        ++draw;
     }
     /* R12: resolve (opengl.py:339-398): mean of the samples in float; the samples of one
      * primitive carry one colour, and the groups are accumulated in ascending draw index,

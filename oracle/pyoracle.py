@@ -69,7 +69,9 @@ class _Scene(C.Structure):
                 ("sky", C.c_double * 3), ("light_pos", C.c_double * 3),
                 ("light_color", C.c_double * 3), ("light_ambient", C.c_double * 3),
                 ("n_polys", C.c_int32), ("n_ents", C.c_int32), ("n_tex", C.c_int32), ("n_mesh", C.c_int32),
-                ("polys", C.c_void_p), ("ents", C.c_void_p), ("tex", C.c_void_p), ("meshes", C.c_void_p)]
+                ("polys", C.c_void_p), ("ents", C.c_void_p), ("tex", C.c_void_p), ("meshes", C.c_void_p),
+                ("view", C.c_int32), ("render_agent", C.c_int32), ("extent", C.c_double * 4),
+                ("agent_radius", C.c_double), ("agent_height", C.c_double)]
 
 
 class AgentState(C.Structure):
@@ -169,7 +171,7 @@ def _mips_for(name, textures=None):
 # ------------------------------------------------------------------ render
 
 def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = None,
-               textures: dict | None = None):
+               textures: dict | None = None, view: str = "agent", render_agent: bool = False):
     """Neutral scene -> (mwo_scene struct, keep-alive list)."""
     P = int(len(scene["polys_nv"]))
     polys = (_Poly * max(P, 1))()
@@ -225,15 +227,22 @@ def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None
     sc.ents = C.addressof(ents)
     sc.tex = C.addressof(texs)
     sc.meshes = C.addressof(mstructs)
+    sc.view = 1 if view == "top" else 0
+    sc.render_agent = int(render_agent)
+    if view == "top":
+        sc.extent[:] = [float(x) for x in scene["extent"]]
+    sc.agent_radius = float(scene.get("agent_radius", 0.4))
+    sc.agent_height = float(scene.get("agent_height", 1.6))
     keep.extend([polys, texs, ents, mstructs])
     return sc, keep
 
 
 def render(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = None,
-           textures: dict | None = None, want_prim=False):
-    """Render a neutral scene.  Returns dict(rgb u8[H,W,3], z16 u16[H,W], depth f32[H,W,1])."""
+           textures: dict | None = None, want_prim=False, view: str = "agent", render_agent: bool = False):
+    """Render a neutral scene.  Returns dict(rgb u8[H,W,3], z16 u16[H,W], depth f32[H,W,1]).
+    view="top" is render_top_view (needs scene["extent"] = min_x, max_x, min_z, max_z)."""
     L = lib()
-    sc, keep = pack_scene(scene, width, height, nsamples, meshes, textures)
+    sc, keep = pack_scene(scene, width, height, nsamples, meshes, textures, view, render_agent)
     rgb = np.zeros((height, width, 3), np.uint8)
     z16 = np.zeros((height, width), np.uint16)
     depth = np.zeros((height, width, 1), np.float32)

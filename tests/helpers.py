@@ -105,6 +105,7 @@ def scene_state_arrays(scenes, E=None):
         "ent_pos": np.zeros((n, E, 3), np.float64),
         "ent_dir": np.zeros((n, E), np.float64),
         "ent_geom": np.zeros((n, E, 9), np.float64),
+        "extent": np.array([s.get("extent", np.zeros(4)) for s in scenes], np.float64),
     }
     for i, s in enumerate(scenes):
         if Es == 0:

@@ -40,3 +40,22 @@ def test_render_matches_golden_and_oracle(case):
         assert diff.max() <= 1, f"{case} frame {f}: max RGB diff {diff.max()}"
         assert np.count_nonzero(diff) == 0, f"{case} frame {f}: {np.count_nonzero(diff)} channel values off by one"
     eng.close()
+
+
+@pytest.mark.parametrize("case", ALL_CASES)
+def test_top_view_matches_oracle(case):
+    """render_top_view (miniworld.py:1088-1175): orthographic map + the agent marker lit by GL's
+    stale current normal; HIP == oracle == committed golden, bit for bit."""
+    import torch
+    s0, tr, meta, obs = helpers.load_case(case)
+    frames = sorted(obs)
+    scenes = [helpers.frame_scene(s0, obs[f]) for f in frames]
+    eng = helpers.make_engine_for_scene(s0, len(scenes), agent_radius=float(meta.get("agent_radius", 0.4)))
+    eng.set_state(helpers.scene_state_arrays(scenes))
+    rgb = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
+    eng.render_top(rgb, None, True)
+    eng.check()
+    rgb = rgb.cpu().numpy()
+    for i, f in enumerate(frames):
+        assert np.array_equal(rgb[i], obs[f]["top_rgb"]), f"{case} frame {f}: {np.count_nonzero(rgb[i] != obs[f]['top_rgb'])} values differ"
+    eng.close()

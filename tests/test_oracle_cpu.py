@@ -58,6 +58,8 @@ def test_render_reproduces_committed_golden(case):
         assert np.array_equal(out["rgb"], fr["rgb"]) and np.array_equal(out["z16"], fr["z16"])
         # get_depth_map: the reference's own numpy expression applied to the resolved depth buffer
         assert np.array_equal(out["depth"][:, :, 0], helpers.depth_from_z16(fr["z16"]))
+        top = pyoracle.render(helpers.frame_scene(s0, fr), meshes=meshes, view="top", render_agent=True)
+        assert np.array_equal(top["rgb"], fr["top_rgb"])
 
 
 def _empty_scene():

@@ -152,6 +152,8 @@ def run_case(name, cls, kwargs, seed, n_actions, steps, frames, meshes):
         r = pyoracle.render(sc, meshes=mesh_arrays)
         out[f"obs/{k}/rgb"] = r["rgb"]
         out[f"obs/{k}/z16"] = r["z16"]
+        # render_top_view(render_agent=True) of the same state, at the observation resolution
+        out[f"obs/{k}/top_rgb"] = pyoracle.render(sc, meshes=mesh_arrays, view="top", render_agent=True)["rgb"]
         for key in ("agent_pos", "agent_dir", "ents_pos", "ents_dir", "ents_kind"):
             out[f"obs/{k}/{key}"] = sc[key]
     out["meta/frames"] = np.array(sorted(scenes.keys()), np.int32)

@@ -103,6 +103,9 @@ def scene_from_ref_env(env):
         "max_forward_step": np.float64(env.max_forward_step),
         "max_episode_steps": np.float64(env.max_episode_steps),
         "step_count": np.int32(env.step_count),
+        "extent": np.array([env.min_x, env.max_x, env.min_z, env.max_z], np.float64),
+        "agent_radius": np.float64(env.agent.radius),
+        "agent_height": np.float64(env.agent.height),
     }
 
 
