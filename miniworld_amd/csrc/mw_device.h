@@ -33,6 +33,18 @@ struct MwMeshDesc {
     uint32_t pad;
 };
 
+// Generator tables; kept in device memory because dynamic indexing into a by-value kernarg
+// struct would force a private (scratch) copy of the whole argument block.
+struct MwGenTables {
+    double gen_tab[12];     // PICKUP: per kind (ball, box, key): radius, height, scale, first mesh id; MAZE: see mw_gen.h
+    double gen_colors[18];  // PICKUP: COLORS of the 6 sorted colour names (entity.py:30-40); MAZE: texcoord scales
+    int32_t tex_nvar[3];    // texture domain randomisation of generated rooms: wall, floor, ceiling
+    int32_t tex_var_id[3][9];
+    double tex_var_scale[3][9][2];
+    double room_wall_height;
+    int32_t room_no_ceiling, pad2;
+};
+
 // Everything the kernels need; passed by value (kernarg).
 struct MwArgs {
     int32_t N, W, H, E;
@@ -45,13 +57,7 @@ struct MwArgs {
     mw_range sky[3], light_pos[3], light_color[3], light_ambient[3], color_bias[3];
     mw_range cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;
     double gen_args[8];
-    double gen_tab[12];     // PICKUP: per kind (ball, box, key): radius, height, scale, first mesh id
-    double gen_colors[18];  // PICKUP: COLORS of the 6 sorted colour names (entity.py:30-40)
-    int32_t tex_nvar[3];    // texture domain randomisation of generated rooms: wall, floor, ceiling
-    int32_t tex_var_id[3][9];
-    double tex_var_scale[3][9][2];
-    double room_wall_height;
-    int32_t room_no_ceiling, pad2;
+    const MwGenTables *gt;  // generator tables (device memory: they are indexed dynamically)
     // --- world state, SoA over envs -------------------------------------------------
     double *ax, *ay, *az, *adir;
     double *cam;        // [4][N]

@@ -370,12 +370,13 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.agent_height = cfg->agent_height > 0.0 ? cfg->agent_height : 1.6;
     a.fwd = cfg->forward_step; a.drift = cfg->forward_drift; a.turn = cfg->turn_step;
     memcpy(a.gen_args, cfg->gen_args, sizeof a.gen_args);
-    memcpy(a.gen_tab, cfg->gen_tab, sizeof a.gen_tab);
-    memcpy(a.gen_colors, cfg->gen_colors, sizeof a.gen_colors);
-    memcpy(a.tex_nvar, cfg->tex_nvar, sizeof a.tex_nvar);
-    memcpy(a.tex_var_id, cfg->tex_var_id, sizeof a.tex_var_id);
-    memcpy(a.tex_var_scale, cfg->tex_var_scale, sizeof a.tex_var_scale);
-    a.room_wall_height = cfg->room_wall_height; a.room_no_ceiling = cfg->room_no_ceiling;
+    MwGenTables gt{};
+    memcpy(gt.gen_tab, cfg->gen_tab, sizeof gt.gen_tab);
+    memcpy(gt.gen_colors, cfg->gen_colors, sizeof gt.gen_colors);
+    memcpy(gt.tex_nvar, cfg->tex_nvar, sizeof gt.tex_nvar);
+    memcpy(gt.tex_var_id, cfg->tex_var_id, sizeof gt.tex_var_id);
+    memcpy(gt.tex_var_scale, cfg->tex_var_scale, sizeof gt.tex_var_scale);
+    gt.room_wall_height = cfg->room_wall_height; gt.room_no_ceiling = cfg->room_no_ceiling;
     for (int i = 0; i < 3; ++i) {
         a.sky[i] = cfg->sky_color[i]; a.light_pos[i] = cfg->light_pos[i]; a.light_color[i] = cfg->light_color[i];
         a.light_ambient[i] = cfg->light_ambient[i]; a.color_bias[i] = cfg->obj_color_bias[i];
@@ -389,6 +390,9 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.ekind, (size_t)E * N); ALLOC(a.emesh, (size_t)E * N); ALLOC(a.estatic, (size_t)E * N);
     ALLOC(a.epos, 3 * (size_t)E * N); ALLOC(a.edir, (size_t)E * N); ALLOC(a.egeom, 9 * (size_t)E * N);
     ALLOC(a.rng, 2 * (size_t)N); ALLOC(a.extent, 4 * (size_t)N);
+    MwGenTables *d_gt = nullptr;
+    ALLOC(d_gt, 1);
+    if (rc == MW_OK) { (void)hipMemcpy(d_gt, &gt, sizeof gt, hipMemcpyHostToDevice); a.gt = d_gt; }
     mw_poly *polys = nullptr; int32_t *npolys = nullptr; double *segs = nullptr; int32_t *nsegs = nullptr;
     ALLOC(polys, (size_t)e->n_sets * cfg->max_polys); ALLOC(npolys, e->n_sets);
     ALLOC(segs, (size_t)e->n_sets * cfg->max_segs * 4); ALLOC(nsegs, e->n_sets);

@@ -144,10 +144,10 @@ __device__ inline void emit_room(const MwArgs &a, int set, const RoomTex &rt, co
 
 __device__ inline MazeRect maze_cell(const MwArgs &a, int i, int j)
 {
-    const double pitch = a.gen_tab[2] + a.gen_tab[3];
+    const double pitch = a.gt->gen_tab[2] + a.gt->gen_tab[3];
     MazeRect r;
-    r.x0 = i * pitch; r.x1 = r.x0 + a.gen_tab[2];
-    r.z0 = j * pitch; r.z1 = r.z0 + a.gen_tab[2];
+    r.x0 = i * pitch; r.x1 = r.x0 + a.gt->gen_tab[2];
+    r.z0 = j * pitch; r.z1 = r.z0 + a.gt->gen_tab[2];
     return r;
 }
 
@@ -168,7 +168,7 @@ __device__ inline void maze_link_outline(const MazeRect &A, const MazeRect &B, i
 __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsigned char *ws, double &bx, double &bz,
                                 double &bdir, double &ax, double &az, double &adir)
 {
-    const int rows = (int)a.gen_tab[0], cols = (int)a.gen_tab[1];
+    const int rows = (int)a.gt->gen_tab[0], cols = (int)a.gt->gen_tab[1];
     const int ncell = rows * cols;
     // direction d: (dj, di) of maze.py:113  (0,1) (0,-1) (-1,0) (1,0); wall of A opened / of B opened
     const int DI[4] = {1, -1, 0, 0}, DJ[4] = {0, 0, -1, 1};
@@ -212,10 +212,10 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
     }
     // ---- geometry ------------------------------------------------------------------------
     RoomTex rt;
-    rt.floor = (int)a.gen_tab[5]; rt.ceil = (int)a.gen_tab[6]; rt.wall = (int)a.gen_tab[7];
-    rt.fu = a.gen_colors[0]; rt.fv = a.gen_colors[1]; rt.cu = a.gen_colors[2]; rt.cv = a.gen_colors[3];
-    rt.wu = a.gen_colors[4]; rt.wv = a.gen_colors[5];
-    rt.height = a.gen_tab[4]; rt.ceiling = true;
+    rt.floor = (int)a.gt->gen_tab[5]; rt.ceil = (int)a.gt->gen_tab[6]; rt.wall = (int)a.gt->gen_tab[7];
+    rt.fu = a.gt->gen_colors[0]; rt.fv = a.gt->gen_colors[1]; rt.cu = a.gt->gen_colors[2]; rt.cv = a.gt->gen_colors[3];
+    rt.wu = a.gt->gen_colors[4]; rt.wv = a.gt->gen_colors[5];
+    rt.height = a.gt->gen_tab[4]; rt.ceiling = true;
     int np = 0, ns = 0;
     for (int cell = 0; cell < ncell; ++cell) {
         const MazeRect c = maze_cell(a, cell % cols, cell / cols);
@@ -233,7 +233,7 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
     const_cast<int32_t *>(a.npolys)[set] = np;
     const_cast<int32_t *>(a.nsegs)[set] = ns;
     // ---- placement: box then agent, room drawn with probability ~ area (miniworld.py:872-905) --
-    const double cell_area = a.gen_tab[2] * a.gen_tab[2], link_area = a.gen_tab[2] * a.gen_tab[3];
+    const double cell_area = a.gt->gen_tab[2] * a.gt->gen_tab[2], link_area = a.gt->gen_tab[2] * a.gt->gen_tab[3];
     const double total = ncell * cell_area + nlink * link_area;
     const double radii[2] = {sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2.0, a.agent_radius};
     double out[2][2];
@@ -284,16 +284,16 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     const size_t N = a.N;
     for (int s = 0; s < a.E; ++s) a.ekind[(size_t)s * N + env] = MW_ENT_NONE;
     double ax = 0, az = 0, adir = 0;
-    if (a.tex_nvar[0] > 0 && !a.shared_geom && a.generator != MW_GEN_MAZE) {
+    if (a.gt->tex_nvar[0] > 0 && !a.shared_geom && a.generator != MW_GEN_MAZE) {
         // Room._gen_static_data with an rng (miniworld.py:295-297): wall, floor, ceiling variant
         // drawn in that order (opengl.py:136-138); the room is re-emitted into this env's own set
         int pick[3];
-        for (int k = 0; k < 3; ++k) pick[k] = a.tex_nvar[k] > 1 ? (int)rng_below(r, (uint32_t)a.tex_nvar[k]) : 0;
+        for (int k = 0; k < 3; ++k) pick[k] = a.gt->tex_nvar[k] > 1 ? (int)rng_below(r, (uint32_t)a.gt->tex_nvar[k]) : 0;
         RoomTex rt;
-        rt.wall = a.tex_var_id[0][pick[0]]; rt.wu = a.tex_var_scale[0][pick[0]][0]; rt.wv = a.tex_var_scale[0][pick[0]][1];
-        rt.floor = a.tex_var_id[1][pick[1]]; rt.fu = a.tex_var_scale[1][pick[1]][0]; rt.fv = a.tex_var_scale[1][pick[1]][1];
-        rt.ceil = a.tex_var_id[2][pick[2]]; rt.cu = a.tex_var_scale[2][pick[2]][0]; rt.cv = a.tex_var_scale[2][pick[2]][1];
-        rt.height = a.room_wall_height; rt.ceiling = !a.room_no_ceiling;
+        rt.wall = a.gt->tex_var_id[0][pick[0]]; rt.wu = a.gt->tex_var_scale[0][pick[0]][0]; rt.wv = a.gt->tex_var_scale[0][pick[0]][1];
+        rt.floor = a.gt->tex_var_id[1][pick[1]]; rt.fu = a.gt->tex_var_scale[1][pick[1]][0]; rt.fv = a.gt->tex_var_scale[1][pick[1]][1];
+        rt.ceil = a.gt->tex_var_id[2][pick[2]]; rt.cu = a.gt->tex_var_scale[2][pick[2]][0]; rt.cv = a.gt->tex_var_scale[2][pick[2]][1];
+        rt.height = a.gt->room_wall_height; rt.ceiling = !a.gt->room_no_ceiling;
         const double px[4] = {a.gen_args[1], a.gen_args[1], a.gen_args[0], a.gen_args[0]};
         const double pz[4] = {a.gen_args[3], a.gen_args[2], a.gen_args[2], a.gen_args[3]};
         int np = 0, ns = 0;
@@ -341,13 +341,13 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
         for (int s = 0; s < n && s < a.E; ++s) {
             const int kind = (int)rng_below(r, 3);          // 0 ball, 1 box, 2 key (obj_types order)
             const int color = (int)rng_below(r, 6);         // index into the sorted COLOR_NAMES
-            const double radius = a.gen_tab[kind * 4 + 0], height = a.gen_tab[kind * 4 + 1];
+            const double radius = a.gt->gen_tab[kind * 4 + 0], height = a.gt->gen_tab[kind * 4 + 1];
             double x, z;
             gen_place(a, env, set, r, radius, s, a.gen_args[0], a.gen_args[1], x, z);
             const double dir = rng_uniform(r, -kGenPi, kGenPi);
             const size_t E = a.E;
             a.ekind[(size_t)s * N + env] = kind == 1 ? MW_ENT_BOX : MW_ENT_MESH;
-            a.emesh[(size_t)s * N + env] = kind == 1 ? -1 : (int)a.gen_tab[kind * 4 + 3] + color;
+            a.emesh[(size_t)s * N + env] = kind == 1 ? -1 : (int)a.gt->gen_tab[kind * 4 + 3] + color;
             a.estatic[(size_t)s * N + env] = 0;
             a.epos[((size_t)0 * E + s) * N + env] = x;
             a.epos[((size_t)1 * E + s) * N + env] = 0.0;
@@ -355,8 +355,8 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
             a.edir[(size_t)s * N + env] = dir;
             const double size = kind == 1 ? 0.9 : 0.0;
             for (int k = 0; k < 3; ++k) a.egeom[((size_t)k * E + s) * N + env] = size;
-            for (int k = 0; k < 3; ++k) a.egeom[((size_t)(3 + k) * E + s) * N + env] = a.gen_colors[color * 3 + k];
-            a.egeom[((size_t)6 * E + s) * N + env] = a.gen_tab[kind * 4 + 2];
+            for (int k = 0; k < 3; ++k) a.egeom[((size_t)(3 + k) * E + s) * N + env] = a.gt->gen_colors[color * 3 + k];
+            a.egeom[((size_t)6 * E + s) * N + env] = a.gt->gen_tab[kind * 4 + 2];
             a.egeom[((size_t)7 * E + s) * N + env] = radius;
             a.egeom[((size_t)8 * E + s) * N + env] = height;
         }
@@ -381,9 +381,9 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     a.ax[env] = ax; a.ay[env] = 0.0; a.az[env] = az; a.adir[env] = adir;
     a.carry[env] = -1; a.step[env] = 0; a.picked[env] = 0;
     if (a.generator == MW_GEN_MAZE) {
-        const double pitch = a.gen_tab[2] + a.gen_tab[3];
-        a.extent[(size_t)0 * N + env] = 0.0; a.extent[(size_t)1 * N + env] = ((int)a.gen_tab[1] - 1) * pitch + a.gen_tab[2];
-        a.extent[(size_t)2 * N + env] = 0.0; a.extent[(size_t)3 * N + env] = ((int)a.gen_tab[0] - 1) * pitch + a.gen_tab[2];
+        const double pitch = a.gt->gen_tab[2] + a.gt->gen_tab[3];
+        a.extent[(size_t)0 * N + env] = 0.0; a.extent[(size_t)1 * N + env] = ((int)a.gt->gen_tab[1] - 1) * pitch + a.gt->gen_tab[2];
+        a.extent[(size_t)2 * N + env] = 0.0; a.extent[(size_t)3 * N + env] = ((int)a.gt->gen_tab[0] - 1) * pitch + a.gt->gen_tab[2];
     } else {
         for (int k = 0; k < 4; ++k) a.extent[(size_t)k * N + env] = a.gen_args[k];
     }

@@ -218,9 +218,12 @@ __device__ inline void raster_tile(const TileCtx &cx, int tx, int ty, const uint
         exact |= __any(m) != 0;
     }
     if (!exact) {
-        bool cov[8];
+        // Per-sample coverage lives in wave-uniform 64-bit lane masks (SGPR pairs): every test
+        // below is a v_cmp producing a mask, every combination is SALU work.
+        uint64_t cov_m[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) cov[s] = false;
+        for (int s = 0; s < 8; ++s) cov_m[s] = 0ull;
+        uint64_t anycov_m = 0ull;
         uint32_t ncov = 0;                           // covered samples of this lane's pixel
         for (int chunk = 0; chunk < ((dbg & 2) ? 0 : nvis) && !exact; chunk += 64) {
             // Tile classification, one primitive per lane.  The edge function is monotone in X
@@ -254,34 +257,39 @@ __device__ inline void raster_tile(const TileCtx &cx, int tx, int ty, const uint
                 bool in0;
                 if ((fullm >> bit) & 1) {
                     // the whole tile lies strictly inside primitive p
-                    if (__any(ncov != 0u)) { exact = true; break; }
+                    if (anycov_m) { exact = true; break; }
                     cnt = 8u; in0 = true;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) cov[s] = true;
+                    for (int s = 0; s < 8; ++s) cov_m[s] = ~0ull;
+                    anycov_m = ~0ull;
                 } else {
                     const float *__restrict__ rr = rr_env + (size_t)p * MW_RASTER_REC;
-                    bool in[8];
+                    uint64_t in_m[8];
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) in[s] = true;
+                    for (int s = 0; s < 8; ++s) in_m[s] = ~0ull;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float E = fmaf(rr[k], Xc, fmaf(rr[4 + k], Yc, rr[8 + k]));
                         if (__all(E > rr[57 + k])) continue;        // tile strictly inside edge k
 #pragma unroll
-                        for (int s = 0; s < 8; ++s) in[s] &= E > rr[16 + k * 8 + s];
+                        for (int s = 0; s < 8; ++s) in_m[s] &= __ballot(E > rr[16 + k * 8 + s]);
                     }
-                    bool clash = false;
+                    uint64_t any_m = 0ull, clash_m = 0ull;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        any_m |= in_m[s];
+                        clash_m |= in_m[s] & cov_m[s];
+                    }
+                    if (clash_m) { exact = true; break; }
+                    if (!any_m) continue;
                     cnt = 0u;
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
-                        clash |= in[s] && cov[s];
-                        cnt += in[s] ? 1u : 0u;
+                        cov_m[s] |= in_m[s];
+                        cnt += __builtin_amdgcn_inverse_ballot_w64(in_m[s]) ? 1u : 0u;
                     }
-                    if (__any(clash)) { exact = true; break; }
-                    if (!__any(cnt != 0u)) continue;
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) cov[s] |= in[s];
-                    in0 = in[0];
+                    anycov_m |= any_m;
+                    in0 = __builtin_amdgcn_inverse_ballot_w64(in_m[0]);
                 }
                 ncov += cnt;
                 if (cnt != 0u) {

@@ -293,7 +293,7 @@ struct PolyGeom {
     uint32_t bbox;                  // tile bounds tx0 | tx1<<8 | ty0<<16 | ty1<<24
 };
 
-__device__ bool cull_poly(const MwArgs &a, const HV h[4], int nv, PolyGeom &g)
+__device__ __forceinline__ bool cull_poly(const MwArgs &a, const HV h[4], int nv, PolyGeom &g)
 {
     edge_coef(h[1], h[2], g.ga[0], g.gb[0], g.gc[0]);
     edge_coef(h[2], h[0], g.ga[1], g.gb[1], g.gc[1]);
@@ -337,7 +337,7 @@ __device__ bool cull_poly(const MwArgs &a, const HV h[4], int nv, PolyGeom &g)
     return true;
 }
 
-__device__ void write_poly(const MwArgs &a, int env, int idx, uint32_t draw_id, const HV h[4], int nv,
+__device__ __forceinline__ void write_poly(const MwArgs &a, int env, int idx, uint32_t draw_id, const HV h[4], int nv,
                            const PolyGeom &g, const float uv[3][2], const float col[3], int tex)
 {
     float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
