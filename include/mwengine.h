@@ -186,6 +186,12 @@ int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);
 /* render_top_view (miniworld.py:1088-1175): orthographic map of the whole floorplan into the same
  * kind of buffers; render_agent != 0 also draws Agent.render's marker (entity.py:518-539) */
 int mw_render_top(mw_engine *e, uint8_t *d_obs, float *d_depth, int32_t render_agent, void *stream);
+/* render() / render_obs(vis_fb) / render_top_view(vis_fb) (miniworld.py:1340-1362): ONE env into a frame
+ * buffer of any size (multiples of 16 x 4) with msaa = 8 or 16 samples (vis_fb = FrameBuffer(800, 600, 16),
+ * miniworld.py:518).  view_flags: bit 0 top view, bit 1 draw the agent marker.
+ *   d_out uint8[height][width][3], d_depth float[height][width] or NULL.  Not the hot path. */
+int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width, int32_t height, int32_t msaa,
+                   uint8_t *d_out, float *d_depth, void *stream);
 /* checks the device-side status word (capacity overflows); synchronises `stream` */
 int mw_check(mw_engine *e, void *stream);
 

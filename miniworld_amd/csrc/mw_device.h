@@ -51,7 +51,7 @@ struct MwArgs {
     int32_t max_polys, max_segs, max_vis, shared_geom;
     int32_t task, goal_ent, num_objs, max_steps;
     int32_t domain_rand, generator, autoreset, tiles_x;
-    int32_t tiles_y, n_tiles, goal_ent2, pad1;
+    int32_t tiles_y, n_tiles, goal_ent2, env_base;    // env_base: first env of this launch (0 for the batched step)
     double agent_radius, max_forward_step, agent_height;
     mw_range fwd, drift, turn;
     mw_range sky[3], light_pos[3], light_color[3], light_ambient[3], color_bias[3];

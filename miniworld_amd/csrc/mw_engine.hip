@@ -28,6 +28,12 @@ extern "C" __global__ void mw_raster_big_kernel(int N, int W, int H, int max_vis
                                                 const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
                                                 uint8_t *obs, float *depth, int dbg, int texel_bytes);
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all);
+extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, const float *hdr, const float *mesh_pos, uint32_t *keys);
+extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
+                                                 const float *rec_shade, const int32_t *nvis, const float *envhdr,
+                                                 const MwTexDesc *texd, const uint32_t *texels, const float *mesh_pos,
+                                                 const float *mesh_nrm, const float *mesh_rgb, const uint32_t *mesh_keys,
+                                                 uint8_t *out, float *depth, int texel_bytes);
 extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                                  const float *rec_raster, const float *rec_shade, const float *rec_cull,
                                                  const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
@@ -56,6 +62,8 @@ struct mw_engine {
     float *d_mesh_pos = nullptr, *d_mesh_nrm = nullptr, *d_mesh_rgb = nullptr;
     bool have_meshes = false;
     bool mesh_lds_ready = false;
+    uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
+    size_t view_keys_bytes = 0;
     // scratch for the step outputs when the caller passes none
     float *d_reward_scratch = nullptr;
     uint8_t *d_flag_scratch = nullptr;
@@ -434,6 +442,7 @@ void mw_destroy(mw_engine *e)
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_texels) (void)hipFree(e->d_texels);
     for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb}) if (p) (void)hipFree(p);
+    if (e->d_view_keys) (void)hipFree(e->d_view_keys);
     for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     for (auto &ev : e->ev_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     delete e;
@@ -577,6 +586,44 @@ int mw_render_top(mw_engine *e, uint8_t *d_obs, float *d_depth, int32_t render_a
     if (!e) return MW_E_INVALID;
     return launch_frame(e, false, 1 | (render_agent ? 2 : 0), e->d_action_scratch, d_obs, d_depth, nullptr, nullptr, nullptr,
                         (hipStream_t)stream);
+}
+
+int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width, int32_t height, int32_t msaa,
+                   uint8_t *d_out, float *d_depth, void *stream)
+{
+    if (!e || !d_out) return fail(e, MW_E_INVALID, "null argument");
+    if (env < 0 || env >= e->cfg.num_envs) return fail(e, MW_E_INVALID, "env %d out of range", env);
+    if (msaa != 8 && msaa != 16) return fail(e, MW_E_INVALID, "msaa must be 8 or 16");
+    if (width <= 0 || height <= 0 || width % MW_TILE_W || height % MW_TILE_H || width > 255 * MW_TILE_W || height > 255 * MW_TILE_H)
+        return fail(e, MW_E_INVALID, "frame buffer size must be a multiple of %dx%d", MW_TILE_W, MW_TILE_H);
+    hipStream_t st = (hipStream_t)stream;
+    MwArgs b = e->args;
+    b.step_override = nullptr;
+    b.W = width; b.H = height;
+    b.tiles_x = width / MW_TILE_W; b.tiles_y = height / MW_TILE_H; b.n_tiles = b.tiles_x * b.tiles_y;
+    b.env_base = env;
+    hipLaunchKernelGGL(mw_step_setup_kernel, dim3(1), dim3(64), 0, st, b, 0, view_flags, e->d_action_scratch,
+                       e->d_reward_scratch, e->d_flag_scratch, e->d_flag_scratch + e->cfg.num_envs);
+    uint32_t *keys = nullptr;
+    if (e->have_meshes) {
+        const size_t need = (size_t)width * height * msaa * 4;
+        if (need > e->view_keys_bytes) {
+            HIP_TRY(e, hipStreamSynchronize(st));
+            if (e->d_view_keys) (void)hipFree(e->d_view_keys);
+            e->d_view_keys = nullptr; e->view_keys_bytes = 0;
+            HIP_TRY(e, hipMalloc((void **)&e->d_view_keys, need));
+            e->view_keys_bytes = need;
+        }
+        keys = e->d_view_keys;
+        HIP_TRY(e, hipMemsetAsync(keys, 0xFF, need, st));
+        hipLaunchKernelGGL(mw_view_mesh_kernel, dim3(128), dim3(256), 0, st, width, height, msaa,
+                           (const float *)(b.envhdr + (size_t)env * MW_ENVHDR), b.mesh_pos, keys);
+    }
+    hipLaunchKernelGGL(mw_view_raster_kernel, dim3(b.n_tiles), dim3(64), 0, st, env, width, height, msaa, b.max_vis, b.tiles_x,
+                       (const float *)b.rec_raster, (const float *)b.rec_shade, (const int32_t *)b.nvis, (const float *)b.envhdr,
+                       b.tex, b.texels, b.mesh_pos, b.mesh_nrm, b.mesh_rgb, (const uint32_t *)keys, d_out, d_depth, e->texel_bytes);
+    HIP_TRY(e, hipGetLastError());
+    return MW_OK;
 }
 
 int mw_check(mw_engine *e, void *stream)

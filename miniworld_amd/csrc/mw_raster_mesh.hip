@@ -69,6 +69,14 @@ __device__ inline float below(float x)
 
 __constant__ float kDx[8] = {0.0625f, -0.0625f, 0.3125f, -0.1875f, -0.3125f, -0.4375f, 0.1875f, 0.4375f};
 __constant__ float kDy[8] = {-0.1875f, 0.1875f, 0.0625f, -0.3125f, 0.3125f, -0.0625f, 0.4375f, -0.4375f};
+// R5 for the 16-sample visualisation buffer (FrameBuffer(800, 600, 16), miniworld.py:518): the
+// D3D standard 16x pattern (9,9)(7,5)(5,10)(12,7)(3,6)(10,13)(13,11)(11,3)(6,14)(8,1)(4,2)(2,12)(0,8)(15,4)(14,15)(1,0)
+__constant__ float kDx16[16] = {0.0625f, -0.0625f, -0.1875f, 0.25f, -0.3125f, 0.125f, 0.3125f, 0.1875f,
+                                -0.125f, 0.0f, -0.25f, -0.375f, -0.5f, 0.4375f, 0.375f, -0.4375f};
+__constant__ float kDy16[16] = {0.0625f, -0.1875f, 0.125f, -0.0625f, -0.125f, 0.3125f, 0.1875f, -0.3125f,
+                                0.375f, -0.4375f, -0.375f, 0.25f, 0.0f, -0.25f, 0.4375f, -0.5f};
+template <int S> __device__ inline float sample_dx(int s) { return S == 16 ? kDx16[s] : kDx[s]; }
+template <int S> __device__ inline float sample_dy(int s) { return S == 16 ? kDy16[s] : kDy[s]; }
 
 // world-space vertices of triangle `tri` of mesh entity e (R11: pos + scale * R_y(dir) * v)
 __device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, int tri, float halfw, float halfh, HV h[3])
@@ -149,6 +157,7 @@ __device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc,
 }
 
 // rasterise one mesh triangle into the LDS key buffer (one lane per triangle)
+template <int S>
 __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, uint32_t *keys)
 {
     const int W = cx.W, H = cx.H;
@@ -193,13 +202,13 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
     }
     // edges 0->1, 1->2, 2->0 in drawing order: coefficients = G2, G0, G1
     const float ea[3] = {ga[2], ga[0], ga[1]}, eb[3] = {gb[2], gb[0], gb[1]}, ec[3] = {gc[2], gc[0], gc[1]};
-    float thr[3][8];
+    float thr[3][S];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const bool tl = (ea[k] > 0.0f) || (ea[k] == 0.0f && eb[k] > 0.0f);
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            const float t = -fmaf(ea[k], kDx[s], eb[k] * kDy[s]);
+        for (int s = 0; s < S; ++s) {
+            const float t = -fmaf(ea[k], sample_dx<S>(s), eb[k] * sample_dy<S>(s));
             thr[k][s] = tl ? below(t) : t;
         }
     }
@@ -208,9 +217,9 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
     const float tb = fmaf(h[2].cz, gb[2], fmaf(h[1].cz, gb[1], h[0].cz * gb[0]));
     const float tc = fmaf(h[2].cz, gc[2], fmaf(h[1].cz, gc[1], h[0].cz * gc[0]));
     const float zx = (ta * invD) * 0.5f, zy = (tb * invD) * 0.5f, zcc = fmaf(tc * invD, 0.5f, 0.5f);
-    float zo[8];
+    float zo[S];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) zo[s] = fmaf(zx, kDx[s], zy * kDy[s]);
+    for (int s = 0; s < S; ++s) zo[s] = fmaf(zx, sample_dx<S>(s), zy * sample_dy<S>(s));
     const uint32_t id = (uint32_t)(e.start + tri);
     for (int py = y0; py <= y1; ++py)
         for (int px = x0; px <= x1; ++px) {
@@ -219,9 +228,9 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
             const float E1 = fmaf(ea[1], Xc, fmaf(eb[1], Yc, ec[1]));
             const float E2 = fmaf(ea[2], Xc, fmaf(eb[2], Yc, ec[2]));
             const float zc = fmaf(zx, Xc, fmaf(zy, Yc, zcc));
-            uint32_t *kp = keys + ((size_t)py * W + px) * 8;
+            uint32_t *kp = keys + ((size_t)py * W + px) * S;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) {
+            for (int s = 0; s < S; ++s) {
                 if (E0 > thr[0][s] && E1 > thr[1][s] && E2 > thr[2][s]) {
                     const float t = fmaf(zc + zo[s], 65535.0f, 0.5f);
                     if (t >= 0.5f && t < 65536.0f) atomicMin(kp + s, ((uint32_t)t << 16) | id);
@@ -269,7 +278,7 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     const int n_mesh = __float_as_int(hdr[3]);
     for (int j = 0; j < n_mesh; ++j) {
         const MeshEnt e = load_ment(hdr, j);
-        for (int t = tid; t < e.ntris; t += 1024) raster_tri(cx, e, t, keys);
+        for (int t = tid; t < e.ntris; t += 1024) raster_tri<8>(cx, e, t, keys);
     }
     __syncthreads();
 
@@ -283,4 +292,142 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
         mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
         raster_tile<true>(cx, tx, ty, mk);
     }
+}
+
+// ======================================================================================
+// Generic-resolution path: render()/vis_fb 800x600x16 (miniworld.py:518, 1340-1362) and any other
+// frame buffer size / sample count.  One env at a time, exact packed-key resolution only; the mesh
+// keys go through a global buffer (the image no longer fits LDS).  Not the hot path.
+// ======================================================================================
+template <int S>
+__device__ inline void view_mesh_body(int W, int H, const float *hdr, const float *mesh_pos, uint32_t *keys)
+{
+    TileCtx cx{};
+    cx.hdr = hdr; cx.mesh_pos = mesh_pos; cx.W = W; cx.H = H;
+    const int n_mesh = __float_as_int(hdr[3]);
+    const int stride = gridDim.x * blockDim.x;
+    for (int j = 0; j < n_mesh; ++j) {
+        const MeshEnt e = load_ment(hdr, j);
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e.ntris; t += stride) raster_tri<S>(cx, e, t, keys);
+    }
+}
+
+extern "C" __global__ __launch_bounds__(256) void mw_view_mesh_kernel(int W, int H, int S, const float *__restrict__ hdr,
+                                                                     const float *__restrict__ mesh_pos, uint32_t *keys)
+{
+    if (S == 16) view_mesh_body<16>(W, H, hdr, mesh_pos, keys);
+    else view_mesh_body<8>(W, H, hdr, mesh_pos, keys);
+}
+
+template <int S>
+__device__ inline void view_tile_body(TileCtx &cx, int tiles_x, const uint32_t *mesh_keys)
+{
+    const int lane = cx.lane, W = cx.W, H = cx.H, nvis = cx.nvis;
+    const int tile = blockIdx.x;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int px = tx * MW_TILE_W + (lane & 15), py = ty * MW_TILE_H + (lane >> 4);
+    const float Xc = (float)px + 0.5f, Yc = (float)py + 0.5f;
+    uint32_t key[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) key[s] = mesh_keys ? mesh_keys[((size_t)py * W + px) * S + s] : 0xFFFFFFFFu;
+    for (int p = 0; p < nvis; ++p) {
+        const float *__restrict__ rr = cx.rr_env + (size_t)p * MW_RASTER_REC;
+        const uint32_t bb = __float_as_uint(rr[15]);
+        const int bx0 = bb & 255u, bx1 = (bb >> 8) & 255u, by0 = (bb >> 16) & 255u, by1 = bb >> 24;
+        if (tx < bx0 || tx > bx1 || ty < by0 || ty > by1) continue;
+        float E[4];
+        bool tl[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            E[k] = fmaf(rr[k], Xc, fmaf(rr[4 + k], Yc, rr[8 + k]));
+            tl[k] = (rr[k] > 0.0f) || (rr[k] == 0.0f && rr[4 + k] > 0.0f);
+        }
+        const bool tri = rr[3] == 0.0f && rr[7] == 0.0f && rr[11] == 1.0f;      // K1's always-true 4th edge
+        const float zc = fmaf(rr[12], Xc, fmaf(rr[13], Yc, rr[14]));
+        const uint32_t id = __float_as_uint(rr[61]);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const float dx = sample_dx<S>(s), dy = sample_dy<S>(s);
+            bool in = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t = -fmaf(rr[k], dx, rr[4 + k] * dy);
+                const float thr = (tl[k] && !(k == 3 && tri)) ? below(t) : t;
+                in &= E[k] > thr;
+            }
+            const float zs = zc + fmaf(rr[12], dx, rr[13] * dy);
+            const float t = fmaf(zs, 65535.0f, 0.5f);
+            const bool ok = in && t >= 0.5f && t < 65536.0f;
+            const uint32_t k = ((uint32_t)t << 16) | id;
+            key[s] = ok ? min(key[s], k) : key[s];
+        }
+    }
+    const uint32_t z16 = key[0] >> 16;
+    uint32_t pid[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) pid[s] = key[s] & 0xFFFFu;
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f;
+    for (;;) {
+        uint32_t sel = 0x10000u;
+#pragma unroll
+        for (int s = 0; s < S; ++s) sel = min(sel, pid[s]);
+        const bool active = sel != 0x10000u;
+        if (!__any(active)) break;
+        if (active) {
+            uint32_t cnt = 0;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const bool eq = pid[s] == sel;
+                cnt += eq ? 1u : 0u;
+                pid[s] = eq ? 0x10000u : pid[s];
+            }
+            RGB c = {cx.sky_r, cx.sky_g, cx.sky_b};
+            if (sel != MW_SKY_PID) c = shade_by_draw_id(cx, sel, Xc, Yc);
+            const float fc = (float)cnt;
+            acc_r = fmaf(fc, c.r, acc_r);
+            acc_g = fmaf(fc, c.g, acc_g);
+            acc_b = fmaf(fc, c.b, acc_b);
+        }
+    }
+    const float inv = 1.0f / (float)S;
+    float v[3] = {acc_r * inv, acc_g * inv, acc_b * inv};
+    uint8_t *dst = cx.obs + ((size_t)py * W + px) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float x = v[c] < 0.0f ? 0.0f : (v[c] > 1.0f ? 1.0f : v[c]);
+        dst[c] = (uint8_t)(int)fmaf(x, 255.0f, 0.5f);
+    }
+    if (cx.depth) {
+        const float z = (float)z16;
+        const float d = z / 65535.0f;
+        const float clip = (d - 0.5f) * 2.0f;
+        const float den = clip * (float)(100.0 - 0.04) - (float)(100.0 + 0.04);
+        cx.depth[(size_t)py * W + px] = (float)(-2.0 * 100.0 * 0.04) / den;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
+    int env, int W, int H, int S, int max_vis, int tiles_x, const float *__restrict__ rec_raster,
+    const float *__restrict__ rec_shade, const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr,
+    const MwTexDesc *__restrict__ texd, const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos,
+    const float *__restrict__ mesh_nrm, const float *__restrict__ mesh_rgb, const uint32_t *mesh_keys,
+    uint8_t *__restrict__ out, float *__restrict__ depth, int texel_bytes)
+{
+    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
+    TileCtx cx;
+    cx.s_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
+    cx.s_cull = nullptr;
+    cx.rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
+    cx.s_pack = nullptr;
+    cx.hdr = hdr;
+    cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb;
+    cx.obs = out; cx.depth = depth;
+    cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
+    cx.te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);
+    cx.te.texd = texd;
+    cx.te.flat = 0;
+    cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
+    cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x;
+    if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
+    else view_tile_body<8>(cx, tiles_x, mesh_keys);
 }

@@ -444,7 +444,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
     uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
 {
     __shared__ unsigned char gen_ws[MW_GEN_WS_BYTES];
-    const int env = blockIdx.x;
+    const int env = a.env_base + blockIdx.x;
     const int lane = threadIdx.x;
     StepCtx c{a, env, lane, a.shared_geom ? 0 : env, 0, 0, 0, 0, 0, -1, -1, {0, 0, 0}, 0};
     c.px = a.ax[env]; c.py = a.ay[env]; c.pz = a.az[env]; c.dir = a.adir[env];

@@ -25,7 +25,7 @@ AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_render_top", "mw_check", "mw_kernel_time_ms",
+    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_check", "mw_kernel_time_ms",
 ]
 
 
@@ -144,6 +144,7 @@ def load_library():
     L.mw_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.mw_render.argtypes = [vp, vp, vp, vp]
     L.mw_render_top.argtypes = [vp, vp, vp, i32, vp]
+    L.mw_render_view.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.mw_check.argtypes = [vp, vp]
     L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = L
@@ -267,6 +268,18 @@ class Engine:
     def render_top(self, obs, depth=None, render_agent=True):
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         self._check(self.lib.mw_render_top(self.h, ptr(obs), ptr(depth), int(render_agent), _stream_ptr()), "mw_render_top")
+
+    def render_view(self, env: int, width: int, height: int, msaa: int = 16, top: bool = False,
+                    render_agent: bool = False, want_depth: bool = False):
+        """One env into a (height, width) buffer with 8 or 16 samples; returns torch tensors."""
+        import torch
+        out = torch.zeros((height, width, 3), dtype=torch.uint8, device=self.device)
+        dep = torch.zeros((height, width, 1), dtype=torch.float32, device=self.device) if want_depth else None
+        flags = (1 if top else 0) | (2 if render_agent else 0)
+        self._check(self.lib.mw_render_view(self.h, env, flags, width, height, msaa, C.c_void_p(out.data_ptr()),
+                                            None if dep is None else C.c_void_p(dep.data_ptr()), _stream_ptr()),
+                    "mw_render_view")
+        return (out, dep) if want_depth else out
 
     def check(self):
         self._check(self.lib.mw_check(self.h, _stream_ptr()), "mw_check")

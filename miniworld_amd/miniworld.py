@@ -146,6 +146,15 @@ class Room:
         self.wall_texcs = np.concatenate(texcs) if texcs else np.array([]).reshape(0, 2)
 
 
+class FrameBuffer:
+    """Size / sample-count descriptor with the reference's FrameBuffer constructor signature
+    (opengl.py:202: FrameBuffer(width, height, num_samples)); the pixels live on the GPU."""
+
+    def __init__(self, width, height, num_samples=1):
+        assert 0 < num_samples <= 16
+        self.width, self.height, self.num_samples = width, height, num_samples
+
+
 class MiniWorldEnv(gym.Env):
     """Base class of all environments: world generation + engine-backed simulation."""
 
@@ -179,6 +188,8 @@ class MiniWorldEnv(gym.Env):
         self.obs_width, self.obs_height = obs_width, obs_height
         self.window_width, self.window_height = window_width, window_height
         self.device_id = device_id
+        self.obs_fb = FrameBuffer(obs_width, obs_height, 8)              # miniworld.py:515
+        self.vis_fb = FrameBuffer(window_width, window_height, 16)       # miniworld.py:518
         # host_only: generate worlds but never touch the GPU (used by MiniWorldVecEnv, which owns
         # a batched engine, and by the CPU tests of world generation); step/render then raise.
         self._host_only = host_only
@@ -354,13 +365,26 @@ class MiniWorldEnv(gym.Env):
         truncation = self.step_count >= self.max_episode_steps
         return obs, 0, False, truncation, {}
 
+    def _is_obs_fb(self, fb):
+        return fb is None or (fb.width == self.obs_width and fb.height == self.obs_height and fb.num_samples == 8)
+
+    def _render_into(self, fb, top, render_agent):
+        self._engine.push_state(self)
+        msaa = 16 if fb.num_samples > 8 else 8
+        return self._engine.engine.render_view(0, fb.width, fb.height, msaa, top=top, render_agent=render_agent).cpu().numpy()
+
     def render_obs(self, frame_buffer=None):
+        if not self._is_obs_fb(frame_buffer):
+            return self._render_into(frame_buffer, False, False)
         return self._engine.render(self)["rgb"]
 
     def render_top_view(self, frame_buffer=None, render_agent=True, return_scale=False):
         """Orthographic map of the whole floorplan at the observation resolution (the reference's
         default frame buffer for this call is obs_fb, miniworld.py:1093-1094)."""
-        img = self._engine.render(self, top_view=True, render_agent=render_agent)["rgb"]
+        if self._is_obs_fb(frame_buffer):
+            img = self._engine.render(self, top_view=True, render_agent=render_agent)["rgb"]
+        else:
+            img = self._render_into(frame_buffer, True, render_agent)
         if not return_scale:
             return img
         min_x, max_x, min_z, max_z = self.min_x - 1, self.max_x + 1, self.min_z - 1, self.max_z + 1
@@ -382,7 +406,8 @@ class MiniWorldEnv(gym.Env):
         if self.render_mode is None:
             gym.logger.warn("You are calling render method without specifying any render mode.")
             return None
-        return self.render_top_view() if self.view == "top" else self.render_obs()
+        # rgb_array / human: the 800 x 600 x 16-sample visualisation buffer (miniworld.py:1354-1362)
+        return self.render_top_view(self.vis_fb) if self.view == "top" else self.render_obs(self.vis_fb)
 
     def close(self):
         if self._engine is not None:
