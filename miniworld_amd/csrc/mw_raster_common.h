@@ -32,37 +32,47 @@ __device__ inline uint32_t ldw(rsrc_t r, uint32_t dword_index)
     return __builtin_amdgcn_raw_buffer_load_b32(r, dword_index << 2, 0, 0);
 }
 
-// R8: GL_LINEAR fetch on one mip level (first texel `off`, dims w x h), GL_REPEAT, centres at +0.5
-__device__ inline RGB bilinear(rsrc_t tx, uint32_t off, int w, int h, float u, float v)
+// u8 channel -> float through the hardware byte converters.  Inline asm keeps the optimiser from
+// rewriting (float)b - (float)a into an integer subtract + convert: on gfx950 every integer /
+// conversion op costs twice an f32 add (tools/ubench), so 12 converts + float subtracts win.
+__device__ inline float ub0(uint32_t t) { float f; asm("v_cvt_f32_ubyte0 %0, %1" : "=v"(f) : "v"(t)); return f; }
+__device__ inline float ub1(uint32_t t) { float f; asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(t)); return f; }
+__device__ inline float ub2(uint32_t t) { float f; asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(t)); return f; }
+
+// R8: GL_LINEAR fetch on one mip level (first texel `off`, dims w x h), GL_REPEAT, centres at +0.5.
+// POT: both dims are powers of two (wave-uniform property of the texture): wrap with a mask.
+template <bool POT>
+__device__ inline RGB bilinear(rsrc_t tx, uint32_t off, int w, int h, float uu, float vv)
 {
-    const float uu = u - floorf(u), vv = v - floorf(v);
     const float x = fmaf(uu, (float)w, -0.5f), y = fmaf(vv, (float)h, -0.5f);
     const float x0f = floorf(x), y0f = floorf(y);
     const float fx = x - x0f, fy = y - y0f;
     int i0 = (int)x0f, j0 = (int)y0f;
     int i1 = i0 + 1, j1 = j0 + 1;
-    if (i0 < 0) i0 += w;
-    if (i1 >= w) i1 -= w;
-    if (j0 < 0) j0 += h;
-    if (j1 >= h) j1 -= h;
+    if (POT) {
+        i0 &= w - 1; i1 &= w - 1; j0 &= h - 1; j1 &= h - 1;
+    } else {
+        if (i0 < 0) i0 += w;
+        if (i1 >= w) i1 -= w;
+        if (j0 < 0) j0 += h;
+        if (j1 >= h) j1 -= h;
+    }
     const uint32_t r0 = off + __umul24((uint32_t)j0, (uint32_t)w), r1 = off + __umul24((uint32_t)j1, (uint32_t)w);
     const uint32_t t00 = ldw(tx, r0 + i0), t10 = ldw(tx, r0 + i1);
     const uint32_t t01 = ldw(tx, r1 + i0), t11 = ldw(tx, r1 + i1);
     RGB o;
     {
-        const float a = (float)(t00 & 255u), b = (float)(t10 & 255u), c = (float)(t01 & 255u), d = (float)(t11 & 255u);
+        const float a = ub0(t00), b = ub0(t10), c = ub0(t01), d = ub0(t11);
         const float r0f = fmaf(fx, b - a, a), r1f = fmaf(fx, d - c, c);
         o.r = fmaf(fy, r1f - r0f, r0f);
     }
     {
-        const float a = (float)((t00 >> 8) & 255u), b = (float)((t10 >> 8) & 255u);
-        const float c = (float)((t01 >> 8) & 255u), d = (float)((t11 >> 8) & 255u);
+        const float a = ub1(t00), b = ub1(t10), c = ub1(t01), d = ub1(t11);
         const float r0f = fmaf(fx, b - a, a), r1f = fmaf(fx, d - c, c);
         o.g = fmaf(fy, r1f - r0f, r0f);
     }
     {
-        const float a = (float)((t00 >> 16) & 255u), b = (float)((t10 >> 16) & 255u);
-        const float c = (float)((t01 >> 16) & 255u), d = (float)((t11 >> 16) & 255u);
+        const float a = ub2(t00), b = ub2(t10), c = ub2(t01), d = ub2(t11);
         const float r0f = fmaf(fx, b - a, a), r1f = fmaf(fx, d - c, c);
         o.b = fmaf(fy, r1f - r0f, r0f);
     }
@@ -73,6 +83,7 @@ __device__ inline int level_dim(int d, int l) { const int s = d >> l; return s >
 
 // Textured fragment colour (R7-R9) for the lanes whose primitive uses texture `tex` (wave-uniform:
 // dims and level count live in SGPRs); the attribute planes come from the lane's shade record.
+template <bool POT>
 __device__ inline RGB shade_tex(const float4 q0, const float4 q1, const float4 q2, rsrc_t td, rsrc_t tx, int tex,
                                 int tw, int th, int q, float Xc, float Yc)
 {
@@ -104,12 +115,13 @@ __device__ inline RGB shade_tex(const float4 q0, const float4 q1, const float4 q
             if (li < q) { l0 = li; l1 = li + 1; fr = lam - lf; }
         }
     }
+    const float uu = u - floorf(u), vv = v - floorf(v);        // GL_REPEAT, shared by both levels
     const uint32_t off0 = ldw(td, desc + (uint32_t)l0);
-    const RGB c0 = bilinear(tx, off0, level_dim(tw, l0), level_dim(th, l0), u, v);
+    const RGB c0 = bilinear<POT>(tx, off0, level_dim(tw, l0), level_dim(th, l0), uu, vv);
     texel = c0;
     if (l1 >= 0) {
         const uint32_t off1 = ldw(td, desc + (uint32_t)l1);
-        const RGB c1 = bilinear(tx, off1, level_dim(tw, l1), level_dim(th, l1), u, v);
+        const RGB c1 = bilinear<POT>(tx, off1, level_dim(tw, l1), level_dim(th, l1), uu, vv);
         texel.r = fmaf(fr, c1.r - c0.r, c0.r);
         texel.g = fmaf(fr, c1.g - c0.g, c0.g);
         texel.b = fmaf(fr, c1.b - c0.b, c0.b);
@@ -162,7 +174,11 @@ __device__ inline RGB shade_prim(const float4 *sr, const TexEnv &te, float Xc, f
             const int t0 = __builtin_amdgcn_readlane(tex, __ffsll((unsigned long long)pending) - 1);
             const MwTexDesc *__restrict__ d = te.texd + t0;
             const bool mine = tex == t0;
-            if (mine) c = shade_tex(q0, q1, q2, te.td, te.tx, t0, (int)d->w, (int)d->h, (int)d->nlevels - 1, Xc, Yc);
+            if (mine) {
+                const int tw = (int)d->w, th = (int)d->h, q = (int)d->nlevels - 1;
+                if (((tw & (tw - 1)) | (th & (th - 1))) == 0) c = shade_tex<true>(q0, q1, q2, te.td, te.tx, t0, tw, th, q, Xc, Yc);
+                else c = shade_tex<false>(q0, q1, q2, te.td, te.tx, t0, tw, th, q, Xc, Yc);
+            }
             pending &= ~__ballot(mine);
         }
     }
