@@ -45,6 +45,16 @@ __constant__ float kBoxN[6][3] = {{0, 0, 1}, {0, 0, -1}, {-1, 0, 0}, {1, 0, 0}, 
 
 __device__ inline uint64_t ballot(bool p) { return __ballot(p); }
 
+// wave-uniform values computed on the VALU are moved to SGPRs so they do not occupy a VGPR each
+__device__ inline float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ inline double uni(double v)
+{
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
 // ---------------------------------------------------------------- dynamics (f64)
 
 struct StepCtx {
@@ -394,15 +404,15 @@ __device__ __forceinline__ void write_poly(const MwArgs &a, int env, int idx, ui
         }
     }
     const float flag = __uint_as_float(may_clip ? 1u : 0u);
-    rr[0] = make_float4(ea[0], ea[1], ea[2], ea[3]);
-    rr[1] = make_float4(eb[0], eb[1], eb[2], eb[3]);
-    rr[2] = make_float4(ec[0], ec[1], ec[2], ec[3]);
+    const float4 e0 = make_float4(ea[0], ea[1], ea[2], ea[3]), e1 = make_float4(eb[0], eb[1], eb[2], eb[3]),
+                 e2 = make_float4(ec[0], ec[1], ec[2], ec[3]);
+    rr[0] = e0; rr[1] = e1; rr[2] = e2;
     rr[3] = make_float4(zx, zy, zc, __uint_as_float(g.bbox));
     rr[12] = make_float4(zo[0], zo[1], zo[2], zo[3]);
     rr[13] = make_float4(zo[4], zo[5], zo[6], zo[7]);
     rr[14] = make_float4(flag, tmaxv[0], tmaxv[1], tmaxv[2]);
     rr[15] = make_float4(tmaxv[3], __uint_as_float(draw_id), 0.0f, 0.0f);       // draw id = list index + mesh triangles drawn before
-    cr[0] = rr[0]; cr[1] = rr[1]; cr[2] = rr[2];
+    cr[0] = e0; cr[1] = e1; cr[2] = e2;
     cr[3] = make_float4(tminv[0], tminv[1], tminv[2], tminv[3]);
     cr[4] = make_float4(tmaxv[0], tmaxv[1], tmaxv[2], tmaxv[3]);
     cr[5] = make_float4(flag, 0.0f, 0.0f, 0.0f);
@@ -580,6 +590,17 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
     Cam cam;
     float sky[3];
     build_camera(a, env, c.px, c.py, c.pz, c.dir, cam, sky, (view_flags & 1) != 0);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cam.m[i][j] = uni(cam.m[i][j]);
+        cam.L[i] = uni(cam.L[i]); cam.amb[i] = uni(cam.amb[i]); cam.lcol[i] = uni(cam.lcol[i]);
+        sky[i] = uni(sky[i]);
+    }
+    cam.p00 = uni(cam.p00); cam.p11 = uni(cam.p11); cam.p22 = uni(cam.p22); cam.p23 = uni(cam.p23);
+    cam.p03 = uni(cam.p03); cam.p13 = uni(cam.p13);
+    c.px = uni(c.px); c.py = uni(c.py); c.pz = uni(c.pz); c.dir = uni(c.dir);
+    c.cpos[0] = uni(c.cpos[0]); c.cpos[1] = uni(c.cpos[1]); c.cpos[2] = uni(c.cpos[2]); c.cdir = uni(c.cdir);
     float stale_n[3] = {0.0f, 1.0f, 0.0f};       // GL's current normal after the last draw (top-view agent marker)
     int count = 0;
     const float white[3] = {1.0f, 1.0f, 1.0f};
