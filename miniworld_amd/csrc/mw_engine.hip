@@ -352,6 +352,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (cfg->abi_version != MW_ABI_VERSION) return fail(nullptr, MW_E_INVALID, "ABI version mismatch: header %d, caller %d", MW_ABI_VERSION, cfg->abi_version);
     if (cfg->num_envs <= 0 || cfg->max_ents < 0 || cfg->max_polys <= 0 || cfg->max_segs <= 0 || cfg->max_visible <= 0)
         return fail(nullptr, MW_E_INVALID, "bad capacities");
+    if (cfg->max_ents > 64) return fail(nullptr, MW_E_CAPACITY, "max_ents > 64 (one entity slot per lane of the env's wavefront)");
     if (cfg->msaa != 8) return fail(nullptr, MW_E_INVALID, "only msaa = 8 is implemented");
     if (cfg->obs_width % MW_TILE_W || cfg->obs_height % MW_TILE_H || cfg->obs_width > 255 * MW_TILE_W || cfg->obs_height > 255 * MW_TILE_H)
         return fail(nullptr, MW_E_INVALID, "obs size must be a multiple of %dx%d", MW_TILE_W, MW_TILE_H);

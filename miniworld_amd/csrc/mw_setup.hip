@@ -47,6 +47,7 @@ __device__ inline uint64_t ballot(bool p) { return __ballot(p); }
 
 // wave-uniform values computed on the VALU are moved to SGPRs so they do not occupy a VGPR each
 __device__ inline float uni(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ inline int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ inline double uni(double v)
 {
     const unsigned long long b = (unsigned long long)__double_as_longlong(v);
@@ -639,34 +640,47 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
     // a mesh entity only reserves its range of draw ids and is described to the mesh raster kernel.
     int mesh_tris = 0, n_mesh = 0;
     float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
+    // kind / static flag of every slot, one slot per lane, as wave-uniform bit masks (max_ents <= 64)
+    uint64_t box_m, mesh_m, static_m;
+    {
+        int kind_l = MW_ENT_NONE, static_l = 0;
+        if (lane < a.E) {
+            kind_l = a.ekind[(size_t)lane * a.N + env];
+            static_l = a.estatic[(size_t)lane * a.N + env];
+        }
+        box_m = ballot(kind_l == MW_ENT_BOX);
+        mesh_m = ballot(kind_l == MW_ENT_MESH);
+        static_m = ballot(static_l != 0);
+    }
     for (int pass = 0; pass < 2; ++pass) {
+        const uint64_t mine_m = pass == 0 ? static_m : ~static_m;
+        const uint64_t mesh_mine = mesh_m & mine_m, box_mine = box_m & mine_m;
         int s0 = 0;
         while (s0 < a.E) {
-            const int kind0 = a.ekind[(size_t)s0 * a.N + env];
-            const bool mine0 = (a.estatic[(size_t)s0 * a.N + env] != 0) == (pass == 0);
-            if (kind0 == MW_ENT_MESH && mine0) {
-                const int mid = a.emesh[(size_t)s0 * a.N + env];
-                const MwMeshDesc md = a.mesh[mid];
-                if (n_mesh < MW_MAX_MESH_ENTS && count + mesh_tris + (int)md.ntris < 0xFFF0) {
-                    const double edir = (s0 == c.live) ? c.cdir : a.edir[(size_t)s0 * a.N + env];
-                    const mw::SinCos sc = mw::sincos_det(edir);
+            if ((mesh_mine >> s0) & 1ull) {
+                const int mid = uni(a.emesh[(size_t)s0 * a.N + env]);
+                const MwMeshDesc *mdp = a.mesh + mid;
+                const int md_ntris = uni((int)mdp->ntris), md_first = uni((int)mdp->first), md_tex = uni((int)mdp->tex);
+                if (n_mesh < MW_MAX_MESH_ENTS && count + mesh_tris + md_ntris < 0xFFF0) {
                     if (lane == 0) {
+                        const double edir = (s0 == c.live) ? c.cdir : a.edir[(size_t)s0 * a.N + env];
+                        const mw::SinCos sc = mw::sincos_det(edir);
                         float *m = hdr + MW_HDR_MESH + 12 * n_mesh;
                         m[0] = __int_as_float(s0);
                         m[1] = __int_as_float(count + mesh_tris);
-                        m[2] = __int_as_float((int)md.ntris);
-                        m[3] = __int_as_float((int)md.first);
+                        m[2] = __int_as_float(md_ntris);
+                        m[3] = __int_as_float(md_first);
                         m[4] = (float)sc.c; m[5] = (float)sc.s;
                         m[6] = (float)ent_geom(a, env, s0, 6);
                         m[7] = (float)ent_pos(c, s0, 0); m[8] = (float)ent_pos(c, s0, 1); m[9] = (float)ent_pos(c, s0, 2);
-                        m[10] = __int_as_float(md.tex);
+                        m[10] = __int_as_float(md_tex);
                         m[11] = 0.0f;
                     }
-                    mesh_tris += (int)md.ntris;
+                    mesh_tris += md_ntris;
                     ++n_mesh;
-                    if (md.ntris > 0) {     // the mesh's last vertex normal stays current
-                        const float *ln = a.mesh_nrm + ((size_t)(md.first + md.ntris - 1) * 3 + 2) * 3;
-                        stale_n[0] = ln[0]; stale_n[1] = ln[1]; stale_n[2] = ln[2];
+                    if (md_ntris > 0) {     // the mesh's last vertex normal stays current
+                        const float *ln = a.mesh_nrm + ((size_t)(md_first + md_ntris - 1) * 3 + 2) * 3;
+                        stale_n[0] = uni(ln[0]); stale_n[1] = uni(ln[1]); stale_n[2] = uni(ln[2]);
                     }
                 } else {
                     atomicOr(a.status, MW_ST_VIS_OVERFLOW);
@@ -674,50 +688,50 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                 ++s0;
                 continue;
             }
-            int s1 = s0;
-            while (s1 < a.E && s1 - s0 < 10) {
-                const int k1 = a.ekind[(size_t)s1 * a.N + env];
-                const bool m1 = (a.estatic[(size_t)s1 * a.N + env] != 0) == (pass == 0);
-                if (k1 == MW_ENT_MESH && m1) break;
-                ++s1;
-            }
+            // the run of slots [s0, s1): up to 10 slots, ends before the next mesh of this pass
+            int s1 = s0 + 10 < a.E ? s0 + 10 : a.E;
             {
+                const uint64_t ahead = mesh_mine >> s0;       // bit 0 is clear here
+                if (ahead) {
+                    const int nxt = s0 + __builtin_ctzll(ahead);
+                    s1 = nxt < s1 ? nxt : s1;
+                }
+            }
+            const uint64_t run_boxes = (box_mine >> s0) & ((1ull << (s1 - s0)) - 1ull);
+            if (run_boxes) {
                 const int i = lane;
                 bool vis = false;
                 HV h[4];
                 PolyGeom g;
                 float col[3] = {0.0f, 0.0f, 0.0f};
                 const int slot = s0 + i / 6, f = i % 6;
-                if (i < (s1 - s0) * 6) {
-                    const int kind = a.ekind[(size_t)slot * a.N + env];
-                    const int is_static = a.estatic[(size_t)slot * a.N + env];
-                    if (kind == MW_ENT_BOX && (is_static != 0) == (pass == 0)) {
-                        // Box.render (entity.py:409-432): T(pos) R_y(dir) drawBox(...)
-                        const double edir = (slot == c.live) ? c.cdir : a.edir[(size_t)slot * a.N + env];
-                        const mw::SinCos sc = mw::sincos_det(edir);
-                        const float cs = (float)sc.c, sn = (float)sc.s;
-                        const float ex = (float)ent_pos(c, slot, 0), ey = (float)ent_pos(c, slot, 1), ez = (float)ent_pos(c, slot, 2);
-                        const double sx = ent_geom(a, env, slot, 0), sy = ent_geom(a, env, slot, 1), sz = ent_geom(a, env, slot, 2);
-                        const float lo[3] = {(float)(-sx / 2), 0.0f, (float)(-sz / 2)};
-                        const float hi[3] = {(float)(sx / 2), (float)sy, (float)(sz / 2)};
-                        const float base_col[3] = {(float)ent_geom(a, env, slot, 3), (float)ent_geom(a, env, slot, 4),
-                                                   (float)ent_geom(a, env, slot, 5)};
+                if (i < (s1 - s0) * 6 && ((run_boxes >> (i / 6)) & 1ull)) {
+                    // Box.render (entity.py:409-432): T(pos) R_y(dir) drawBox(...)
+                    const double edir = (slot == c.live) ? c.cdir : a.edir[(size_t)slot * a.N + env];
+                    const mw::SinCos sc = mw::sincos_det(edir);
+                    const float cs = (float)sc.c, sn = (float)sc.s;
+                    const float ex = (float)ent_pos(c, slot, 0), ey = (float)ent_pos(c, slot, 1), ez = (float)ent_pos(c, slot, 2);
+                    const float hx = (float)(ent_geom(a, env, slot, 0) / 2), sy = (float)ent_geom(a, env, slot, 1),
+                                hz = (float)(ent_geom(a, env, slot, 2) / 2);
+                    const float lo[3] = {-hx, 0.0f, -hz};
+                    const float hi[3] = {hx, sy, hz};
+                    const float base_col[3] = {(float)ent_geom(a, env, slot, 3), (float)ent_geom(a, env, slot, 4),
+                                               (float)ent_geom(a, env, slot, 5)};
 #pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const int sel = kBoxSel[f][k];
-                            const float lx = (sel & 1) ? hi[0] : lo[0];
-                            const float ly = (sel & 2) ? hi[1] : lo[1];
-                            const float lz = (sel & 4) ? hi[2] : lo[2];
-                            const float wx = fmaf(cs, lx, sn * lz) + ex;
-                            const float wy = ly + ey;
-                            const float wz = fmaf(cs, lz, -(sn * lx)) + ez;
-                            h[k] = xform(cam, wx, wy, wz);
-                        }
-                        const float n[3] = {fmaf(cs, kBoxN[f][0], sn * kBoxN[f][2]), kBoxN[f][1],
-                                            fmaf(cs, kBoxN[f][2], -(sn * kBoxN[f][0]))};
-                        light(cam, n, base_col, col);
-                        vis = cull_poly(a, h, 4, g);
+                    for (int k = 0; k < 4; ++k) {
+                        const int sel = kBoxSel[f][k];
+                        const float lx = (sel & 1) ? hi[0] : lo[0];
+                        const float ly = (sel & 2) ? hi[1] : lo[1];
+                        const float lz = (sel & 4) ? hi[2] : lo[2];
+                        const float wx = fmaf(cs, lx, sn * lz) + ex;
+                        const float wy = ly + ey;
+                        const float wz = fmaf(cs, lz, -(sn * lx)) + ez;
+                        h[k] = xform(cam, wx, wy, wz);
                     }
+                    const float n[3] = {fmaf(cs, kBoxN[f][0], sn * kBoxN[f][2]), kBoxN[f][1],
+                                        fmaf(cs, kBoxN[f][2], -(sn * kBoxN[f][0]))};
+                    light(cam, n, base_col, col);
+                    vis = cull_poly(a, h, 4, g);
                 }
                 const int idx = compact(lane, vis, count);
                 if (vis) {
@@ -728,12 +742,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                         atomicOr(a.status, MW_ST_VIS_OVERFLOW);
                     }
                 }
-            }
-            // drawBox ends with glNormal3f(0, -1, 0) (opengl.py:495): current after the last box of the run
-            for (int sb = s0; sb < s1; ++sb) {
-                const int kb = a.ekind[(size_t)sb * a.N + env];
-                const bool mb = (a.estatic[(size_t)sb * a.N + env] != 0) == (pass == 0);
-                if (kb == MW_ENT_BOX && mb) { stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f; }
+                // drawBox ends with glNormal3f(0, -1, 0) (opengl.py:495): current after the last box of the run
+                stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f;
             }
             s0 = s1;
         }
