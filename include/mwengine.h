@@ -192,6 +192,12 @@ int mw_render_top(mw_engine *e, uint8_t *d_obs, float *d_depth, int32_t render_a
  *   d_out uint8[height][width][3], d_depth float[height][width] or NULL.  Not the hot path. */
 int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width, int32_t height, int32_t msaa,
                    uint8_t *d_out, float *d_depth, void *stream);
+/* get_visible_ents (miniworld.py:1238-1333) for envs [first_env, first_env + count): rooms drawn depth-only
+ * into the obs frame, then one GL_ANY_SAMPLES_PASSED query per entity around its 0.2 m proxy box, in
+ * entity-slot (= self.entities) order with depth writes on.  d_vis uint8[count][max_ents], 1 = visible;
+ * empty slots report 0.  Needs obs_width * obs_height * 32 bytes of LDS (<= 160 KiB).  Not the hot path. */
+int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_vis, void *stream);
+
 /* checks the device-side status word (capacity overflows); synchronises `stream` */
 int mw_check(mw_engine *e, void *stream);
 

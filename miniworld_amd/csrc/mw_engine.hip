@@ -34,6 +34,8 @@ extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, i
                                                  const MwTexDesc *texd, const uint32_t *texels, const float *mesh_pos,
                                                  const float *mesh_nrm, const float *mesh_rgb, const uint32_t *mesh_keys,
                                                  uint8_t *out, float *depth, int texel_bytes);
+extern "C" __global__ void mw_visible_kernel(int env_base, int W, int H, int max_vis, int E, const float *rec_raster,
+                                             const int32_t *nvis, uint8_t *vis);
 extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                                  const float *rec_raster, const float *rec_shade, const float *rec_cull,
                                                  const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
@@ -63,6 +65,7 @@ struct mw_engine {
     bool have_meshes = false;
     bool mesh_lds_ready = false;
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
+    bool visible_attr_set = false;
     size_t view_keys_bytes = 0;
     // scratch for the step outputs when the caller passes none
     float *d_reward_scratch = nullptr;
@@ -623,6 +626,29 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     hipLaunchKernelGGL(mw_view_raster_kernel, dim3(b.n_tiles), dim3(64), 0, st, env, width, height, msaa, b.max_vis, b.tiles_x,
                        (const float *)b.rec_raster, (const float *)b.rec_shade, (const int32_t *)b.nvis, (const float *)b.envhdr,
                        b.tex, b.texels, b.mesh_pos, b.mesh_nrm, b.mesh_rgb, (const uint32_t *)keys, d_out, d_depth, e->texel_bytes);
+    HIP_TRY(e, hipGetLastError());
+    return MW_OK;
+}
+
+int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_vis, void *stream)
+{
+    if (!e || !d_vis) return fail(e, MW_E_INVALID, "null argument");
+    if (first_env < 0 || count <= 0 || first_env + count > e->cfg.num_envs) return fail(e, MW_E_INVALID, "env range out of bounds");
+    const size_t lds = (size_t)e->cfg.obs_width * e->cfg.obs_height * 8 * 4;
+    if (lds + 1024 > 160 * 1024) return fail(e, MW_E_CAPACITY, "obs frame too large for the in-LDS depth buffer of mw_visible_ents");
+    hipStream_t st = (hipStream_t)stream;
+    MwArgs b = e->args;
+    b.step_override = nullptr;
+    b.env_base = first_env;
+    // K1 in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
+    hipLaunchKernelGGL(mw_step_setup_kernel, dim3(count), dim3(64), 0, st, b, 0, 4, e->d_action_scratch,
+                       e->d_reward_scratch, e->d_flag_scratch, e->d_flag_scratch + e->cfg.num_envs);
+    if (!e->visible_attr_set) {
+        HIP_TRY(e, hipFuncSetAttribute((const void *)mw_visible_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        e->visible_attr_set = true;
+    }
+    hipLaunchKernelGGL(mw_visible_kernel, dim3(count), dim3(256), lds, st, first_env, e->cfg.obs_width, e->cfg.obs_height,
+                       b.max_vis, e->cfg.max_ents, (const float *)b.rec_raster, (const int32_t *)b.nvis, d_vis);
     HIP_TRY(e, hipGetLastError());
     return MW_OK;
 }

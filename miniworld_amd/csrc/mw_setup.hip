@@ -652,6 +652,10 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
         mesh_m = ballot(kind_l == MW_ENT_MESH);
         static_m = ballot(static_l != 0);
     }
+    // get_visible_ents (miniworld.py:1296-1313): instead of the entities themselves, an axis-aligned
+    // 0.2 m proxy box per entity, in self.entities (= slot) order, tagged with its slot
+    const bool proxy = (view_flags & 4) != 0;
+    if (proxy) { box_m |= mesh_m; mesh_m = 0ull; static_m = ~0ull; }
     for (int pass = 0; pass < 2; ++pass) {
         const uint64_t mine_m = pass == 0 ? static_m : ~static_m;
         const uint64_t mesh_mine = mesh_m & mine_m, box_mine = box_m & mine_m;
@@ -723,9 +727,14 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                         const float lx = (sel & 1) ? hi[0] : lo[0];
                         const float ly = (sel & 2) ? hi[1] : lo[1];
                         const float lz = (sel & 4) ? hi[2] : lo[2];
-                        const float wx = fmaf(cs, lx, sn * lz) + ex;
-                        const float wy = ly + ey;
-                        const float wz = fmaf(cs, lz, -(sn * lx)) + ez;
+                        float wx = fmaf(cs, lx, sn * lz) + ex;
+                        float wy = ly + ey;
+                        float wz = fmaf(cs, lz, -(sn * lx)) + ez;
+                        if (proxy) {    // drawBox(pos -+ 0.1, pos.y .. pos.y + 0.2) evaluated in double, glVertex3f
+                            wx = (float)(ent_pos(c, slot, 0) + ((sel & 1) ? 0.1 : -0.1));
+                            wy = (sel & 2) ? (float)(ent_pos(c, slot, 1) + 0.2) : (float)ent_pos(c, slot, 1);
+                            wz = (float)(ent_pos(c, slot, 2) + ((sel & 4) ? 0.1 : -0.1));
+                        }
                         h[k] = xform(cam, wx, wy, wz);
                     }
                     const float n[3] = {fmaf(cs, kBoxN[f][0], sn * kBoxN[f][2]), kBoxN[f][1],
@@ -737,7 +746,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                 if (vis) {
                     if (idx < a.max_vis) {
                         const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-                        write_poly(a, env, idx, (uint32_t)(idx + mesh_tris), h, 4, g, uv, col, -1);
+                        write_poly(a, env, idx, proxy ? (0x10000u | (uint32_t)slot) : (uint32_t)(idx + mesh_tris), h, 4, g, uv, col, -1);
                     } else {
                         atomicOr(a.status, MW_ST_VIS_OVERFLOW);
                     }

@@ -25,7 +25,7 @@ AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_check", "mw_kernel_time_ms",
+    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_check", "mw_kernel_time_ms",
 ]
 
 
@@ -145,6 +145,7 @@ def load_library():
     L.mw_render.argtypes = [vp, vp, vp, vp]
     L.mw_render_top.argtypes = [vp, vp, vp, i32, vp]
     L.mw_render_view.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
+    L.mw_visible_ents.argtypes = [vp, i32, i32, vp, vp]
     L.mw_check.argtypes = [vp, vp]
     L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = L
@@ -280,6 +281,15 @@ class Engine:
                                             None if dep is None else C.c_void_p(dep.data_ptr()), _stream_ptr()),
                     "mw_render_view")
         return (out, dep) if want_depth else out
+
+    def visible_ents(self, first_env: int = 0, count: int | None = None):
+        """get_visible_ents (miniworld.py:1238-1333): uint8[count, max_ents] on the device, 1 = visible."""
+        import torch
+        count = self.N - first_env if count is None else count
+        vis = torch.zeros((count, self.E), dtype=torch.uint8, device=self.device)
+        self._check(self.lib.mw_visible_ents(self.h, first_env, count, C.c_void_p(vis.data_ptr()), _stream_ptr()),
+                    "mw_visible_ents")
+        return vis
 
     def check(self):
         self._check(self.lib.mw_check(self.h, _stream_ptr()), "mw_check")

@@ -402,6 +402,11 @@ class MiniWorldEnv(gym.Env):
     def render_depth(self, frame_buffer=None):
         return self._engine.render(self, want_depth=True)["depth"]
 
+    def get_visible_ents(self):
+        """Set of entities whose 0.2 m proxy box passes an occlusion query from the agent's camera
+        (miniworld.py:1238-1333)."""
+        return self._engine.visible_ents(self)
+
     def render(self):
         if self.render_mode is None:
             gym.logger.warn("You are calling render method without specifying any render mode.")

@@ -260,6 +260,11 @@ class EngineBinding:
         self._pull_state(env)
         return self.obs[0].cpu().numpy()
 
+    def visible_ents(self, env):
+        self.push_state(env)
+        vis = self.engine.visible_ents(0, 1)[0].cpu().numpy()
+        return {e for i, e in enumerate(self._ents) if vis[i]}
+
     def render(self, env, want_depth=False, top_view=False, render_agent=True):
         self.push_state(env)
         if top_view:

@@ -212,5 +212,10 @@ class MiniWorldVecEnv:
         self.engine.render_top(out, None, render_agent)
         return out
 
+    def get_visible_ents(self):
+        """bool[N, max_ents]: which entity slots each agent currently sees (get_visible_ents,
+        miniworld.py:1238-1333: occlusion queries around 0.2 m proxy boxes)."""
+        return self.engine.visible_ents().bool()
+
     def close(self):
         self.engine.close()

@@ -97,6 +97,10 @@ void mwo_build_mips(const uint8_t *rgb, int32_t w, int32_t h, uint8_t *out);
  * prim  : int32 [H][W][nsamples] winning draw index per sample (-1 = sky), may be NULL */
 int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16, float *depth, int32_t *prim);
 
+/* MiniWorldEnv.get_visible_ents (miniworld.py:1238-1333).  sc->ents in self.entities order;
+ * vis: uint8[n_ents], 1 = the entity's 0.2 m proxy box passed at least one sample. */
+int mwo_visible_ents(const mwo_scene *sc, uint8_t *vis);
+
 /* ---- dynamics (MiniWorldEnv.step and friends) --------------------------------- */
 enum { MWO_TASK_NONE = 0, MWO_TASK_GOTO = 1, MWO_TASK_PICKUP = 2, MWO_TASK_PUTNEXT = 3 };
 

@@ -396,8 +396,10 @@ typedef struct {
     float *cbuf;        /* [H][W][S][3] */
 } target;
 
-static void draw_prim(const mwo_scene *sc, target *tg, const prim *p, int draw_index)
+/* returns the number of samples that passed the depth test (what an occlusion query counts) */
+static int draw_prim(const mwo_scene *sc, target *tg, const prim *p, int draw_index)
 {
+    int passed = 0;
     float thr[4][MAXS], zo[MAXS];
     for (int s = 0; s < tg->S; ++s) {
         float dx = (float)(tg->pat[s][0] - 8) * 0.0625f, dy = (float)(tg->pat[s][1] - 8) * 0.0625f;
@@ -424,16 +426,18 @@ static void draw_prim(const mwo_scene *sc, target *tg, const prim *p, int draw_i
                 uint16_t z16 = (uint16_t)(uint32_t)t;
                 if (!(z16 < tg->zbuf[base + s])) continue;        /* GL_LESS */
                 if (!shaded) { shade(sc, p, Xc, Yc, col); shaded = 1; }
+                ++passed;
                 tg->zbuf[base + s] = z16;
                 tg->ibuf[base + s] = draw_index;
                 memcpy(&tg->cbuf[(base + s) * 3], col, sizeof col);
             }
         }
+    return passed;
 }
 
-static void draw_poly(const mwo_scene *sc, const camera *cam, target *tg, const float (*v)[3],
-                      const float (*uv)[2], const float n[3], const float base[3], int nv, int tex,
-                      int draw_index)
+static int draw_poly(const mwo_scene *sc, const camera *cam, target *tg, const float (*v)[3],
+                     const float (*uv)[2], const float n[3], const float base[3], int nv, int tex,
+                     int draw_index)
 {
     hvert h[4];
     float vcol[3][3];
@@ -442,7 +446,8 @@ static void draw_poly(const mwo_scene *sc, const camera *cam, target *tg, const 
     memcpy(vcol[1], vcol[0], sizeof vcol[0]);
     memcpy(vcol[2], vcol[0], sizeof vcol[0]);
     prim p;
-    if (setup_prim(sc, h, nv, uv, (const float (*)[3])vcol, 0, tex, &p)) draw_prim(sc, tg, &p, draw_index);
+    if (setup_prim(sc, h, nv, uv, (const float (*)[3])vcol, 0, tex, &p)) return draw_prim(sc, tg, &p, draw_index);
+    return 0;
 }
 
 /* opengl.py:460-503 drawBox, vertex order and normals as listed there */
@@ -607,6 +612,61 @@ int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out, float *d
             if (primout)
                 for (int s = 0; s < tg.S; ++s) primout[base + s] = tg.ibuf[base + s];
         }
+    free(tg.zbuf); free(tg.ibuf); free(tg.cbuf);
+    return 0;
+}
+
+/* MiniWorldEnv.get_visible_ents (miniworld.py:1238-1333): the rooms are drawn untextured into the
+ * cleared obs frame buffer (same camera as render_obs, :1263-1288; Room._render :1291-1293), then,
+ * per entity in the order of self.entities, an axis-aligned 0.2 m proxy box at ent.pos is drawn
+ * inside a GL_ANY_SAMPLES_PASSED query (:1296-1313): depth-tested (GL_LESS) AND depth-written, so
+ * an earlier proxy can hide a later one; back faces are culled (:512) and produce no samples.
+ * sc->ents must be in self.entities order here (not draw order); vis[i] = query result != 0. */
+int mwo_visible_ents(const mwo_scene *sc, uint8_t *vis)
+{
+    target tg;
+    tg.W = sc->width; tg.H = sc->height; tg.S = sc->nsamples;
+    switch (sc->nsamples) {
+    case 1: tg.pat = PAT1; break;
+    case 4: tg.pat = PAT4; break;
+    case 8: tg.pat = PAT8; break;
+    case 16: tg.pat = PAT16; break;
+    default: return -1;
+    }
+    int64_t ns = (int64_t)tg.W * tg.H * tg.S;
+    tg.zbuf = (uint16_t *)malloc(ns * sizeof(uint16_t));
+    tg.ibuf = (int32_t *)malloc(ns * sizeof(int32_t));
+    tg.cbuf = (float *)malloc(ns * 3 * sizeof(float));
+    if (!tg.zbuf || !tg.ibuf || !tg.cbuf) return -2;
+    camera cam;
+    build_camera(sc, &cam);
+    for (int64_t i = 0; i < ns; ++i) { tg.zbuf[i] = 65535; tg.ibuf[i] = -1; }
+    memset(tg.cbuf, 0, ns * 3 * sizeof(float));
+    static const float white[3] = {1.0f, 1.0f, 1.0f};
+    int draw = 0;
+    for (int i = 0; i < sc->n_polys; ++i, ++draw) {
+        const mwo_poly *q = &sc->polys[i];
+        draw_poly(sc, &cam, &tg, q->v, q->uv, q->n, white, q->nv, -1, draw);        /* glDisable(GL_TEXTURE_2D) */
+    }
+    for (int e = 0; e < sc->n_ents; ++e) {
+        const mwo_ent *en = &sc->ents[e];
+        vis[e] = 0;
+        if (en->kind == MWO_ENT_NONE) continue;
+        /* drawBox arguments are computed in double (python floats) and reach GL through glVertex3f */
+        float lo[3] = {(float)(en->pos[0] - 0.1), (float)en->pos[1], (float)(en->pos[2] - 0.1)};
+        float hi[3] = {(float)(en->pos[0] + 0.1), (float)(en->pos[1] + 0.2), (float)(en->pos[2] + 0.1)};
+        int passed = 0;
+        for (int f = 0; f < 6; ++f, ++draw) {
+            float v[4][3];
+            for (int k = 0; k < 4; ++k) {
+                v[k][0] = BOXV[f][k][0] ? hi[0] : lo[0];
+                v[k][1] = BOXV[f][k][1] ? hi[1] : lo[1];
+                v[k][2] = BOXV[f][k][2] ? hi[2] : lo[2];
+            }
+            passed += draw_poly(sc, &cam, &tg, (const float (*)[3])v, NULL, BOXN[f], white, 4, -1, draw);
+        }
+        vis[e] = passed != 0;
+    }
     free(tg.zbuf); free(tg.ibuf); free(tg.cbuf);
     return 0;
 }

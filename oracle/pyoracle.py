@@ -102,6 +102,7 @@ def lib():
         L.mwo_mip_bytes.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]
         L.mwo_build_mips.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         L.mwo_render_obs.argtypes = [C.POINTER(_Scene), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.mwo_visible_ents.argtypes = [C.POINTER(_Scene), C.c_void_p]
         L.mwo_step.argtypes = [C.POINTER(AgentState), C.POINTER(PhysEnt), C.POINTER(PhysEnt), C.c_void_p,
                                C.c_int32, C.c_int32, C.c_double, C.c_double, C.c_double,
                                C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
@@ -171,8 +172,10 @@ def _mips_for(name, textures=None):
 # ------------------------------------------------------------------ render
 
 def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = None,
-               textures: dict | None = None, view: str = "agent", render_agent: bool = False):
-    """Neutral scene -> (mwo_scene struct, keep-alive list)."""
+               textures: dict | None = None, view: str = "agent", render_agent: bool = False,
+               ent_order: str = "draw"):
+    """Neutral scene -> (mwo_scene struct, keep-alive list).  ent_order: "draw" (static entities
+    first, what render_obs needs) or "list" (self.entities order, what get_visible_ents needs)."""
     P = int(len(scene["polys_nv"]))
     polys = (_Poly * max(P, 1))()
     pv = np.asarray(scene["polys_v"], np.float32).reshape(P, 12)
@@ -197,14 +200,16 @@ def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None
     # draw order: static entities first, then dynamic ones (miniworld.py:1058-1060, 1075-1077)
     stat = [int(x) for x in scene.get("ents_static", np.zeros(E, np.int32))]
     order = [i for i in range(E) if stat[i]] + [i for i in range(E) if not stat[i]]
+    if ent_order == "list":
+        order = list(range(E))
     for j, i in enumerate(order):
         ents[j].kind = int(scene["ents_kind"][i])
-        ents[i].mesh = int(scene["ents_mesh"][i])
-        ents[i].pos[:] = [float(x) for x in scene["ents_pos"][i]]
-        ents[i].dir = float(scene["ents_dir"][i])
-        ents[i].size[:] = [float(x) for x in scene["ents_size"][i]]
-        ents[i].color[:] = [float(x) for x in scene["ents_color"][i]]
-        ents[i].scale = float(scene["ents_scale"][i])
+        ents[j].mesh = int(scene["ents_mesh"][i])
+        ents[j].pos[:] = [float(x) for x in scene["ents_pos"][i]]
+        ents[j].dir = float(scene["ents_dir"][i])
+        ents[j].size[:] = [float(x) for x in scene["ents_size"][i]]
+        ents[j].color[:] = [float(x) for x in scene["ents_color"][i]]
+        ents[j].scale = float(scene["ents_scale"][i])
     mesh_names = [str(m) for m in scene.get("mesh_names", [])]
     mstructs = (_Mesh * max(len(mesh_names), 1))()
     for i, name in enumerate(mesh_names):
@@ -255,6 +260,20 @@ def render(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None = N
     if want_prim:
         out["prim"] = prim
     return out
+
+
+def visible_ents(scene: dict, width=80, height=60, nsamples=8):
+    """MiniWorldEnv.get_visible_ents (miniworld.py:1238-1333): bool[E] in self.entities order."""
+    L = lib()
+    bare = dict(scene)
+    bare["tex_names"], bare["mesh_names"] = [], []          # depth only: no texture, proxies instead of meshes
+    sc, keep = pack_scene(bare, width, height, nsamples, ent_order="list")
+    E = int(len(scene["ents_kind"]))
+    vis = np.zeros(max(E, 1), np.uint8)
+    rc = L.mwo_visible_ents(C.byref(sc), vis.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"mwo_visible_ents failed: {rc}")
+    return vis[:E].astype(bool)
 
 
 # ------------------------------------------------------------------ dynamics

@@ -357,3 +357,54 @@ def test_render_800x600x16_matches_oracle(case, top):
         # the reference's own consistency check (tests/test_miniworld.py:26-31)
         assert abs(float(o.mean()) - float(img.mean())) < 5
     env.close()
+
+
+def test_vec_env_get_visible_ents_matches_oracle():
+    """get_visible_ents (miniworld.py:1238-1333) for a whole batch: occlusion queries around the
+    0.2 m proxy boxes, compared env by env with the oracle's restatement; removed entities report 0."""
+    import torch
+    import pyoracle
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 96
+    vec = MiniWorldVecEnv("MiniWorld-PickupObjects-v0", n, domain_rand=True, seed=21)
+    vec.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    seen_any = seen_none = 0
+    for rnd in range(3):
+        for t in range(40):
+            act = torch.randint(0, 5, (n,), generator=g, device="cuda", dtype=torch.int32)
+            vec.step(act)
+        vis = vec.get_visible_ents().cpu().numpy()
+        assert vis.shape == (n, vec.engine.E) and vis.dtype == bool
+        st = vec.engine.get_state()
+        for i in range(n):
+            want = pyoracle.visible_ents(_scene_of_env(vec, st, i))
+            assert np.array_equal(vis[i, :len(want)], want), f"round {rnd} env {i}: {vis[i]} vs {want}"
+            assert not vis[i][st["ent_kind"][i] == 0].any()
+        seen_any += int(vis.any(axis=1).sum())
+        seen_none += int((~vis.any(axis=1)).sum())
+    assert seen_any > 0 and seen_none > 0
+    vec.engine.check()
+    vec.close()
+
+
+@pytest.mark.parametrize("case", ["roomobjects_s0", "putnext_s0", "fourrooms_s0", "hallway_s0", "pickup_fwd_s2", "pickup_dr_s1"])
+def test_single_env_get_visible_ents(case):
+    """MiniWorldEnv.get_visible_ents returns the set of entity objects, along a trajectory."""
+    import pyoracle
+    from miniworld_amd import envs
+    from miniworld_amd.scene import scene_from_env
+    s0, tr, meta, obs = helpers.load_case(case)
+    env = getattr(envs, str(meta["env"]))(domain_rand=bool(meta["domain_rand"]))
+    env.reset(seed=int(meta["seed"]))
+    for t, a in enumerate(tr["action"][:60]):
+        if t % 6 == 0:
+            got = env.get_visible_ents()
+            ents = [e for e in env.entities if e is not env.agent]
+            want = pyoracle.visible_ents(scene_from_env(env))
+            assert got == {e for e, v in zip(ents, want) if v}, f"step {t}"
+            assert env.agent not in got
+        _, _, term, trunc, _ = env.step(int(a))
+        if term or trunc:
+            break
+    env.close()

@@ -125,3 +125,26 @@ def test_mip_chain_even_and_odd():
     assert np.array_equal(lv[2][0, 0], (2 * acc + 6) // 12)
     big = pyoracle.mip_levels(pyoracle.texture_rgb_bottom_up("concrete_tiles_1"))    # 768: 768..3,1
     assert [l.shape[0] for l in big] == [768, 384, 192, 96, 48, 24, 12, 6, 3, 1]
+
+
+def test_oracle_visible_ents_geometry():
+    """get_visible_ents restatement (miniworld.py:1238-1333): a box in front of the camera passes its
+    query, one behind the agent or behind a wall does not, and a nearer proxy hides a farther one."""
+    from miniworld_amd import envs
+    from miniworld_amd.scene import scene_from_env
+    env = envs.OneRoom(host_only=True)
+    env.reset(seed=0)
+    sc = scene_from_env(env)
+    sc["agent_pos"], sc["agent_dir"] = np.array([5.0, 0.0, 5.0]), 0.0           # looking along +x
+    for pos, want in (([9.0, 0.0, 5.0], True), ([1.0, 0.0, 5.0], False), ([7.0, 0.0, 5.0 + 4.9], False),
+                      ([12.0, 0.0, 5.0], False)):                                 # 12 m: beyond the wall at x = 10
+        sc["ents_pos"] = np.array([pos])
+        assert bool(pyoracle.visible_ents(sc)[0]) == want, pos
+    # two entities in line: the far proxy is completely covered by the near one only if it is drawn later
+    two = dict(sc)
+    for k in ("ents_kind", "ents_mesh", "ents_dir", "ents_size", "ents_color", "ents_scale", "ents_radius", "ents_height", "ents_static"):
+        two[k] = np.concatenate([sc[k], sc[k]])
+    two["ents_pos"] = np.array([[5.6, 1.4, 5.0], [9.0, 1.4, 5.0]])            # near one first, at eye height
+    assert pyoracle.visible_ents(two).tolist() == [True, False]
+    two["ents_pos"] = two["ents_pos"][::-1].copy()                              # far one drawn first: both pass
+    assert pyoracle.visible_ents(two).tolist() == [True, True]
