@@ -181,6 +181,15 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
  * All device pointers; asynchronous on `stream`. */
 int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_depth,
             float *d_reward, uint8_t *d_term, uint8_t *d_trunc, void *stream);
+/* Layout of the d_obs buffer written by mw_step / mw_render / mw_render_top — the reference's
+ * observation wrappers (wrappers.py) folded into the raster kernel's store:
+ *   MW_OBS_HWC_U8   uint8 [N][H][W][3]   the env's own observation (default)
+ *   MW_OBS_CWH_U8   uint8 [N][3][W][H]   PyTorchObsWrapper.observation: transpose(2, 1, 0)   (wrappers.py:11-25)
+ *   MW_OBS_GREY_F64 double[N][H][W][1]   GreyscaleWrapper.observation: 0.30 R + 0.59 G + 0.11 B evaluated as
+ *                                        numpy does, in float64, left to right             (wrappers.py:28-46) */
+enum { MW_OBS_HWC_U8 = 0, MW_OBS_CWH_U8 = 1, MW_OBS_GREY_F64 = 2 };
+int mw_set_obs_layout(mw_engine *e, int32_t layout);
+
 /* render_obs / render_depth only (miniworld.py:1177-1236) */
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);
 /* render_top_view (miniworld.py:1088-1175): orthographic map of the whole floorplan into the same

@@ -27,6 +27,16 @@ extern "C" __global__ void mw_raster_big_kernel(int N, int W, int H, int max_vis
                                                 const float *rec_shade, const float *rec_cull, const int32_t *nvis,
                                                 const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
                                                 uint8_t *obs, float *depth, int dbg, int texel_bytes);
+extern "C" __global__ void mw_raster_wrap_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                                 int waves_per_env, int tiles_per_wave, const float *rec_raster,
+                                                 const float *rec_shade, const float *rec_cull, const int32_t *nvis,
+                                                 const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
+                                                 uint8_t *obs, float *depth, int dbg, int texel_bytes);
+extern "C" __global__ void mw_raster_big_wrap_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                                     int waves_per_env, int tiles_per_wave, const float *rec_raster,
+                                                     const float *rec_shade, const float *rec_cull, const int32_t *nvis,
+                                                     const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
+                                                     uint8_t *obs, float *depth, int dbg, int texel_bytes);
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all);
 extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, const float *hdr, const float *mesh_pos, uint32_t *keys);
 extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
@@ -66,6 +76,7 @@ struct mw_engine {
     bool mesh_lds_ready = false;
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
     bool visible_attr_set = false;
+    int obs_layout = MW_OBS_HWC_U8;
     size_t view_keys_bytes = 0;
     // scratch for the step outputs when the caller passes none
     float *d_reward_scratch = nullptr;
@@ -323,17 +334,19 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         hipLaunchKernelGGL(mw_raster_mesh_kernel, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
-                           a.mesh_rgb, d_obs, d_depth, e->dbg_flags, e->texel_bytes);
+                           a.mesh_rgb, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes);
     } else {
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
         const int groups = (N + 7) / 8;
         const bool big = e->cfg.max_visible > 64;      // records stay in global memory
         const size_t lds = big ? 192 : (size_t)e->cfg.max_visible * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
-        hipLaunchKernelGGL(big ? mw_raster_big_kernel : mw_raster_kernel, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+        auto k2 = big ? mw_raster_big_kernel : mw_raster_kernel;
+        if (e->obs_layout != MW_OBS_HWC_U8) k2 = big ? mw_raster_big_wrap_kernel : mw_raster_wrap_kernel;
+        hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                            a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis,
-                           (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags, e->texel_bytes);
+                           (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes);
     }
     if (e->timing) {
         (void)hipEventRecord(ev.c, st);
@@ -627,6 +640,14 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
                        (const float *)b.rec_raster, (const float *)b.rec_shade, (const int32_t *)b.nvis, (const float *)b.envhdr,
                        b.tex, b.texels, b.mesh_pos, b.mesh_nrm, b.mesh_rgb, (const uint32_t *)keys, d_out, d_depth, e->texel_bytes);
     HIP_TRY(e, hipGetLastError());
+    return MW_OK;
+}
+
+int mw_set_obs_layout(mw_engine *e, int32_t layout)
+{
+    if (!e) return MW_E_INVALID;
+    if (layout != MW_OBS_HWC_U8 && layout != MW_OBS_CWH_U8 && layout != MW_OBS_GREY_F64) return fail(e, MW_E_INVALID, "unknown obs layout %d", layout);
+    e->obs_layout = layout;
     return MW_OK;
 }
 

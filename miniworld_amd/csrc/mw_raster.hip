@@ -30,7 +30,7 @@ __device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc,
 // LDS_RECS = true : the env's shade / classification records are staged in LDS (small scenes);
 // LDS_RECS = false: they are read in place from global memory (L1/L2) — scenes with hundreds of
 //                   visible primitives (Maze) would not leave room for enough resident waves.
-template <bool LDS_RECS>
+template <bool LDS_RECS, int FMT>
 __device__ inline void raster_kernel_body(
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave,
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
@@ -78,7 +78,7 @@ __device__ inline void raster_kernel_body(
     const int t_end = min(t_begin + tiles_per_wave, n_tiles);
     int tx = t_begin % tiles_x, ty = t_begin / tiles_x;
     for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
-        raster_tile<false>(cx, tx, ty, nullptr);
+        raster_tile_fmt<false, FMT>(cx, tx, ty, nullptr);
     }
 }
 
@@ -92,10 +92,21 @@ __device__ inline void raster_kernel_body(
 
 extern "C" __global__ __launch_bounds__(64) void mw_raster_kernel(MW_RASTER_ARGS)
 {
-    raster_kernel_body<true>(MW_RASTER_FWD);
+    raster_kernel_body<true, 0>(MW_RASTER_FWD);
 }
 
 extern "C" __global__ __launch_bounds__(64) void mw_raster_big_kernel(MW_RASTER_ARGS)
 {
-    raster_kernel_body<false>(MW_RASTER_FWD);
+    raster_kernel_body<false, 0>(MW_RASTER_FWD);
+}
+
+// the same kernels storing the frame in a wrapper layout (mw_set_obs_layout; layout in dbg bits 8-9)
+extern "C" __global__ __launch_bounds__(64) void mw_raster_wrap_kernel(MW_RASTER_ARGS)
+{
+    raster_kernel_body<true, -1>(MW_RASTER_FWD);
+}
+
+extern "C" __global__ __launch_bounds__(64) void mw_raster_big_wrap_kernel(MW_RASTER_ARGS)
+{
+    raster_kernel_body<false, -1>(MW_RASTER_FWD);
 }

@@ -203,8 +203,10 @@ struct TileCtx {
     int env, nvis, W, H, dbg, lane;
 };
 
-template <bool MESH>
-__device__ inline void raster_tile(const TileCtx &cx, int tx, int ty, const uint32_t *mesh_key)
+// FMT: output layout fixed at compile time (0: the plain observation, the hot path) or -1: read from
+// the launch flags (the wrapper layouts; kept out of the hot instantiation)
+template <bool MESH, int FMT>
+__device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const uint32_t *mesh_key)
 {
     const int lane = cx.lane, nvis = cx.nvis, dbg = cx.dbg, env = cx.env, W = cx.W, H = cx.H;
     const float4 *s_shade = cx.s_shade, *s_cull = cx.s_cull;
@@ -408,21 +410,44 @@ __device__ inline void raster_tile(const TileCtx &cx, int tx, int ty, const uint
     }
     const uint32_t R = to_u8(acc_r), G = to_u8(acc_g), B = to_u8(acc_b);
 
-    // ---- pack: tile rows of 16 px * 3 B = 48 B = 12 dwords; 4 rows -> 48 dword stores
+    // ---- pack.  Output layout (mw_set_obs_layout; the reference's wrappers.py folded into the store):
+    //   0  uint8 [H][W][3]      the observation itself
+    //   1  uint8 [3][W][H]      PyTorchObsWrapper: observation.transpose(2, 1, 0)   (wrappers.py:24)
+    //   2  double[H][W][1]      GreyscaleWrapper: 0.30 R + 0.59 G + 0.11 B in numpy's float64 (wrappers.py:44)
+    const int fmt = FMT >= 0 ? FMT : ((dbg >> 8) & 3);
     const int row = lane >> 4, col = lane & 15;
-    s_pack[row * 48 + col * 3 + 0] = (uint8_t)R;
-    s_pack[row * 48 + col * 3 + 1] = (uint8_t)G;
-    s_pack[row * 48 + col * 3 + 2] = (uint8_t)B;
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    if (lane < 48) {
-        const int r = lane / 12, d = lane % 12;
-        const uint32_t w = reinterpret_cast<const uint32_t *>(s_pack)[r * 12 + d];
-        uint8_t *dst = obs + ((size_t)env * H + (ty * MW_TILE_H + r)) * W * 3 + (size_t)tx * (MW_TILE_W * 3) + d * 4;
-        *reinterpret_cast<uint32_t *>(dst) = w;
+    if (fmt == 2) {
+        const double g = (0.30 * (double)R + 0.59 * (double)G) + 0.11 * (double)B;
+        reinterpret_cast<double *>(obs)[((size_t)env * H + py) * W + px] = g;
+    } else {
+        if (fmt == 0) {
+            // tile rows of 16 px * 3 B = 48 B = 12 dwords; 4 rows -> 48 dword stores
+            s_pack[row * 48 + col * 3 + 0] = (uint8_t)R;
+            s_pack[row * 48 + col * 3 + 1] = (uint8_t)G;
+            s_pack[row * 48 + col * 3 + 2] = (uint8_t)B;
+        } else {
+            // per channel, the 4 rows of one column are contiguous: 16 dwords per channel
+            s_pack[0 * 64 + col * 4 + row] = (uint8_t)R;
+            s_pack[1 * 64 + col * 4 + row] = (uint8_t)G;
+            s_pack[2 * 64 + col * 4 + row] = (uint8_t)B;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (lane < 48) {
+            const uint32_t w = reinterpret_cast<const uint32_t *>(s_pack)[lane];
+            uint8_t *dst;
+            if (fmt == 0) {
+                const int r = lane / 12, d = lane % 12;
+                dst = obs + ((size_t)env * H + (ty * MW_TILE_H + r)) * W * 3 + (size_t)tx * (MW_TILE_W * 3) + d * 4;
+            } else {
+                const int ch = lane >> 4, c = lane & 15;
+                dst = obs + (((size_t)env * 3 + ch) * W + (tx * MW_TILE_W + c)) * H + ty * MW_TILE_H;
+            }
+            *reinterpret_cast<uint32_t *>(dst) = w;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    __builtin_amdgcn_wave_barrier();
     if (depth) {
         // R13 / R14: resolved depth = sample 0; get_depth_map in float32 as numpy evaluates it
         const float z = (float)z16;

@@ -290,7 +290,7 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
         const uint4 k0 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8);
         const uint4 k1 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8 + 4);
         mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
-        raster_tile<true>(cx, tx, ty, mk);
+        raster_tile_fmt<true, -1>(cx, tx, ty, mk);
     }
 }
 

@@ -21,11 +21,12 @@ ENT_NONE, ENT_BOX, ENT_MESH = 0, 1, 2
 TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT = 0, 1, 2, 3
 GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE = 0, 1, 2, 3, 4
 AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
+OBS_HWC_U8, OBS_CWH_U8, OBS_GREY_F64 = 0, 1, 2
 
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_check", "mw_kernel_time_ms",
+    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_check", "mw_kernel_time_ms",
 ]
 
 
@@ -146,6 +147,7 @@ def load_library():
     L.mw_render_top.argtypes = [vp, vp, vp, i32, vp]
     L.mw_render_view.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.mw_visible_ents.argtypes = [vp, i32, i32, vp, vp]
+    L.mw_set_obs_layout.argtypes = [vp, i32]
     L.mw_check.argtypes = [vp, vp]
     L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = L
@@ -169,6 +171,8 @@ class Engine:
         self.cfg = cfg
         self.N = cfg.num_envs
         self.E = max(cfg.max_ents, 1)
+        self.W, self.H = cfg.obs_width, cfg.obs_height
+        self.obs_layout = OBS_HWC_U8
         self.device = torch.device("cuda", cfg.device_id)
         h = C.c_void_p()
         rc = self.lib.mw_create(C.byref(cfg), C.byref(h))
@@ -281,6 +285,22 @@ class Engine:
                                             None if dep is None else C.c_void_p(dep.data_ptr()), _stream_ptr()),
                     "mw_render_view")
         return (out, dep) if want_depth else out
+
+    def set_obs_layout(self, layout: int):
+        """Layout of the obs buffer the raster kernel writes: OBS_HWC_U8 | OBS_CWH_U8 | OBS_GREY_F64."""
+        self._check(self.lib.mw_set_obs_layout(self.h, int(layout)), "mw_set_obs_layout")
+        self.obs_layout = int(layout)
+
+    def obs_buffer(self, count: int | None = None):
+        """A device tensor of the right shape / dtype for the current obs layout."""
+        import torch
+        n = self.N if count is None else count
+        layout = self.obs_layout
+        if layout == OBS_CWH_U8:
+            return torch.zeros((n, 3, self.W, self.H), dtype=torch.uint8, device=self.device)
+        if layout == OBS_GREY_F64:
+            return torch.zeros((n, self.H, self.W, 1), dtype=torch.float64, device=self.device)
+        return torch.zeros((n, self.H, self.W, 3), dtype=torch.uint8, device=self.device)
 
     def visible_ents(self, first_env: int = 0, count: int | None = None):
         """get_visible_ents (miniworld.py:1238-1333): uint8[count, max_ents] on the device, 1 = visible."""

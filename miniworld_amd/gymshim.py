@@ -112,6 +112,18 @@ except Exception:  # noqa: BLE001
         def __getattr__(self, name):
             return getattr(self.env, name)
 
+        @property
+        def np_random(self):            # gymnasium.Wrapper forwards the rng to the wrapped env
+            return self.env.np_random
+
+        @np_random.setter
+        def np_random(self, value):
+            self.env.np_random = value
+
+        @property
+        def unwrapped(self):
+            return self.env.unwrapped
+
         def reset(self, **kw):
             return self.env.reset(**kw)
 

@@ -40,9 +40,16 @@ _KIND = {
 
 class MiniWorldVecEnv:
     def __init__(self, env_id: str, num_envs: int, device_id: int = 0, domain_rand: bool = False,
-                 want_depth: bool = False, seed: int = 0, autoreset: bool = True, **env_kwargs):
+                 want_depth: bool = False, seed: int = 0, autoreset: bool = True, obs_layout: str = "hwc",
+                 **env_kwargs):
+        """obs_layout: "hwc" uint8[N,H,W,3] (the env's observation), "cwh" uint8[N,3,W,H]
+        (PyTorchObsWrapper, wrappers.py:24) or "grey" float64[N,H,W,1] (GreyscaleWrapper, wrappers.py:44):
+        the raster kernel stores the frame in that layout, there is no extra pass."""
         import torch
         self.torch = torch
+        if obs_layout not in ("hwc", "cwh", "grey"):
+            raise ValueError(f"obs_layout must be 'hwc', 'cwh' or 'grey', not {obs_layout!r}")
+        self.obs_layout = obs_layout
         if env_id not in _KIND:
             raise KeyError(f"{env_id!r} is not available in the batched engine yet; have {sorted(_KIND)}")
         cls_name, generator, task, n_actions = _KIND[env_id]
@@ -142,7 +149,8 @@ class MiniWorldVecEnv:
                 self.engine.upload_mesh(self.mesh_ids[name], m.verts, m.norms, m.texcs, m.colors)
         dev = self.engine.device
         H, W = self.template.obs_height, self.template.obs_width
-        self.obs = torch.zeros((num_envs, H, W, 3), dtype=torch.uint8, device=dev)
+        self.engine.set_obs_layout({"hwc": eng.OBS_HWC_U8, "cwh": eng.OBS_CWH_U8, "grey": eng.OBS_GREY_F64}[obs_layout])
+        self.obs = self.engine.obs_buffer()
         self.depth = torch.zeros((num_envs, H, W, 1), dtype=torch.float32, device=dev) if want_depth else None
         self.reward = torch.zeros(num_envs, dtype=torch.float32, device=dev)
         self.terminated = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
@@ -208,8 +216,11 @@ class MiniWorldVecEnv:
 
     def render_top_view(self, render_agent=True):
         """uint8[N,H,W,3] map views (render_top_view, miniworld.py:1088-1175) of every env."""
-        out = self.torch.zeros_like(self.obs)
+        layout = self.engine.obs_layout
+        self.engine.set_obs_layout(eng.OBS_HWC_U8)
+        out = self.engine.obs_buffer()
         self.engine.render_top(out, None, render_agent)
+        self.engine.set_obs_layout(layout)
         return out
 
     def get_visible_ents(self):

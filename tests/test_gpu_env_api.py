@@ -408,3 +408,33 @@ def test_single_env_get_visible_ents(case):
         if term or trunc:
             break
     env.close()
+
+
+@pytest.mark.parametrize("env_id,kw", [("MiniWorld-Hallway-v0", {}), ("MiniWorld-PickupObjects-v0", {"domain_rand": True})])
+def test_vec_env_fused_wrapper_layouts(env_id, kw):
+    """obs_layout="cwh" / "grey": the raster kernel's store in the layout of PyTorchObsWrapper /
+    GreyscaleWrapper equals those wrappers applied to the plain observation (wrappers.py:24, :44),
+    bit for bit (greyscale in numpy's float64 evaluation order), for both raster kernels."""
+    import torch
+    from miniworld_amd import wrappers
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 64
+    vecs = {k: MiniWorldVecEnv(env_id, n, seed=5, obs_layout=k, **kw) for k in ("hwc", "cwh", "grey")}
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for v in vecs.values():
+        v.reset()
+    for t in range(12):
+        act = torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32)
+        act = wrappers.stochastic_actions(act, prob=0.8, random_action=2, generator=g)
+        outs = {k: v.step(act)[0].cpu().numpy() for k, v in vecs.items()}
+        raw = outs["hwc"]
+        assert outs["cwh"].shape == (n, 3, 80, 60) and outs["cwh"].dtype == np.uint8
+        assert np.array_equal(outs["cwh"], raw.transpose(0, 3, 2, 1))
+        assert outs["grey"].shape == (n, 60, 80, 1) and outs["grey"].dtype == np.float64
+        want = 0.30 * raw[..., 0] + 0.59 * raw[..., 1] + 0.11 * raw[..., 2]
+        assert np.array_equal(outs["grey"][..., 0], want)
+    top = vecs["cwh"].render_top_view()
+    assert top.shape == (n, 60, 80, 3) and np.array_equal(top.cpu().numpy(), vecs["hwc"].render_top_view().cpu().numpy())
+    for v in vecs.values():
+        v.engine.check()
+        v.close()

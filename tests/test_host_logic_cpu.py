@@ -87,3 +87,52 @@ def test_engine_fails_loudly_without_gpu():
     from miniworld_amd import engine, envs
     with pytest.raises(engine.EngineError):
         envs.Hallway()          # no silent CPU fallback
+
+
+def test_wrappers_semantics_on_host():
+    """wrappers.py:7-73: transpose to (C, W, H); float64 greyscale (H, W, 1); stochastic action stream."""
+    from miniworld_amd import wrappers
+    from miniworld_amd.gymshim import gym
+
+    class Fake(gym.Env):
+        observation_space = gym.spaces.Box(0, 255, (60, 80, 3), dtype=np.uint8)
+        action_space = gym.spaces.Discrete(8)
+
+        def __init__(self):
+            self.rng = np.random.default_rng(0)
+            self.last_action = None
+
+        def reset(self, *, seed=None, options=None):
+            super().reset(seed=seed)
+            return self.rng.integers(0, 256, (60, 80, 3), dtype=np.uint8), {}
+
+        def step(self, action):
+            self.last_action = action
+            return self.rng.integers(0, 256, (60, 80, 3), dtype=np.uint8), 0.0, False, False, {}
+
+    base = Fake()
+    w = wrappers.PyTorchObsWrapper(base)
+    assert tuple(w.observation_space.shape) == (3, 80, 60)
+    base.rng = np.random.default_rng(5)
+    o, _ = w.reset(seed=1)
+    base.rng = np.random.default_rng(5)
+    raw, _ = base.reset(seed=1)
+    assert o.shape == (3, 80, 60) and np.array_equal(o, raw.transpose(2, 1, 0))
+    g = wrappers.GreyscaleWrapper(base)
+    assert tuple(g.observation_space.shape) == (60, 80, 1)
+    base.rng = np.random.default_rng(5)
+    og, _ = g.reset(seed=1)
+    assert og.dtype == np.float64 and og.shape == (60, 80, 1)
+    assert np.array_equal(og[:, :, 0], 0.30 * raw[:, :, 0] + 0.59 * raw[:, :, 1] + 0.11 * raw[:, :, 2])
+    s = wrappers.StochasticActionWrapper(base, prob=0.5, random_action=7)
+    s.reset(seed=3)
+    ref = np.random.Generator(np.random.PCG64(np.random.SeedSequence(3)))
+    for a in range(40):
+        s.step(a % 3)
+        assert base.last_action == ((a % 3) if ref.uniform() < 0.5 else 7)
+    s = wrappers.StochasticActionWrapper(base, prob=0.3)
+    s.reset(seed=4)
+    ref = np.random.Generator(np.random.PCG64(np.random.SeedSequence(4)))
+    for a in range(40):
+        s.step(2)
+        assert base.last_action == (2 if ref.uniform() < 0.3 else ref.integers(0, 6))
