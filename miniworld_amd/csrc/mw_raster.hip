@@ -77,7 +77,25 @@ __device__ inline void raster_kernel_body(
     const int t_begin = part * tiles_per_wave;
     const int t_end = min(t_begin + tiles_per_wave, n_tiles);
     int tx = t_begin % tiles_x, ty = t_begin / tiles_x;
+    // small scenes: classify (tile, primitive) pairs for as many tiles as fit in the 64 lanes at once
+    const bool pairs = LDS_RECS && nvis > 0 && nvis <= 32 && !(dbg & 2);
+    const int per_group = pairs ? 64 / nvis : 0;
+    const uint64_t prim_mask = pairs ? ((1ull << nvis) - 1ull) : 0ull;
+    uint64_t T = 0ull, F = 0ull, Cl = 0ull;
+    int gi = 0, G = 0;
+    cx.have_pre = pairs ? 1 : 0;
+    cx.pre_touch = cx.pre_full = cx.pre_clip = 0ull;
     for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
+        if (pairs) {
+            if (gi == G) {
+                G = min(per_group, t_end - tile);
+                gi = 0;
+                classify_group(s_cull, lane, nvis, tile, G, tiles_x, T, F, Cl);
+            }
+            const int sh = gi * nvis;
+            cx.pre_touch = (T >> sh) & prim_mask; cx.pre_full = (F >> sh) & prim_mask; cx.pre_clip = (Cl >> sh) & prim_mask;
+            ++gi;
+        }
         raster_tile_fmt<false, FMT>(cx, tx, ty, nullptr);
     }
 }

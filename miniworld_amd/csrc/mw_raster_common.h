@@ -201,7 +201,54 @@ struct TileCtx {
     TexEnv te;
     float sky_r, sky_g, sky_b;
     int env, nvis, W, H, dbg, lane;
+    // tile classification done ahead for a group of tiles (classify_group): valid when have_pre
+    uint64_t pre_touch, pre_full, pre_clip;
+    int have_pre;
 };
+
+// Tile classification of primitive lp against the tile whose pixel centres span [Xlo, Xhi] x [Ylo, Yhi].
+// The edge function is monotone in X and Y (rounding included), so its extremes over the tile's
+// pixel centres sit at corners:  touch = every edge's maximum exceeds its smallest sample threshold,
+//                                full  = every edge's minimum exceeds its largest sample threshold.
+__device__ inline void classify_prim(const float4 *s_cull, int lp, float Xlo, float Xhi, float Ylo, float Yhi,
+                                     bool &touch, bool &full, bool &clipf)
+{
+    const float4 A = s_cull[lp * 6 + 0], B = s_cull[lp * 6 + 1], C = s_cull[lp * 6 + 2];
+    const float4 TMIN = s_cull[lp * 6 + 3], TMAX = s_cull[lp * 6 + 4];
+    const float ea[4] = {A.x, A.y, A.z, A.w}, eb[4] = {B.x, B.y, B.z, B.w}, ec[4] = {C.x, C.y, C.z, C.w};
+    const float tmn[4] = {TMIN.x, TMIN.y, TMIN.z, TMIN.w}, tmx[4] = {TMAX.x, TMAX.y, TMAX.z, TMAX.w};
+    touch = true; full = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float emax = fmaf(ea[k], ea[k] > 0.0f ? Xhi : Xlo, fmaf(eb[k], eb[k] > 0.0f ? Yhi : Ylo, ec[k]));
+        const float emin = fmaf(ea[k], ea[k] > 0.0f ? Xlo : Xhi, fmaf(eb[k], eb[k] > 0.0f ? Ylo : Yhi, ec[k]));
+        touch &= emax > tmn[k];
+        full &= emin > tmx[k];
+    }
+    clipf = __float_as_uint(s_cull[lp * 6 + 5].x) != 0u;
+}
+
+// Classification of a GROUP of consecutive tiles in one pass, one (tile, primitive) pair per lane:
+// with the dozen primitives of a typical indoor frame a per-tile pass would leave most lanes idle.
+// Lane l < G * nvis handles tile (tile0 + l / nvis), primitive l % nvis; the three ballots hold,
+// for the g-th tile of the group, its masks in bits [g * nvis, (g + 1) * nvis).
+__device__ inline void classify_group(const float4 *s_cull, int lane, int nvis, int tile0, int G, int tiles_x,
+                                      uint64_t &T, uint64_t &F, uint64_t &Cl)
+{
+    const uint32_t inv_n = (65536u + (uint32_t)nvis - 1u) / (uint32_t)nvis;      // lane / nvis, exact for lane < 64
+    const int g = (int)(((uint32_t)lane * inv_n) >> 16);
+    const int p = lane - g * nvis;
+    bool touch = false, full = false, clipf = false;
+    if (g < G) {
+        const uint32_t idx = (uint32_t)(tile0 + g);
+        const uint32_t ty = __umulhi(idx, 0xFFFFFFFFu / (uint32_t)tiles_x + 1u);  // idx / tiles_x, exact for idx < 2^16
+        const uint32_t tx = idx - ty * (uint32_t)tiles_x;
+        const float Xlo = (float)(tx * MW_TILE_W) + 0.5f, Xhi = Xlo + (float)(MW_TILE_W - 1);
+        const float Ylo = (float)(ty * MW_TILE_H) + 0.5f, Yhi = Ylo + (float)(MW_TILE_H - 1);
+        classify_prim(s_cull, p, Xlo, Xhi, Ylo, Yhi, touch, full, clipf);
+    }
+    T = __ballot(touch); F = __ballot(full); Cl = __ballot(clipf);
+}
 
 // FMT: output layout fixed at compile time (0: the plain observation, the hot path) or -1: read from
 // the launch flags (the wrapper layouts; kept out of the hot instantiation)
@@ -248,24 +295,16 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             // and Y (rounding included), so its extremes over the tile's pixel centres sit at
             // corners:  touch = every edge's maximum exceeds its smallest sample threshold,
             //           full  = every edge's minimum exceeds its largest sample threshold.
-            const int lp = chunk + lane;
-            bool touch = lp < nvis, full = touch, clipf = false;
-            if (touch) {
-                const float4 A = s_cull[lp * 6 + 0], B = s_cull[lp * 6 + 1], C = s_cull[lp * 6 + 2];
-                const float4 TMIN = s_cull[lp * 6 + 3], TMAX = s_cull[lp * 6 + 4];
-                const float ea[4] = {A.x, A.y, A.z, A.w}, eb[4] = {B.x, B.y, B.z, B.w}, ec[4] = {C.x, C.y, C.z, C.w};
-                const float tmn[4] = {TMIN.x, TMIN.y, TMIN.z, TMIN.w}, tmx[4] = {TMAX.x, TMAX.y, TMAX.z, TMAX.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float emax = fmaf(ea[k], ea[k] > 0.0f ? Xhi : Xlo, fmaf(eb[k], eb[k] > 0.0f ? Yhi : Ylo, ec[k]));
-                    const float emin = fmaf(ea[k], ea[k] > 0.0f ? Xlo : Xhi, fmaf(eb[k], eb[k] > 0.0f ? Ylo : Yhi, ec[k]));
-                    touch &= emax > tmn[k];
-                    full &= emin > tmx[k];
-                }
-                clipf = __float_as_uint(s_cull[lp * 6 + 5].x) != 0u;
+            uint64_t todo, fullm, clipm;
+            if (cx.have_pre) {
+                todo = cx.pre_touch; fullm = cx.pre_full; clipm = cx.pre_clip;
+            } else {
+                const int lp = chunk + lane;
+                bool touch = lp < nvis, full = touch, clipf = false;
+                if (touch) classify_prim(s_cull, lp, Xlo, Xhi, Ylo, Yhi, touch, full, clipf);
+                todo = __ballot(touch);
+                fullm = __ballot(full); clipm = __ballot(clipf);
             }
-            uint64_t todo = __ballot(touch);
-            const uint64_t fullm = __ballot(full), clipm = __ballot(clipf);
             if (todo & clipm) { exact = true; break; }
             while (todo) {
                 const int bit = __ffsll((unsigned long long)todo) - 1;
@@ -335,20 +374,15 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 #pragma unroll
         for (int s = 0; s < 8; ++s) key[s] = MESH ? mesh_key[s] : 0xFFFFFFFFu;
         for (int chunk = 0; chunk < nvis; chunk += 64) {
-            const int lp = chunk + lane;
-            bool touch = lp < nvis;
-            if (touch) {
-                const float4 A = s_cull[lp * 6 + 0], B = s_cull[lp * 6 + 1], C = s_cull[lp * 6 + 2];
-                const float4 TMIN = s_cull[lp * 6 + 3];
-                const float ea[4] = {A.x, A.y, A.z, A.w}, eb[4] = {B.x, B.y, B.z, B.w}, ec[4] = {C.x, C.y, C.z, C.w};
-                const float tmn[4] = {TMIN.x, TMIN.y, TMIN.z, TMIN.w};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float emax = fmaf(ea[k], ea[k] > 0.0f ? Xhi : Xlo, fmaf(eb[k], eb[k] > 0.0f ? Yhi : Ylo, ec[k]));
-                    touch &= emax > tmn[k];
-                }
+            uint64_t todo;
+            if (cx.have_pre) {
+                todo = cx.pre_touch;
+            } else {
+                const int lp = chunk + lane;
+                bool touch = lp < nvis, full = false, clipf = false;
+                if (touch) classify_prim(s_cull, lp, Xlo, Xhi, Ylo, Yhi, touch, full, clipf);
+                todo = __ballot(touch);
             }
-            uint64_t todo = __ballot(touch);
             while (todo) {
                 const int p = chunk + (__ffsll((unsigned long long)todo) - 1);
                 todo &= todo - 1;
