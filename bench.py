@@ -36,6 +36,23 @@ ALGO_BYTES_PER_ENV_STEP = 14540
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 
 
+def pmc_traffic(kernel, config, n):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/pmc_hbm_summary.json,
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same command, KiB per launch).
+    Only meaningful for the workload the passes were run on (the headline config); None otherwise."""
+    if config != "hallway" or n != ENVS_PER_GPU:
+        return None, None
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_hbm_summary.json")))
+    if not files:
+        return None, None
+    try:
+        d = json.load(open(files[-1])).get(kernel)
+        return (d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024.0, os.path.relpath(files[-1], ROOT)
+    except Exception:  # noqa: BLE001
+        return None, None
+
+
 def cpu_baseline():
     """The CPU oracle (oracle/, a port of the reference path) on the host: a bounded sample of
     the same workload — one Hallway env stepped + rendered in a C loop on one core."""
@@ -118,6 +135,8 @@ def main():
     if rank == 0:
         steps_per_s = world * n * args.steps / elapsed
         achieved = algo_bytes * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
+        dominant = "mw_raster_mesh_kernel" if vec.mesh_ids else "mw_raster_kernel"
+        traffic, traffic_src = pmc_traffic(dominant, args.config, n)
         out = {
             "metric": "env-steps/s (batched, 80x60 RGB)",
             "value": steps_per_s,
@@ -137,17 +156,19 @@ def main():
             "samples_per_s": steps_per_s * 80 * 60 * 8,
             "roofline": {
                 "bound": "hbm",
-                "kernel": "mw_raster_mesh_kernel" if vec.mesh_ids else "mw_raster_kernel",
+                "kernel": dominant,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": algo_bytes * n,
                 "kernel_ms": raster_ms,
                 "setup_kernel_ms": setup_ms,
                 "launches_timed": launches,
-                "note": "path is raster/texture VALU bound, not HBM bound (SURVEY.md section 8d)",
+                "note": "path is raster/texture VALU bound, not HBM bound (SURVEY.md section 8d); traffic = PMC "
+                        "FETCH_SIZE + WRITE_SIZE per launch, bytes",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
