@@ -8,11 +8,15 @@ from .pickupobjects import PickupObjects
 from .putnext import PutNext
 from .roomobjects import RoomObjects
 from .tmaze import TMaze, TMazeLeft, TMazeRight
+from .ymaze import YMaze, YMazeLeft, YMazeRight
 
-__all__ = ["FourRooms", "PutNext", "RoomObjects", "TMaze", "TMazeLeft", "TMazeRight", "Hallway", "Maze", "MazeS2", "MazeS3", "MazeS3Fast", "OneRoom", "OneRoomS6", "OneRoomS6Fast",
+__all__ = ["YMaze", "YMazeLeft", "YMazeRight", "FourRooms", "PutNext", "RoomObjects", "TMaze", "TMazeLeft", "TMazeRight", "Hallway", "Maze", "MazeS2", "MazeS3", "MazeS3Fast", "OneRoom", "OneRoomS6", "OneRoomS6Fast",
            "PickupObjects"]
 
 ENV_IDS = {
+    "MiniWorld-YMaze-v0": "YMaze",
+    "MiniWorld-YMazeLeft-v0": "YMazeLeft",
+    "MiniWorld-YMazeRight-v0": "YMazeRight",
     "MiniWorld-FourRooms-v0": "FourRooms",
     "MiniWorld-PutNext-v0": "PutNext",
     "MiniWorld-RoomObjects-v0": "RoomObjects",
@@ -30,7 +34,7 @@ ENV_IDS = {
     "MiniWorld-PickupObjects-v0": "PickupObjects",
 }
 
-_MODULE_OF = {"FourRooms": "fourrooms", "PutNext": "putnext", "RoomObjects": "roomobjects", "TMaze": "tmaze",
+_MODULE_OF = {"YMaze": "ymaze", "YMazeLeft": "ymaze", "YMazeRight": "ymaze", "FourRooms": "fourrooms", "PutNext": "putnext", "RoomObjects": "roomobjects", "TMaze": "tmaze",
               "TMazeLeft": "tmaze", "TMazeRight": "tmaze","Hallway": "hallway", "Maze": "maze", "MazeS2": "maze", "MazeS3": "maze", "MazeS3Fast": "maze",
               "OneRoom": "oneroom", "OneRoomS6": "oneroom", "OneRoomS6Fast": "oneroom",
               "PickupObjects": "pickupobjects"}

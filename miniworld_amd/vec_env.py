@@ -33,6 +33,9 @@ _KIND = {
     "MiniWorld-TMaze-v0": ("TMaze", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-TMazeLeft-v0": ("TMazeLeft", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-TMazeRight-v0": ("TMazeRight", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-YMaze-v0": ("YMaze", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-YMazeLeft-v0": ("YMazeLeft", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-YMazeRight-v0": ("YMazeRight", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-PutNext-v0": ("PutNext", eng.GEN_NONE, eng.TASK_PUTNEXT, 8),
     "MiniWorld-RoomObjects-v0": ("RoomObjects", eng.GEN_NONE, eng.TASK_NONE, 8),
 }

@@ -58,6 +58,8 @@ CASES = [
     # reference's success rule (putnext.py:74-78) fires and is pinned
     ("putnext_poke_s1", "PutNext", {}, 1, [0.12, 0.1, 0.38, 0.05, 0.2, 0.15, 0.0, 0.0], 250, [0, 40]),
     ("putnext_dr_s3", "PutNext", {"domain_rand": True}, 3, [0.12, 0.1, 0.38, 0.05, 0.2, 0.15, 0.0, 0.0], 250, [0, 125]),
+    ("ymaze_s0", "YMaze", {}, 0, [0.1, 0.1, 0.8], 280, [0, 30, 90]),
+    ("ymazeleft_s1", "YMazeLeft", {"domain_rand": True}, 1, [0.12, 0.08, 0.8], 280, [0, 60]),
     ("roomobjects_s0", "RoomObjects", {}, 0, [0.15, 0.1, 0.4, 0.05, 0.2, 0.1, 0.0, 0.0], 150, [0, 75, 149]),
 ]
 
@@ -166,9 +168,15 @@ def run_case(name, cls, kwargs, seed, n_actions, steps, frames, meshes):
 def main():
     os.makedirs(OUT, exist_ok=True)
     meshes = {}
+    only = set(sys.argv[1:])               # optional: names of the cases to (re)generate
     for case in CASES:
-        run_case(*case, meshes)
+        if not only or case[0] in only:
+            run_case(*case, meshes)
     mout = {}
+    mpath = os.path.join(OUT, "meshes.npz")
+    if only and os.path.exists(mpath):       # partial run: keep the meshes of the other cases
+        old = np.load(mpath)
+        mout.update({k: old[k] for k in old.files})
     for k, v in meshes.items():
         if k.startswith("kd:"):
             mout[k] = v
