@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MW_ABI_VERSION 1
+#define MW_ABI_VERSION 2
 
 enum {
     MW_OK = 0,
@@ -35,8 +35,10 @@ enum {
     MW_E_OVERFLOW = -6      /* a kernel reported a per-env capacity overflow */
 };
 
-/* entity kinds (entity.py: Box :386, MeshEnt :124 / Ball :445 / Key :435) */
-enum { MW_ENT_NONE = 0, MW_ENT_BOX = 1, MW_ENT_MESH = 2 };
+/* entity kinds (entity.py: Box :386, MeshEnt :124 / Ball :445 / Key :435, ImageFrame :168 / TextFrame :262).
+ * MW_ENT_FRAME: the entity's quads are part of the static polygon list (mw_set_geometry) — it is an entity
+ * only for collisions (radius 0, miniworld.py:951-961) and for mw_visible_ents. */
+enum { MW_ENT_NONE = 0, MW_ENT_BOX = 1, MW_ENT_MESH = 2, MW_ENT_FRAME = 3 };
 
 /* env reward / termination rule applied after MiniWorldEnv.step (miniworld.py:670-730) */
 enum {
@@ -109,13 +111,19 @@ typedef struct {
     int32_t pad_;
 } mw_config;
 
-/* One room polygon exactly as Room._render feeds it to GL (miniworld.py:401-434). */
+#define MW_POLY_ENTITY 0x100
+
+/* One static polygon exactly as it is fed to GL inside display list 1: a room polygon of Room._render
+ * (miniworld.py:401-434, colour 1,1,1) or a quad of a static ImageFrame / TextFrame (entity.py:193-259,
+ * 303-383: textured front in 1,1,1, border in 0,0,0), already in world coordinates. */
 typedef struct {
     float v[4][3];              /* glVertex3f   */
     float uv[4][2];             /* glTexCoord2f */
     float n[3];                 /* glNormal3f   */
-    int32_t nv;                 /* 3 or 4       */
+    int32_t nv;                 /* 3 or 4; | MW_POLY_ENTITY for a quad of a static entity (not drawn by mw_visible_ents,
+                                 * which renders rooms only: miniworld.py:1291-1293) */
     int32_t tex;                /* texture id from mw_upload_texture, -1 = untextured */
+    float rgb[3];               /* glColor3f    */
 } mw_poly;
 
 /* Host view of the world state of `count` consecutive envs; any pointer may be NULL
@@ -149,7 +157,8 @@ const char *mw_last_error(const mw_engine *e);
 /* ---- assets ----------------------------------------------------------------- */
 /* replaces Texture.load (opengl.py:148-184): RGB8, rows bottom-up; builds the mip pyramid */
 int mw_upload_texture(mw_engine *e, int32_t tex_id, const uint8_t *rgb_bottom_up, int32_t w, int32_t h);
-/* replaces ObjMesh's vertex lists (objmesh.py:139-207): per-face-vertex arrays [ntris][3][k] */
+/* replaces ObjMesh's vertex lists (objmesh.py:139-207): per-face-vertex arrays [ntris][3][k] (pos, nrm, rgb:
+ * k = 3; uv: k = 2); tex_id = the chunk's map_Kd texture (objmesh.py:209-216, 280-292) or -1 */
 int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float *nrm, const float *uv,
                    const float *rgb, int32_t ntris, int32_t tex_id);
 

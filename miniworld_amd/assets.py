@@ -65,13 +65,18 @@ def texture_variants(tex_name: str) -> list:
 
 
 def texture_rgb_top_down(variant: str) -> np.ndarray:
+    """``variant`` is a texture variant ``name_i`` (textures/, may contain a sub-directory such as
+    ``chars/ch_0x66_1``) or ``mesh:<name>`` for the map_Kd image of a mesh (meshes/<name>.png)."""
     if variant not in _tex_cache:
         pack = _pack_file()
         key = "tex:" + variant
         if key in pack:
             arr = pack[key]
         else:
-            path = _find_file("textures", variant + ".png")
+            if variant.startswith("mesh:"):
+                path = _find_file("meshes", variant[5:] + ".png")
+            else:
+                path = _find_file("textures", variant + ".png")
             if path is None:
                 raise FileNotFoundError(f"texture {variant!r} not found in the asset pack or $MINIWORLD_ASSET_PATH")
             from PIL import Image
@@ -100,12 +105,21 @@ def mesh_sources(mesh_name: str):
     if ("obj:" + base) in pack and ("kd:" + mesh_name) in pack:
         text = bytes(pack["obj:" + base]).decode()
         return text, {"TheMaterial": {"Kd": np.array(pack["kd:" + mesh_name], np.float64)}}
+    if ("obj:" + mesh_name) in pack:
+        # meshes without an MTL: only the default material, textured iff meshes/<name>.png exists
+        # (objmesh.py:222-231)
+        default = {"Kd": np.array([1.0, 1.0, 1.0])}
+        if ("tex:mesh:" + mesh_name) in pack:
+            default["map_Kd"] = "mesh:" + mesh_name
+        return bytes(pack["obj:" + mesh_name]).decode(), {"": default}
     path = _find_file("meshes", mesh_name + ".obj")
     if path is None:
         raise FileNotFoundError(f"mesh {mesh_name!r} not found in the asset pack or $MINIWORLD_ASSET_PATH")
     with open(path) as f:
         text = f.read()
-    mats = {}
+    mats = {"": {"Kd": np.array([1.0, 1.0, 1.0])}}
+    if os.path.exists(os.path.splitext(path)[0] + ".png"):      # default material's texture (objmesh.py:227-231)
+        mats[""]["map_Kd"] = "mesh:" + mesh_name
     mtl = os.path.splitext(path)[0] + ".mtl"
     if os.path.exists(mtl):
         cur = None
@@ -120,5 +134,5 @@ def mesh_sources(mesh_name: str):
                 elif tok[0] == "Kd" and cur is not None:
                     cur["Kd"] = np.array([float(t) for t in tok[1:4]])
                 elif tok[0] == "map_Kd" and cur is not None:
-                    cur["map_Kd"] = os.path.join(os.path.dirname(path), tok[-1])
+                    cur["map_Kd"] = "mesh:" + os.path.splitext(tok[-1])[0]
     return text, mats

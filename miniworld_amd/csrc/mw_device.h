@@ -13,8 +13,8 @@
 #define MW_TILE_W 16
 #define MW_TILE_H 4
 #define MW_SKY_PID 0xFFFFu
-#define MW_ENVHDR 128         // floats per env: sky, camera, light, mesh-entity table (K1 -> K2/K3)
-#define MW_MAX_MESH_ENTS 8    // mesh entities drawn per env
+#define MW_ENVHDR 288         // floats per env: sky, camera, light, mesh-entity table (K1 -> K2/K3)
+#define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
 #define MW_HDR_MESH 32        // first float of the mesh-entity table; 12 floats per entry
 
 // status bits written by kernels, read by mw_check()
@@ -82,6 +82,7 @@ struct MwArgs {
     const float *mesh_pos;  // [tris][3][3]
     const float *mesh_nrm;  // [tris][3][3]
     const float *mesh_rgb;  // [tris][3][3]
+    const float *mesh_uv;   // [tris][3][2]
     // --- per-step scratch -----------------------------------------------------------
     float *rec_raster;      // [N][max_vis][64]
     float *rec_shade;       // [N][max_vis][16]

@@ -42,7 +42,7 @@ extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, const float 
 extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
                                                  const float *rec_shade, const int32_t *nvis, const float *envhdr,
                                                  const MwTexDesc *texd, const uint32_t *texels, const float *mesh_pos,
-                                                 const float *mesh_nrm, const float *mesh_rgb, const uint32_t *mesh_keys,
+                                                 const float *mesh_nrm, const float *mesh_rgb, const float *mesh_uv, const uint32_t *mesh_keys,
                                                  uint8_t *out, float *depth, int texel_bytes);
 extern "C" __global__ void mw_visible_kernel(int env_base, int W, int H, int max_vis, int E, const float *rec_raster,
                                              const int32_t *nvis, uint8_t *vis);
@@ -50,7 +50,7 @@ extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vi
                                                  const float *rec_raster, const float *rec_shade, const float *rec_cull,
                                                  const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
                                                  const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
-                                                 const float *mesh_rgb, uint8_t *obs, float *depth, int dbg, int texel_bytes);
+                                                 const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes);
 
 namespace {
 thread_local std::string g_create_error;
@@ -70,8 +70,8 @@ struct mw_engine {
     MwTexDesc *d_texdesc = nullptr;
     MwMeshDesc *d_meshdesc = nullptr;
     std::vector<MwMeshDesc> mesh_desc;
-    std::vector<std::vector<float>> mesh_pos, mesh_nrm, mesh_rgb;   // per mesh id, [ntris][9]
-    float *d_mesh_pos = nullptr, *d_mesh_nrm = nullptr, *d_mesh_rgb = nullptr;
+    std::vector<std::vector<float>> mesh_pos, mesh_nrm, mesh_rgb, mesh_uv;   // per mesh id, [ntris][9] ([6] for uv)
+    float *d_mesh_pos = nullptr, *d_mesh_nrm = nullptr, *d_mesh_rgb = nullptr, *d_mesh_uv = nullptr;
     bool have_meshes = false;
     bool mesh_lds_ready = false;
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
@@ -334,7 +334,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         hipLaunchKernelGGL(mw_raster_mesh_kernel, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
-                           a.mesh_rgb, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes);
+                           a.mesh_rgb, a.mesh_uv, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes);
     } else {
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -441,7 +441,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
         (void)hipMemcpy(a.rng, seeds.data(), 16 * (size_t)N, hipMemcpyHostToDevice);
     }
     e->mesh_desc.assign(MW_MAX_MESH, MwMeshDesc{});
-    e->mesh_pos.assign(MW_MAX_MESH, {}); e->mesh_nrm.assign(MW_MAX_MESH, {}); e->mesh_rgb.assign(MW_MAX_MESH, {});
+    e->mesh_pos.assign(MW_MAX_MESH, {}); e->mesh_nrm.assign(MW_MAX_MESH, {}); e->mesh_rgb.assign(MW_MAX_MESH, {}); e->mesh_uv.assign(MW_MAX_MESH, {});
     e->tex_desc.assign(MW_MAX_TEX, MwTexDesc{});
     e->tex_data.assign(MW_MAX_TEX, {});
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
@@ -458,7 +458,7 @@ void mw_destroy(mw_engine *e)
     (void)hipDeviceSynchronize();
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_texels) (void)hipFree(e->d_texels);
-    for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb}) if (p) (void)hipFree(p);
+    for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb, e->d_mesh_uv}) if (p) (void)hipFree(p);
     if (e->d_view_keys) (void)hipFree(e->d_view_keys);
     for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     for (auto &ev : e->ev_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
@@ -477,33 +477,36 @@ int mw_upload_texture(mw_engine *e, int32_t tex_id, const uint8_t *rgb, int32_t 
 int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float *nrm, const float *uv,
                    const float *rgb, int32_t ntris, int32_t tex_id)
 {
-    (void)uv;
     if (!e || !pos || !nrm || !rgb) return fail(e, MW_E_INVALID, "null argument");
+    if (tex_id >= MW_MAX_TEX || (tex_id >= 0 && !uv)) return fail(e, MW_E_INVALID, "textured mesh needs texcoords and a valid texture id");
     if (mesh_id < 0 || mesh_id >= MW_MAX_MESH) return fail(e, MW_E_CAPACITY, "mesh id %d out of range (max %d)", mesh_id, MW_MAX_MESH);
     if (ntris <= 0 || ntris > 60000) return fail(e, MW_E_CAPACITY, "mesh with %d triangles (1..60000 supported: 16-bit draw ids)", ntris);
-    if (tex_id >= 0) return fail(e, MW_E_INVALID, "textured meshes are not implemented yet (tex_id must be -1)");
     e->mesh_pos[mesh_id].assign(pos, pos + (size_t)ntris * 9);
     e->mesh_nrm[mesh_id].assign(nrm, nrm + (size_t)ntris * 9);
     e->mesh_rgb[mesh_id].assign(rgb, rgb + (size_t)ntris * 9);
+    if (uv) e->mesh_uv[mesh_id].assign(uv, uv + (size_t)ntris * 6);
+    else e->mesh_uv[mesh_id].assign((size_t)ntris * 6, 0.0f);
     e->mesh_desc[mesh_id].ntris = (uint32_t)ntris;
     e->mesh_desc[mesh_id].tex = tex_id;
     // repack all pools (uploads are rare)
     size_t total = 0;
     for (int i = 0; i < MW_MAX_MESH; ++i) { e->mesh_desc[i].first = (uint32_t)total; total += e->mesh_desc[i].ntris; }
-    for (float **p : {&e->d_mesh_pos, &e->d_mesh_nrm, &e->d_mesh_rgb})
+    for (float **p : {&e->d_mesh_pos, &e->d_mesh_nrm, &e->d_mesh_rgb, &e->d_mesh_uv})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_pos, total * 36));
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_nrm, total * 36));
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_rgb, total * 36));
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_uv, total * 24));
     for (int i = 0; i < MW_MAX_MESH; ++i) {
         const size_t n = e->mesh_desc[i].ntris, off = (size_t)e->mesh_desc[i].first * 9;
         if (!n) continue;
         HIP_TRY(e, hipMemcpy(e->d_mesh_pos + off, e->mesh_pos[i].data(), n * 36, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_nrm + off, e->mesh_nrm[i].data(), n * 36, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_rgb + off, e->mesh_rgb[i].data(), n * 36, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->d_mesh_uv + (size_t)e->mesh_desc[i].first * 6, e->mesh_uv[i].data(), n * 24, hipMemcpyHostToDevice));
     }
     HIP_TRY(e, hipMemcpy(e->d_meshdesc, e->mesh_desc.data(), sizeof(MwMeshDesc) * MW_MAX_MESH, hipMemcpyHostToDevice));
-    e->args.mesh_pos = e->d_mesh_pos; e->args.mesh_nrm = e->d_mesh_nrm; e->args.mesh_rgb = e->d_mesh_rgb;
+    e->args.mesh_pos = e->d_mesh_pos; e->args.mesh_nrm = e->d_mesh_nrm; e->args.mesh_rgb = e->d_mesh_rgb; e->args.mesh_uv = e->d_mesh_uv;
     e->have_meshes = true;
     return MW_OK;
 }
@@ -521,7 +524,8 @@ int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_p
         set = env;
     }
     for (int i = 0; i < n_polys; ++i) {
-        if (polys[i].nv != 3 && polys[i].nv != 4) return fail(e, MW_E_INVALID, "polygon %d has %d vertices (3 or 4 supported)", i, polys[i].nv);
+        const int nv = polys[i].nv & ~MW_POLY_ENTITY;
+        if (nv != 3 && nv != 4) return fail(e, MW_E_INVALID, "polygon %d has %d vertices (3 or 4 supported)", i, nv);
         if (polys[i].tex >= MW_MAX_TEX) return fail(e, MW_E_INVALID, "polygon %d: bad texture id", i);
         if (polys[i].tex >= 0 && e->tex_desc[polys[i].tex].nlevels == 0) return fail(e, MW_E_INVALID, "polygon %d uses texture %d which was never uploaded", i, polys[i].tex);
     }
@@ -638,7 +642,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     }
     hipLaunchKernelGGL(mw_view_raster_kernel, dim3(b.n_tiles), dim3(64), 0, st, env, width, height, msaa, b.max_vis, b.tiles_x,
                        (const float *)b.rec_raster, (const float *)b.rec_shade, (const int32_t *)b.nvis, (const float *)b.envhdr,
-                       b.tex, b.texels, b.mesh_pos, b.mesh_nrm, b.mesh_rgb, (const uint32_t *)keys, d_out, d_depth, e->texel_bytes);
+                       b.tex, b.texels, b.mesh_pos, b.mesh_nrm, b.mesh_rgb, b.mesh_uv, (const uint32_t *)keys, d_out, d_depth, e->texel_bytes);
     HIP_TRY(e, hipGetLastError());
     return MW_OK;
 }

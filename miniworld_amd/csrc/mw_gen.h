@@ -107,7 +107,7 @@ __device__ inline void emit_room(const MwArgs &a, int set, const RoomTex &rt, co
             q.v[k][0] = (float)px[k]; q.v[k][1] = 0.0f; q.v[k][2] = (float)pz[k];
             q.uv[k][0] = (float)(px[k] * rt.fu); q.uv[k][1] = (float)(pz[k] * rt.fv);
         }
-        q.n[0] = 0.0f; q.n[1] = 1.0f; q.n[2] = 0.0f; q.nv = 4; q.tex = tex_f;
+        q.n[0] = 0.0f; q.n[1] = 1.0f; q.n[2] = 0.0f; q.nv = 4; q.tex = tex_f; q.rgb[0] = q.rgb[1] = q.rgb[2] = 1.0f;
     }
     if (rt.ceiling) {   // ceiling: flipped outline at wall height, normal -Y (:304-306, 418-425)
         mw_poly &q = polys[np++];
@@ -116,7 +116,7 @@ __device__ inline void emit_room(const MwArgs &a, int set, const RoomTex &rt, co
             q.v[k][0] = (float)x; q.v[k][1] = (float)(0.0 + h * 1.0); q.v[k][2] = (float)z;
             q.uv[k][0] = (float)(x * rt.cu); q.uv[k][1] = (float)(z * rt.cv);
         }
-        q.n[0] = 0.0f; q.n[1] = -1.0f; q.n[2] = 0.0f; q.nv = 4; q.tex = tex_c;
+        q.n[0] = 0.0f; q.n[1] = -1.0f; q.n[2] = 0.0f; q.nv = 4; q.tex = tex_c; q.rgb[0] = q.rgb[1] = q.rgb[2] = 1.0f;
     }
     for (int w = 0; w < 4; ++w) {
         if (!((keep_walls >> w) & 1u)) continue;
@@ -136,7 +136,7 @@ __device__ inline void emit_room(const MwArgs &a, int set, const RoomTex &rt, co
         // normal = -cross(b - a, Y) / |.|   (miniworld.py:335-336)
         const double ex = bx - ax, ez = bz - az, len = sqrt(ez * ez + ex * ex);
         q.n[0] = (float)(-(-ez) / len); q.n[1] = 0.0f; q.n[2] = (float)(-(ex) / len);
-        q.nv = 4; q.tex = tex_w;
+        q.nv = 4; q.tex = tex_w; q.rgb[0] = q.rgb[1] = q.rgb[2] = 1.0f;
         segs[ns * 4 + 0] = bx; segs[ns * 4 + 1] = bz; segs[ns * 4 + 2] = ax; segs[ns * 4 + 3] = az;   // [s_p1, s_p0]
         ++ns;
     }

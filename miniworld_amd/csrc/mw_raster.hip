@@ -70,7 +70,7 @@ __device__ inline void raster_kernel_body(
 
     TileCtx cx;
     cx.s_shade = LDS_RECS ? s_shade : g_shade; cx.s_cull = LDS_RECS ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = nullptr;
-    cx.mesh_pos = cx.mesh_nrm = cx.mesh_rgb = nullptr;
+    cx.mesh_pos = cx.mesh_nrm = cx.mesh_rgb = cx.mesh_uv = nullptr;
     cx.obs = obs; cx.depth = depth; cx.te = te;
     cx.sky_r = sky_r; cx.sky_g = sky_g; cx.sky_b = sky_b;
     cx.env = env; cx.nvis = nvis; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane;

@@ -160,29 +160,35 @@ struct TexEnv {
     int flat;
 };
 
+// Textured fragment colour for the lanes with tex >= 0: attribute planes q0 / q1 / q2.x, base colour in
+// q2.yzw (GL_MODULATE); a waterfall over the distinct texture ids among the active lanes.
+__device__ inline RGB apply_texture(const float4 q0, const float4 q1, const float4 q2, int tex, const TexEnv &te,
+                                    float Xc, float Yc)
+{
+    RGB c = {q2.y, q2.z, q2.w};                                 // untextured: the base colour
+    uint64_t pending = __ballot(tex >= 0);
+    while (pending) {
+        const int t0 = __builtin_amdgcn_readlane(tex, __ffsll((unsigned long long)pending) - 1);
+        const MwTexDesc *__restrict__ d = te.texd + t0;
+        const bool mine = tex == t0;
+        if (mine) {
+            const int tw = (int)d->w, th = (int)d->h, q = (int)d->nlevels - 1;
+            if (((tw & (tw - 1)) | (th & (th - 1))) == 0) c = shade_tex<true>(q0, q1, q2, te.td, te.tx, t0, tw, th, q, Xc, Yc);
+            else c = shade_tex<false>(q0, q1, q2, te.td, te.tx, t0, tw, th, q, Xc, Yc);
+        }
+        pending &= ~__ballot(mine);
+    }
+    return c;
+}
+
 // fragment colour of the primitive with LDS shade record `sr` at the pixel centre; executed by
-// the lanes that need it, textures handled by a waterfall over the distinct ids among them
+// the lanes that need it
 __device__ inline RGB shade_prim(const float4 *sr, const TexEnv &te, float Xc, float Yc)
 {
     const float4 q2 = sr[2];
     const int tex = te.flat ? -1 : __float_as_int(sr[3].x);
-    RGB c = {q2.y, q2.z, q2.w};                                 // untextured: the lit face colour
-    uint64_t pending = __ballot(tex >= 0);
-    if (pending) {
-        const float4 q0 = sr[0], q1 = sr[1];
-        while (pending) {
-            const int t0 = __builtin_amdgcn_readlane(tex, __ffsll((unsigned long long)pending) - 1);
-            const MwTexDesc *__restrict__ d = te.texd + t0;
-            const bool mine = tex == t0;
-            if (mine) {
-                const int tw = (int)d->w, th = (int)d->h, q = (int)d->nlevels - 1;
-                if (((tw & (tw - 1)) | (th & (th - 1))) == 0) c = shade_tex<true>(q0, q1, q2, te.td, te.tx, t0, tw, th, q, Xc, Yc);
-                else c = shade_tex<false>(q0, q1, q2, te.td, te.tx, t0, tw, th, q, Xc, Yc);
-            }
-            pending &= ~__ballot(mine);
-        }
-    }
-    return c;
+    if (!__any(tex >= 0)) return RGB{q2.y, q2.z, q2.w};
+    return apply_texture(sr[0], sr[1], q2, tex, te, Xc, Yc);
 }
 
 struct TileCtx;
@@ -195,7 +201,7 @@ struct TileCtx {
     const float *__restrict__ rr_env;   // [nvis][64] raster records (scalar loads)
     uint8_t *s_pack;                // 192 B of LDS per wavefront
     const float *hdr;               // env header (mesh kernel only)
-    const float *mesh_pos, *mesh_nrm, *mesh_rgb;
+    const float *mesh_pos, *mesh_nrm, *mesh_rgb, *mesh_uv;
     uint8_t *__restrict__ obs;
     float *__restrict__ depth;
     TexEnv te;

@@ -91,8 +91,10 @@ __device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, int tri, f
     }
 }
 
-// Gouraud fragment colour of mesh triangle (e, tri) at the pixel centre (R9-R11)
-__device__ inline RGB shade_mesh_tri(const TileCtx &cx, const MeshEnt &e, int tri, float Xc, float Yc)
+// Mesh triangle (e, tri) at the pixel centre (R9-R11): Gouraud colour in q2.yzw and, for a textured
+// mesh (objmesh.py:209-216), the texcoord / 1/w planes in q0, q1, q2.x for apply_texture
+__device__ inline void mesh_tri_fragment(const TileCtx &cx, const MeshEnt &e, int tri, float Xc, float Yc,
+                                         float4 &q0, float4 &q1, float4 &q2)
 {
     const float halfw = (float)cx.W * 0.5f, halfh = (float)cx.H * 0.5f;
     HV h[3];
@@ -119,10 +121,9 @@ __device__ inline RGB shade_mesh_tri(const TileCtx &cx, const MeshEnt &e, int tr
     }
     const float Wa = (ga[0] + ga[1]) + ga[2], Wb = (gb[0] + gb[1]) + gb[2], Wc = (gc[0] + gc[1]) + gc[2];
     const float Wq = fmaf(Wa, Xc, fmaf(Wb, Yc, Wc));
-    RGB o;
+    float out[3] = {col[0][0], col[0][1], col[0][2]};
     if (Wq > 0.0f) {
         const float iw = 1.0f / Wq;
-        float out[3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float Ca = fmaf(col[2][i], ga[2], fmaf(col[1][i], ga[1], col[0][i] * ga[0]));
@@ -130,19 +131,31 @@ __device__ inline RGB shade_mesh_tri(const TileCtx &cx, const MeshEnt &e, int tr
             const float Cc = fmaf(col[2][i], gc[2], fmaf(col[1][i], gc[1], col[0][i] * gc[0]));
             out[i] = fmaf(Ca, Xc, fmaf(Cb, Yc, Cc)) * iw;
         }
-        o.r = out[0]; o.g = out[1]; o.b = out[2];
-    } else {
-        o.r = col[0][0]; o.g = col[0][1]; o.b = col[0][2];
     }
-    return o;
+    float U[3] = {0.0f, 0.0f, 0.0f}, V[3] = {0.0f, 0.0f, 0.0f};
+    if (e.tex >= 0) {
+        const float *uv = cx.mesh_uv + (size_t)(e.first + tri) * 6;
+        U[0] = fmaf(uv[4], ga[2], fmaf(uv[2], ga[1], uv[0] * ga[0]));
+        U[1] = fmaf(uv[4], gb[2], fmaf(uv[2], gb[1], uv[0] * gb[0]));
+        U[2] = fmaf(uv[4], gc[2], fmaf(uv[2], gc[1], uv[0] * gc[0]));
+        V[0] = fmaf(uv[5], ga[2], fmaf(uv[3], ga[1], uv[1] * ga[0]));
+        V[1] = fmaf(uv[5], gb[2], fmaf(uv[3], gb[1], uv[1] * gb[0]));
+        V[2] = fmaf(uv[5], gc[2], fmaf(uv[3], gc[1], uv[1] * gc[0]));
+    }
+    q0 = make_float4(U[0], U[1], U[2], V[0]);
+    q1 = make_float4(V[1], V[2], Wa, Wb);
+    q2 = make_float4(Wc, out[0], out[1], out[2]);
 }
 
-// draw id -> record: ids inside a mesh entity's range are triangles, the others index the
+// draw id -> fragment colour: ids inside a mesh entity's range are triangles, the others index the
 // visible-primitive list once the triangles drawn before them are subtracted
 __device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc, float Yc)
 {
     const int n_mesh = __float_as_int(cx.hdr[3]);
     int vis = (int)id;
+    float4 q0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), q1 = q0, q2 = q0;
+    int tex = -1;
+    bool is_tri = false;
     for (int j = 0; j < n_mesh; ++j) {
         const int start = __float_as_int(cx.hdr[MW_HDR_MESH + 12 * j + 1]);
         const int nt = __float_as_int(cx.hdr[MW_HDR_MESH + 12 * j + 2]);
@@ -150,10 +163,20 @@ __device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc,
             vis -= nt;
         } else if ((int)id >= start) {
             const MeshEnt e = load_ment(cx.hdr, j);
-            return shade_mesh_tri(cx, e, (int)id - start, Xc, Yc);
+            mesh_tri_fragment(cx, e, (int)id - start, Xc, Yc, q0, q1, q2);
+            tex = e.tex;
+            is_tri = true;
+            break;
         }
     }
-    return shade_prim(cx.s_shade + vis * (MW_SHADE_REC / 4), cx.te, Xc, Yc);
+    if (!is_tri) {
+        const float4 *sr = cx.s_shade + vis * (MW_SHADE_REC / 4);
+        q0 = sr[0]; q1 = sr[1]; q2 = sr[2];
+        tex = __float_as_int(sr[3].x);
+    }
+    if (cx.te.flat) tex = -1;
+    if (!__any(tex >= 0)) return RGB{q2.y, q2.z, q2.w};
+    return apply_texture(q0, q1, q2, tex, cx.te, Xc, Yc);
 }
 
 // rasterise one mesh triangle into the LDS key buffer (one lane per triangle)
@@ -246,7 +269,7 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
     const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
-    const float *__restrict__ mesh_rgb, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes)
+    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                     // [H][W][8]
@@ -265,7 +288,7 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     cx.rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     cx.s_pack = s_pack;
     cx.hdr = hdr;
-    cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb;
+    cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.obs = obs; cx.depth = depth;
     cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
     cx.te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);
@@ -410,7 +433,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     int env, int W, int H, int S, int max_vis, int tiles_x, const float *__restrict__ rec_raster,
     const float *__restrict__ rec_shade, const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr,
     const MwTexDesc *__restrict__ texd, const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos,
-    const float *__restrict__ mesh_nrm, const float *__restrict__ mesh_rgb, const uint32_t *mesh_keys,
+    const float *__restrict__ mesh_nrm, const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, const uint32_t *mesh_keys,
     uint8_t *__restrict__ out, float *__restrict__ depth, int texel_bytes)
 {
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
@@ -420,7 +443,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     cx.s_pack = nullptr;
     cx.hdr = hdr;
-    cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb;
+    cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.obs = out; cx.depth = depth;
     cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
     cx.te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);

@@ -604,7 +604,6 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
     c.cpos[0] = uni(c.cpos[0]); c.cpos[1] = uni(c.cpos[1]); c.cpos[2] = uni(c.cpos[2]); c.cdir = uni(c.cdir);
     float stale_n[3] = {0.0f, 1.0f, 0.0f};       // GL's current normal after the last draw (top-view agent marker)
     int count = 0;
-    const float white[3] = {1.0f, 1.0f, 1.0f};
     const mw_poly *polys = a.polys + (size_t)c.set * a.max_polys;
     const int np = a.npolys[c.set];
     for (int base = 0; base < np; base += 64) {         // display list 1: rooms
@@ -615,15 +614,17 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
         mw_poly q;
         if (i < np) {
             q = polys[i];
+            const bool ent_poly = (q.nv & MW_POLY_ENTITY) != 0;
+            q.nv &= 0xFF;
 #pragma unroll
             for (int k = 0; k < 4; ++k) h[k] = xform(cam, q.v[k][0], q.v[k][1], q.v[k][2]);
-            vis = cull_poly(a, h, q.nv, g);
+            vis = cull_poly(a, h, q.nv, g) && !(ent_poly && (view_flags & 4));     // the queries draw rooms only
         }
         const int idx = compact(lane, vis, count);
         if (vis) {
             if (idx < a.max_vis) {
                 float col[3];
-                light(cam, q.n, white, col);
+                light(cam, q.n, q.rgb, col);
                 const float uv[3][2] = {{q.uv[0][0], q.uv[0][1]}, {q.uv[1][0], q.uv[1][1]}, {q.uv[2][0], q.uv[2][1]}};
                 write_poly(a, env, idx, (uint32_t)idx, h, q.nv, g, uv, col, q.tex);
             } else {
@@ -641,7 +642,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
     int mesh_tris = 0, n_mesh = 0;
     float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
     // kind / static flag of every slot, one slot per lane, as wave-uniform bit masks (max_ents <= 64)
-    uint64_t box_m, mesh_m, static_m;
+    uint64_t box_m, mesh_m, frame_m, static_m;
     {
         int kind_l = MW_ENT_NONE, static_l = 0;
         if (lane < a.E) {
@@ -650,12 +651,13 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
         }
         box_m = ballot(kind_l == MW_ENT_BOX);
         mesh_m = ballot(kind_l == MW_ENT_MESH);
+        frame_m = ballot(kind_l == MW_ENT_FRAME);
         static_m = ballot(static_l != 0);
     }
     // get_visible_ents (miniworld.py:1296-1313): instead of the entities themselves, an axis-aligned
     // 0.2 m proxy box per entity, in self.entities (= slot) order, tagged with its slot
     const bool proxy = (view_flags & 4) != 0;
-    if (proxy) { box_m |= mesh_m; mesh_m = 0ull; static_m = ~0ull; }
+    if (proxy) { box_m |= mesh_m | frame_m; mesh_m = 0ull; static_m = ~0ull; }
     for (int pass = 0; pass < 2; ++pass) {
         const uint64_t mine_m = pass == 0 ? static_m : ~static_m;
         const uint64_t mesh_mine = mesh_m & mine_m, box_mine = box_m & mine_m;

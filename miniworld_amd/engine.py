@@ -16,8 +16,9 @@ import numpy as np
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
 
-ABI_VERSION = 1
-ENT_NONE, ENT_BOX, ENT_MESH = 0, 1, 2
+ABI_VERSION = 2
+ENT_NONE, ENT_BOX, ENT_MESH, ENT_FRAME = 0, 1, 2, 3
+POLY_ENTITY = 0x100          # mw_poly.nv flag: quad of a static entity, not a room
 TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT = 0, 1, 2, 3
 GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE = 0, 1, 2, 3, 4
 AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
@@ -62,12 +63,12 @@ class MwConfig(C.Structure):
 
 class MwPoly(C.Structure):
     _fields_ = [("v", C.c_float * 12), ("uv", C.c_float * 8), ("n", C.c_float * 3),
-                ("nv", C.c_int32), ("tex", C.c_int32)]
+                ("nv", C.c_int32), ("tex", C.c_int32), ("rgb", C.c_float * 3)]
 
 
 POLY_DTYPE = np.dtype([("v", np.float32, (4, 3)), ("uv", np.float32, (4, 2)), ("n", np.float32, (3,)),
-                       ("nv", np.int32), ("tex", np.int32)])
-assert POLY_DTYPE.itemsize == C.sizeof(MwPoly) == 100
+                       ("nv", np.int32), ("tex", np.int32), ("rgb", np.float32, (3,))])
+assert POLY_DTYPE.itemsize == C.sizeof(MwPoly) == 112
 
 
 class MwStateView(C.Structure):

@@ -10,6 +10,7 @@ import numpy as np
 
 from .math import X_VEC, Y_VEC, Z_VEC, gen_rot_matrix
 from .objmesh import ObjMesh
+from .texture import Texture
 
 COLORS = {
     "red": np.array([1.0, 0.0, 0.0]),
@@ -64,6 +65,88 @@ class MeshEnt(Entity):
     @property
     def is_static(self):
         return self.static
+
+
+class _Frame(Entity):
+    """Common part of ImageFrame / TextFrame: a static quad strip on a wall, facing +x of its own
+    frame, plus a black border.  The reference draws it into display list 1 with
+    glTranslatef(pos) glRotatef(dir) around raw quads (entity.py:193-259, 303-383); here `quads()`
+    returns the same quads as data, for scene_from_env to append to the static polygon list."""
+
+    @property
+    def is_static(self):
+        return True
+
+    def _front(self):
+        """[(texture or None, z_0, z_1)] front faces, left to right in texture space."""
+        raise NotImplementedError
+
+    def _sx(self):
+        return self.depth
+
+    def quads(self):
+        """[(verts[4][3] local, texcs[4][2], normal[3] local, rgb[3], texture or None)] in draw order."""
+        sx, hz, hy = self._sx(), self.width / 2, self.height / 2
+        out = []
+        for tex, z0, z1 in self._front():
+            out.append(([(sx, +hy, z0), (sx, +hy, z1), (sx, -hy, z1), (sx, -hy, z0)],
+                        [(1, 1), (0, 1), (0, 0), (1, 0)], (1, 0, 0), (1, 1, 1), tex))
+        black, uv0 = (0, 0, 0), [(0, 0)] * 4
+        out.append(([(0, +hy, -hz), (+sx, +hy, -hz), (+sx, -hy, -hz), (0, -hy, -hz)], uv0, (0, 0, -1), black, None))
+        out.append(([(+sx, +hy, +hz), (0, +hy, +hz), (0, -hy, +hz), (+sx, -hy, +hz)], uv0, (0, 0, 1), black, None))
+        out.append(([(+sx, +hy, +hz), (+sx, +hy, -hz), (0, +hy, -hz), (0, +hy, +hz)], uv0, (0, 1, 0), black, None))
+        out.append(([(+sx, -hy, -hz), (+sx, -hy, +hz), (0, -hy, +hz), (0, -hy, -hz)], uv0, (0, -1, 0), black, None))
+        return out
+
+
+class ImageFrame(_Frame):
+    """Frame to display an image on a wall; pos is the middle of the frame, on the wall (entity.py:168-259)."""
+
+    def __init__(self, pos, dir, tex_name, width, depth=0.05):  # noqa: A002
+        super().__init__()
+        self.pos = pos
+        self.dir = dir
+        self.tex = Texture.get(tex_name)
+        self.width = width
+        self.depth = depth
+        self.height = (float(self.tex.height) / self.tex.width) * self.width
+
+    def _front(self):
+        hz = self.width / 2
+        return [(self.tex, -hz, +hz)]
+
+
+class TextFrame(_Frame):
+    """Frame to display text or numbers on a wall (entity.py:262-383): one textured quad per character."""
+
+    def __init__(self, pos, dir, str, height=0.15, depth=0.05):  # noqa: A002
+        super().__init__()
+        self.pos = pos
+        self.dir = dir
+        self.str = str
+        self.depth = depth
+        self.height = height
+        self.width = len(str) * height
+        self.texs = []
+
+    def randomize(self, params, rng):
+        self.texs = []
+        for ch in self.str:
+            try:
+                self.texs.append(None if ch == " " else Texture.get(f"chars/ch_0x{ord(ch)}", rng))
+            except Exception:
+                raise ValueError("only alphanumerical characters supported in TextFrame")
+
+    def _sx(self):
+        return 0.05             # the reference stores `depth` but draws with sx = 0.05 (entity.py:311)
+
+    def _front(self):
+        hz, cw = self.width / 2, self.height
+        out = []
+        for idx in range(len(self.str)):
+            z0 = hz - cw * (idx + 1)
+            out.append((self.texs[idx], z0, z0 + cw))
+        return out
 
 
 class Box(Entity):

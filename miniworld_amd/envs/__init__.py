@@ -1,4 +1,4 @@
-"""Environment classes and their Gymnasium ids (the subset of envs/__init__.py:44-157 built so far)."""
+"""Environment classes and their Gymnasium ids (all 24 ids of envs/__init__.py:44-157)."""
 from ..gymshim import gym
 from .fourrooms import FourRooms
 from .hallway import Hallway
@@ -9,11 +9,21 @@ from .putnext import PutNext
 from .roomobjects import RoomObjects
 from .tmaze import TMaze, TMazeLeft, TMazeRight
 from .ymaze import YMaze, YMazeLeft, YMazeRight
+from .collecthealth import CollectHealth
+from .sidewalk import Sidewalk
+from .sign import Sign
+from .threerooms import ThreeRooms
+from .wallgap import WallGap
 
-__all__ = ["YMaze", "YMazeLeft", "YMazeRight", "FourRooms", "PutNext", "RoomObjects", "TMaze", "TMazeLeft", "TMazeRight", "Hallway", "Maze", "MazeS2", "MazeS3", "MazeS3Fast", "OneRoom", "OneRoomS6", "OneRoomS6Fast",
+__all__ = ["CollectHealth", "Sidewalk", "Sign", "ThreeRooms", "WallGap", "YMaze", "YMazeLeft", "YMazeRight", "FourRooms", "PutNext", "RoomObjects", "TMaze", "TMazeLeft", "TMazeRight", "Hallway", "Maze", "MazeS2", "MazeS3", "MazeS3Fast", "OneRoom", "OneRoomS6", "OneRoomS6Fast",
            "PickupObjects"]
 
 ENV_IDS = {
+    "MiniWorld-CollectHealth-v0": "CollectHealth",
+    "MiniWorld-Sidewalk-v0": "Sidewalk",
+    "MiniWorld-Sign-v0": "Sign",
+    "MiniWorld-ThreeRooms-v0": "ThreeRooms",
+    "MiniWorld-WallGap-v0": "WallGap",
     "MiniWorld-YMaze-v0": "YMaze",
     "MiniWorld-YMazeLeft-v0": "YMazeLeft",
     "MiniWorld-YMazeRight-v0": "YMazeRight",
@@ -34,7 +44,7 @@ ENV_IDS = {
     "MiniWorld-PickupObjects-v0": "PickupObjects",
 }
 
-_MODULE_OF = {"YMaze": "ymaze", "YMazeLeft": "ymaze", "YMazeRight": "ymaze", "FourRooms": "fourrooms", "PutNext": "putnext", "RoomObjects": "roomobjects", "TMaze": "tmaze",
+_MODULE_OF = {"CollectHealth": "collecthealth", "Sidewalk": "sidewalk", "Sign": "sign", "ThreeRooms": "threerooms", "WallGap": "wallgap", "YMaze": "ymaze", "YMazeLeft": "ymaze", "YMazeRight": "ymaze", "FourRooms": "fourrooms", "PutNext": "putnext", "RoomObjects": "roomobjects", "TMaze": "tmaze",
               "TMazeLeft": "tmaze", "TMazeRight": "tmaze","Hallway": "hallway", "Maze": "maze", "MazeS2": "maze", "MazeS3": "maze", "MazeS3Fast": "maze",
               "OneRoom": "oneroom", "OneRoomS6": "oneroom", "OneRoomS6Fast": "oneroom",
               "PickupObjects": "pickupobjects"}

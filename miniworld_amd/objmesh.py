@@ -86,3 +86,9 @@ class ObjMesh:
         self.verts, self.norms, self.texcs, self.colors = verts, norms, texcs, colors
         self.chunks = chunks
         self.num_faces = n
+        # map_Kd texture of the chunks (objmesh.py:209-216).  The engine keeps one texture per mesh:
+        # every mesh the environments use is a single chunk.
+        texs = {c["mtl"].get("map_Kd") for c in chunks}
+        if len(texs) > 1:
+            raise NotImplementedError(f"mesh {mesh_name!r}: chunks with different textures are not supported")
+        self.tex_variant = texs.pop() if texs else None

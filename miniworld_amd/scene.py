@@ -10,7 +10,10 @@ from __future__ import annotations
 import numpy as np
 
 from . import engine as eng
-from .entity import Box, MeshEnt
+import math
+
+from .entity import Box, MeshEnt, _Frame
+from .texture import Texture
 
 
 def _f32(a):
@@ -25,16 +28,17 @@ def scene_from_env(env) -> dict:
             tex_names.append(tex.variant)
         return tex_names.index(tex.variant)
 
-    pv, puv, pn, pnv, ptex = [], [], [], [], []
+    pv, puv, pn, pnv, ptex, prgb = [], [], [], [], [], []
 
-    def add_poly(verts, texcs, normal, tex):
+    def add_poly(verts, texcs, normal, tex, rgb=(1, 1, 1), flags=0):
         n = len(verts)
         if n not in (3, 4):
             raise NotImplementedError("room outlines with more than 4 corners are not supported yet")
         v = np.zeros((4, 3), np.float32)
         uv = np.zeros((4, 2), np.float32)
         v[:n], uv[:n] = _f32(verts), _f32(texcs)
-        pv.append(v); puv.append(uv); pn.append(_f32(normal)); pnv.append(n); ptex.append(tex_id(tex))
+        pv.append(v); puv.append(uv); pn.append(_f32(normal)); pnv.append(n | flags)
+        ptex.append(tex_id(tex) if tex is not None else -1); prgb.append(_f32(rgb))
 
     for room in env.rooms:       # draw order of Room._render: floor, ceiling, walls
         add_poly(room.floor_verts, room.floor_texcs, (0, 1, 0), room.floor_tex)
@@ -46,7 +50,19 @@ def scene_from_env(env) -> dict:
 
     ents = [e for e in env.entities if e is not env.agent]
     E = len(ents)
+    # static ImageFrame / TextFrame quads are part of display list 1 (miniworld.py:1058-1060): appended
+    # to the polygon list in world coordinates, T(pos) R_y(dir) applied in double and rounded once
+    # to what glVertex3f / glNormal3f would receive
+    for e in ents:
+        if isinstance(e, _Frame):
+            c, s_ = math.cos(e.dir), math.sin(e.dir)
+            px, py, pz = (float(x) for x in e.pos)
+            for verts, texcs, normal, rgb, tex in e.quads():
+                world = [(px + c * lx + s_ * lz, py + ly, pz + c * lz - s_ * lx) for lx, ly, lz in verts]
+                nx, ny, nz = normal
+                add_poly(world, texcs, (c * nx + s_ * nz, ny, c * nz - s_ * nx), tex, rgb, eng.POLY_ENTITY)
     mesh_names: list = []
+    mesh_tex: list = []
     kind = np.zeros(E, np.int32)
     mesh = np.full(E, -1, np.int32)
     size = np.zeros((E, 3)); color = np.ones((E, 3)); scale = np.ones(E)
@@ -59,8 +75,12 @@ def scene_from_env(env) -> dict:
             kind[i] = eng.ENT_MESH
             if e.mesh_name not in mesh_names:
                 mesh_names.append(e.mesh_name)
+                tv = e.mesh.tex_variant
+                mesh_tex.append(tex_id(Texture.load(tv)) if tv else -1)
             mesh[i] = mesh_names.index(e.mesh_name)
             scale[i] = float(e.scale)
+        elif isinstance(e, _Frame):
+            kind[i] = eng.ENT_FRAME          # drawn through the polygon list; entity for physics / queries
         else:
             raise NotImplementedError(f"entity type {type(e).__name__} has no engine representation yet")
     carrying = ents.index(env.agent.carrying) if env.agent.carrying is not None else -1
@@ -71,6 +91,7 @@ def scene_from_env(env) -> dict:
         "polys_n": np.array(pn, np.float32).reshape(-1, 3),
         "polys_nv": np.array(pnv, np.int32),
         "polys_tex": np.array(ptex, np.int32),
+        "polys_rgb": np.array(prgb, np.float32).reshape(-1, 3),
         "tex_names": np.array(tex_names),
         "ents_kind": kind,
         "ents_mesh": mesh,
@@ -83,6 +104,7 @@ def scene_from_env(env) -> dict:
         "ents_height": np.array([float(e.height) for e in ents], np.float64).reshape(E),
         "ents_static": np.array([int(bool(e.is_static)) for e in ents], np.int32).reshape(E),
         "mesh_names": np.array(mesh_names),
+        "mesh_tex": np.array(mesh_tex, np.int32),
         "agent_pos": np.array(env.agent.pos, np.float64),
         "agent_dir": np.float64(env.agent.dir),
         "agent_carrying": np.int32(carrying),
@@ -104,15 +126,25 @@ def scene_from_env(env) -> dict:
     }
 
 
-def upload_scene_meshes(engine, scene: dict, mesh_ids: dict) -> dict:
-    """Make sure every mesh named by the scene is resident; returns scene-index -> engine mesh id."""
+def upload_scene_meshes(engine, scene: dict, mesh_ids: dict, tex_ids: dict | None = None) -> dict:
+    """Make sure every mesh named by the scene is resident; returns scene-index -> engine mesh id.
+    tex_ids: texture variant -> engine texture id (a textured mesh uploads its map_Kd image on demand)."""
     from .objmesh import ObjMesh
+    from .texture import Texture
     out = {}
     for i, name in enumerate([str(m) for m in scene.get("mesh_names", [])]):
         if name not in mesh_ids:
             mesh_ids[name] = len(mesh_ids)
             m = ObjMesh.get(name)
-            engine.upload_mesh(mesh_ids[name], m.verts, m.norms, m.texcs, m.colors)
+            tid = -1
+            if m.tex_variant:
+                if tex_ids is None:
+                    raise ValueError(f"mesh {name!r} is textured: upload_scene_meshes needs the texture id table")
+                if m.tex_variant not in tex_ids:
+                    tex_ids[m.tex_variant] = len(tex_ids)
+                    engine.upload_texture(tex_ids[m.tex_variant], Texture.load(m.tex_variant).rgb_bottom_up())
+                tid = tex_ids[m.tex_variant]
+            engine.upload_mesh(mesh_ids[name], m.verts, m.norms, m.texcs, m.colors, tid)
         out[i] = mesh_ids[name]
     return out
 
@@ -122,7 +154,8 @@ def polys_array(scene: dict, tex_map=None) -> np.ndarray:
     polys = np.zeros(P, eng.POLY_DTYPE)
     polys["v"], polys["uv"], polys["n"] = scene["polys_v"], scene["polys_uv"], scene["polys_n"]
     polys["nv"] = scene["polys_nv"]
-    polys["tex"] = scene["polys_tex"] if tex_map is None else [tex_map[int(t)] for t in scene["polys_tex"]]
+    polys["rgb"] = scene["polys_rgb"] if "polys_rgb" in scene else 1.0
+    polys["tex"] = scene["polys_tex"] if tex_map is None else [(tex_map[int(t)] if t >= 0 else -1) for t in scene["polys_tex"]]
     return polys
 
 
@@ -238,7 +271,7 @@ class EngineBinding:
 
     def push_state(self, env, scene=None):
         scene = scene_from_env(env) if scene is None else scene
-        mm = upload_scene_meshes(self.engine, scene, self.mesh_ids)
+        mm = upload_scene_meshes(self.engine, scene, self.mesh_ids, self.tex_ids)
         self.engine.set_state(state_arrays([scene], self.engine.E, [mm]))
         self._ents = [e for e in env.entities if e is not env.agent]
 

@@ -26,6 +26,14 @@ class Texture:
             cls.tex_cache[variant] = Texture(variant, tex_name)
         return cls.tex_cache[variant]
 
+    @classmethod
+    def load(cls, variant: str):
+        """A texture addressed directly instead of through the variant lookup: the map_Kd image of a
+        mesh, ``mesh:<name>`` (objmesh.py:211 calls Texture.load(path))."""
+        if variant not in cls.tex_cache:
+            cls.tex_cache[variant] = Texture(variant, variant)
+        return cls.tex_cache[variant]
+
     def rgb_bottom_up(self):
         return assets.texture_rgb_bottom_up(self.variant)
 

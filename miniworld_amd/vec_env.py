@@ -36,6 +36,8 @@ _KIND = {
     "MiniWorld-YMaze-v0": ("YMaze", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-YMazeLeft-v0": ("YMazeLeft", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-YMazeRight-v0": ("YMazeRight", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-WallGap-v0": ("WallGap", eng.GEN_NONE, eng.TASK_GOTO, 3),
+    "MiniWorld-ThreeRooms-v0": ("ThreeRooms", eng.GEN_NONE, eng.TASK_NONE, 3),
     "MiniWorld-PutNext-v0": ("PutNext", eng.GEN_NONE, eng.TASK_PUTNEXT, 8),
     "MiniWorld-RoomObjects-v0": ("RoomObjects", eng.GEN_NONE, eng.TASK_NONE, 8),
 }
@@ -188,7 +190,7 @@ class MiniWorldVecEnv:
             if not self.engine.cfg.shared_geometry:
                 tex_map = {k: self.tex_ids[str(v)] for k, v in enumerate(sc["tex_names"])}
                 self.engine.set_geometry(i, polys_array(sc, tex_map), sc["wall_segs"])
-            mm = upload_scene_meshes(self.engine, sc, self.mesh_ids)
+            mm = upload_scene_meshes(self.engine, sc, self.mesh_ids, self.tex_ids)
             self.engine.set_state(state_arrays([sc], self.engine.E, [mm]), first=i, count=1)
 
     # ------------------------------------------------------------------ API

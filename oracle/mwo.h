@@ -27,15 +27,22 @@ extern "C" {
 
 /* ---- scene description (what the reference hands to GL, as data) -------------- */
 
-typedef struct {            /* one room polygon: miniworld.py:401-434 (Room._render)   */
+typedef struct {            /* one polygon of display list 1: a room polygon (miniworld.py:401-434,
+                             * Room._render) or a quad of a static ImageFrame / TextFrame
+                             * (entity.py:193-259, 303-383) in world coordinates              */
     float v[4][3];          /* glVertex3f   */
     float uv[4][2];         /* glTexCoord2f */
     float n[3];             /* glNormal3f   */
-    int32_t nv;             /* 3 or 4 vertices */
+    int32_t nv;             /* 3 or 4 vertices; | MWO_POLY_ENTITY for a quad of a static entity */
     int32_t tex;            /* index into scene.tex, or -1 (untextured) */
+    float rgb[3];           /* glColor3f: 1,1,1 for rooms and frame fronts, 0,0,0 for frame borders */
 } mwo_poly;
 
-enum { MWO_ENT_NONE = 0, MWO_ENT_BOX = 1, MWO_ENT_MESH = 2 };
+#define MWO_POLY_ENTITY 0x100
+
+/* FRAME: an ImageFrame / TextFrame; its quads are in the polygon list, it is an entity only for
+ * collisions (radius 0) and for get_visible_ents */
+enum { MWO_ENT_NONE = 0, MWO_ENT_BOX = 1, MWO_ENT_MESH = 2, MWO_ENT_FRAME = 3 };
 
 typedef struct {            /* entity.py:409-432 (Box.render), :150-161 (MeshEnt.render) */
     int32_t kind;

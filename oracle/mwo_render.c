@@ -486,12 +486,11 @@ int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out, float *d
         tg.cbuf[i * 3 + 0] = cam.sky[0]; tg.cbuf[i * 3 + 1] = cam.sky[1]; tg.cbuf[i * 3 + 2] = cam.sky[2];
     }
     int draw = 0;
-    static const float white[3] = {1.0f, 1.0f, 1.0f};
     float stale_n[3] = {0.0f, 1.0f, 0.0f};      /* the GL "current normal" left behind by the last draw */
     /* display list 1: rooms (miniworld.py:1053-1055) */
     for (int i = 0; i < sc->n_polys; ++i, ++draw) {
         const mwo_poly *q = &sc->polys[i];
-        draw_poly(sc, &cam, &tg, q->v, q->uv, q->n, white, q->nv, q->tex, draw);
+        draw_poly(sc, &cam, &tg, q->v, q->uv, q->n, q->rgb, q->nv & 0xFF, q->tex, draw);
         memcpy(stale_n, q->n, sizeof stale_n);
     }
     /* entities, already in draw order */
@@ -646,6 +645,7 @@ int mwo_visible_ents(const mwo_scene *sc, uint8_t *vis)
     int draw = 0;
     for (int i = 0; i < sc->n_polys; ++i, ++draw) {
         const mwo_poly *q = &sc->polys[i];
+        if (q->nv & MWO_POLY_ENTITY) continue;          /* only room._render() is drawn (:1291-1293) */
         draw_poly(sc, &cam, &tg, q->v, q->uv, q->n, white, q->nv, -1, draw);        /* glDisable(GL_TEXTURE_2D) */
     }
     for (int e = 0; e < sc->n_ents; ++e) {

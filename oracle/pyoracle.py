@@ -42,7 +42,7 @@ def build(force: bool = False) -> str:
 
 class _Poly(C.Structure):
     _fields_ = [("v", C.c_float * 12), ("uv", C.c_float * 8), ("n", C.c_float * 3),
-                ("nv", C.c_int32), ("tex", C.c_int32)]
+                ("nv", C.c_int32), ("tex", C.c_int32), ("rgb", C.c_float * 3)]
 
 
 class _Ent(C.Structure):
@@ -181,12 +181,14 @@ def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None
     pv = np.asarray(scene["polys_v"], np.float32).reshape(P, 12)
     puv = np.asarray(scene["polys_uv"], np.float32).reshape(P, 8)
     pn = np.asarray(scene["polys_n"], np.float32).reshape(P, 3)
+    prgb = np.asarray(scene["polys_rgb"], np.float32).reshape(P, 3) if "polys_rgb" in scene else np.ones((P, 3), np.float32)
     for i in range(P):
         polys[i].v[:] = pv[i].tolist()
         polys[i].uv[:] = puv[i].tolist()
         polys[i].n[:] = pn[i].tolist()
         polys[i].nv = int(scene["polys_nv"][i])
         polys[i].tex = int(scene["polys_tex"][i])
+        polys[i].rgb[:] = prgb[i].tolist()
     tex_names = [str(t) for t in scene["tex_names"]]
     texs = (_Tex * max(len(tex_names), 1))()
     keep = []
@@ -217,7 +219,7 @@ def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None
         arrs = [np.ascontiguousarray(m[k], np.float32) for k in ("verts", "norms", "texcs", "colors")]
         keep.extend(arrs)
         mstructs[i].ntris = arrs[0].shape[0]
-        mstructs[i].tex = -1
+        mstructs[i].tex = int(scene["mesh_tex"][i]) if "mesh_tex" in scene else -1
         mstructs[i].pos, mstructs[i].nrm, mstructs[i].uv, mstructs[i].rgb = (a.ctypes.data for a in arrs)
     sc = _Scene()
     sc.width, sc.height, sc.nsamples = width, height, nsamples

@@ -25,8 +25,10 @@ def golden_meshes(scene):
     out = {}
     for name in [str(m) for m in scene.get("mesh_names", [])]:
         base = name.split("_")[0]
+        base = base if f"{base}/verts" in d.files else name        # ball / key geometry is stored once per shape
         m = {k: d[f"{base}/{k}"] for k in ("verts", "norms", "texcs")}
-        m["colors"] = np.broadcast_to(d["kd:" + name].astype(np.float32), m["verts"].shape).copy()
+        kd = d["kd:" + name] if ("kd:" + name) in d.files else np.ones(3)
+        m["colors"] = np.broadcast_to(kd.astype(np.float32), m["verts"].shape).copy()
         out[name] = m
     return out
 
@@ -40,7 +42,23 @@ def frame_scene(s0, frame):
 
 
 def task_of(meta):
-    return {"PickupObjects": 2, "PutNext": 3, "RoomObjects": 0}.get(str(meta["env"]), 1)
+    if rule_of(meta) != "engine":
+        return 0
+    return {"PickupObjects": 2, "PutNext": 3, "RoomObjects": 0, "ThreeRooms": 0}.get(str(meta["env"]), 1)
+
+
+def rule_of(meta):
+    """"engine": the env's reward / termination rule is one of K1's task rules; "host": it is Python on top
+    of the engine's physics (C-level tests compare poses only); "api_only": the host also moves entities."""
+    return str(meta["rule"]) if "rule" in meta else "engine"
+
+
+def env_kwargs_of(meta):
+    import ast
+    kw = ast.literal_eval(str(meta["kwargs"])) if "kwargs" in meta else {}
+    if bool(meta["domain_rand"]):
+        kw["domain_rand"] = True
+    return kw
 
 
 def goals_of(meta):
@@ -80,9 +98,11 @@ def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_ran
     polys = np.zeros(P, eng.POLY_DTYPE)
     polys["v"], polys["uv"], polys["n"] = s0["polys_v"], s0["polys_uv"], s0["polys_n"]
     polys["nv"], polys["tex"] = s0["polys_nv"], s0["polys_tex"]
+    polys["rgb"] = s0["polys_rgb"] if "polys_rgb" in s0 else 1.0
     e.set_geometry(-1, polys, s0["wall_segs"])
     from miniworld_amd.scene import upload_scene_meshes
-    e._test_mesh_map = upload_scene_meshes(e, s0, {})
+    tex_ids = {str(t): i for i, t in enumerate(s0["tex_names"])}
+    e._test_mesh_map = upload_scene_meshes(e, s0, {}, tex_ids)
     return e
 
 

@@ -17,10 +17,11 @@ def test_single_env_reset_and_trajectory_match_reference(case):
     frames (world generation + HIP step + HIP render, end to end through the Python API)."""
     from miniworld_amd import envs
     s0, tr, meta, obs = helpers.load_case(case)
-    env = getattr(envs, str(meta["env"]))(domain_rand=bool(meta["domain_rand"]))
+    env = getattr(envs, str(meta["env"]))(**helpers.env_kwargs_of(meta))
+    img = lambda x: x["obs"] if isinstance(x, dict) else x            # Sign returns {"obs", "goal"} (sign.py:170-186)
     o, info = env.reset(seed=int(meta["seed"]))
-    assert o.shape == env.observation_space.shape and o.dtype == np.uint8
-    assert np.array_equal(o, obs[0]["rgb"])
+    assert img(o).shape == (60, 80, 3) and img(o).dtype == np.uint8
+    assert np.array_equal(img(o), obs[0]["rgb"])
     poke = meta.get("poke", np.array([-1.0]))
     ents = [e for e in env.entities if e is not env.agent]
     for t in range(len(tr["action"])):
@@ -30,7 +31,7 @@ def test_single_env_reset_and_trajectory_match_reference(case):
         assert r == tr["reward"][t] and te == bool(tr["term"][t]) and tu == bool(tr["trunc"][t]), (case, t)
         assert np.abs(env.agent.pos - tr["pos"][t]).max() < 1e-12 and abs(env.agent.dir - tr["dir"][t]) < 1e-12
         if (t + 1) in obs:
-            assert np.array_equal(o, obs[t + 1]["rgb"]), (case, t + 1)
+            assert np.array_equal(img(o), obs[t + 1]["rgb"]), (case, t + 1)
     env.close()
 
 
@@ -144,6 +145,7 @@ def _scene_of_env(vec, st, i):
     sc["ents_scale"], sc["ents_radius"], sc["ents_height"] = st["ent_geom"][i, :, 6], st["ent_geom"][i, :, 7], st["ent_geom"][i, :, 8]
     sc["ents_static"] = st["ent_static"][i]
     sc["mesh_names"] = np.array(names)
+    sc["mesh_tex"] = np.full(len(names), -1, np.int32)         # ball / key meshes are untextured
     return sc
 
 
@@ -344,8 +346,7 @@ def test_render_800x600x16_matches_oracle(case, top):
     from miniworld_amd import envs
     from miniworld_amd.scene import scene_from_env
     s0, tr, meta, obs = helpers.load_case(case)
-    env = getattr(envs, str(meta["env"]))(domain_rand=bool(meta["domain_rand"]), render_mode="rgb_array",
-                                           view="top" if top else "agent")
+    env = getattr(envs, str(meta["env"]))(render_mode="rgb_array", view="top" if top else "agent", **helpers.env_kwargs_of(meta))
     o, _ = env.reset(seed=int(meta["seed"]))
     img = env.render()
     assert img.shape == (600, 800, 3) and img.dtype == np.uint8
@@ -395,7 +396,7 @@ def test_single_env_get_visible_ents(case):
     from miniworld_amd import envs
     from miniworld_amd.scene import scene_from_env
     s0, tr, meta, obs = helpers.load_case(case)
-    env = getattr(envs, str(meta["env"]))(domain_rand=bool(meta["domain_rand"]))
+    env = getattr(envs, str(meta["env"]))(**helpers.env_kwargs_of(meta))
     env.reset(seed=int(meta["seed"]))
     for t, a in enumerate(tr["action"][:60]):
         if t % 6 == 0:

@@ -18,6 +18,9 @@ pytestmark = pytest.mark.gpu
 def test_step_matches_reference_trajectory(case):
     import torch
     s0, tr, meta, obs = helpers.load_case(case)
+    rule = helpers.rule_of(meta)
+    if rule == "api_only":
+        pytest.skip("the env's Python rule moves entities (CollectHealth respawn): covered through the env API")
     task = helpers.task_of(meta)
     g0, g1 = helpers.goals_of(meta)
     eng = helpers.make_engine_for_scene(s0, 1, task=task, goal_ent=g0, goal_ent2=g1,
@@ -41,8 +44,10 @@ def test_step_matches_reference_trajectory(case):
         act[0] = int(tr["action"][t])
         eng.step(act, rgb, None, rew, term, trunc)
         st = eng.get_state()
-        assert np.float32(tr["reward"][t]) == rew.item(), (case, t)
-        assert bool(term.item()) == bool(tr["term"][t]) and bool(trunc.item()) == bool(tr["trunc"][t]), (case, t)
+        if rule == "engine":
+            assert np.float32(tr["reward"][t]) == rew.item(), (case, t)
+            assert bool(term.item()) == bool(tr["term"][t]), (case, t)
+        assert bool(trunc.item()) == bool(tr["trunc"][t]), (case, t)
         assert int(st["carrying"][0]) == int(tr["carrying"][t]), (case, t)
         maxerr = max(maxerr, np.abs(st["agent_pos"][0] - tr["pos"][t]).max(), abs(st["agent_dir"][0] - tr["dir"][t]))
         alive = tr["ents_alive"][t].astype(bool)

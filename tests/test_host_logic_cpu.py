@@ -18,7 +18,7 @@ def test_world_generation_is_seed_exact_with_reference(case):
     from miniworld_amd import envs
     from miniworld_amd.scene import scene_from_env
     s0, tr, meta, obs = helpers.load_case(case)
-    env = getattr(envs, str(meta["env"]))(domain_rand=bool(meta["domain_rand"]), host_only=True)
+    env = getattr(envs, str(meta["env"]))(host_only=True, **helpers.env_kwargs_of(meta))
     env.reset(seed=int(meta["seed"]))
     sc = scene_from_env(env)
     for k, want in s0.items():
@@ -77,7 +77,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(engine.LIB_PATH)
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in mwengine.h but not exported"
-    assert ctypes.sizeof(engine.MwPoly) == 100
+    assert ctypes.sizeof(engine.MwPoly) == 112
 
 
 def test_engine_fails_loudly_without_gpu():

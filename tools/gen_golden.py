@@ -60,6 +60,17 @@ CASES = [
     ("putnext_dr_s3", "PutNext", {"domain_rand": True}, 3, [0.12, 0.1, 0.38, 0.05, 0.2, 0.15, 0.0, 0.0], 250, [0, 125]),
     ("ymaze_s0", "YMaze", {}, 0, [0.1, 0.1, 0.8], 280, [0, 30, 90]),
     ("ymazeleft_s1", "YMazeLeft", {"domain_rand": True}, 1, [0.12, 0.08, 0.8], 280, [0, 60]),
+    # textured static meshes (building, cones), ImageFrame / TextFrame, host-side task rules
+    ("wallgap_s0", "WallGap", {}, 0, [0.15, 0.15, 0.7], 300, [0, 12, 60]),
+    ("wallgap_dr_s1", "WallGap", {"domain_rand": True}, 1, [0.2, 0.2, 0.6], 120, [0, 80]),
+    ("sidewalk_s0", "Sidewalk", {}, 0, [0.12, 0.08, 0.8], 150, [0, 10, 40]),
+    ("sidewalk_s3", "Sidewalk", {}, 3, [0.3, 0.1, 0.6], 150, [0, 5]),
+    # seed 13: two kits are consumed and respawn (114 steps survived)
+    ("collecthealth_s13", "CollectHealth", {}, 13, [0.1, 0.1, 0.45, 0.05, 0.3, 0.0, 0.0, 0.0], 120, [0, 30, 100]),
+    ("threerooms_s0", "ThreeRooms", {}, 0, [0.2, 0.2, 0.6], 160, [0, 50, 159]),
+    ("threerooms_dr_s2", "ThreeRooms", {"domain_rand": True}, 2, [0.25, 0.15, 0.6], 90, [0, 89]),
+    ("sign_s0", "Sign", {}, 0, [0.3, 0.3, 0.4, 0.0], 20, [0, 3, 9]),
+    ("sign_green_key_s1", "Sign", {"color_index": 2, "goal": 1}, 1, [0.2, 0.2, 0.55, 0.05], 20, [0, 6]),
     ("roomobjects_s0", "RoomObjects", {}, 0, [0.15, 0.1, 0.4, 0.05, 0.2, 0.1, 0.0, 0.0], 150, [0, 75, 149]),
 ]
 
@@ -126,7 +137,8 @@ def run_case(name, cls, kwargs, seed, n_actions, steps, frames, meshes):
             full["ents_pos"] = tr["ents_pos"][-1]
             full["ents_dir"] = tr["ents_dir"][-1]
             full["ents_kind"] = np.where(alive > 0, s0["ents_kind"], 0).astype(np.int32)
-            scenes[t + 1] = full
+            # CollectHealth re-places consumed kits at the end of self.entities: keep the live order
+            scenes[t + 1] = sc if cls == "CollectHealth" else full
         if term or trunc:
             break
     out = {}
@@ -138,6 +150,10 @@ def run_case(name, cls, kwargs, seed, n_actions, steps, frames, meshes):
     out["meta/seed"] = np.int32(seed)
     out["meta/domain_rand"] = np.int32(bool(kwargs.get("domain_rand", False)))
     out["meta/env"] = np.array(cls)
+    # which layer implements the env's reward / termination rule: "engine" (K1 task rules), "host" (Python on top
+    # of the engine's physics: compare poses only at the C level) or "api_only" (the host also moves entities)
+    out["meta/rule"] = np.array({"Sidewalk": "host", "Sign": "host", "CollectHealth": "api_only"}.get(cls, "engine"))
+    out["meta/kwargs"] = np.array(repr({k: v for k, v in kwargs.items() if k != "domain_rand"}))
     out["meta/poke"] = poke
     goal, goal2 = 0, -1
     if cls == "PutNext":

@@ -9,12 +9,25 @@ import os
 import numpy as np
 
 
+def _variant_of_path(path):
+    """Variant name of a texture file: relative to textures/ without extension (`chars/ch_0x66_1`),
+    or `mesh:<name>` for the map_Kd image next to a mesh."""
+    path = os.path.normpath(path)
+    parts = path.split(os.sep)
+    stem = os.path.splitext(parts[-1])[0]
+    if "meshes" in parts:
+        return "mesh:" + stem
+    i = len(parts) - 1 - parts[::-1].index("textures")
+    return "/".join(parts[i + 1:-1] + [stem])
+
+
 def _tex_variant(tex):
-    return os.path.splitext(os.path.basename(tex.tex.path))[0]
+    return _variant_of_path(tex.tex.path if hasattr(tex, "tex") else tex.path)
 
 
 def scene_from_ref_env(env):
-    polys_v, polys_uv, polys_n, polys_nv, polys_tex = [], [], [], [], []
+    import math
+    polys_v, polys_uv, polys_n, polys_nv, polys_tex, polys_rgb = [], [], [], [], [], []
     tex_names = []
 
     def tex_id(tex):
@@ -23,7 +36,7 @@ def scene_from_ref_env(env):
             tex_names.append(name)
         return tex_names.index(name)
 
-    def add_poly(verts, texcs, normal, tex):
+    def add_poly(verts, texcs, normal, tex, rgb=(1, 1, 1), flags=0):
         n = len(verts)
         assert n in (3, 4), "n-gon rooms are not part of the BASELINE configs"
         v = np.zeros((4, 3), np.float32)
@@ -33,8 +46,9 @@ def scene_from_ref_env(env):
         polys_v.append(v)
         polys_uv.append(uv)
         polys_n.append(np.asarray(normal, np.float64).astype(np.float32))
-        polys_nv.append(n)
-        polys_tex.append(tex_id(tex))
+        polys_nv.append(n | flags)
+        polys_tex.append(tex_id(tex) if tex is not None else -1)
+        polys_rgb.append(np.asarray(rgb, np.float64).astype(np.float32))
 
     for room in env.rooms:                       # Room._render, miniworld.py:401-434
         add_poly(room.floor_verts, room.floor_texcs, (0, 1, 0), room.floor_tex)
@@ -45,8 +59,32 @@ def scene_from_ref_env(env):
             add_poly(room.wall_verts[sl], room.wall_texcs[sl], room.wall_norms[4 * q], room.wall_tex)
 
     kinds, meshes, pos, dirs, sizes, colors, scales, radii, heights, statics = ([] for _ in range(10))
-    mesh_names = []
+    mesh_names, mesh_tex = [], []
     ents = [e for e in env.entities if e is not env.agent]
+    # static ImageFrame / TextFrame quads (entity.py:193-259, 303-383; drawn into display list 1,
+    # miniworld.py:1058-1060): T(pos) R_y(dir) applied in double, rounded once for glVertex3f / glNormal3f
+    for e in ents:
+        cname = type(e).__name__
+        if cname not in ("ImageFrame", "TextFrame"):
+            continue
+        hz, hy = e.width / 2, e.height / 2
+        if cname == "ImageFrame":
+            sx, fronts = e.depth, [(e.tex, -hz, +hz)]
+        else:
+            sx, fronts = 0.05, [(e.texs[i], hz - e.height * (i + 1), hz - e.height * (i + 1) + e.height) for i in range(len(e.str))]
+        quads = [([(sx, +hy, z0), (sx, +hy, z1), (sx, -hy, z1), (sx, -hy, z0)], [(1, 1), (0, 1), (0, 0), (1, 0)],
+                  (1, 0, 0), (1, 1, 1), t) for t, z0, z1 in fronts]
+        uv0, black = [(0, 0)] * 4, (0, 0, 0)
+        quads.append(([(0, +hy, -hz), (+sx, +hy, -hz), (+sx, -hy, -hz), (0, -hy, -hz)], uv0, (0, 0, -1), black, None))
+        quads.append(([(+sx, +hy, +hz), (0, +hy, +hz), (0, -hy, +hz), (+sx, -hy, +hz)], uv0, (0, 0, 1), black, None))
+        quads.append(([(+sx, +hy, +hz), (+sx, +hy, -hz), (0, +hy, -hz), (0, +hy, +hz)], uv0, (0, 1, 0), black, None))
+        quads.append(([(+sx, -hy, -hz), (+sx, -hy, +hz), (0, -hy, +hz), (0, -hy, -hz)], uv0, (0, -1, 0), black, None))
+        c, s_ = math.cos(e.dir), math.sin(e.dir)
+        px, py, pz = (float(x) for x in e.pos)
+        for verts, texcs, normal, rgb, tex in quads:
+            world = [(px + c * lx + s_ * lz, py + ly, pz + c * lz - s_ * lx) for lx, ly, lz in verts]
+            nx, ny, nz = normal
+            add_poly(world, texcs, (c * nx + s_ * nz, ny, c * nz - s_ * nx), tex, rgb, 0x100)
     for e in ents:
         cname = type(e).__name__
         pos.append(np.array(e.pos, np.float64))
@@ -63,9 +101,18 @@ def scene_from_ref_env(env):
             mname = mesh_name_of(e)
             if mname not in mesh_names:
                 mesh_names.append(mname)
+                texs = {(_variant_of_path(t.path) if t else None) for t in e.mesh.textures}
+                assert len(texs) == 1, "multi-texture meshes are not used by any environment"
+                tv = texs.pop()
+                if tv and tv not in tex_names:
+                    tex_names.append(tv)
+                mesh_tex.append(tex_names.index(tv) if tv else -1)
             kinds.append(2); meshes.append(mesh_names.index(mname))
             sizes.append(np.zeros(3)); colors.append(np.ones(3))
             scales.append(float(e.scale))
+        elif cname in ("ImageFrame", "TextFrame"):
+            kinds.append(3); meshes.append(-1)
+            sizes.append(np.zeros(3)); colors.append(np.ones(3)); scales.append(1.0)
         else:
             raise NotImplementedError(cname)
     E = len(ents)
@@ -76,6 +123,7 @@ def scene_from_ref_env(env):
         "polys_n": np.array(polys_n, np.float32).reshape(-1, 3),
         "polys_nv": np.array(polys_nv, np.int32),
         "polys_tex": np.array(polys_tex, np.int32),
+        "polys_rgb": np.array(polys_rgb, np.float32).reshape(-1, 3),
         "tex_names": np.array(tex_names),
         "ents_kind": np.array(kinds, np.int32),
         "ents_mesh": np.array(meshes, np.int32),
@@ -88,6 +136,7 @@ def scene_from_ref_env(env):
         "ents_height": np.array(heights, np.float64),
         "ents_static": np.array(statics, np.int32),
         "mesh_names": np.array(mesh_names),
+        "mesh_tex": np.array(mesh_tex, np.int32),
         "agent_pos": np.array(env.agent.pos, np.float64),
         "agent_dir": np.float64(env.agent.dir),
         "agent_carrying": np.int32(carrying),
