@@ -30,7 +30,7 @@ struct MwMeshDesc {
     uint32_t ntris;
     int32_t tex;
     uint32_t first;                // first triangle in the mesh pools
-    uint32_t pad;
+    uint32_t bound_bits;           // float bits: max |vertex| (radius of the bounding sphere about the mesh origin)
 };
 
 // Generator tables; kept in device memory because dynamic indexing into a by-value kernarg

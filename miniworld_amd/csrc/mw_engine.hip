@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -488,6 +489,13 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
     else e->mesh_uv[mesh_id].assign((size_t)ntris * 6, 0.0f);
     e->mesh_desc[mesh_id].ntris = (uint32_t)ntris;
     e->mesh_desc[mesh_id].tex = tex_id;
+    {
+        float r2 = 0.0f;
+        for (size_t i = 0; i < (size_t)ntris * 3; ++i)
+            r2 = std::max(r2, pos[i * 3] * pos[i * 3] + pos[i * 3 + 1] * pos[i * 3 + 1] + pos[i * 3 + 2] * pos[i * 3 + 2]);
+        const float r = std::sqrt(r2) * 1.0001f;
+        memcpy(&e->mesh_desc[mesh_id].bound_bits, &r, 4);
+    }
     // repack all pools (uploads are rare)
     size_t total = 0;
     for (int i = 0; i < MW_MAX_MESH; ++i) { e->mesh_desc[i].first = (uint32_t)total; total += e->mesh_desc[i].ntris; }

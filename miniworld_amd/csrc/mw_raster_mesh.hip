@@ -193,9 +193,25 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
     edge_coef(h[0], h[1], ga[2], gb[2], gc[2]);
     const float D = fmaf(h[0].hx, ga[0], fmaf(h[0].hy, gb[0], h[0].hw * gc[0]));
     if (!(D > 0.0f)) return;                                  // back face (R4)
-    // pixel bounds of the part in front of w = 0.01 (conservative: coverage itself never clips, R4)
+    // Pixel bounds (R4m).  A mesh triangle with all three vertices in front of the eye is rasterised
+    // inside the pixel bounding box of its projected vertices, floor(min) .. floor(max) — part of the
+    // pinned semantics (the oracle computes the same box from the same divisions), not only an
+    // optimisation: a near-degenerate sliver's edge functions are rounding noise and would otherwise
+    // claim samples away from it.  A triangle reaching behind the eye is bounded loosely instead, by the
+    // part in front of w = 0.01 plus a pixel (coverage itself never clips, R4).
     int x0, y0, x1, y1;
-    {
+    if (h[0].hw > 0.0f && h[1].hw > 0.0f && h[2].hw > 0.0f) {
+        float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float X = h[k].hx / h[k].hw, Y = h[k].hy / h[k].hw;
+            xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+        }
+        const float fx0 = floorf(xmin), fx1 = floorf(xmax), fy0 = floorf(ymin), fy1 = floorf(ymax);
+        if (!(fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= (float)(W - 1) && fy0 <= (float)(H - 1))) return;     // off screen (or NaN)
+        x0 = (int)fmaxf(fx0, 0.0f); x1 = (int)fminf(fx1, (float)(W - 1));
+        y0 = (int)fmaxf(fy0, 0.0f); y1 = (int)fminf(fy1, (float)(H - 1));
+    } else {
         const float wc = 0.01f;
         float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
         bool some = false;

@@ -667,7 +667,24 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                 const int mid = uni(a.emesh[(size_t)s0 * a.N + env]);
                 const MwMeshDesc *mdp = a.mesh + mid;
                 const int md_ntris = uni((int)mdp->ntris), md_first = uni((int)mdp->first), md_tex = uni((int)mdp->tex);
-                if (n_mesh < MW_MAX_MESH_ENTS && count + mesh_tris + md_ntris < 0xFFF0) {
+                // whole-entity frustum cull (perspective views): the bounding sphere of the scaled mesh about its
+                // origin against the near and the four side planes, conservative — a skipped mesh has no pixel
+                bool in_view = true;
+                if (!cam.ortho) {
+                    const float brad = __int_as_float(uni((int)mdp->bound_bits)) * (float)ent_geom(a, env, s0, 6) * 1.001f + 1e-3f;
+                    const float wx = (float)ent_pos(c, s0, 0), wy = (float)ent_pos(c, s0, 1), wz = (float)ent_pos(c, s0, 2);
+                    const float ex = fmaf(cam.m[0][0], wx, fmaf(cam.m[0][1], wy, fmaf(cam.m[0][2], wz, cam.m[0][3])));
+                    const float ey = fmaf(cam.m[1][0], wx, fmaf(cam.m[1][1], wy, fmaf(cam.m[1][2], wz, cam.m[1][3])));
+                    const float ez = fmaf(cam.m[2][0], wx, fmaf(cam.m[2][1], wy, fmaf(cam.m[2][2], wz, cam.m[2][3])));
+                    const float w = -ez;
+                    const float lx = sqrtf(fmaf(cam.p00, cam.p00, 1.0f)), ly = sqrtf(fmaf(cam.p11, cam.p11, 1.0f));
+                    in_view = !(w + brad < 0.04f) && !(w - fabsf(cam.p00 * ex) < -(brad * lx)) &&
+                              !(w - fabsf(cam.p11 * ey) < -(brad * ly));
+                    in_view = uni((int)in_view) != 0;
+                }
+                if (!in_view) {
+                    // nothing to draw; GL's current normal still ends up at the mesh's last one (below)
+                } else if (n_mesh < MW_MAX_MESH_ENTS && count + mesh_tris + md_ntris < 0xFFF0) {
                     if (lane == 0) {
                         const double edir = (s0 == c.live) ? c.cdir : a.edir[(size_t)s0 * a.N + env];
                         const mw::SinCos sc = mw::sincos_det(edir);
@@ -684,12 +701,12 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                     }
                     mesh_tris += md_ntris;
                     ++n_mesh;
-                    if (md_ntris > 0) {     // the mesh's last vertex normal stays current
-                        const float *ln = a.mesh_nrm + ((size_t)(md_first + md_ntris - 1) * 3 + 2) * 3;
-                        stale_n[0] = uni(ln[0]); stale_n[1] = uni(ln[1]); stale_n[2] = uni(ln[2]);
-                    }
                 } else {
                     atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+                }
+                if (md_ntris > 0) {     // the mesh's last vertex normal stays current
+                    const float *ln = a.mesh_nrm + ((size_t)(md_first + md_ntris - 1) * 3 + 2) * 3;
+                    stale_n[0] = uni(ln[0]); stale_n[1] = uni(ln[1]); stale_n[2] = uni(ln[2]);
                 }
                 ++s0;
                 continue;

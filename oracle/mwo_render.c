@@ -252,7 +252,8 @@ static int setup_prim(const mwo_scene *sc, const hvert *h, int nv, const float (
             p->Cc[i] = fmaf(vcol[2][i], gc[2], fmaf(vcol[1][i], gc[1], vcol[0][i] * gc[0]));
         }
     }
-    /* conservative bbox (an optimisation of this oracle only; never changes coverage) */
+    /* pixel bounds: conservative for polygons (an optimisation that never changes their coverage in
+     * practice), exact and part of the semantics for mesh triangles (R4m below) */
     int allpos = 1;
     for (int k = 0; k < nv; ++k) allpos &= (h[k].hw > 0.0f);
     p->x0 = 0; p->y0 = 0; p->x1 = sc->width - 1; p->y1 = sc->height - 1;
@@ -262,6 +263,19 @@ static int setup_prim(const mwo_scene *sc, const hvert *h, int nv, const float (
             float X = h[k].hx / h[k].hw, Y = h[k].hy / h[k].hw;
             xmin = fminf(xmin, X); xmax = fmaxf(xmax, X);
             ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
+        }
+        if (gouraud) {
+            /* R4m: a mesh triangle (GL_TRIANGLES of a vertex list) in front of the eye is rasterised inside
+             * the pixel bounding box of its projected vertices, floor(min) .. floor(max).  This is
+             * semantics, not only speed: the edge functions of a near-degenerate sliver are rounding
+             * noise and would otherwise claim samples away from it (real rasterisers snap vertices to
+             * a sub-pixel grid, where such slivers collapse to nothing). */
+            float fx0 = floorf(xmin), fx1 = floorf(xmax), fy0 = floorf(ymin), fy1 = floorf(ymax);
+            if (!(fx1 >= 0.0f && fy1 >= 0.0f && fx0 <= (float)(sc->width - 1) && fy0 <= (float)(sc->height - 1)))
+                return 0;
+            p->x0 = (int)fmaxf(fx0, 0.0f); p->x1 = (int)fminf(fx1, (float)(sc->width - 1));
+            p->y0 = (int)fmaxf(fy0, 0.0f); p->y1 = (int)fminf(fy1, (float)(sc->height - 1));
+            return 1;
         }
         p->x0 = clampi(floorf(xmin) - 1.0f, 0, sc->width - 1);
         p->x1 = clampi(floorf(xmax) + 1.0f, 0, sc->width - 1);

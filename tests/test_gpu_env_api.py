@@ -439,3 +439,38 @@ def test_vec_env_fused_wrapper_layouts(env_id, kw):
     for v in vecs.values():
         v.engine.check()
         v.close()
+
+
+@pytest.mark.parametrize("env_id,case", [("MiniWorld-WallGap-v0", "wallgap_s0"), ("MiniWorld-ThreeRooms-v0", "threerooms_s0"),
+                                         ("MiniWorld-YMaze-v0", "ymaze_s0")])
+def test_vec_env_host_generated_families(env_id, case):
+    """Batched envs of the host-generated families (textured meshes, picture frames, rotated rooms): env 0 with
+    seed s equals the reference's reset(seed=s) frame, stepping keeps every frame equal to the oracle."""
+    import torch
+    import pyoracle
+    from miniworld_amd.objmesh import ObjMesh
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    s0, tr, meta, obs = helpers.load_case(case)
+    n = 6
+    vec = MiniWorldVecEnv(env_id, n, seed=int(meta["seed"]))
+    vec.reset()
+    assert np.array_equal(vec.obs[0].cpu().numpy(), obs[0]["rgb"])
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for t in range(25):
+        vec.step(torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32))
+    vec.engine.check()
+    st = vec.engine.get_state()
+    from miniworld_amd.scene import scene_from_env
+    for i in range(n):
+        env = vec._host_envs[i]
+        sc = scene_from_env(env)
+        sc["agent_pos"], sc["agent_dir"] = st["agent_pos"][i], st["agent_dir"][i]
+        E = len(sc["ents_kind"])
+        sc["ents_pos"], sc["ents_dir"] = st["ent_pos"][i, :E], st["ent_dir"][i, :E]
+        meshes = {}
+        for name in [str(m) for m in sc["mesh_names"]]:
+            m = ObjMesh.get(name)
+            meshes[name] = {"verts": m.verts, "norms": m.norms, "texcs": m.texcs, "colors": m.colors}
+        want = pyoracle.render(sc, meshes=meshes)
+        assert np.array_equal(vec.obs[i].cpu().numpy(), want["rgb"]), f"env {i}"
+    vec.close()
