@@ -51,7 +51,8 @@ extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vi
                                                  const float *rec_raster, const float *rec_shade, const float *rec_cull,
                                                  const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
                                                  const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
-                                                 const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes);
+                                                 const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes,
+                                                 unsigned long long *prof);
 
 namespace {
 thread_local std::string g_create_error;
@@ -77,6 +78,7 @@ struct mw_engine {
     bool mesh_lds_ready = false;
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
     bool visible_attr_set = false;
+    unsigned long long *d_k3prof = nullptr;   // MW_K3_PROF=<file>: per-env cycle counts of the mesh kernel
     int obs_layout = MW_OBS_HWC_U8;
     size_t view_keys_bytes = 0;
     // scratch for the step outputs when the caller passes none
@@ -335,7 +337,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         hipLaunchKernelGGL(mw_raster_mesh_kernel, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
-                           a.mesh_rgb, a.mesh_uv, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes);
+                           a.mesh_rgb, a.mesh_uv, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes, e->d_k3prof);
     } else {
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -448,6 +450,9 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
+    if (getenv("MW_K3_PROF")) {
+        if (dev_alloc(e, &e->d_k3prof, (size_t)e->cfg.num_envs * 4) != MW_OK) e->d_k3prof = nullptr;
+    }
     *out = e;
     return MW_OK;
 }
@@ -457,6 +462,11 @@ void mw_destroy(mw_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipDeviceSynchronize();
+    if (e->d_k3prof) {      // dump the last frame's per-env cycle counts: [env][mesh phase, tile phase, meshes, triangles]
+        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 4);
+        if (hipMemcpy(h.data(), e->d_k3prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = fopen(getenv("MW_K3_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_texels) (void)hipFree(e->d_texels);
     for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb, e->d_mesh_uv}) if (p) (void)hipFree(p);

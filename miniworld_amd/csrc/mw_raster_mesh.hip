@@ -285,19 +285,20 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
     const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
-    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes)
+    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes,
+    unsigned long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                     // [H][W][8]
+    const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
     const int nkeys = W * H * 8;
     const int env = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *s_pack = smem + (size_t)nkeys * 4 + wave * 192;
-
+    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     for (int i = tid; i < nkeys; i += 1024) keys[i] = 0xFFFFFFFFu;
     __syncthreads();
 
-    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     TileCtx cx;
     cx.s_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
     cx.s_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
@@ -314,12 +315,13 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     cx.env = env; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane; cx.have_pre = 0;
 
     // ---- phase 1: every mesh triangle -> LDS keys, one triangle per lane -------------------
-    const int n_mesh = __float_as_int(hdr[3]);
+    const int n_mesh = (dbg & 8) ? 0 : __float_as_int(hdr[3]);       // MW_DEBUG_FLAGS bit 3: perf experiments only
     for (int j = 0; j < n_mesh; ++j) {
         const MeshEnt e = load_ment(hdr, j);
         for (int t = tid; t < e.ntris; t += 1024) raster_tri<8>(cx, e, t, keys);
     }
     __syncthreads();
+    const unsigned long long t_mesh = prof ? __builtin_readcyclecounter() : 0ull;
 
     // ---- phase 2: tiles, 16 wavefronts round-robin --------------------------------------------
     for (int tile = wave; tile < n_tiles; tile += 16) {
@@ -330,6 +332,18 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
         const uint4 k1 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8 + 4);
         mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
         raster_tile_fmt<true, -1>(cx, tx, ty, mk);
+    }
+    if (prof) {     // MW_K3_PROF: per-env cycle counts (perf experiments only)
+        __syncthreads();
+        if (tid == 0) {
+            const unsigned long long t_end = __builtin_readcyclecounter();
+            prof[(size_t)env * 4 + 0] = t_mesh - t_start;
+            prof[(size_t)env * 4 + 1] = t_end - t_mesh;
+            prof[(size_t)env * 4 + 2] = (unsigned long long)n_mesh;
+            unsigned long long nt = 0;
+            for (int j = 0; j < n_mesh; ++j) nt += (unsigned long long)__float_as_int(hdr[MW_HDR_MESH + 12 * j + 2]);
+            prof[(size_t)env * 4 + 3] = nt;
+        }
     }
 }
 
