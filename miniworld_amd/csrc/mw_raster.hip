@@ -71,7 +71,8 @@ __device__ inline void raster_kernel_body(
     TileCtx cx;
     cx.s_shade = LDS_RECS ? s_shade : g_shade; cx.s_cull = LDS_RECS ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = nullptr;
     cx.mesh_pos = cx.mesh_nrm = cx.mesh_rgb = cx.mesh_uv = nullptr;
-    cx.obs = obs; cx.depth = depth; cx.te = te;
+    cx.obs = obs; cx.depth = depth;
+    cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3); cx.te = te;
     cx.sky_r = sky_r; cx.sky_g = sky_g; cx.sky_b = sky_b;
     cx.env = env; cx.nvis = nvis; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane;
     const int t_begin = part * tiles_per_wave;

@@ -135,8 +135,8 @@ __device__ inline RGB shade_tex(const float4 q0, const float4 q1, const float4 q
 
 __device__ inline uint32_t to_u8(float acc)     // R12: mean of 8, clamp, round half up
 {
-    float v = acc * 0.125f;
-    v = v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v);
+    // clamp through v_med3_f32: one instruction instead of two compare + select pairs (acc is finite)
+    const float v = __builtin_amdgcn_fmed3f(acc * 0.125f, 0.0f, 1.0f);
     return (uint32_t)(int)fmaf(v, 255.0f, 0.5f);
 }
 
@@ -204,6 +204,7 @@ struct TileCtx {
     const float *mesh_pos, *mesh_nrm, *mesh_rgb, *mesh_uv;
     uint8_t *__restrict__ obs;
     float *__restrict__ depth;
+    rsrc_t obs_rsrc;                // this env's uint8[H][W][3] frame as a raw buffer (HWC layout only)
     TexEnv te;
     float sky_r, sky_g, sky_b;
     int env, nvis, W, H, dbg, lane;
@@ -448,6 +449,16 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             }
         }
     }
+    if (dbg & 32) {
+        // MW_DEBUG_FLAGS bit 5, perf experiments only: 64 extra dependent-free VALU instructions per tile
+        // (is the kernel bound by VALU issue or by latency?)
+        float t0 = acc_r, t1 = acc_g, t2 = acc_b, t3 = Xc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            asm volatile("v_add_f32 %0, 1.0, %0\n\tv_add_f32 %1, 1.0, %1\n\tv_add_f32 %2, 1.0, %2\n\tv_add_f32 %3, 1.0, %3"
+                         : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+        if (t0 + t1 + t2 + t3 == 12345.678f) acc_r = t0;      // keeps the chain alive, never true in practice
+    }
     const uint32_t R = to_u8(acc_r), G = to_u8(acc_g), B = to_u8(acc_b);
 
     // ---- pack.  Output layout (mw_set_obs_layout; the reference's wrappers.py folded into the store):
@@ -475,15 +486,18 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         if (lane < 48) {
             const uint32_t w = reinterpret_cast<const uint32_t *>(s_pack)[lane];
-            uint8_t *dst;
             if (fmt == 0) {
+                // raw buffer store: the per-lane part of the address is a 32-bit offset that does not depend
+                // on the tile, the tile / env part is scalar (no 64-bit VALU address arithmetic per tile)
                 const int r = lane / 12, d = lane % 12;
-                dst = obs + ((size_t)env * H + (ty * MW_TILE_H + r)) * W * 3 + (size_t)tx * (MW_TILE_W * 3) + d * 4;
+                const uint32_t voff = (uint32_t)(r * W * 3 + d * 4);
+                const uint32_t soff = (uint32_t)((ty * MW_TILE_H) * W * 3 + tx * (MW_TILE_W * 3));
+                __builtin_amdgcn_raw_buffer_store_b32(w, cx.obs_rsrc, voff, soff, 0);
             } else {
                 const int ch = lane >> 4, c = lane & 15;
-                dst = obs + (((size_t)env * 3 + ch) * W + (tx * MW_TILE_W + c)) * H + ty * MW_TILE_H;
+                uint8_t *dst = obs + (((size_t)env * 3 + ch) * W + (tx * MW_TILE_W + c)) * H + ty * MW_TILE_H;
+                *reinterpret_cast<uint32_t *>(dst) = w;
             }
-            *reinterpret_cast<uint32_t *>(dst) = w;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();

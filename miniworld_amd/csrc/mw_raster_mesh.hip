@@ -307,6 +307,7 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     cx.hdr = hdr;
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.obs = obs; cx.depth = depth;
+    cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3);
     cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
     cx.te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);
     cx.te.texd = texd;
@@ -475,6 +476,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.hdr = hdr;
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.obs = out; cx.depth = depth;
+    cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, H * W * 3, MW_RSRC_WORD3);
     cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
     cx.te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);
     cx.te.texd = texd;
