@@ -57,6 +57,13 @@ enum {
     MW_GEN_MAZE = 4         /* maze.py:73-153 (needs shared_geometry = 0)     */
 };
 
+/* Random stream of device-side resets.  MW_RNG_PHILOX: Philox4x32-10 keyed by the env's seed (same
+ * distributions as the reference, different numbers; every generator, with or without domain
+ * randomisation).  MW_RNG_PCG64: numpy's Generator(PCG64(SeedSequence(seed))) itself, drawn in the
+ * reference's call order (miniworld.py:551, 872-905; hallway.py:59-65, oneroom.py:61-62), so that env i
+ * reset with seed s is the world of the reference's env.reset(seed=s), and later episodes continue that
+ * stream like env.reset() does; MW_GEN_HALLWAY / MW_GEN_ONEROOM with domain_rand = 0 only. */
+enum { MW_RNG_PHILOX = 0, MW_RNG_PCG64 = 1 };
 enum { MW_AUTORESET_OFF = 0, MW_AUTORESET_SAME_STEP = 1 };
 
 typedef struct mw_engine mw_engine;
@@ -108,7 +115,7 @@ typedef struct {
     double tex_var_scale[3][9][2];
     double room_wall_height;    /* Room.wall_height of the generated room (2.74) */
     int32_t room_no_ceiling;    /* Room(no_ceiling=True) */
-    int32_t pad_;
+    int32_t rng_mode;           /* MW_RNG_* stream of the device generators */
 } mw_config;
 
 #define MW_POLY_ENTITY 0x100
@@ -198,6 +205,10 @@ int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_dep
  *                                        numpy does, in float64, left to right             (wrappers.py:28-46) */
 enum { MW_OBS_HWC_U8 = 0, MW_OBS_CWH_U8 = 1, MW_OBS_GREY_F64 = 2 };
 int mw_set_obs_layout(mw_engine *e, int32_t layout);
+
+/* Test hook, host only (no device, no engine): the first n doubles of the MW_RNG_PCG64 stream for `seed`, i.e. of
+ * numpy.random.Generator(PCG64(SeedSequence(seed))).random() — what the device generators draw from. */
+int mw_pcg64_doubles(uint64_t seed, int32_t n, double *out);
 
 /* render_obs / render_depth only (miniworld.py:1177-1236) */
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);

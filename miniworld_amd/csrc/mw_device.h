@@ -52,6 +52,7 @@ struct MwArgs {
     int32_t task, goal_ent, num_objs, max_steps;
     int32_t domain_rand, generator, autoreset, tiles_x;
     int32_t tiles_y, n_tiles, goal_ent2, env_base;    // env_base: first env of this launch (0 for the batched step)
+    int32_t rng_mode, pad0;
     double agent_radius, max_forward_step, agent_height;
     mw_range fwd, drift, turn;
     mw_range sky[3], light_pos[3], light_color[3], light_ambient[3], color_bias[3];
@@ -68,7 +69,7 @@ struct MwArgs {
     double *edir;       // [E][N]
     double *egeom;      // [9][E][N]
     double *extent;     // [4][N] world extents min_x, max_x, min_z, max_z (top view)
-    uint64_t *rng;      // [2][N]  seed, counter
+    uint64_t *rng;      // [4][N]  Philox: seed, counter; PCG64: state hi, lo, increment hi, lo
     const double *step_override;        // [N][3] or null
     // --- geometry -------------------------------------------------------------------
     const mw_poly *polys;   // [sets][max_polys]

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "mw_device.h"
+#include "mw_rng.h"
 
 extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                 float *reward, uint8_t *term, uint8_t *trunc);
@@ -131,6 +132,55 @@ int dev_alloc(mw_engine *e, T **out, size_t count, bool zero = true)
     e->allocs.push_back(p);
     *out = static_cast<T *>(p);
     return MW_OK;
+}
+
+// numpy.random.SeedSequence(seed).generate_state(4, uint64) for a non-negative integer seed (the
+// published SeedSequence algorithm: 4-word pool, hashmix / mix with the constants below), then PCG64's
+// pcg_setseq_128_srandom_r — what gymnasium's np_random(seed) builds (miniworld.py:551).
+void pcg64_seed(uint64_t seed, uint64_t out[4])
+{
+    const uint32_t INIT_A = 0x43b0d7e5u, MULT_A = 0x931e8875u, INIT_B = 0x8b51f9ddu, MULT_B = 0x58f38dedu;
+    const uint32_t MIX_L = 0xca01f9ddu, MIX_R = 0x4973f715u;
+    uint32_t ent[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    const int n_ent = ent[1] ? 2 : 1;
+    uint32_t hc = INIT_A;
+    auto hashmix = [&](uint32_t v) { v ^= hc; hc *= MULT_A; v *= hc; v ^= v >> 16; return v; };
+    auto mix = [&](uint32_t x, uint32_t y) { uint32_t r = MIX_L * x - MIX_R * y; r ^= r >> 16; return r; };
+    uint32_t pool[4];
+    for (int i = 0; i < 4; ++i) pool[i] = hashmix(i < n_ent ? ent[i] : 0u);
+    for (int s = 0; s < 4; ++s)
+        for (int d = 0; d < 4; ++d)
+            if (s != d) pool[d] = mix(pool[d], hashmix(pool[s]));
+    uint32_t hb = INIT_B, w[8];
+    for (int i = 0; i < 8; ++i) {
+        uint32_t v = pool[i & 3];
+        v ^= hb; hb *= MULT_B; v *= hb; v ^= v >> 16;
+        w[i] = v;
+    }
+    uint64_t st[4];
+    for (int i = 0; i < 4; ++i) st[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    // initstate = st[0]:st[1], initseq = st[2]:st[3];  inc = (initseq << 1) | 1
+    const uint64_t inc_hi = (st[2] << 1) | (st[3] >> 63), inc_lo = (st[3] << 1) | 1ull;
+    uint64_t hi = 0, lo = 0;
+    mw::pcg64_step(hi, lo, inc_hi, inc_lo);
+    const uint64_t sl = lo + st[1];
+    hi += st[0] + (sl < lo ? 1ull : 0ull);
+    lo = sl;
+    mw::pcg64_step(hi, lo, inc_hi, inc_lo);
+    out[0] = hi; out[1] = lo; out[2] = inc_hi; out[3] = inc_lo;
+}
+
+// (re)seed env i in a host copy of the uint64[4][N] rng array
+void seed_env(const mw_engine *e, uint64_t *rng, int i, uint64_t seed)
+{
+    const size_t N = (size_t)e->cfg.num_envs;
+    if (e->cfg.rng_mode == MW_RNG_PCG64) {
+        uint64_t s[4];
+        pcg64_seed(seed, s);
+        for (int k = 0; k < 4; ++k) rng[(size_t)k * N + i] = s[k];
+    } else {
+        rng[i] = seed; rng[N + i] = 0; rng[2 * N + i] = 0; rng[3 * N + i] = 0;
+    }
 }
 
 // R8: mip pyramid.  level k+1 dims max(1, floor(n/2)); even axis = 2-tap box, odd
@@ -371,6 +421,9 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (cfg->abi_version != MW_ABI_VERSION) return fail(nullptr, MW_E_INVALID, "ABI version mismatch: header %d, caller %d", MW_ABI_VERSION, cfg->abi_version);
     if (cfg->num_envs <= 0 || cfg->max_ents < 0 || cfg->max_polys <= 0 || cfg->max_segs <= 0 || cfg->max_visible <= 0)
         return fail(nullptr, MW_E_INVALID, "bad capacities");
+    if (cfg->rng_mode != MW_RNG_PHILOX && cfg->rng_mode != MW_RNG_PCG64) return fail(nullptr, MW_E_INVALID, "unknown rng_mode %d", cfg->rng_mode);
+    if (cfg->rng_mode == MW_RNG_PCG64 && ((cfg->generator != MW_GEN_HALLWAY && cfg->generator != MW_GEN_ONEROOM) || cfg->domain_rand))
+        return fail(nullptr, MW_E_INVALID, "MW_RNG_PCG64 (the reference's own numpy stream) is implemented for MW_GEN_HALLWAY / MW_GEN_ONEROOM without domain randomisation");
     if (cfg->max_ents > 64) return fail(nullptr, MW_E_CAPACITY, "max_ents > 64 (one entity slot per lane of the env's wavefront)");
     if (cfg->msaa != 8) return fail(nullptr, MW_E_INVALID, "only msaa = 8 is implemented");
     if (cfg->obs_width % MW_TILE_W || cfg->obs_height % MW_TILE_H || cfg->obs_width > 255 * MW_TILE_W || cfg->obs_height > 255 * MW_TILE_H)
@@ -392,6 +445,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.max_polys = cfg->max_polys; a.max_segs = cfg->max_segs; a.max_vis = cfg->max_visible;
     a.shared_geom = cfg->shared_geometry ? 1 : 0;
     a.task = cfg->task; a.goal_ent = cfg->goal_ent; a.goal_ent2 = cfg->goal_ent2; a.num_objs = cfg->num_objs; a.max_steps = cfg->max_episode_steps;
+    a.rng_mode = cfg->rng_mode;
     a.domain_rand = cfg->domain_rand; a.generator = cfg->generator; a.autoreset = cfg->autoreset;
     a.tiles_x = a.W / MW_TILE_W; a.tiles_y = a.H / MW_TILE_H; a.n_tiles = a.tiles_x * a.tiles_y;
     a.agent_radius = cfg->agent_radius; a.max_forward_step = cfg->max_forward_step;
@@ -417,7 +471,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.carry, N); ALLOC(a.step, N); ALLOC(a.picked, N);
     ALLOC(a.ekind, (size_t)E * N); ALLOC(a.emesh, (size_t)E * N); ALLOC(a.estatic, (size_t)E * N);
     ALLOC(a.epos, 3 * (size_t)E * N); ALLOC(a.edir, (size_t)E * N); ALLOC(a.egeom, 9 * (size_t)E * N);
-    ALLOC(a.rng, 2 * (size_t)N); ALLOC(a.extent, 4 * (size_t)N);
+    ALLOC(a.rng, 4 * (size_t)N); ALLOC(a.extent, 4 * (size_t)N);
     MwGenTables *d_gt = nullptr;
     ALLOC(d_gt, 1);
     if (rc == MW_OK) { (void)hipMemcpy(d_gt, &gt, sizeof gt, hipMemcpyHostToDevice); a.gt = d_gt; }
@@ -439,9 +493,9 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     {
         std::vector<int32_t> m1((size_t)N, -1);
         (void)hipMemcpy(a.carry, m1.data(), 4 * (size_t)N, hipMemcpyHostToDevice);
-        std::vector<uint64_t> seeds(2 * (size_t)N, 0);
-        for (int i = 0; i < N; ++i) seeds[i] = (uint64_t)i;
-        (void)hipMemcpy(a.rng, seeds.data(), 16 * (size_t)N, hipMemcpyHostToDevice);
+        std::vector<uint64_t> seeds(4 * (size_t)N, 0);
+        for (int i = 0; i < N; ++i) seed_env(e, seeds.data(), i, (uint64_t)i);
+        (void)hipMemcpy(a.rng, seeds.data(), 32 * (size_t)N, hipMemcpyHostToDevice);
     }
     e->mesh_desc.assign(MW_MAX_MESH, MwMeshDesc{});
     e->mesh_pos.assign(MW_MAX_MESH, {}); e->mesh_nrm.assign(MW_MAX_MESH, {}); e->mesh_rgb.assign(MW_MAX_MESH, {}); e->mesh_uv.assign(MW_MAX_MESH, {});
@@ -594,11 +648,12 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
     const int N = e->cfg.num_envs;
     hipStream_t st = (hipStream_t)stream;
     if (seeds) {
-        std::vector<uint64_t> cur(2 * (size_t)N);
-        HIP_TRY(e, hipMemcpy(cur.data(), e->args.rng, 16 * (size_t)N, hipMemcpyDeviceToHost));
+        std::vector<uint64_t> cur(4 * (size_t)N);
+        HIP_TRY(e, hipStreamSynchronize(st));
+        HIP_TRY(e, hipMemcpy(cur.data(), e->args.rng, 32 * (size_t)N, hipMemcpyDeviceToHost));
         for (int i = 0; i < N; ++i)
-            if (!mask || mask[i]) { cur[i] = seeds[i]; cur[(size_t)N + i] = 0; }
-        HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 16 * (size_t)N, hipMemcpyHostToDevice));
+            if (!mask || mask[i]) seed_env(e, cur.data(), i, seeds[i]);
+        HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 32 * (size_t)N, hipMemcpyHostToDevice));
     }
     if (mask) HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, N, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(mw_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, st, e->args, e->d_mask, mask ? 0 : 1);
@@ -662,6 +717,16 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
                        (const float *)b.rec_raster, (const float *)b.rec_shade, (const int32_t *)b.nvis, (const float *)b.envhdr,
                        b.tex, b.texels, b.mesh_pos, b.mesh_nrm, b.mesh_rgb, b.mesh_uv, (const uint32_t *)keys, d_out, d_depth, e->texel_bytes);
     HIP_TRY(e, hipGetLastError());
+    return MW_OK;
+}
+
+int mw_pcg64_doubles(uint64_t seed, int32_t n, double *out)
+{
+    if (!out || n < 0) return MW_E_INVALID;
+    uint64_t s[4];
+    pcg64_seed(seed, s);
+    mw::Rng r{s[0], s[1], s[2], s[3], 1};
+    for (int i = 0; i < n; ++i) out[i] = mw::rng_double(r);
     return MW_OK;
 }
 

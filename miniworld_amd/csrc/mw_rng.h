@@ -3,14 +3,18 @@
 // keyed by the env's 64-bit seed, indexed by a 64-bit draw counter.  Doubles are formed
 // like numpy's Generator.uniform: lo + (hi - lo) * (u64 >> 11) * 2^-53 (the reference
 // draws from np_random.uniform, params.py:99), i.e. same distribution, different stream
-// (stream-exact PCG64 parity is host-side only).
+// (MW_RNG_PCG64 reproduces numpy's own stream instead, for the generators that support it).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mw {
 
-struct Rng { uint64_t seed, ctr; };
+// Two streams share the interface.  kind 0: Philox (a = seed, b = draw counter).  kind 1: numpy's PCG64
+// (XSL-RR 128/64, O'Neill 2014) exactly as numpy.random.Generator(PCG64(SeedSequence(seed))) runs it —
+// (a, b) = 128-bit state, (c, d) = 128-bit increment, seeded on the host (mw_engine.hip) — so that a
+// device reset draws the very numbers the reference's env.reset(seed=...) draws (miniworld.py:551).
+struct Rng { uint64_t a, b, c, d; int kind; };
 
 __host__ __device__ inline void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
@@ -23,17 +27,35 @@ __host__ __device__ inline void philox_round(uint32_t c[4], uint32_t k0, uint32_
     c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
 }
 
+// state = state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128)
+__host__ __device__ inline void pcg64_step(uint64_t &hi, uint64_t &lo, uint64_t inc_hi, uint64_t inc_lo)
+{
+    const uint64_t mh = 2549297995355413924ull, ml = 4865540595714422341ull;
+    const unsigned __int128 p = (unsigned __int128)lo * ml;
+    uint64_t nh = (uint64_t)(p >> 64) + lo * mh + hi * ml;
+    uint64_t nl = (uint64_t)p;
+    const uint64_t sl = nl + inc_lo;
+    nh += inc_hi + (sl < nl ? 1ull : 0ull);
+    hi = nh; lo = sl;
+}
+
 __host__ __device__ inline uint64_t rng_next_u64(Rng &r)
 {
-    uint32_t c[4] = {(uint32_t)r.ctr, (uint32_t)(r.ctr >> 32), 0x6d77656eu, 0x67696e65u};
-    uint32_t k0 = (uint32_t)r.seed, k1 = (uint32_t)(r.seed >> 32);
+    if (r.kind == 1) {      // pcg64_next64: step, then XSL-RR of the new state
+        pcg64_step(r.a, r.b, r.c, r.d);
+        const uint64_t x = r.a ^ r.b;
+        const unsigned rot = (unsigned)(r.a >> 58);
+        return (x >> rot) | (x << ((64u - rot) & 63u));
+    }
+    uint32_t c[4] = {(uint32_t)r.b, (uint32_t)(r.b >> 32), 0x6d77656eu, 0x67696e65u};
+    uint32_t k0 = (uint32_t)r.a, k1 = (uint32_t)(r.a >> 32);
 #pragma unroll
     for (int i = 0; i < 10; ++i) {
         philox_round(c, k0, k1);
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    r.ctr += 1;
+    r.b += 1;
     return ((uint64_t)c[1] << 32) | c[0];
 }
 
@@ -52,7 +74,15 @@ __host__ __device__ inline uint32_t rng_below(Rng &r, uint32_t n)   // unbiased 
     return (uint32_t)(((rng_next_u64(r) >> 32) * (uint64_t)n) >> 32);
 }
 
-__device__ inline Rng rng_load(const uint64_t *p, int N, int env) { return Rng{p[env], p[(size_t)N + env]}; }
-__device__ inline void rng_store(uint64_t *p, int N, int env, const Rng &r) { p[(size_t)N + env] = r.ctr; }
+// storage: uint64[4][N] (a, b, c, d); the kind is a property of the engine (mw_config.rng_mode)
+__device__ inline Rng rng_load(const uint64_t *p, int N, int env, int kind)
+{
+    return Rng{p[env], p[(size_t)N + env], kind ? p[(size_t)2 * N + env] : 0ull, kind ? p[(size_t)3 * N + env] : 0ull, kind};
+}
+__device__ inline void rng_store(uint64_t *p, int N, int env, const Rng &r)
+{
+    p[(size_t)N + env] = r.b;
+    if (r.kind) p[env] = r.a;
+}
 
 }  // namespace mw

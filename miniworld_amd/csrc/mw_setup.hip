@@ -482,7 +482,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
             fwd_drift = a.step_override[(size_t)env * 3 + 1];
             turn_step = a.step_override[(size_t)env * 3 + 2];
         } else if (a.domain_rand) {
-            mw::Rng rng = mw::rng_load(a.rng, a.N, env);
+            mw::Rng rng = mw::rng_load(a.rng, a.N, env, a.rng_mode);
             fwd_step = mw::rng_uniform(rng, a.fwd.lo, a.fwd.hi);
             fwd_drift = mw::rng_uniform(rng, a.drift.lo, a.drift.hi);
             turn_step = mw::rng_uniform(rng, a.turn.lo, a.turn.hi);

@@ -23,11 +23,12 @@ TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT = 0, 1, 2, 3
 GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE = 0, 1, 2, 3, 4
 AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
 OBS_HWC_U8, OBS_CWH_U8, OBS_GREY_F64 = 0, 1, 2
+RNG_PHILOX, RNG_PCG64 = 0, 1
 
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_check", "mw_kernel_time_ms",
+    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_doubles", "mw_check", "mw_kernel_time_ms",
 ]
 
 
@@ -57,7 +58,7 @@ class MwConfig(C.Structure):
         ("gen_colors", C.c_double * 18),
         ("tex_nvar", C.c_int32 * 3), ("tex_var_id", (C.c_int32 * 9) * 3),
         ("tex_var_scale", ((C.c_double * 2) * 9) * 3),
-        ("room_wall_height", C.c_double), ("room_no_ceiling", C.c_int32), ("pad_", C.c_int32),
+        ("room_wall_height", C.c_double), ("room_no_ceiling", C.c_int32), ("rng_mode", C.c_int32),
     ]
 
 
@@ -149,6 +150,7 @@ def load_library():
     L.mw_render_view.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.mw_visible_ents.argtypes = [vp, i32, i32, vp, vp]
     L.mw_set_obs_layout.argtypes = [vp, i32]
+    L.mw_pcg64_doubles.argtypes = [C.c_uint64, i32, vp]
     L.mw_check.argtypes = [vp, vp]
     L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = L

@@ -46,10 +46,14 @@ _KIND = {
 class MiniWorldVecEnv:
     def __init__(self, env_id: str, num_envs: int, device_id: int = 0, domain_rand: bool = False,
                  want_depth: bool = False, seed: int = 0, autoreset: bool = True, obs_layout: str = "hwc",
-                 **env_kwargs):
+                 rng: str = "auto", **env_kwargs):
         """obs_layout: "hwc" uint8[N,H,W,3] (the env's observation), "cwh" uint8[N,3,W,H]
         (PyTorchObsWrapper, wrappers.py:24) or "grey" float64[N,H,W,1] (GreyscaleWrapper, wrappers.py:44):
-        the raster kernel stores the frame in that layout, there is no extra pass."""
+        the raster kernel stores the frame in that layout, there is no extra pass.
+        rng: stream of the device-side resets. "pcg64" = numpy's own Generator(PCG64(SeedSequence(seed + i))) drawn in
+        the reference's call order, so that env i IS the reference's env.reset(seed=seed + i) and its later episodes
+        continue like env.reset() (Hallway / OneRoom without domain randomisation); "philox" = the engine's
+        counter-based stream (any generator); "auto" = pcg64 where it is implemented."""
         import torch
         self.torch = torch
         if obs_layout not in ("hwc", "cwh", "grey"):
@@ -143,6 +147,11 @@ class MiniWorldVecEnv:
             self._tex_dr_variants = names
             cfg.room_wall_height = float(room0.wall_height)
             cfg.room_no_ceiling = int(bool(room0.no_ceiling))
+        pcg_ok = generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM) and not domain_rand
+        if rng not in ("auto", "pcg64", "philox") or (rng == "pcg64" and not pcg_ok):
+            raise ValueError(f"rng={rng!r} is not available for {env_id} (domain_rand={domain_rand})")
+        cfg.rng_mode = eng.RNG_PCG64 if (pcg_ok and rng != "philox") else eng.RNG_PHILOX
+        self.rng_mode = "pcg64" if cfg.rng_mode == eng.RNG_PCG64 else "philox"
         self.engine = eng.Engine(cfg)
         self.host_autoreset = autoreset and generator == eng.GEN_NONE
         self._upload_assets(sc)

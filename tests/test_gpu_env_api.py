@@ -474,3 +474,61 @@ def test_vec_env_host_generated_families(env_id, case):
         want = pyoracle.render(sc, meshes=meshes)
         assert np.array_equal(vec.obs[i].cpu().numpy(), want["rgb"]), f"env {i}"
     vec.close()
+
+
+@pytest.mark.parametrize("env_id,cls_name", [("MiniWorld-Hallway-v0", "Hallway"), ("MiniWorld-OneRoom-v0", "OneRoom"),
+                                             ("MiniWorld-OneRoomS6-v0", "OneRoomS6")])
+def test_device_reset_draws_the_reference_stream(env_id, cls_name):
+    """rng="pcg64" (the default where implemented): env i of a batch seeded with s is, bit for bit, the world of
+    env.reset(seed=s + i) of the host classes (themselves seed-exact with the reference, test_host_logic_cpu),
+    and the next episode continues the same numpy stream like env.reset() without a seed does — both through
+    an explicit mw_reset and through the same-step auto-reset inside K1."""
+    import torch
+    from miniworld_amd import envs
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n, s = 96, 1000
+    vec = MiniWorldVecEnv(env_id, n, seed=s)
+    assert vec.rng_mode == "pcg64"
+    vec.reset()
+    hosts = [getattr(envs, cls_name)(host_only=True) for _ in range(n)]
+
+    def check(tag, which=None):
+        st = vec.engine.get_state()
+        for i in (range(n) if which is None else which):
+            h = hosts[i]
+            assert np.array_equal(st["agent_pos"][i], h.agent.pos) and st["agent_dir"][i] == h.agent.dir, (tag, i)
+            assert np.array_equal(st["ent_pos"][i, 0], h.box.pos) and st["ent_dir"][i, 0] == h.box.dir, (tag, i)
+
+    for i, h in enumerate(hosts):
+        h.reset(seed=s + i)
+    check("first episode")
+    for h in hosts:
+        h.reset()                         # no seed: the episode continues the env's stream (miniworld.py:551)
+    vec.engine.reset(None, None)          # same on the device: regenerate every env, keep the streams
+    check("second episode")
+    # same-step auto-reset: walk until some envs finish; their new worlds are the hosts' third episodes
+    g = torch.Generator(device="cuda").manual_seed(4)
+    done_once = np.zeros(n, bool)
+    for t in range(400):
+        act = torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32)
+        act[torch.rand(n, generator=g, device="cuda") < 0.6] = 2
+        _, _, term, trunc = vec.step(act)
+        d = (term | trunc).bool().cpu().numpy()
+        fresh = d & ~done_once
+        if fresh.any():
+            for i in np.nonzero(fresh)[0]:
+                hosts[i].reset()
+            check(f"auto-reset at step {t}", np.nonzero(fresh)[0])
+            done_once |= d
+        if done_once.sum() > n // 3:
+            break
+    assert done_once.any()
+    vec.engine.check()
+    vec.close()
+    # the Philox stream is still there and differs
+    vec2 = MiniWorldVecEnv(env_id, 8, seed=s, rng="philox")
+    vec2.reset()
+    st = vec2.engine.get_state()
+    hosts[0].reset(seed=s)
+    assert not np.array_equal(st["agent_pos"][0], hosts[0].agent.pos)
+    vec2.close()

@@ -136,3 +136,17 @@ def test_wrappers_semantics_on_host():
     for a in range(40):
         s.step(2)
         assert base.last_action == (2 if ref.uniform() < 0.3 else ref.integers(0, 6))
+
+
+def test_pcg64_stream_of_the_engine_is_numpys():
+    """MW_RNG_PCG64: the host-side seeding (SeedSequence + pcg_setseq_128_srandom_r) and the generator the
+    device code shares (mw_rng.h) reproduce numpy.random.Generator(PCG64(SeedSequence(seed))) — the stream
+    gymnasium's np_random(seed) hands the reference (miniworld.py:551)."""
+    import ctypes
+    from miniworld_amd import engine
+    lib = engine.load_library()
+    for seed in (0, 1, 7, 4095, 123456789, 2 ** 32 + 17, 2 ** 63 + 3):
+        out = np.zeros(64)
+        assert lib.mw_pcg64_doubles(ctypes.c_uint64(seed), 64, out.ctypes.data) == 0
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        assert np.array_equal(out, g.random(64)), seed
