@@ -18,6 +18,9 @@
 
 extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                 float *reward, uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_step_setup_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
+                                                    float *reward, uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_reset_pcg_kernel(MwArgs a, const uint8_t *mask, int force_all);
 extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                             int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                             const float *rec_shade, const float *rec_cull, const int32_t *nvis,
@@ -132,6 +135,12 @@ int dev_alloc(mw_engine *e, T **out, size_t count, bool zero = true)
     e->allocs.push_back(p);
     *out = static_cast<T *>(p);
     return MW_OK;
+}
+
+// K1 for the engine's random stream (the device code is compiled once per stream, mw_rng.h)
+auto k1_of(const mw_engine *e) -> decltype(&mw_step_setup_kernel)
+{
+    return e->cfg.rng_mode == MW_RNG_PCG64 ? mw_step_setup_pcg_kernel : mw_step_setup_kernel;
 }
 
 // numpy.random.SeedSequence(seed).generate_state(4, uint64) for a non-negative integer seed (the
@@ -372,7 +381,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         ev = get_events(e);
         (void)hipEventRecord(ev.a, st);
     }
-    hipLaunchKernelGGL(mw_step_setup_kernel, dim3(N), dim3(64), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
+    hipLaunchKernelGGL(k1_of(e), dim3(N), dim3(64), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
                        d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
                        d_trunc ? d_trunc : e->d_flag_scratch + N);
     if (e->timing) (void)hipEventRecord(ev.b, st);
@@ -656,7 +665,7 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
         HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 32 * (size_t)N, hipMemcpyHostToDevice));
     }
     if (mask) HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, N, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(mw_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, st, e->args, e->d_mask, mask ? 0 : 1);
+    hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, st, e->args, e->d_mask, mask ? 0 : 1);
     HIP_TRY(e, hipGetLastError());
     return MW_OK;
 }
@@ -696,7 +705,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     b.W = width; b.H = height;
     b.tiles_x = width / MW_TILE_W; b.tiles_y = height / MW_TILE_H; b.n_tiles = b.tiles_x * b.tiles_y;
     b.env_base = env;
-    hipLaunchKernelGGL(mw_step_setup_kernel, dim3(1), dim3(64), 0, st, b, 0, view_flags, e->d_action_scratch,
+    hipLaunchKernelGGL(k1_of(e), dim3(1), dim3(64), 0, st, b, 0, view_flags, e->d_action_scratch,
                        e->d_reward_scratch, e->d_flag_scratch, e->d_flag_scratch + e->cfg.num_envs);
     uint32_t *keys = nullptr;
     if (e->have_meshes) {
@@ -749,7 +758,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     b.step_override = nullptr;
     b.env_base = first_env;
     // K1 in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
-    hipLaunchKernelGGL(mw_step_setup_kernel, dim3(count), dim3(64), 0, st, b, 0, 4, e->d_action_scratch,
+    hipLaunchKernelGGL(k1_of(e), dim3(count), dim3(64), 0, st, b, 0, 4, e->d_action_scratch,
                        e->d_reward_scratch, e->d_flag_scratch, e->d_flag_scratch + e->cfg.num_envs);
     if (!e->visible_attr_set) {
         HIP_TRY(e, hipFuncSetAttribute((const void *)mw_visible_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -42,9 +42,9 @@ __device__ inline bool gen_place(const MwArgs &a, int env, int set, Rng &r, doub
     for (int attempt = 0; attempt < 4096; ++attempt) {
         // reference stream: np_random.choice(len(rooms), p=room_probs) draws one double even for a single
         // room, and uniform(low=[x, 0, z], high=[x, 0, z]) one for the y component (miniworld.py:873-895)
-        if (r.kind == 1) (void)rng_double(r);
+        if (rng_is_pcg(r)) (void)rng_double(r);
         const double x = rng_uniform(r, lx - radius, hx + radius);
-        if (r.kind == 1) (void)rng_uniform(r, 0.0, 0.0);
+        if (rng_is_pcg(r)) (void)rng_uniform(r, 0.0, 0.0);
         const double z = rng_uniform(r, rz0 - radius, rz1 + radius);
         // Room.point_inside (miniworld.py:272-284): strictly inside every edge
         if (!(x > rx0 && x < rx1 && z > rz0 && z < rz1)) continue;
@@ -284,7 +284,7 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
 {
     const int set = a.shared_geom ? 0 : env;
     const bool dr = a.domain_rand != 0;
-    Rng r = rng_load(a.rng, a.N, env, a.rng_mode);
+    Rng r = rng_load(a.rng, a.N, env);
     const size_t N = a.N;
     for (int s = 0; s < a.E; ++s) a.ekind[(size_t)s * N + env] = MW_ENT_NONE;
     double ax = 0, az = 0, adir = 0;
@@ -323,7 +323,7 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
             // Hallway passes dir=np_random.uniform(-pi/4, pi/4) to place_agent: drawn before the placement
             // (hallway.py:62-65); OneRoom's place_agent() draws the direction after it (miniworld.py:899).
             // The Philox stream keeps its historical order (direction first) for both.
-            const bool dir_last = r.kind == 1 && a.generator == MW_GEN_ONEROOM;
+            const bool dir_last = rng_is_pcg(r) && a.generator == MW_GEN_ONEROOM;
             if (!dir_last) adir = rng_uniform(r, -a.gen_args[6], a.gen_args[6]);
             gen_place(a, env, set, r, a.agent_radius, 1, a.gen_args[0], a.gen_args[5], ax, az);
             if (dir_last) adir = rng_uniform(r, -a.gen_args[6], a.gen_args[6]);

@@ -1,7 +1,10 @@
 // mw_reset_kernel — batched MiniWorldEnv.reset (miniworld.py:544-604): one thread per env.
 #include "mw_gen.h"
 
-extern "C" __global__ __launch_bounds__(64) void mw_reset_kernel(MwArgs a, const uint8_t *__restrict__ mask, int force_all)
+#ifndef MW_RESET_KERNEL_NAME
+#define MW_RESET_KERNEL_NAME mw_reset_kernel
+#endif
+extern "C" __global__ __launch_bounds__(64) void MW_RESET_KERNEL_NAME(MwArgs a, const uint8_t *__restrict__ mask, int force_all)
 {
     __shared__ unsigned char ws[64][MW_GEN_WS_BYTES];
     const int env = blockIdx.x * 64 + threadIdx.x;

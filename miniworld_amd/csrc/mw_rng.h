@@ -16,6 +16,21 @@ namespace mw {
 // device reset draws the very numbers the reference's env.reset(seed=...) draws (miniworld.py:551).
 struct Rng { uint64_t a, b, c, d; int kind; };
 
+// Device code is compiled once per stream (MW_RNG_KIND = 0 in mw_setup.hip / mw_reset.hip, 1 in their
+// *_pcg.hip twins, which only re-include them): a kernel carries one generator, not a run-time switch
+// at each of its dozens of inlined draw sites.  Host code (seeding, the test hook) looks at r.kind.
+#ifndef MW_RNG_KIND
+#define MW_RNG_KIND 0
+#endif
+__host__ __device__ inline bool rng_is_pcg(const Rng &r)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return MW_RNG_KIND == 1;
+#else
+    return r.kind == 1;
+#endif
+}
+
 __host__ __device__ inline void philox_round(uint32_t c[4], uint32_t k0, uint32_t k1)
 {
     const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
@@ -41,7 +56,7 @@ __host__ __device__ inline void pcg64_step(uint64_t &hi, uint64_t &lo, uint64_t 
 
 __host__ __device__ inline uint64_t rng_next_u64(Rng &r)
 {
-    if (r.kind == 1) {      // pcg64_next64: step, then XSL-RR of the new state
+    if (rng_is_pcg(r)) {    // pcg64_next64: step, then XSL-RR of the new state
         pcg64_step(r.a, r.b, r.c, r.d);
         const uint64_t x = r.a ^ r.b;
         const unsigned rot = (unsigned)(r.a >> 58);
@@ -75,14 +90,15 @@ __host__ __device__ inline uint32_t rng_below(Rng &r, uint32_t n)   // unbiased 
 }
 
 // storage: uint64[4][N] (a, b, c, d); the kind is a property of the engine (mw_config.rng_mode)
-__device__ inline Rng rng_load(const uint64_t *p, int N, int env, int kind)
+__device__ inline Rng rng_load(const uint64_t *p, int N, int env)
 {
-    return Rng{p[env], p[(size_t)N + env], kind ? p[(size_t)2 * N + env] : 0ull, kind ? p[(size_t)3 * N + env] : 0ull, kind};
+    const bool pcg = MW_RNG_KIND == 1;
+    return Rng{p[env], p[(size_t)N + env], pcg ? p[(size_t)2 * N + env] : 0ull, pcg ? p[(size_t)3 * N + env] : 0ull, MW_RNG_KIND};
 }
 __device__ inline void rng_store(uint64_t *p, int N, int env, const Rng &r)
 {
     p[(size_t)N + env] = r.b;
-    if (r.kind) p[env] = r.a;
+    if (MW_RNG_KIND == 1) p[env] = r.a;
 }
 
 }  // namespace mw

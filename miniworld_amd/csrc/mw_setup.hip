@@ -450,7 +450,10 @@ __device__ inline int compact(int lane, bool vis, int &count)
 
 // ---------------------------------------------------------------- the kernel
 
-extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void mw_step_setup_kernel(
+#ifndef MW_SETUP_KERNEL_NAME
+#define MW_SETUP_KERNEL_NAME mw_step_setup_kernel
+#endif
+extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void MW_SETUP_KERNEL_NAME(
     MwArgs a, int do_step, int view_flags, const int32_t *__restrict__ actions, float *__restrict__ reward,
     uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
 {
@@ -482,7 +485,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
             fwd_drift = a.step_override[(size_t)env * 3 + 1];
             turn_step = a.step_override[(size_t)env * 3 + 2];
         } else if (a.domain_rand) {
-            mw::Rng rng = mw::rng_load(a.rng, a.N, env, a.rng_mode);
+            mw::Rng rng = mw::rng_load(a.rng, a.N, env);
             fwd_step = mw::rng_uniform(rng, a.fwd.lo, a.fwd.hi);
             fwd_drift = mw::rng_uniform(rng, a.drift.lo, a.drift.hi);
             turn_step = mw::rng_uniform(rng, a.turn.lo, a.turn.hi);
