@@ -166,7 +166,7 @@ def main():
                 "algorithmic_bytes_per_launch": algo_bytes * n,
                 "kernel_ms": raster_ms,
                 "setup_kernel_ms": setup_ms,
-                "launches_timed": launches,
+                "launches_timed": launches,      # one launch in 8 is bracketed with HIP events (mwengine.h)
                 "note": "path is raster/texture VALU bound, not HBM bound (SURVEY.md section 8d); traffic = PMC "
                         "FETCH_SIZE + WRITE_SIZE per launch, bytes",
             },

@@ -231,9 +231,10 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
 int mw_check(mw_engine *e, void *stream);
 
 /* ---- measurement ------------------------------------------------------------- */
-/* average duration (ms) of the dominant (raster) kernel over the launches since the last
- * call, measured with HIP events on the stream the kernel ran on; enables timing on
- * first use.  Returns <0 on error. */
+/* average duration (ms) of the dominant (raster) kernel and of the setup kernel over the launches since
+ * the last call, measured with HIP events on the stream the kernels ran on; enables timing on first use
+ * (reset < 0 switches it off).  One launch in 8 is bracketed with events (recording on every launch costs
+ * ~4 % of the step rate); `launches` is the number of launches measured.  Returns <0 on error. */
 int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *setup_ms, int64_t *launches);
 
 #ifdef __cplusplus
