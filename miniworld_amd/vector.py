@@ -1,0 +1,62 @@
+"""Gymnasium VectorEnv-style adapter over MiniWorldVecEnv.
+
+    envs = MiniWorldVectorEnv("MiniWorld-Hallway-v0", num_envs=4096)
+    obs, infos = envs.reset(seed=0)
+    obs, rewards, terminations, truncations, infos = envs.step(actions)
+
+follows gymnasium.vector.VectorEnv's calling convention (num_envs, single_* / batched spaces,
+reset -> (obs, infos), step -> 5-tuple, autoreset mode "same-step": the observation returned with
+a finished episode is the first one of the next episode).  Observations, rewards and flags stay
+torch tensors on the engine's GPU by default (`to_numpy=True` copies them to the host like a
+classic VectorEnv); actions may be a torch tensor, a numpy array or a list.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from .gymshim import spaces
+from .vec_env import MiniWorldVecEnv
+
+
+class MiniWorldVectorEnv:
+    metadata = {"autoreset_mode": "same-step", "render_modes": ["rgb_array"]}
+
+    def __init__(self, env_id: str, num_envs: int, to_numpy: bool = False, **kwargs):
+        self.vec = MiniWorldVecEnv(env_id, num_envs, **kwargs)
+        self.num_envs = num_envs
+        self.to_numpy = to_numpy
+        shape, dtype = tuple(self.vec.obs.shape[1:]), {"grey": np.float64}.get(self.vec.obs_layout, np.uint8)
+        self.single_observation_space = spaces.Box(0, 255, shape, dtype=dtype)
+        self.observation_space = spaces.Box(0, 255, (num_envs,) + shape, dtype=dtype)
+        self.single_action_space = spaces.Discrete(self.vec.n_actions)
+        self.action_space = spaces.Box(0, self.vec.n_actions - 1, (num_envs,), dtype=np.int64)
+        self.render_mode = "rgb_array"
+        self.closed = False
+
+    def _out(self, t):
+        return t.cpu().numpy() if self.to_numpy else t
+
+    def reset(self, *, seed: int | None = None, options: dict | None = None):
+        """Env i is seeded with seed + i (gymnasium's convention for an integer seed)."""
+        obs = self.vec.reset(seed)
+        return self._out(obs), {}
+
+    def step(self, actions):
+        torch = self.vec.torch
+        if not torch.is_tensor(actions):
+            actions = torch.as_tensor(np.asarray(actions), device=self.vec.engine.device)
+        actions = actions.to(device=self.vec.engine.device, dtype=torch.int32)
+        obs, rew, term, trunc = self.vec.step(actions)
+        return self._out(obs), self._out(rew), self._out(term.bool()), self._out(trunc.bool()), {}
+
+    def render(self):
+        """Tuple-free batched render: the map view of every env (uint8[N, H, W, 3])."""
+        return self._out(self.vec.render_top_view())
+
+    def get_visible_ents(self):
+        return self._out(self.vec.get_visible_ents())
+
+    def close(self):
+        if not self.closed:
+            self.vec.close()
+            self.closed = True

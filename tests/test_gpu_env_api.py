@@ -532,3 +532,23 @@ def test_device_reset_draws_the_reference_stream(env_id, cls_name):
     hosts[0].reset(seed=s)
     assert not np.array_equal(st["agent_pos"][0], hosts[0].agent.pos)
     vec2.close()
+
+
+def test_vector_env_adapter_follows_gymnasium_convention():
+    """MiniWorldVectorEnv: reset -> (obs, infos), step -> 5-tuple, same-step autoreset, numpy or torch."""
+    from miniworld_amd.vector import MiniWorldVectorEnv
+    envs = MiniWorldVectorEnv("MiniWorld-OneRoomS6-v0", 32, to_numpy=True, seed=3)
+    assert envs.num_envs == 32 and envs.single_action_space.n == 3
+    assert tuple(envs.single_observation_space.shape) == (60, 80, 3) and tuple(envs.observation_space.shape) == (32, 60, 80, 3)
+    obs, infos = envs.reset(seed=11)
+    assert isinstance(obs, np.ndarray) and obs.shape == (32, 60, 80, 3) and obs.dtype == np.uint8 and infos == {}
+    rng = np.random.default_rng(0)
+    n_done = 0
+    for t in range(150):
+        obs, rew, term, trunc, infos = envs.step(rng.integers(0, 3, 32))
+        assert obs.shape == (32, 60, 80, 3) and rew.shape == (32,) and term.dtype == bool and trunc.dtype == bool
+        n_done += int((term | trunc).sum())
+        assert 1.0 < obs.mean() < 254.0
+    assert n_done >= 32          # max_episode_steps = 100: every env finished at least once and kept running
+    assert envs.render().shape == (32, 60, 80, 3)
+    envs.close()
