@@ -62,7 +62,8 @@ enum {
  * randomisation).  MW_RNG_PCG64: numpy's Generator(PCG64(SeedSequence(seed))) itself, drawn in the
  * reference's call order (miniworld.py:551, 872-905; hallway.py:59-65, oneroom.py:61-62), so that env i
  * reset with seed s is the world of the reference's env.reset(seed=s), and later episodes continue that
- * stream like env.reset() does; MW_GEN_HALLWAY / MW_GEN_ONEROOM with domain_rand = 0 only. */
+ * stream like env.reset() does (with domain randomisation the per-step parameters come from it too,
+ * miniworld.py:677-680).  Every device generator; not Maze with domain_rand (no per-room texture variants). */
 enum { MW_RNG_PHILOX = 0, MW_RNG_PCG64 = 1 };
 enum { MW_AUTORESET_OFF = 0, MW_AUTORESET_SAME_STEP = 1 };
 
@@ -206,9 +207,11 @@ int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_dep
 enum { MW_OBS_HWC_U8 = 0, MW_OBS_CWH_U8 = 1, MW_OBS_GREY_F64 = 2 };
 int mw_set_obs_layout(mw_engine *e, int32_t layout);
 
-/* Test hook, host only (no device, no engine): the first n doubles of the MW_RNG_PCG64 stream for `seed`, i.e. of
- * numpy.random.Generator(PCG64(SeedSequence(seed))).random() — what the device generators draw from. */
-int mw_pcg64_doubles(uint64_t seed, int32_t n, double *out);
+/* Test hook, host only (no device, no engine): the first n draws of the MW_RNG_PCG64 stream for `seed`, with the very
+ * functions the device generators inline.  bounds[i] == 0 (or bounds == NULL): a double in [0, 1), i.e.
+ * Generator(PCG64(SeedSequence(seed))).random(); bounds[i] = k > 0: an integer in [0, k), i.e. Generator.integers(0, k)
+ * / Generator.choice(k), returned as a double. */
+int mw_pcg64_draws(uint64_t seed, int32_t n, const int32_t *bounds, double *out);
 
 /* render_obs / render_depth only (miniworld.py:1177-1236) */
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);

@@ -69,7 +69,7 @@ struct MwArgs {
     double *edir;       // [E][N]
     double *egeom;      // [9][E][N]
     double *extent;     // [4][N] world extents min_x, max_x, min_z, max_z (top view)
-    uint64_t *rng;      // [4][N]  Philox: seed, counter; PCG64: state hi, lo, increment hi, lo
+    uint64_t *rng;      // [5][N]  Philox: seed, counter; PCG64: state hi, lo, increment hi, lo, buffered uint32
     const double *step_override;        // [N][3] or null
     // --- geometry -------------------------------------------------------------------
     const mw_poly *polys;   // [sets][max_polys]

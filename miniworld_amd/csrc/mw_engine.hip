@@ -190,8 +190,9 @@ void seed_env(const mw_engine *e, uint64_t *rng, int i, uint64_t seed)
         uint64_t s[4];
         pcg64_seed(seed, s);
         for (int k = 0; k < 4; ++k) rng[(size_t)k * N + i] = s[k];
+        rng[4 * N + i] = 0;
     } else {
-        rng[i] = seed; rng[N + i] = 0; rng[2 * N + i] = 0; rng[3 * N + i] = 0;
+        rng[i] = seed; rng[N + i] = 0; rng[2 * N + i] = 0; rng[3 * N + i] = 0; rng[4 * N + i] = 0;
     }
 }
 
@@ -437,8 +438,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (cfg->num_envs <= 0 || cfg->max_ents < 0 || cfg->max_polys <= 0 || cfg->max_segs <= 0 || cfg->max_visible <= 0)
         return fail(nullptr, MW_E_INVALID, "bad capacities");
     if (cfg->rng_mode != MW_RNG_PHILOX && cfg->rng_mode != MW_RNG_PCG64) return fail(nullptr, MW_E_INVALID, "unknown rng_mode %d", cfg->rng_mode);
-    if (cfg->rng_mode == MW_RNG_PCG64 && ((cfg->generator != MW_GEN_HALLWAY && cfg->generator != MW_GEN_ONEROOM) || cfg->domain_rand))
-        return fail(nullptr, MW_E_INVALID, "MW_RNG_PCG64 (the reference's own numpy stream) is implemented for MW_GEN_HALLWAY / MW_GEN_ONEROOM without domain randomisation");
+    if (cfg->rng_mode == MW_RNG_PCG64 && (cfg->generator == MW_GEN_NONE || (cfg->generator == MW_GEN_MAZE && cfg->domain_rand)))
+        return fail(nullptr, MW_E_INVALID, "MW_RNG_PCG64 (the reference's own numpy stream) needs a device generator; the Maze generator has no per-room texture randomisation");
     if (cfg->max_ents > 64) return fail(nullptr, MW_E_CAPACITY, "max_ents > 64 (one entity slot per lane of the env's wavefront)");
     if (cfg->msaa != 8) return fail(nullptr, MW_E_INVALID, "only msaa = 8 is implemented");
     if (cfg->obs_width % MW_TILE_W || cfg->obs_height % MW_TILE_H || cfg->obs_width > 255 * MW_TILE_W || cfg->obs_height > 255 * MW_TILE_H)
@@ -486,7 +487,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.carry, N); ALLOC(a.step, N); ALLOC(a.picked, N);
     ALLOC(a.ekind, (size_t)E * N); ALLOC(a.emesh, (size_t)E * N); ALLOC(a.estatic, (size_t)E * N);
     ALLOC(a.epos, 3 * (size_t)E * N); ALLOC(a.edir, (size_t)E * N); ALLOC(a.egeom, 9 * (size_t)E * N);
-    ALLOC(a.rng, 4 * (size_t)N); ALLOC(a.extent, 4 * (size_t)N);
+    ALLOC(a.rng, 5 * (size_t)N); ALLOC(a.extent, 4 * (size_t)N);
     MwGenTables *d_gt = nullptr;
     ALLOC(d_gt, 1);
     if (rc == MW_OK) { (void)hipMemcpy(d_gt, &gt, sizeof gt, hipMemcpyHostToDevice); a.gt = d_gt; }
@@ -508,9 +509,9 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     {
         std::vector<int32_t> m1((size_t)N, -1);
         (void)hipMemcpy(a.carry, m1.data(), 4 * (size_t)N, hipMemcpyHostToDevice);
-        std::vector<uint64_t> seeds(4 * (size_t)N, 0);
+        std::vector<uint64_t> seeds(5 * (size_t)N, 0);
         for (int i = 0; i < N; ++i) seed_env(e, seeds.data(), i, (uint64_t)i);
-        (void)hipMemcpy(a.rng, seeds.data(), 32 * (size_t)N, hipMemcpyHostToDevice);
+        (void)hipMemcpy(a.rng, seeds.data(), 40 * (size_t)N, hipMemcpyHostToDevice);
     }
     e->mesh_desc.assign(MW_MAX_MESH, MwMeshDesc{});
     e->mesh_pos.assign(MW_MAX_MESH, {}); e->mesh_nrm.assign(MW_MAX_MESH, {}); e->mesh_rgb.assign(MW_MAX_MESH, {}); e->mesh_uv.assign(MW_MAX_MESH, {});
@@ -663,12 +664,12 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
     const int N = e->cfg.num_envs;
     hipStream_t st = (hipStream_t)stream;
     if (seeds) {
-        std::vector<uint64_t> cur(4 * (size_t)N);
+        std::vector<uint64_t> cur(5 * (size_t)N);
         HIP_TRY(e, hipStreamSynchronize(st));
-        HIP_TRY(e, hipMemcpy(cur.data(), e->args.rng, 32 * (size_t)N, hipMemcpyDeviceToHost));
+        HIP_TRY(e, hipMemcpy(cur.data(), e->args.rng, 40 * (size_t)N, hipMemcpyDeviceToHost));
         for (int i = 0; i < N; ++i)
             if (!mask || mask[i]) seed_env(e, cur.data(), i, seeds[i]);
-        HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 32 * (size_t)N, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 40 * (size_t)N, hipMemcpyHostToDevice));
     }
     if (mask) HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, N, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, st, e->args, e->d_mask, mask ? 0 : 1);
@@ -735,13 +736,14 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     return MW_OK;
 }
 
-int mw_pcg64_doubles(uint64_t seed, int32_t n, double *out)
+int mw_pcg64_draws(uint64_t seed, int32_t n, const int32_t *bounds, double *out)
 {
     if (!out || n < 0) return MW_E_INVALID;
     uint64_t s[4];
     pcg64_seed(seed, s);
-    mw::Rng r{s[0], s[1], s[2], s[3], 1};
-    for (int i = 0; i < n; ++i) out[i] = mw::rng_double(r);
+    mw::Rng r{s[0], s[1], s[2], s[3], 1, 0u, 0u};
+    for (int i = 0; i < n; ++i)
+        out[i] = (bounds && bounds[i] > 0) ? (double)mw::rng_below(r, (uint32_t)bounds[i]) : mw::rng_double(r);
     return MW_OK;
 }
 

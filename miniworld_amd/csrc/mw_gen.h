@@ -263,6 +263,7 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
                 rr.z0 = fmin(fmin(pz[0], pz[1]), fmin(pz[2], pz[3])); rr.z1 = fmax(fmax(pz[0], pz[1]), fmax(pz[2], pz[3]));
             }
             const double x = rng_uniform(r, rr.x0 - rad, rr.x1 + rad);
+            if (rng_is_pcg(r)) (void)rng_uniform(r, 0.0, 0.0);       // the y component of the 3-vector draw
             const double z = rng_uniform(r, rr.z0 - rad, rr.z1 + rad);
             if (!(x > rr.x0 && x < rr.x1 && z > rr.z0 && z < rr.z1)) continue;        // Room.point_inside
             if (gen_hits_wall(a, set, x, z, rad)) continue;
@@ -288,9 +289,11 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     const size_t N = a.N;
     for (int s = 0; s < a.E; ++s) a.ekind[(size_t)s * N + env] = MW_ENT_NONE;
     double ax = 0, az = 0, adir = 0;
-    if (a.gt->tex_nvar[0] > 0 && !a.shared_geom && a.generator != MW_GEN_MAZE) {
-        // Room._gen_static_data with an rng (miniworld.py:295-297): wall, floor, ceiling variant
-        // drawn in that order (opengl.py:136-138); the room is re-emitted into this env's own set
+    // Room._gen_static_data with an rng (miniworld.py:295-297): wall, floor, ceiling variant drawn in that
+    // order (opengl.py:136-138); the room is re-emitted into this env's own set.  The reference runs it
+    // inside the first place_entity (miniworld.py:856-857), i.e. after whatever _gen_world drew before.
+    auto pick_textures = [&]() {
+        if (!(a.gt->tex_nvar[0] > 0 && !a.shared_geom && a.generator != MW_GEN_MAZE)) return;
         int pick[3];
         for (int k = 0; k < 3; ++k) pick[k] = a.gt->tex_nvar[k] > 1 ? (int)rng_below(r, (uint32_t)a.gt->tex_nvar[k]) : 0;
         RoomTex rt;
@@ -304,7 +307,11 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
         emit_room(a, set, rt, px, pz, 15u, np, ns);
         const_cast<int32_t *>(a.npolys)[set] = np;
         const_cast<int32_t *>(a.nsegs)[set] = ns;
-    }
+    };
+    // PickupObjects draws its first object's kind and colour before the first placement; the Philox
+    // stream keeps its historical order (textures first)
+    const bool tex_late = rng_is_pcg(r) && a.generator == MW_GEN_PICKUP;
+    if (!tex_late) pick_textures();
     if (a.generator == MW_GEN_HALLWAY || a.generator == MW_GEN_ONEROOM || a.generator == MW_GEN_MAZE) {
         // the red box (hallway.py:59, oneroom.py:61, maze.py:151), then the agent
         const double size = a.generator == MW_GEN_MAZE ? 0.8 : a.gen_args[7];
@@ -350,6 +357,7 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
         for (int s = 0; s < n && s < a.E; ++s) {
             const int kind = (int)rng_below(r, 3);          // 0 ball, 1 box, 2 key (obj_types order)
             const int color = (int)rng_below(r, 6);         // index into the sorted COLOR_NAMES
+            if (tex_late && s == 0) pick_textures();
             const double radius = a.gt->gen_tab[kind * 4 + 0], height = a.gt->gen_tab[kind * 4 + 1];
             double x, z;
             gen_place(a, env, set, r, radius, s, a.gen_args[0], a.gen_args[1], x, z);

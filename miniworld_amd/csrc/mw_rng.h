@@ -14,7 +14,7 @@ namespace mw {
 // (XSL-RR 128/64, O'Neill 2014) exactly as numpy.random.Generator(PCG64(SeedSequence(seed))) runs it —
 // (a, b) = 128-bit state, (c, d) = 128-bit increment, seeded on the host (mw_engine.hip) — so that a
 // device reset draws the very numbers the reference's env.reset(seed=...) draws (miniworld.py:551).
-struct Rng { uint64_t a, b, c, d; int kind; };
+struct Rng { uint64_t a, b, c, d; int kind; uint32_t has32, buf32; };   // has32 / buf32: PCG64's buffered upper half
 
 // Device code is compiled once per stream (MW_RNG_KIND = 0 in mw_setup.hip / mw_reset.hip, 1 in their
 // *_pcg.hip twins, which only re-include them): a kernel carries one generator, not a run-time switch
@@ -84,21 +84,53 @@ __host__ __device__ inline double rng_uniform(Rng &r, double lo, double hi)
     return lo + (hi - lo) * rng_double(r);
 }
 
-__host__ __device__ inline uint32_t rng_below(Rng &r, uint32_t n)   // unbiased enough for n << 2^32
+// numpy's pcg64_next32: a 64-bit output serves two 32-bit draws, low half first; doubles never touch
+// the buffered half
+__host__ __device__ inline uint32_t rng_next_u32(Rng &r)
 {
+    if (r.has32) { r.has32 = 0; return r.buf32; }
+    const uint64_t v = rng_next_u64(r);
+    r.has32 = 1; r.buf32 = (uint32_t)(v >> 32);
+    return (uint32_t)v;
+}
+
+// uniform integer in [0, n), n >= 1.  PCG64 stream: exactly Generator.integers(0, n) / Generator.choice(n)
+// for n <= 2^32 (random_bounded_uint64 -> buffered_bounded_lemire_uint32, numpy/random/src/distributions):
+// no draw at all for n == 1.  Philox stream: one 64-bit draw, multiply-shift.
+__host__ __device__ inline uint32_t rng_below(Rng &r, uint32_t n)
+{
+    if (rng_is_pcg(r)) {
+        if (n <= 1u) return 0u;
+        const uint32_t rng = n - 1u, rng_excl = n;
+        uint64_t m = (uint64_t)rng_next_u32(r) * rng_excl;
+        uint32_t leftover = (uint32_t)m;
+        if (leftover < rng_excl) {
+            const uint32_t threshold = (0xFFFFFFFFu - rng) % rng_excl;
+            while (leftover < threshold) {
+                m = (uint64_t)rng_next_u32(r) * rng_excl;
+                leftover = (uint32_t)m;
+            }
+        }
+        return (uint32_t)(m >> 32);
+    }
     return (uint32_t)(((rng_next_u64(r) >> 32) * (uint64_t)n) >> 32);
 }
 
-// storage: uint64[4][N] (a, b, c, d); the kind is a property of the engine (mw_config.rng_mode)
+// storage: uint64[5][N] (a, b, c, d, has32 << 32 | buf32); the kind is a property of the kernel (MW_RNG_KIND)
 __device__ inline Rng rng_load(const uint64_t *p, int N, int env)
 {
     const bool pcg = MW_RNG_KIND == 1;
-    return Rng{p[env], p[(size_t)N + env], pcg ? p[(size_t)2 * N + env] : 0ull, pcg ? p[(size_t)3 * N + env] : 0ull, MW_RNG_KIND};
+    const uint64_t w4 = pcg ? p[(size_t)4 * N + env] : 0ull;
+    return Rng{p[env], p[(size_t)N + env], pcg ? p[(size_t)2 * N + env] : 0ull, pcg ? p[(size_t)3 * N + env] : 0ull, MW_RNG_KIND,
+               (uint32_t)(w4 >> 32), (uint32_t)w4};
 }
 __device__ inline void rng_store(uint64_t *p, int N, int env, const Rng &r)
 {
     p[(size_t)N + env] = r.b;
-    if (MW_RNG_KIND == 1) p[env] = r.a;
+    if (MW_RNG_KIND == 1) {
+        p[env] = r.a;
+        p[(size_t)4 * N + env] = ((uint64_t)r.has32 << 32) | r.buf32;
+    }
 }
 
 }  // namespace mw

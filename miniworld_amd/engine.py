@@ -28,7 +28,7 @@ RNG_PHILOX, RNG_PCG64 = 0, 1
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_doubles", "mw_check", "mw_kernel_time_ms",
+    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms",
 ]
 
 
@@ -150,7 +150,7 @@ def load_library():
     L.mw_render_view.argtypes = [vp, i32, i32, i32, i32, i32, vp, vp, vp]
     L.mw_visible_ents.argtypes = [vp, i32, i32, vp, vp]
     L.mw_set_obs_layout.argtypes = [vp, i32]
-    L.mw_pcg64_doubles.argtypes = [C.c_uint64, i32, vp]
+    L.mw_pcg64_draws.argtypes = [C.c_uint64, i32, vp, vp]
     L.mw_check.argtypes = [vp, vp]
     L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     _lib = L

@@ -52,8 +52,8 @@ class MiniWorldVecEnv:
         the raster kernel stores the frame in that layout, there is no extra pass.
         rng: stream of the device-side resets. "pcg64" = numpy's own Generator(PCG64(SeedSequence(seed + i))) drawn in
         the reference's call order, so that env i IS the reference's env.reset(seed=seed + i) and its later episodes
-        continue like env.reset() (Hallway / OneRoom without domain randomisation); "philox" = the engine's
-        counter-based stream (any generator); "auto" = pcg64 where it is implemented."""
+        continue like env.reset(), per-step domain-randomisation draws included (every device generator; not
+        Maze with domain_rand); "philox" = the engine's counter-based stream; "auto" = pcg64 where implemented."""
         import torch
         self.torch = torch
         if obs_layout not in ("hwc", "cwh", "grey"):
@@ -147,7 +147,7 @@ class MiniWorldVecEnv:
             self._tex_dr_variants = names
             cfg.room_wall_height = float(room0.wall_height)
             cfg.room_no_ceiling = int(bool(room0.no_ceiling))
-        pcg_ok = generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM) and not domain_rand
+        pcg_ok = generator != eng.GEN_NONE and not (generator == eng.GEN_MAZE and domain_rand)
         if rng not in ("auto", "pcg64", "philox") or (rng == "pcg64" and not pcg_ok):
             raise ValueError(f"rng={rng!r} is not available for {env_id} (domain_rand={domain_rand})")
         cfg.rng_mode = eng.RNG_PCG64 if (pcg_ok and rng != "philox") else eng.RNG_PHILOX

@@ -552,3 +552,75 @@ def test_vector_env_adapter_follows_gymnasium_convention():
     assert n_done >= 32          # max_episode_steps = 100: every env finished at least once and kept running
     assert envs.render().shape == (32, 60, 80, 3)
     envs.close()
+
+
+def _assert_same_world(vec, st, i, h, tag):
+    """Device state of env i == host env h (same seed, same episode): poses, entity table, per-episode parameters."""
+    from miniworld_amd.entity import Box, MeshEnt
+    assert np.array_equal(st["agent_pos"][i], h.agent.pos) and st["agent_dir"][i] == h.agent.dir, (tag, i, "agent")
+    cam = [h.agent.cam_height, h.agent.cam_fwd_disp, h.agent.cam_pitch, h.agent.cam_fov_y]
+    assert np.array_equal(st["cam"][i], np.array(cam, np.float64)), (tag, i, "camera")
+    light = np.concatenate([h.sky_color, h.light_pos, h.light_color, h.light_ambient]).astype(np.float64)
+    assert np.array_equal(st["light"][i], light), (tag, i, "sky / light")
+    ents = [e for e in h.entities if e is not h.agent]
+    assert int((st["ent_kind"][i] != 0).sum()) == len(ents), (tag, i, "entity count")
+    inv_mesh = {v: k for k, v in vec.mesh_ids.items()}
+    for k, e in enumerate(ents):
+        assert np.array_equal(st["ent_pos"][i, k], e.pos) and st["ent_dir"][i, k] == e.dir, (tag, i, k, "entity pose")
+        if isinstance(e, Box):
+            assert st["ent_kind"][i, k] == 1 and np.array_equal(st["ent_geom"][i, k, 3:6], e.color_vec), (tag, i, k, "box")
+            assert np.array_equal(st["ent_geom"][i, k, 0:3], np.asarray(e.size, np.float64)), (tag, i, k, "box size")
+        elif isinstance(e, MeshEnt):
+            assert st["ent_kind"][i, k] == 2 and inv_mesh[int(st["ent_mesh"][i, k])] == e.mesh_name, (tag, i, k, "mesh")
+            assert st["ent_geom"][i, k, 6] == e.scale and st["ent_geom"][i, k, 7] == e.radius, (tag, i, k, "mesh scale")
+
+
+@pytest.mark.parametrize("env_id,cls_name,dr", [
+    ("MiniWorld-Hallway-v0", "Hallway", True), ("MiniWorld-OneRoom-v0", "OneRoom", True),
+    ("MiniWorld-PickupObjects-v0", "PickupObjects", False), ("MiniWorld-PickupObjects-v0", "PickupObjects", True),
+    ("MiniWorld-MazeS3-v0", "MazeS3", False), ("MiniWorld-Maze-v0", "Maze", False)])
+def test_device_reset_reference_stream_all_generators(env_id, cls_name, dr):
+    """MW_RNG_PCG64 for every device generator, with domain randomisation: bounded integers (object kinds, colours,
+    texture variants, the maze's neighbour orders), the area-weighted room choice, per-episode parameters and the
+    three per-step parameter draws all come out of numpy's stream in the reference's order, so a batch seeded
+    with s holds the worlds of env.reset(seed=s+i), episode after episode."""
+    import torch
+    from miniworld_amd import envs
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n, s, k_steps = (24, 77, 7) if "Maze" in env_id else (48, 500, 9)
+    vec = MiniWorldVecEnv(env_id, n, seed=s, domain_rand=dr, autoreset=False)
+    assert vec.rng_mode == "pcg64"
+    vec.reset()
+    hosts = [getattr(envs, cls_name)(host_only=True, domain_rand=dr) for _ in range(n)]
+    for i, h in enumerate(hosts):
+        h.reset(seed=s + i)
+    st = vec.engine.get_state()
+    for i, h in enumerate(hosts):
+        _assert_same_world(vec, st, i, h, "episode 1")
+    if "Maze" in env_id or dr:
+        # per-env geometry: the room polygons (and with DR their texture variants) are the host's
+        from miniworld_amd.scene import polys_array, scene_from_env
+        for i in (0, n // 2, n - 1):
+            polys, segs = vec.engine.get_geometry(i)
+            sc = scene_from_env(hosts[i])
+            want = polys_array(sc, {k: vec.tex_ids[str(v)] for k, v in enumerate(sc["tex_names"])})
+            assert len(polys) == len(want), (i, len(polys), len(want))
+            for f in ("v", "uv", "n", "nv", "tex"):
+                assert np.array_equal(polys[f], want[f]), (i, f)
+            assert np.array_equal(segs, np.asarray(sc["wall_segs"], np.float64).reshape(-1, 2, 2)), i
+    # a few steps (with DR each one draws forward_step, forward_drift, turn_step: miniworld.py:677-680), then episode 2
+    g = torch.Generator(device="cuda").manual_seed(8)
+    for t in range(k_steps):
+        vec.step(torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32))
+    vec.engine.reset(None, None)
+    for h in hosts:
+        if dr:
+            for t in range(k_steps):
+                for name in ("forward_step", "forward_drift", "turn_step"):
+                    h.params.sample(h.np_random, name)
+        h.reset()
+    st = vec.engine.get_state()
+    for i, h in enumerate(hosts):
+        _assert_same_world(vec, st, i, h, "episode 2")
+    vec.engine.check()
+    vec.close()

@@ -139,14 +139,22 @@ def test_wrappers_semantics_on_host():
 
 
 def test_pcg64_stream_of_the_engine_is_numpys():
-    """MW_RNG_PCG64: the host-side seeding (SeedSequence + pcg_setseq_128_srandom_r) and the generator the
-    device code shares (mw_rng.h) reproduce numpy.random.Generator(PCG64(SeedSequence(seed))) — the stream
-    gymnasium's np_random(seed) hands the reference (miniworld.py:551)."""
+    """MW_RNG_PCG64: the host-side seeding (SeedSequence + pcg_setseq_128_srandom_r) and the draw functions the
+    device code inlines (mw_rng.h) reproduce numpy.random.Generator(PCG64(SeedSequence(seed))) — the stream
+    gymnasium's np_random(seed) hands the reference (miniworld.py:551): doubles, and bounded integers through
+    the buffered 32-bit Lemire path of Generator.integers / Generator.choice, freely interleaved."""
     import ctypes
     from miniworld_amd import engine
     lib = engine.load_library()
     for seed in (0, 1, 7, 4095, 123456789, 2 ** 32 + 17, 2 ** 63 + 3):
         out = np.zeros(64)
-        assert lib.mw_pcg64_doubles(ctypes.c_uint64(seed), 64, out.ctypes.data) == 0
+        assert lib.mw_pcg64_draws(ctypes.c_uint64(seed), 64, None, out.ctypes.data) == 0
         g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
         assert np.array_equal(out, g.random(64)), seed
+        pick = np.random.default_rng(seed)
+        bounds = pick.choice([0, 0, 1, 2, 3, 4, 6, 9, 127, 1000003], 400).astype(np.int32)
+        out = np.zeros(400)
+        assert lib.mw_pcg64_draws(ctypes.c_uint64(seed), 400, bounds.ctypes.data, out.ctypes.data) == 0
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        want = [g.random() if b == 0 else (g.integers(0, b) if i % 2 else g.choice(int(b))) for i, b in enumerate(bounds)]
+        assert np.array_equal(out, np.array(want, np.float64)), seed
