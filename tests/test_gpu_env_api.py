@@ -624,3 +624,44 @@ def test_device_reset_reference_stream_all_generators(env_id, cls_name, dr):
         _assert_same_world(vec, st, i, h, "episode 2")
     vec.engine.check()
     vec.close()
+
+
+_DEVICE_FAMILIES = {"Hallway": "MiniWorld-Hallway-v0", "OneRoom": "MiniWorld-OneRoom-v0", "Maze": "MiniWorld-Maze-v0",
+                    "MazeS3": "MiniWorld-MazeS3-v0", "PickupObjects": "MiniWorld-PickupObjects-v0"}
+
+
+@pytest.mark.parametrize("case", [c for c in ALL_CASES if c.split("_")[0] in ("hallway", "oneroom", "maze", "mazes3", "pickup")])
+def test_batched_env_reproduces_reference_trajectory_from_seed(case):
+    """The whole path with nothing from the host classes in between: a batched env seeded like the reference run
+    that produced the fixture (tools/gen_golden.py: the reference's own miniworld.py under GL stubs) generates
+    that world on the device (MW_RNG_PCG64), and the reference's action sequence then reproduces its rewards,
+    flags, poses — with domain randomisation also its per-step forward_step / drift / turn_step draws — and
+    the stored frames."""
+    import torch
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    s0, tr, meta, obs = helpers.load_case(case)
+    env_id = _DEVICE_FAMILIES[str(meta["env"])]
+    vec = MiniWorldVecEnv(env_id, 2, seed=int(meta["seed"]), domain_rand=bool(meta["domain_rand"]), autoreset=False)
+    assert vec.rng_mode == "pcg64"
+    o = vec.reset()
+    st = vec.engine.get_state()
+    assert np.array_equal(st["agent_pos"][0], s0["agent_pos"]) and st["agent_dir"][0] == s0["agent_dir"]
+    E = len(s0["ents_kind"])
+    assert np.array_equal(st["ent_pos"][0, :E], s0["ents_pos"]) and np.array_equal(st["ent_dir"][0, :E], s0["ents_dir"])
+    assert np.array_equal(o[0].cpu().numpy(), obs[0]["rgb"])
+    act = torch.zeros(2, dtype=torch.int32, device="cuda")
+    worst = 0.0
+    for t in range(len(tr["action"])):
+        act[:] = int(tr["action"][t])
+        o, rew, term, trunc = vec.step(act)
+        assert np.float32(tr["reward"][t]) == rew[0].item(), (case, t)
+        assert bool(term[0].item()) == bool(tr["term"][t]) and bool(trunc[0].item()) == bool(tr["trunc"][t]), (case, t)
+        if (t + 1) in obs or t % 16 == 0 or t == len(tr["action"]) - 1:
+            st = vec.engine.get_state()
+            worst = max(worst, np.abs(st["agent_pos"][0] - tr["pos"][t]).max(), abs(st["agent_dir"][0] - tr["dir"][t]))
+            assert int(st["carrying"][0]) == int(tr["carrying"][t]), (case, t)
+        if (t + 1) in obs:
+            assert np.array_equal(o[0].cpu().numpy(), obs[t + 1]["rgb"]), (case, t + 1)
+    assert worst < 1e-12, (case, worst)
+    vec.engine.check()
+    vec.close()
