@@ -89,6 +89,7 @@ struct MwArgs {
     float *rec_shade;       // [N][max_vis][16]
     float *rec_cull;        // [N][max_vis][MW_CULL_REC] per-primitive tile classification data
     int32_t *nvis;          // [N]
+    uint16_t *rec_order;    // [N][max_vis + 1] big scenes only: [0] sorted flag, then list indices by ascending depth bound
     float *envhdr;          // [N][MW_ENVHDR]
     uint32_t *status;
 };

@@ -21,27 +21,31 @@ extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, int view_
 extern "C" __global__ void mw_step_setup_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                     float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_reset_pcg_kernel(MwArgs a, const uint8_t *mask, int force_all);
+extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
+                                                     float *reward, uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
+                                                         float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                             int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                             const float *rec_shade, const float *rec_cull, const int32_t *nvis,
                                             const float *envhdr,
                                             const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth, int dbg,
-                                            int texel_bytes);
+                                            int texel_bytes, const uint16_t *rec_order);
 extern "C" __global__ void mw_raster_big_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                                 int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                                 const float *rec_shade, const float *rec_cull, const int32_t *nvis,
                                                 const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
-                                                uint8_t *obs, float *depth, int dbg, int texel_bytes);
+                                                uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
 extern "C" __global__ void mw_raster_wrap_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                                  int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                                  const float *rec_shade, const float *rec_cull, const int32_t *nvis,
                                                  const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
-                                                 uint8_t *obs, float *depth, int dbg, int texel_bytes);
+                                                 uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
 extern "C" __global__ void mw_raster_big_wrap_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                                      int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                                      const float *rec_shade, const float *rec_cull, const int32_t *nvis,
                                                      const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
-                                                     uint8_t *obs, float *depth, int dbg, int texel_bytes);
+                                                     uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all);
 extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, const float *hdr, const float *mesh_pos, uint32_t *keys);
 extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
@@ -140,11 +144,16 @@ int dev_alloc(mw_engine *e, T **out, size_t count, bool zero = true)
     return MW_OK;
 }
 
-// K1 for the engine's random stream (the device code is compiled once per stream, mw_rng.h)
+// K1 for the engine's random stream (the device code is compiled once per stream, mw_rng.h) and scene size
+// (big scenes also get the depth-sorted visiting order, mw_setup_sort.hip)
 auto k1_of(const mw_engine *e) -> decltype(&mw_step_setup_kernel)
 {
-    return e->cfg.rng_mode == MW_RNG_PCG64 ? mw_step_setup_pcg_kernel : mw_step_setup_kernel;
+    const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
+    if (e->args.rec_order) return pcg ? mw_step_setup_sort_pcg_kernel : mw_step_setup_sort_kernel;   // big scenes
+    return pcg ? mw_step_setup_pcg_kernel : mw_step_setup_kernel;
 }
+
+int k1_threads(const mw_engine *e) { return e->args.rec_order ? 256 : 64; }     // MW_K1_WAVES of the variant (mw_setup.hip)
 
 // numpy.random.SeedSequence(seed).generate_state(4, uint64) for a non-negative integer seed (the
 // published SeedSequence algorithm: 4-word pool, hashmix / mix with the constants below), then PCG64's
@@ -388,7 +397,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         ev = get_events(e);
         (void)hipEventRecord(ev.a, st);
     }
-    hipLaunchKernelGGL(k1_of(e), dim3(N), dim3(64), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
+    hipLaunchKernelGGL(k1_of(e), dim3(N), dim3(k1_threads(e)), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
                        d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
                        d_trunc ? d_trunc : e->d_flag_scratch + N);
     if (timed) (void)hipEventRecord(ev.b, st);
@@ -415,7 +424,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                            a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis,
-                           (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes);
+                           (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes,
+                           (const uint16_t *)a.rec_order);
     }
     if (timed) {
         (void)hipEventRecord(ev.c, st);
@@ -500,6 +510,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.rec_raster, (size_t)N * cfg->max_visible * MW_RASTER_REC);
     ALLOC(a.rec_shade, (size_t)N * cfg->max_visible * MW_SHADE_REC);
     ALLOC(a.rec_cull, (size_t)N * cfg->max_visible * MW_CULL_REC);
+    if (cfg->max_visible > 64) ALLOC(a.rec_order, (size_t)N * (cfg->max_visible + 1));     // big scenes: visiting order (mw_raster_big_kernel)
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
@@ -712,7 +723,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     b.W = width; b.H = height;
     b.tiles_x = width / MW_TILE_W; b.tiles_y = height / MW_TILE_H; b.n_tiles = b.tiles_x * b.tiles_y;
     b.env_base = env;
-    hipLaunchKernelGGL(k1_of(e), dim3(1), dim3(64), 0, st, b, 0, view_flags, e->d_action_scratch,
+    hipLaunchKernelGGL(k1_of(e), dim3(1), dim3(k1_threads(e)), 0, st, b, 0, view_flags, e->d_action_scratch,
                        e->d_reward_scratch, e->d_flag_scratch, e->d_flag_scratch + e->cfg.num_envs);
     uint32_t *keys = nullptr;
     if (e->have_meshes) {
@@ -766,7 +777,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     b.step_override = nullptr;
     b.env_base = first_env;
     // K1 in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
-    hipLaunchKernelGGL(k1_of(e), dim3(count), dim3(64), 0, st, b, 0, 4, e->d_action_scratch,
+    hipLaunchKernelGGL(k1_of(e), dim3(count), dim3(k1_threads(e)), 0, st, b, 0, 4, e->d_action_scratch,
                        e->d_reward_scratch, e->d_flag_scratch, e->d_flag_scratch + e->cfg.num_envs);
     if (!e->visible_attr_set) {
         HIP_TRY(e, hipFuncSetAttribute((const void *)mw_visible_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -35,7 +35,8 @@ __device__ inline void raster_kernel_body(
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave,
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
-    const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes)
+    const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes,
+    const uint16_t *__restrict__ rec_order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lds_recs = LDS_RECS ? max_vis : 0;
@@ -85,6 +86,7 @@ __device__ inline void raster_kernel_body(
     uint64_t T = 0ull, F = 0ull, Cl = 0ull;
     int gi = 0, G = 0;
     cx.have_pre = pairs ? 1 : 0;
+    cx.order = (!LDS_RECS && rec_order) ? rec_order + (size_t)env * (max_vis + 1) : nullptr;
     cx.pre_touch = cx.pre_full = cx.pre_clip = 0ull;
     for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
         if (pairs) {
@@ -97,7 +99,8 @@ __device__ inline void raster_kernel_body(
             cx.pre_touch = (T >> sh) & prim_mask; cx.pre_full = (F >> sh) & prim_mask; cx.pre_clip = (Cl >> sh) & prim_mask;
             ++gi;
         }
-        raster_tile_fmt<false, FMT>(cx, tx, ty, nullptr);
+        if (!LDS_RECS && rec_order) raster_tile_fmt<false, FMT, true>(cx, tx, ty, nullptr);
+        else raster_tile_fmt<false, FMT>(cx, tx, ty, nullptr);
     }
 }
 
@@ -105,9 +108,10 @@ __device__ inline void raster_kernel_body(
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave, \
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull, \
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd, \
-    const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes
+    const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, \
+    const uint16_t *__restrict__ rec_order
 #define MW_RASTER_FWD N, W, H, max_vis, tiles_x, n_tiles, waves_per_env, tiles_per_wave, rec_raster, rec_shade, rec_cull, \
-    nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes
+    nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order
 
 extern "C" __global__ __launch_bounds__(64) void mw_raster_kernel(MW_RASTER_ARGS)
 {

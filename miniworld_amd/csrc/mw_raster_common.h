@@ -211,6 +211,7 @@ struct TileCtx {
     // tile classification done ahead for a group of tiles (classify_group): valid when have_pre
     uint64_t pre_touch, pre_full, pre_clip;
     int have_pre;
+    const uint16_t *order;          // SORTED kernels: [0] sorted flag, [1 + k] list index of the k-th nearest polygon
 };
 
 // Tile classification of primitive lp against the tile whose pixel centres span [Xlo, Xhi] x [Ylo, Yhi].
@@ -259,7 +260,11 @@ __device__ inline void classify_group(const float4 *s_cull, int lane, int nvis, 
 
 // FMT: output layout fixed at compile time (0: the plain observation, the hot path) or -1: read from
 // the launch flags (the wrapper layouts; kept out of the hot instantiation)
-template <bool MESH, int FMT>
+// SORTED: the env's polygons come with a visiting order by ascending depth bound (K1, big scenes).  Tiles then
+// go straight to the exact pass, walk the polygons front to back and stop as soon as every sample of the tile
+// holds something nearer than the next polygon's bound — in a maze that is after a handful of the dozens of
+// polygons stacked behind each other in the view.  Keys, winners and colours do not depend on the visiting order.
+template <bool MESH, int FMT, bool SORTED = false>
 __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const uint32_t *mesh_key)
 {
     const int lane = cx.lane, nvis = cx.nvis, dbg = cx.dbg, env = cx.env, W = cx.W, H = cx.H;
@@ -283,6 +288,8 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     // visiting the primitives in ascending draw index IS the resolve order of R12.  Each
     // visit shades immediately.  Any contention abandons the tile to pass B (exact keys).
     bool exact = (dbg & 4) != 0;
+    const bool sorted = SORTED && cx.order[0] != 0;
+    if (SORTED && sorted) exact = true;
     if (MESH) {
         bool m = false;
 #pragma unroll
@@ -380,19 +387,34 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         uint32_t key[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) key[s] = MESH ? mesh_key[s] : 0xFFFFFFFFu;
-        for (int chunk = 0; chunk < nvis; chunk += 64) {
+        bool done = false;
+        uint32_t far16 = 0xFFFFu;        // SORTED: the farthest depth stored in the tile (0xFFFF while a sample is empty)
+        for (int chunk = 0; chunk < nvis && !done; chunk += 64) {
             uint64_t todo;
+            int pidx = chunk + lane;        // list index of the polygon this lane classifies
+            uint32_t zlo = 0u;              // SORTED: conservative 16-bit lower bound of its depth
             if (cx.have_pre) {
                 todo = cx.pre_touch;
             } else {
                 const int lp = chunk + lane;
                 bool touch = lp < nvis, full = false, clipf = false;
-                if (touch) classify_prim(s_cull, lp, Xlo, Xhi, Ylo, Yhi, touch, full, clipf);
+                if (touch) {
+                    if (SORTED && sorted) pidx = (int)cx.order[1 + lp];
+                    classify_prim(s_cull, pidx, Xlo, Xhi, Ylo, Yhi, touch, full, clipf);
+                    if (SORTED && sorted) {
+                        const float zb = fmaf(s_cull[pidx * 6 + 5].y, 65535.0f, 0.5f);     // the key formula of R6 on the bound
+                        zlo = zb >= 2.0f ? (uint32_t)zb - 2u : 0u;                          // 2 LSB of slack for rounding
+                    }
+                }
                 todo = __ballot(touch);
             }
             while (todo) {
-                const int p = chunk + (__ffsll((unsigned long long)todo) - 1);
+                const int bit = __ffsll((unsigned long long)todo) - 1;
+                const int p = (SORTED && sorted) ? __builtin_amdgcn_readlane(pidx, bit) : chunk + bit;
                 todo &= todo - 1;
+                if (SORTED && sorted) {
+                    if ((uint32_t)__builtin_amdgcn_readlane((int)zlo, bit) > far16) { done = true; break; }
+                }
                 const float *__restrict__ rr = rr_env + (size_t)p * MW_RASTER_REC;
                 bool in[8];
 #pragma unroll
@@ -417,6 +439,12 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     const uint32_t id = MESH ? __float_as_uint(rr[61]) : (uint32_t)p;     // draw id
                     const uint32_t k = ((uint32_t)t << 16) | id;
                     key[s] = ok ? min(key[s], k) : key[s];
+                }
+                if (SORTED && sorted) {
+                    uint32_t m = max(max(max(key[0], key[1]), max(key[2], key[3])), max(max(key[4], key[5]), max(key[6], key[7])));
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
+                    far16 = m >> 16;
                 }
             }
         }

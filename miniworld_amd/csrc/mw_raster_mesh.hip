@@ -313,7 +313,7 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     cx.te.texd = texd;
     cx.te.flat = dbg & 1;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
-    cx.env = env; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane; cx.have_pre = 0;
+    cx.env = env; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane; cx.have_pre = 0; cx.order = nullptr;
 
     // ---- phase 1: every mesh triangle -> LDS keys, one triangle per lane -------------------
     const int n_mesh = (dbg & 8) ? 0 : __float_as_int(hdr[3]);       // MW_DEBUG_FLAGS bit 3: perf experiments only
@@ -482,7 +482,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.te.texd = texd;
     cx.te.flat = 0;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
-    cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0;
+    cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
     else view_tile_body<8>(cx, tiles_x, mesh_keys);
 }

@@ -19,6 +19,11 @@
 #include "mw_rng.h"
 #include "mw_gen.h"
 
+#ifndef MW_SORT_VIS
+#define MW_SORT_VIS 0       // 1: also emit the depth-sorted visiting order of big scenes (mw_setup_sort*.hip)
+#endif
+#define MW_SORT_CAP 1024    // polygons sorted per env (their packed sort keys sit in 8 KiB of LDS)
+
 namespace {
 
 constexpr double kPi = 3.14159265358979323846;
@@ -349,7 +354,7 @@ __device__ __forceinline__ bool cull_poly(const MwArgs &a, const HV h[4], int nv
 }
 
 __device__ __forceinline__ void write_poly(const MwArgs &a, int env, int idx, uint32_t draw_id, const HV h[4], int nv,
-                           const PolyGeom &g, const float uv[3][2], const float col[3], int tex)
+                           const PolyGeom &g, const float uv[3][2], const float col[3], int tex, unsigned long long *s_zmin)
 {
     float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
     float4 *sr = reinterpret_cast<float4 *>(a.rec_shade + ((size_t)env * a.max_vis + idx) * MW_SHADE_REC);
@@ -416,7 +421,25 @@ __device__ __forceinline__ void write_poly(const MwArgs &a, int env, int idx, ui
     cr[0] = e0; cr[1] = e1; cr[2] = e2;
     cr[3] = make_float4(tminv[0], tminv[1], tminv[2], tminv[3]);
     cr[4] = make_float4(tmaxv[0], tmaxv[1], tmaxv[2], tmaxv[3]);
-    cr[5] = make_float4(flag, 0.0f, 0.0f, 0.0f);
+    float zmin = 0.0f;
+#if MW_SORT_VIS
+    {
+        // lower bound of the polygon's window depth (its depth plane is linear on screen, so the minimum over
+        // the covered samples is no smaller than the minimum over the vertices); 0 = nearest possible when a
+        // vertex is behind the eye.  The raster kernel visits polygons in ascending order of this bound and
+        // stops once a tile's farthest stored sample is nearer than the next bound.
+        bool allpos = true;
+        float m = 1e30f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < nv) { allpos &= h[k].hw > 0.0f; m = fminf(m, h[k].cz / h[k].hw); }
+        zmin = allpos ? fmaf(m, 0.5f, 0.5f) : 0.0f;
+        if (!(zmin >= 0.0f)) zmin = 0.0f;
+        // sort key: the bound's bit pattern (monotone for non-negative floats), ties broken by the list index
+        if (idx < MW_SORT_CAP) s_zmin[idx] = ((unsigned long long)__float_as_uint(zmin) << 16) | (unsigned long long)idx;
+    }
+#endif
+    cr[5] = make_float4(flag, zmin, 0.0f, 0.0f);
     // shade record: attribute planes (unnormalised), face colour, texture, depth plane again
     float U[3] = {0, 0, 0}, V[3] = {0, 0, 0};
     if (tex >= 0) {
@@ -453,13 +476,32 @@ __device__ inline int compact(int lane, bool vis, int &count)
 #ifndef MW_SETUP_KERNEL_NAME
 #define MW_SETUP_KERNEL_NAME mw_step_setup_kernel
 #endif
-extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void MW_SETUP_KERNEL_NAME(
+// MW_K1_WAVES wavefronts per env.  Small scenes: 1 (thousands of envs already fill the chip with one wave each).
+// Big scenes (MW_SORT_VIS: a Maze has 510 polygons and the BASELINE batch is 1024 envs per GPU = one wave per
+// SIMD): 4 — every wave runs the scalar part (physics, camera) redundantly, thread 0 alone writes state, the
+// polygon batches are dealt round-robin to the waves with an ordered compaction across them, entities stay on
+// wave 0, and all 256 threads sort.
+#if MW_SORT_VIS
+#define MW_K1_WAVES 4
+#else
+#define MW_K1_WAVES 1
+#endif
+extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void MW_SETUP_KERNEL_NAME(
     MwArgs a, int do_step, int view_flags, const int32_t *__restrict__ actions, float *__restrict__ reward,
     uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
 {
+    constexpr int KW = MW_K1_WAVES;
+    __shared__ int s_cnt[2][KW];
     __shared__ unsigned char gen_ws[MW_GEN_WS_BYTES];
+#if MW_SORT_VIS
+    __shared__ unsigned long long s_zmin_buf[MW_SORT_CAP];
+    unsigned long long *s_zmin = s_zmin_buf;
+#else
+    unsigned long long *s_zmin = nullptr;
+#endif
     const int env = a.env_base + blockIdx.x;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool writer = threadIdx.x == 0;       // the one thread that writes the env's state
     StepCtx c{a, env, lane, a.shared_geom ? 0 : env, 0, 0, 0, 0, 0, -1, -1, {0, 0, 0}, 0};
     c.px = a.ax[env]; c.py = a.ay[env]; c.pz = a.az[env]; c.dir = a.adir[env];
     c.cam_height = a.cam[env];
@@ -480,16 +522,18 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
         int picked = a.picked[env];
         // the three per-step parameters (miniworld.py:677-680)
         double fwd_step = a.fwd.def, fwd_drift = a.drift.def, turn_step = a.turn.def;
+        mw::Rng rng{};
+        bool drew = false;
         if (a.step_override) {
             fwd_step = a.step_override[(size_t)env * 3 + 0];
             fwd_drift = a.step_override[(size_t)env * 3 + 1];
             turn_step = a.step_override[(size_t)env * 3 + 2];
         } else if (a.domain_rand) {
-            mw::Rng rng = mw::rng_load(a.rng, a.N, env);
+            rng = mw::rng_load(a.rng, a.N, env);
             fwd_step = mw::rng_uniform(rng, a.fwd.lo, a.fwd.hi);
             fwd_drift = mw::rng_uniform(rng, a.drift.lo, a.drift.hi);
             turn_step = mw::rng_uniform(rng, a.turn.lo, a.turn.hi);
-            if (lane == 0) mw::rng_store(a.rng, a.N, env, rng);
+            drew = true;            // stored below, once every wave of the env has read the old state
         }
         const int action = actions[env];
         switch (action) {
@@ -556,7 +600,9 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                 if (picked == a.num_objs) tm = 1;
             }
         }
-        if (lane == 0) {
+        if (KW > 1) __syncthreads();        // every wave has read the state it needs: thread 0 may now overwrite it
+        if (writer) {
+            if (drew) mw::rng_store(a.rng, a.N, env, rng);
             reward[env] = (float)rew;
             term[env] = (uint8_t)tm;
             trunc[env] = (uint8_t)tr;
@@ -567,7 +613,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
 
     // ---- state write-back (agent + carried entity) ------------------------------
     bool regenerated = false;
-    if (do_step && lane == 0) {
+    if (do_step && writer) {
         a.ax[env] = c.px; a.ay[env] = c.py; a.az[env] = c.pz; a.adir[env] = c.dir;
         if (c.live >= 0) {
             a.epos[((size_t)0 * a.E + c.live) * a.N + env] = c.cpos[0];
@@ -582,7 +628,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
         // next episode (the reference leaves the reset to the caller, scripts/benchmark.py:36-37)
         regenerated = (tm | tr) != 0;
         if (regenerated) {
-            if (lane == 0) mw::generate_world(a, env, gen_ws);
+            if (writer) mw::generate_world(a, env, gen_ws);
             __syncthreads();
             c.px = a.ax[env]; c.py = a.ay[env]; c.pz = a.az[env]; c.dir = a.adir[env];
             c.carry = -1; c.live = -1;
@@ -609,8 +655,8 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
     int count = 0;
     const mw_poly *polys = a.polys + (size_t)c.set * a.max_polys;
     const int np = a.npolys[c.set];
-    for (int base = 0; base < np; base += 64) {         // display list 1: rooms
-        const int i = base + lane;
+    for (int base = 0, round = 0; base < np; base += 64 * KW, ++round) {         // display list 1: rooms
+        const int i = base + wave * 64 + lane;
         bool vis = false;
         HV h[4];
         PolyGeom g;
@@ -623,13 +669,30 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
             for (int k = 0; k < 4; ++k) h[k] = xform(cam, q.v[k][0], q.v[k][1], q.v[k][2]);
             vis = cull_poly(a, h, q.nv, g) && !(ent_poly && (view_flags & 4));     // the queries draw rooms only
         }
-        const int idx = compact(lane, vis, count);
+        int idx;
+        if (KW == 1) {
+            idx = compact(lane, vis, count);
+        } else {
+            // ordered compaction across the waves of the env: wave w's batch comes after those of waves < w
+            const uint64_t m = ballot(vis);
+            if (lane == 0) s_cnt[round & 1][wave] = __popcll((unsigned long long)m);
+            __syncthreads();
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < KW; ++w) {
+                const int cw = s_cnt[round & 1][w];
+                before += w < wave ? cw : 0;
+                total += cw;
+            }
+            idx = count + before + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+            count += total;
+        }
         if (vis) {
             if (idx < a.max_vis) {
                 float col[3];
                 light(cam, q.n, q.rgb, col);
                 const float uv[3][2] = {{q.uv[0][0], q.uv[0][1]}, {q.uv[1][0], q.uv[1][1]}, {q.uv[2][0], q.uv[2][1]}};
-                write_poly(a, env, idx, (uint32_t)idx, h, q.nv, g, uv, col, q.tex);
+                write_poly(a, env, idx, (uint32_t)idx, h, q.nv, g, uv, col, q.tex, s_zmin);
             } else {
                 atomicOr(a.status, MW_ST_VIS_OVERFLOW);
             }
@@ -644,6 +707,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
     // a mesh entity only reserves its range of draw ids and is described to the mesh raster kernel.
     int mesh_tris = 0, n_mesh = 0;
     float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
+    if (KW == 1 || wave == 0) {     // entities (and the agent marker) are few: wave 0 of the env alone
     // kind / static flag of every slot, one slot per lane, as wave-uniform bit masks (max_ents <= 64)
     uint64_t box_m, mesh_m, frame_m, static_m;
     {
@@ -768,7 +832,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
                 if (vis) {
                     if (idx < a.max_vis) {
                         const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-                        write_poly(a, env, idx, proxy ? (0x10000u | (uint32_t)slot) : (uint32_t)(idx + mesh_tris), h, 4, g, uv, col, -1);
+                        write_poly(a, env, idx, proxy ? (0x10000u | (uint32_t)slot) : (uint32_t)(idx + mesh_tris), h, 4, g, uv, col, -1, s_zmin);
                     } else {
                         atomicOr(a.status, MW_ST_VIS_OVERFLOW);
                     }
@@ -809,13 +873,52 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4
         if (vis) {
             if (idx < a.max_vis) {
                 const float uv[3][2] = {{0, 0}, {0, 0}, {0, 0}};
-                write_poly(a, env, idx, (uint32_t)(idx + mesh_tris), h, 3, g, uv, col, -1);
+                write_poly(a, env, idx, (uint32_t)(idx + mesh_tris), h, 3, g, uv, col, -1, s_zmin);
             } else {
                 atomicOr(a.status, MW_ST_VIS_OVERFLOW);
             }
         }
     }
-    if (lane == 0) {
+    }       // wave 0
+#if MW_SORT_VIS
+    if (KW > 1) {       // the other waves learn the final count
+        __syncthreads();
+        if (writer) s_cnt[0][0] = count;
+        __syncthreads();
+        count = s_cnt[0][0];
+    }
+    if (a.rec_order) {
+        // visiting order for the raster kernel: list indices sorted by ascending depth bound; order[0] = 1 marks
+        // the list as sorted
+        const int n = count < a.max_vis ? count : a.max_vis;
+        uint16_t *ord = a.rec_order + (size_t)env * (a.max_vis + 1);
+        __syncthreads();
+        if (n <= MW_SORT_CAP) {
+            // bitonic sort of the packed (bound, index) keys in LDS by the 64 lanes of the wave
+            int P = 64;
+            while (P < n) P <<= 1;
+            for (int i = n + (int)threadIdx.x; i < P; i += 64 * KW) s_zmin[i] = ~0ull;
+            __syncthreads();
+            for (int k = 2; k <= P; k <<= 1) {
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int t = (int)threadIdx.x; t < (P >> 1); t += 64 * KW) {
+                        const int i = 2 * t - (t & (j - 1));        // index with a zero inserted at bit log2(j)
+                        const int l = i | j;
+                        const unsigned long long x = s_zmin[i], y = s_zmin[l];
+                        const bool up = (i & k) == 0;
+                        if ((x > y) == up) { s_zmin[i] = y; s_zmin[l] = x; }
+                    }
+                    __syncthreads();
+                }
+            }
+            for (int r = (int)threadIdx.x; r < n; r += 64 * KW) ord[1 + r] = (uint16_t)(s_zmin[r] & 0xFFFFull);
+            if (writer) ord[0] = 1;
+        } else if (writer) {
+            ord[0] = 0;
+        }
+    }
+#endif
+    if (writer) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
         hdr[0] = sky[0]; hdr[1] = sky[1]; hdr[2] = sky[2];
         hdr[3] = __int_as_float(n_mesh);
