@@ -683,7 +683,8 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
         HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 40 * (size_t)N, hipMemcpyHostToDevice));
     }
     if (mask) HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, N, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel, dim3((N + 63) / 64), dim3(64), 0, st, e->args, e->d_mask, mask ? 0 : 1);
+    hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel,
+                       dim3(e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64), dim3(64), 0, st, e->args, e->d_mask, mask ? 0 : 1);
     HIP_TRY(e, hipGetLastError());
     return MW_OK;
 }

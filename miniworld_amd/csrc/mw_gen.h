@@ -167,9 +167,11 @@ __device__ inline void maze_link_outline(const MazeRect &A, const MazeRect &B, i
     }
 }
 
-#define MW_GEN_WS_BYTES 384     // per-env scratch of the generators (LDS, provided by the caller)
+#define MW_GEN_WS_BYTES 400     // per-env scratch of the generators (LDS, provided by the caller)
 
-__device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsigned char *ws, double &bx, double &bz,
+// Called by all 64 lanes of one wavefront: lane 0 carves and places (the random stream is sequential), the
+// 127 rooms are emitted one per lane.
+__device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsigned char *ws, int lane, double &bx, double &bz,
                                 double &bdir, double &ax, double &az, double &adir)
 {
     const int rows = (int)a.gt->gen_tab[0], cols = (int)a.gt->gen_tab[1];
@@ -181,6 +183,8 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
     unsigned char *open = ws;               // per cell: bit w = wall w replaced by a portal
     unsigned char *link_cell = ws + 64, *link_dir = ws + 128;
     unsigned char *st_cell = ws + 192, *st_perm = ws + 256, *st_next = ws + 320;
+    int *s_nlink = reinterpret_cast<int *>(ws + 384);
+    if (lane == 0) {
     unsigned long long visited = 0ull;
     for (int k = 0; k < ncell; ++k) open[k] = 0;
     int nlink = 0, sp = 0;
@@ -214,28 +218,57 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
         link_cell[nlink] = (unsigned char)cell; link_dir[nlink] = (unsigned char)d; ++nlink;
         enter(ncellidx);
     }
-    // ---- geometry ------------------------------------------------------------------------
+    *s_nlink = nlink;
+    }       // lane 0
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int nlink = *s_nlink;
+    // ---- geometry: one room per lane, offsets from an ordered prefix sum over the rooms ------
     RoomTex rt;
     rt.floor = (int)a.gt->gen_tab[5]; rt.ceil = (int)a.gt->gen_tab[6]; rt.wall = (int)a.gt->gen_tab[7];
     rt.fu = a.gt->gen_colors[0]; rt.fv = a.gt->gen_colors[1]; rt.cu = a.gt->gen_colors[2]; rt.cv = a.gt->gen_colors[3];
     rt.wu = a.gt->gen_colors[4]; rt.wv = a.gt->gen_colors[5];
     rt.height = a.gt->gen_tab[4]; rt.ceiling = true;
-    int np = 0, ns = 0;
-    for (int cell = 0; cell < ncell; ++cell) {
-        const MazeRect c = maze_cell(a, cell % cols, cell / cols);
-        const double px[4] = {c.x1, c.x1, c.x0, c.x0}, pz[4] = {c.z1, c.z0, c.z0, c.z1};   // add_rect_room outline
-        emit_room(a, set, rt, px, pz, (~(unsigned)open[cell]) & 15u, np, ns);
+    {
+        const int nroom = ncell + nlink;
+        int np_base = 0, ns_base = 0;
+        for (int r0 = 0; r0 < nroom; r0 += 64) {
+            const int room = r0 + lane;
+            double px[4] = {0, 0, 0, 0}, pz[4] = {0, 0, 0, 0};
+            unsigned keep = 0u;
+            if (room < ncell) {
+                const MazeRect c = maze_cell(a, room % cols, room / cols);
+                px[0] = c.x1; px[1] = c.x1; px[2] = c.x0; px[3] = c.x0;       // add_rect_room outline
+                pz[0] = c.z1; pz[1] = c.z0; pz[2] = c.z0; pz[3] = c.z1;
+                keep = (~(unsigned)open[room]) & 15u;
+            } else if (room < nroom) {
+                const int k = room - ncell, cell = link_cell[k], d = link_dir[k];
+                const MazeRect A = maze_cell(a, cell % cols, cell / cols);
+                const MazeRect B = maze_cell(a, cell % cols + DI[d], cell / cols + DJ[d]);
+                maze_link_outline(A, B, d, px, pz);
+                keep = 5u;          // walls 1 and 3 are portals (miniworld.py:836-837)
+            }
+            const int nw = __popc(keep);
+            int cnt = room < nroom ? (2 + nw) | (nw << 16) : 0;       // polygons | segments << 16
+            int incl = cnt;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int up = __shfl_up(incl, off);
+                if (lane >= off) incl += up;
+            }
+            int np = np_base + ((incl - cnt) & 0xFFFF), ns = ns_base + ((incl - cnt) >> 16);
+            if (room < nroom) emit_room(a, set, rt, px, pz, keep, np, ns);
+            const int tot = __shfl(incl, 63);
+            np_base += tot & 0xFFFF; ns_base += tot >> 16;
+        }
+        if (lane == 0) {
+            const_cast<int32_t *>(a.npolys)[set] = np_base;
+            const_cast<int32_t *>(a.nsegs)[set] = ns_base;
+        }
     }
-    for (int k = 0; k < nlink; ++k) {
-        const int cell = link_cell[k], d = link_dir[k];
-        const MazeRect A = maze_cell(a, cell % cols, cell / cols);
-        const MazeRect B = maze_cell(a, cell % cols + DI[d], cell / cols + DJ[d]);
-        double px[4], pz[4];
-        maze_link_outline(A, B, d, px, pz);
-        emit_room(a, set, rt, px, pz, 5u, np, ns);          // walls 1 and 3 are portals (miniworld.py:836-837)
-    }
-    const_cast<int32_t *>(a.npolys)[set] = np;
-    const_cast<int32_t *>(a.nsegs)[set] = ns;
+    __threadfence();                // lane 0 tests the placement against the segments the other lanes wrote
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
     // ---- placement: box then agent, room drawn with probability ~ area (miniworld.py:872-905) --
     const double cell_area = a.gt->gen_tab[2] * a.gt->gen_tab[2], link_area = a.gt->gen_tab[2] * a.gt->gen_tab[3];
     const double total = ncell * cell_area + nlink * link_area;
@@ -281,8 +314,10 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
 }
 
 // One full reset of env `env`.  Writes every per-env state array.
-__device__ inline void generate_world(const MwArgs &a, int env, unsigned char *ws)
+// Called by the 64 lanes of one wavefront; everything but the Maze's room emission runs on lane 0.
+__device__ inline void generate_world(const MwArgs &a, int env, unsigned char *ws, int lane)
 {
+    if (a.generator != MW_GEN_MAZE && lane != 0) return;
     const int set = a.shared_geom ? 0 : env;
     const bool dr = a.domain_rand != 0;
     Rng r = rng_load(a.rng, a.N, env);
@@ -318,7 +353,8 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
         double col[3] = {1.0, 0.0, 0.0};                       // COLORS["red"] entity.py:31
         if (a.generator == MW_GEN_MAZE) {
             double bx, bz, bdir;
-            gen_maze(a, env, set, r, ws, bx, bz, bdir, ax, az, adir);
+            gen_maze(a, env, set, r, ws, lane, bx, bz, bdir, ax, az, adir);
+            if (lane != 0) return;
             gen_store_box(a, env, 0, bx, bz, bdir, size, col);
         } else {
             const double brad = sqrt(size * size + size * size) / 2.0;

@@ -1,4 +1,5 @@
-// mw_reset_kernel — batched MiniWorldEnv.reset (miniworld.py:544-604): one thread per env.
+// mw_reset_kernel — batched MiniWorldEnv.reset (miniworld.py:544-604): one thread per env, or one wavefront per
+// env for the Maze generator (its 127 rooms are emitted one per lane; grid = N blocks then).
 #include "mw_gen.h"
 
 #ifndef MW_RESET_KERNEL_NAME
@@ -7,8 +8,9 @@
 extern "C" __global__ __launch_bounds__(64) void MW_RESET_KERNEL_NAME(MwArgs a, const uint8_t *__restrict__ mask, int force_all)
 {
     __shared__ unsigned char ws[64][MW_GEN_WS_BYTES];
-    const int env = blockIdx.x * 64 + threadIdx.x;
+    const bool wave_per_env = a.generator == MW_GEN_MAZE;
+    const int env = wave_per_env ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x);
     if (env >= a.N) return;
     if (!force_all && !mask[env]) return;
-    mw::generate_world(a, env, ws[threadIdx.x]);
+    mw::generate_world(a, env, wave_per_env ? ws[0] : ws[threadIdx.x], wave_per_env ? (int)threadIdx.x : 0);
 }
