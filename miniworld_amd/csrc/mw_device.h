@@ -92,4 +92,8 @@ struct MwArgs {
     uint16_t *rec_order;    // [N][max_vis + 1] big scenes only: [0] sorted flag, then list indices by ascending depth bound
     float *envhdr;          // [N][MW_ENVHDR]
     uint32_t *status;
+    // mesh kernel scheduling (longest processing time first): K1 leaves each env's mesh triangles in view,
+    // mw_mesh_order_kernel turns them into the order in which the mesh kernel's blocks take the envs
+    int32_t *k3_cost;       // [N]
+    int32_t *k3_order;      // [N] env ids, heaviest first
 };

@@ -60,7 +60,8 @@ extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vi
                                                  const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
                                                  const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
                                                  const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes,
-                                                 unsigned long long *prof);
+                                                 unsigned long long *prof, const int32_t *env_order);
+extern "C" __global__ void mw_mesh_order_kernel(int N, const int32_t *cost, int32_t *order);
 
 #define MW_TIMING_STRIDE 8
 
@@ -409,10 +410,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             HIP_TRY(e, hipFuncSetAttribute((const void *)mw_raster_mesh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             e->mesh_lds_ready = true;
         }
+        hipLaunchKernelGGL(mw_mesh_order_kernel, dim3(1), dim3(1024), 0, st, N, (const int32_t *)a.k3_cost, a.k3_order);
         hipLaunchKernelGGL(mw_raster_mesh_kernel, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
-                           a.mesh_rgb, a.mesh_uv, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes, e->d_k3prof);
+                           a.mesh_rgb, a.mesh_uv, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes, e->d_k3prof,
+                           (const int32_t *)a.k3_order);
     } else {
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -510,6 +513,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.rec_raster, (size_t)N * cfg->max_visible * MW_RASTER_REC);
     ALLOC(a.rec_shade, (size_t)N * cfg->max_visible * MW_SHADE_REC);
     ALLOC(a.rec_cull, (size_t)N * cfg->max_visible * MW_CULL_REC);
+    ALLOC(a.k3_cost, (size_t)N); ALLOC(a.k3_order, (size_t)N);
     if (cfg->max_visible > 64) ALLOC(a.rec_order, (size_t)N * (cfg->max_visible + 1));     // big scenes: visiting order (mw_raster_big_kernel)
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);

@@ -286,13 +286,16 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
     const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
     const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes,
-    unsigned long long *__restrict__ prof)
+    unsigned long long *__restrict__ prof, const int32_t *__restrict__ env_order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                     // [H][W][8]
     const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
     const int nkeys = W * H * 8;
-    const int env = blockIdx.x;
+    // block b draws the b-th env in order of decreasing mesh work (mw_mesh_order_kernel): blocks are dispatched
+    // roughly in index order, one per CU at a time, and their costs are heavy-tailed, so the heavy envs must start
+    // first and the light ones fill the gaps at the end
+    const int env = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *s_pack = smem + (size_t)nkeys * 4 + wave * 192;
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
@@ -485,4 +488,24 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
     else view_tile_body<8>(cx, tiles_x, mesh_keys);
+}
+
+// Order in which mw_raster_mesh_kernel's blocks take the envs: a counting sort of the envs by mesh triangles in
+// view (K1's k3_cost), most first; one workgroup, bins of 2048 triangles.  The order inside a bin is whatever the
+// LDS atomics produce — no output depends on which block draws which env.
+extern "C" __global__ __launch_bounds__(1024) void mw_mesh_order_kernel(int N, const int32_t *__restrict__ cost, int32_t *__restrict__ order)
+{
+    constexpr int BINS = 16;
+    __shared__ int hist[BINS], start[BINS];
+    const int tid = threadIdx.x;
+    if (tid < BINS) hist[tid] = 0;
+    __syncthreads();
+    for (int e = tid; e < N; e += 1024) atomicAdd(&hist[(BINS - 1) - min(cost[e] >> 11, BINS - 1)], 1);
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int b = 0; b < BINS; ++b) { start[b] = acc; acc += hist[b]; }
+    }
+    __syncthreads();
+    for (int e = tid; e < N; e += 1024) order[atomicAdd(&start[(BINS - 1) - min(cost[e] >> 11, BINS - 1)], 1)] = e;
 }

@@ -920,6 +920,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
 #endif
     if (writer) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
+        a.k3_cost[env] = mesh_tris;             // mesh triangles in view: the mesh kernel's scheduling weight
         hdr[0] = sky[0]; hdr[1] = sky[1]; hdr[2] = sky[2];
         hdr[3] = __int_as_float(n_mesh);
 #pragma unroll
