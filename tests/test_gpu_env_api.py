@@ -665,3 +665,57 @@ def test_batched_env_reproduces_reference_trajectory_from_seed(case):
     assert worst < 1e-12, (case, worst)
     vec.engine.check()
     vec.close()
+
+
+@pytest.mark.parametrize("w,h", [(160, 120), (96, 64), (16, 4)])
+def test_other_observation_sizes_match_oracle(w, h):
+    """MiniWorldEnv(obs_width, obs_height) (miniworld.py:473-474): any multiple of the 16x4 tile; the hot kernels
+    at another size, including the degenerate single-tile frame, equal the oracle at that size."""
+    import pyoracle
+    from miniworld_amd import envs
+    from miniworld_amd.scene import scene_from_env
+    env = envs.FourRooms(obs_width=w, obs_height=h)
+    o, _ = env.reset(seed=5)
+    assert o.shape == (h, w, 3)
+    for a in (2, 2, 0, 2, 1, 1, 2):
+        o, *_ = env.step(a)
+    want = pyoracle.render(scene_from_env(env), width=w, height=h)
+    assert np.array_equal(o, want["rgb"])
+    assert np.array_equal(env.render_depth(), want["depth"])
+    env.close()
+
+
+def test_capacity_overflow_is_reported_not_silent():
+    """More visible primitives than max_visible: the kernels set a status bit, mw_check turns it into an error
+    (nothing is dropped silently); a too small entity table is refused at mw_set_state."""
+    import torch
+    from miniworld_amd import engine as eng
+    s0, tr, meta, obs = helpers.load_case("maze_s0")          # dozens of polygons in view
+    e = helpers.make_engine_for_scene(s0, 1, max_visible=16)
+    e.set_state(helpers.scene_state_arrays([s0]))
+    rgb = torch.zeros((1, 60, 80, 3), dtype=torch.uint8, device="cuda")
+    e.render(rgb, None)
+    with pytest.raises(eng.EngineError, match="max_visible"):
+        e.check()
+    e.close()
+
+
+def test_two_engines_are_independent():
+    """Engines do not share state (the reference's display list id 1 and texture cache are process-global,
+    miniworld.py:1027, opengl.py:111): two batches of different envs interleave their steps on one device."""
+    import torch
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    a = MiniWorldVecEnv("MiniWorld-Hallway-v0", 64, seed=1)
+    b = MiniWorldVecEnv("MiniWorld-OneRoom-v0", 32, seed=1)
+    a2 = MiniWorldVecEnv("MiniWorld-Hallway-v0", 64, seed=1)
+    a.reset(); b.reset(); a2.reset()
+    g = torch.Generator(device="cuda").manual_seed(0)
+    for t in range(30):
+        act = torch.randint(0, 3, (64,), generator=g, device="cuda", dtype=torch.int32)
+        oa = a.step(act)[0].clone()
+        b.step(act[:32])
+        oa2 = a2.step(act)[0]
+        assert torch.equal(oa, oa2), t
+    for v in (a, b, a2):
+        v.engine.check()
+        v.close()
