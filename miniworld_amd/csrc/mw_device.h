@@ -96,4 +96,5 @@ struct MwArgs {
     // mw_mesh_order_kernel turns them into the order in which the mesh kernel's blocks take the envs
     int32_t *k3_cost;       // [N]
     int32_t *k3_order;      // [N] env ids, heaviest first
+    unsigned long long *k1_prof;   // MW_K1_PROF: [N][8] cycle counters of K1's phases (perf experiments only), else null
 };

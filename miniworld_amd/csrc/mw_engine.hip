@@ -535,6 +535,9 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
+    if (getenv("MW_K1_PROF")) {
+        if (dev_alloc(e, &e->args.k1_prof, (size_t)e->cfg.num_envs * 8) != MW_OK) e->args.k1_prof = nullptr;
+    }
     if (getenv("MW_K3_PROF")) {
         if (dev_alloc(e, &e->d_k3prof, (size_t)e->cfg.num_envs * 4) != MW_OK) e->d_k3prof = nullptr;
     }
@@ -547,6 +550,11 @@ void mw_destroy(mw_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipDeviceSynchronize();
+    if (e->args.k1_prof) {
+        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 8);
+        if (hipMemcpy(h.data(), e->args.k1_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = fopen(getenv("MW_K1_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
     if (e->d_k3prof) {      // dump the last frame's per-env cycle counts: [env][mesh phase, tile phase, meshes, triangles]
         std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 4);
         if (hipMemcpy(h.data(), e->d_k3prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)

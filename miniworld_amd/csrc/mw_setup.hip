@@ -499,6 +499,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
 #else
     unsigned long long *s_zmin = nullptr;
 #endif
+    const unsigned long long pt0 = a.k1_prof ? __builtin_readcyclecounter() : 0ull;
     const int env = a.env_base + blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool writer = threadIdx.x == 0;       // the one thread that writes the env's state
@@ -636,6 +637,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         }
     }
 
+    const unsigned long long pt1 = a.k1_prof ? __builtin_readcyclecounter() : 0ull;
     // ---- camera + primitive setup -----------------------------------------------
     Cam cam;
     float sky[3];
@@ -651,6 +653,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
     cam.p03 = uni(cam.p03); cam.p13 = uni(cam.p13);
     c.px = uni(c.px); c.py = uni(c.py); c.pz = uni(c.pz); c.dir = uni(c.dir);
     c.cpos[0] = uni(c.cpos[0]); c.cpos[1] = uni(c.cpos[1]); c.cpos[2] = uni(c.cpos[2]); c.cdir = uni(c.cdir);
+    const unsigned long long pt2 = a.k1_prof ? __builtin_readcyclecounter() : 0ull;
     float stale_n[3] = {0.0f, 1.0f, 0.0f};       // GL's current normal after the last draw (top-view agent marker)
     int count = 0;
     const mw_poly *polys = a.polys + (size_t)c.set * a.max_polys;
@@ -705,6 +708,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
     // entities in draw order: static ones first, then dynamic (miniworld.py:1058-1060, 1075-1077).
     // Boxes become 6 polygons each (runs of up to 10 consecutive boxes share one 64-lane batch);
     // a mesh entity only reserves its range of draw ids and is described to the mesh raster kernel.
+    const unsigned long long pt3 = a.k1_prof ? __builtin_readcyclecounter() : 0ull;
     int mesh_tris = 0, n_mesh = 0;
     float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
     if (KW == 1 || wave == 0) {     // entities (and the agent marker) are few: wave 0 of the env alone
@@ -918,6 +922,11 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         }
     }
 #endif
+    if (writer && a.k1_prof) {      // MW_K1_PROF: cycles of the phases (perf experiments only, tools/perf/k1prof.py)
+        const unsigned long long pt4 = __builtin_readcyclecounter();
+        unsigned long long *pp = a.k1_prof + (size_t)env * 8;
+        pp[0] = pt1 - pt0; pp[1] = pt2 - pt1; pp[2] = pt3 - pt2; pp[3] = pt4 - pt3; pp[4] = (unsigned long long)regenerated;
+    }
     if (writer) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
         a.k3_cost[env] = mesh_tris;             // mesh triangles in view: the mesh kernel's scheduling weight
