@@ -89,6 +89,8 @@ struct mw_engine {
     bool mesh_lds_ready = false;
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
     bool visible_attr_set = false;
+    hipStream_t side_stream = nullptr;      // co-run of K2 beside the mesh kernel
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     unsigned long long *d_k3prof = nullptr;   // MW_K3_PROF=<file>: per-env cycle counts of the mesh kernel
     int obs_layout = MW_OBS_HWC_U8;
     size_t view_keys_bytes = 0;
@@ -410,12 +412,38 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             HIP_TRY(e, hipFuncSetAttribute((const void *)mw_raster_mesh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             e->mesh_lds_ready = true;
         }
+        // Co-run: the mesh kernel holds one workgroup per CU (its key buffer fills the LDS) but only 352 of a
+        // SIMD's 512 VGPRs, so the envs WITHOUT a mesh in view are drawn at the same time, in its shadow, by the
+        // records-from-global variant of K2 (192 B of LDS per wave) on a second stream; both kernels run over all
+        // envs with flag 16 and each workgroup checks its env's mesh count first.
+        const int kflags = e->dbg_flags | (e->obs_layout << 8) | 16;
+        if (!e->side_stream) {
+            int prio_least = 0, prio_greatest = 0;      // the filler kernel must not keep the mesh kernel's workgroups out
+            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+            HIP_TRY(e, hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, prio_least));
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        }
+        HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+        HIP_TRY(e, hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+        {
+            const int wpe = e->waves_per_env;
+            const int tpw = (a.n_tiles + wpe - 1) / wpe;
+            const int groups = (N + 7) / 8;
+            auto k2 = e->obs_layout != MW_OBS_HWC_U8 ? mw_raster_big_wrap_kernel : mw_raster_big_kernel;
+            hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), 192, e->side_stream, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+                               a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
+                               (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, kflags, e->texel_bytes,
+                               (const uint16_t *)nullptr);
+        }
+        HIP_TRY(e, hipEventRecord(e->ev_join, e->side_stream));
         hipLaunchKernelGGL(mw_mesh_order_kernel, dim3(1), dim3(1024), 0, st, N, (const int32_t *)a.k3_cost, a.k3_order);
         hipLaunchKernelGGL(mw_raster_mesh_kernel, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
-                           a.mesh_rgb, a.mesh_uv, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes, e->d_k3prof,
+                           a.mesh_rgb, a.mesh_uv, d_obs, d_depth, kflags, e->texel_bytes, e->d_k3prof,
                            (const int32_t *)a.k3_order);
+        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));
     } else {
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -564,6 +592,7 @@ void mw_destroy(mw_engine *e)
     if (e->d_texels) (void)hipFree(e->d_texels);
     for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb, e->d_mesh_uv}) if (p) (void)hipFree(p);
     if (e->d_view_keys) (void)hipFree(e->d_view_keys);
+    if (e->side_stream) { (void)hipStreamDestroy(e->side_stream); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
     for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     for (auto &ev : e->ev_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     delete e;

@@ -52,6 +52,8 @@ __device__ inline void raster_kernel_body(
     const int part = slot % waves_per_env;
     if (env >= N) return;
     const int lane = threadIdx.x;
+    // co-run mode (flag 16): envs with a mesh in view belong to mw_raster_mesh_kernel
+    if ((dbg & 16) && __float_as_int(envhdr[(size_t)env * MW_ENVHDR + 3]) != 0) return;
     const int nvis = nvis_arr[env];
     const float *__restrict__ rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     const float4 *g_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);

@@ -298,6 +298,9 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     const int env = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint8_t *s_pack = smem + (size_t)nkeys * 4 + wave * 192;
+    // co-run mode (flag 16): the envs without a mesh in view are being drawn at the same time by
+    // mw_raster_big_kernel on a second stream (they come last in the block order, so these blocks retire at once)
+    if ((dbg & 16) && __float_as_int(envhdr[(size_t)env * MW_ENVHDR + 3]) == 0) return;
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     for (int i = tid; i < nkeys; i += 1024) keys[i] = 0xFFFFFFFFu;
     __syncthreads();
