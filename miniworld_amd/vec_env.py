@@ -38,6 +38,10 @@ _KIND = {
     "MiniWorld-YMazeRight-v0": ("YMazeRight", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-WallGap-v0": ("WallGap", eng.GEN_NONE, eng.TASK_GOTO, 3),
     "MiniWorld-ThreeRooms-v0": ("ThreeRooms", eng.GEN_NONE, eng.TASK_NONE, 3),
+    # reward / termination rule evaluated on the host after the device step (_host_rule below): the engine's
+    # task rules are GOTO / PICKUP / PUTNEXT; these two envs add a forbidden area resp. a touch table
+    "MiniWorld-Sidewalk-v0": ("Sidewalk", eng.GEN_NONE, eng.TASK_NONE, 3),
+    "MiniWorld-Sign-v0": ("Sign", eng.GEN_NONE, eng.TASK_NONE, 4),
     "MiniWorld-PutNext-v0": ("PutNext", eng.GEN_NONE, eng.TASK_PUTNEXT, 8),
     "MiniWorld-RoomObjects-v0": ("RoomObjects", eng.GEN_NONE, eng.TASK_NONE, 8),
 }
@@ -67,7 +71,9 @@ class MiniWorldVecEnv:
         self.generator = generator
         cls = getattr(_envs, cls_name)
         # template world: geometry, textures, capacities (host-side world generation only)
-        self.template = cls(domain_rand=False, host_only=True, **env_kwargs)
+        # (Sign fixes domain_rand=False itself and does not take the argument, sign.py:92-98)
+        self._dr_kw = (lambda dr: {}) if cls_name == "Sign" else (lambda dr: {"domain_rand": dr})
+        self.template = cls(host_only=True, **self._dr_kw(False), **env_kwargs)
         self.template.reset(seed=seed)
         self._cls, self._env_kwargs = cls, env_kwargs
         sc = scene_from_env(self.template)
@@ -154,6 +160,7 @@ class MiniWorldVecEnv:
         self.rng_mode = "pcg64" if cfg.rng_mode == eng.RNG_PCG64 else "philox"
         self.engine = eng.Engine(cfg)
         self.host_autoreset = autoreset and generator == eng.GEN_NONE
+        self._host_rule = {"Sidewalk": self._rule_sidewalk, "Sign": self._rule_sign}.get(cls_name)
         self._upload_assets(sc)
         if pickup_meshes:
             from .objmesh import ObjMesh
@@ -192,7 +199,7 @@ class MiniWorldVecEnv:
         for i, s in zip(indices, seeds):
             env = self._host_envs[i]
             if env is None:
-                env = self._cls(domain_rand=self.domain_rand, host_only=True, **self._env_kwargs)
+                env = self._cls(host_only=True, **self._dr_kw(self.domain_rand), **self._env_kwargs)
                 self._host_envs[i] = env
             env.reset(seed=int(s))
             sc = scene_from_env(env)
@@ -219,6 +226,8 @@ class MiniWorldVecEnv:
     def step(self, actions):
         """actions: int32 torch tensor [N] on the engine's device."""
         self.engine.step(actions, self.obs, self.depth, self.reward, self.terminated, self.truncated)
+        if self._host_rule is not None:
+            self._host_rule(actions)
         if self.host_autoreset:
             done = (self.terminated | self.truncated).nonzero().flatten().tolist()
             if done:
@@ -227,6 +236,42 @@ class MiniWorldVecEnv:
                 self._host_generate(done, seeds)
                 self.engine.render(self.obs, self.depth)
         return self.obs, self.reward, self.terminated, self.truncated
+
+    # ------------------------------------------------------------------ env rules evaluated on the host
+    def _near(self, st, slot):
+        """MiniWorldEnv.near (miniworld.py:965-975) for every env: agent vs entity `slot`."""
+        d = np.linalg.norm(st["agent_pos"] - st["ent_pos"][:, slot], axis=1)
+        return d < self.template.agent.radius + st["ent_geom"][:, slot, 7] + 1.1 * self.template.max_forward_step
+
+    def _rule_sidewalk(self, actions):
+        """Sidewalk.step (sidewalk.py:93-104): entering the street zeroes the reward and ends the episode; reaching
+        the box adds the GOTO reward and ends it too."""
+        st = self.engine.get_state()
+        t = self.template
+        r = t.street
+        p = st["agent_pos"]
+        street = (p[:, 0] > r.min_x) & (p[:, 0] < r.max_x) & (p[:, 2] > r.min_z) & (p[:, 2] < r.max_z)    # Room.point_inside
+        ents = [e for e in t.entities if e is not t.agent]
+        near = self._near(st, ents.index(t.box))
+        reward = np.where(near, 1.0 - 0.2 * (st["step_count"] / float(t.max_episode_steps)), 0.0)
+        self.reward.copy_(self.torch.as_tensor(reward.astype(np.float32)))
+        self.terminated.copy_(self.torch.as_tensor((street | near).astype(np.uint8)))
+
+    def _rule_sign(self, actions):
+        """Sign.step (sign.py:152-170): the extra action ends the episode; touching any object ends it with +1 for
+        the object of the sign's colour and the goal's shape, -1 otherwise (a later object in the table wins)."""
+        st = self.engine.get_state()
+        t = self.template
+        ents = [e for e in t.entities if e is not t.agent]
+        term = (actions.cpu().numpy() == t.actions.move_forward + 1)
+        reward = np.zeros(self.num_envs)
+        for obj_index, pair in enumerate(t._objects):
+            for color_index, obj in enumerate(pair):
+                near = self._near(st, ents.index(obj))
+                term = term | near
+                reward = np.where(near, float(color_index == t._color_index and obj_index == t._goal) * 2 - 1, reward)
+        self.reward.copy_(self.torch.as_tensor(reward.astype(np.float32)))
+        self.terminated.copy_(self.torch.as_tensor(term.astype(np.uint8)))
 
     def render_top_view(self, render_agent=True):
         """uint8[N,H,W,3] map views (render_top_view, miniworld.py:1088-1175) of every env."""

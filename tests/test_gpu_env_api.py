@@ -719,3 +719,28 @@ def test_two_engines_are_independent():
     for v in (a, b, a2):
         v.engine.check()
         v.close()
+
+
+@pytest.mark.parametrize("case", ["sidewalk_s0", "sidewalk_s3", "sign_s0", "sign_green_key_s1"])
+def test_vec_env_host_rule_families_follow_reference_trajectory(case):
+    """Sidewalk and Sign in the batched API: device physics + rendering, reward / termination evaluated on the host
+    after the step (forbidden street area; touch table and the extra end-of-episode action).  Env 0, generated
+    from the fixture's seed, reproduces the reference's rewards, flags and poses."""
+    import torch
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    s0, tr, meta, obs = helpers.load_case(case)
+    kw = helpers.env_kwargs_of(meta)
+    vec = MiniWorldVecEnv("MiniWorld-%s-v0" % str(meta["env"]), 3, seed=int(meta["seed"]), autoreset=False, **kw)
+    o = vec.reset()
+    assert np.array_equal(o[0].cpu().numpy(), obs[0]["rgb"])
+    act = torch.zeros(3, dtype=torch.int32, device="cuda")
+    for t in range(len(tr["action"])):
+        act[:] = int(tr["action"][t])
+        o, rew, term, trunc = vec.step(act)
+        assert np.float32(tr["reward"][t]) == rew[0].item(), (case, t)
+        assert bool(term[0].item()) == bool(tr["term"][t]) and bool(trunc[0].item()) == bool(tr["trunc"][t]), (case, t)
+        if (t + 1) in obs:
+            assert np.array_equal(o[0].cpu().numpy(), obs[t + 1]["rgb"]), (case, t + 1)
+    st = vec.engine.get_state()
+    assert np.abs(st["agent_pos"][0] - tr["pos"][-1]).max() < 1e-12
+    vec.close()
