@@ -42,6 +42,7 @@ _KIND = {
     # task rules are GOTO / PICKUP / PUTNEXT; these two envs add a forbidden area resp. a touch table
     "MiniWorld-Sidewalk-v0": ("Sidewalk", eng.GEN_NONE, eng.TASK_NONE, 3),
     "MiniWorld-Sign-v0": ("Sign", eng.GEN_NONE, eng.TASK_NONE, 4),
+    "MiniWorld-CollectHealth-v0": ("CollectHealth", eng.GEN_NONE, eng.TASK_NONE, 8),
     "MiniWorld-PutNext-v0": ("PutNext", eng.GEN_NONE, eng.TASK_PUTNEXT, 8),
     "MiniWorld-RoomObjects-v0": ("RoomObjects", eng.GEN_NONE, eng.TASK_NONE, 8),
 }
@@ -160,7 +161,9 @@ class MiniWorldVecEnv:
         self.rng_mode = "pcg64" if cfg.rng_mode == eng.RNG_PCG64 else "philox"
         self.engine = eng.Engine(cfg)
         self.host_autoreset = autoreset and generator == eng.GEN_NONE
-        self._host_rule = {"Sidewalk": self._rule_sidewalk, "Sign": self._rule_sign}.get(cls_name)
+        self._host_rule = {"Sidewalk": self._rule_sidewalk, "Sign": self._rule_sign,
+                           "CollectHealth": self._rule_collecthealth}.get(cls_name)
+        self._health = np.full(num_envs, 100, np.int64)
         self._upload_assets(sc)
         if pickup_meshes:
             from .objmesh import ObjMesh
@@ -202,6 +205,7 @@ class MiniWorldVecEnv:
                 env = self._cls(host_only=True, **self._dr_kw(self.domain_rand), **self._env_kwargs)
                 self._host_envs[i] = env
             env.reset(seed=int(s))
+            self._health[i] = 100
             sc = scene_from_env(env)
             if not self.engine.cfg.shared_geometry:
                 tex_map = {k: self.tex_ids[str(v)] for k, v in enumerate(sc["tex_names"])}
@@ -272,6 +276,33 @@ class MiniWorldVecEnv:
                 reward = np.where(near, float(color_index == t._color_index and obj_index == t._goal) * 2 - 1, reward)
         self.reward.copy_(self.torch.as_tensor(reward.astype(np.float32)))
         self.terminated.copy_(self.torch.as_tensor(term.astype(np.uint8)))
+
+    def _rule_collecthealth(self, actions):
+        """CollectHealth.step (collecthealth.py:79-98): health drops by 2 per step; a kit that has just been
+        picked up is consumed (health back to 100) and re-placed with the env's own numpy stream — done on the
+        env's host object, whose entity list then has the kit at the end like the reference's, and pushed back;
+        +2 per step survived, -100 and termination when the health runs out."""
+        st = self.engine.get_state()
+        act = actions.cpu().numpy()
+        self._health -= 2
+        for i in np.nonzero((act == self.template.actions.pickup) & (st["carrying"] >= 0))[0]:
+            h = self._host_envs[i]
+            ents = [e for e in h.entities if e is not h.agent]
+            h.agent.pos, h.agent.dir = st["agent_pos"][i].copy(), float(st["agent_dir"][i])
+            for k, e in enumerate(ents):
+                e.pos, e.dir = st["ent_pos"][i, k].copy(), float(st["ent_dir"][i, k])
+            kit = ents[int(st["carrying"][i])]
+            h.entities.remove(kit)
+            h.place_entity(kit)
+            h.agent.carrying = None
+            h.step_count = int(st["step_count"][i])
+            sc = scene_from_env(h)
+            mm = upload_scene_meshes(self.engine, sc, self.mesh_ids, self.tex_ids)
+            self.engine.set_state(state_arrays([sc], self.engine.E, [mm]), first=int(i), count=1)
+            self._health[i] = 100
+        dead = self._health <= 0
+        self.reward.copy_(self.torch.as_tensor(np.where(dead, -100.0, 2.0).astype(np.float32)))
+        self.terminated.copy_(self.torch.as_tensor(dead.astype(np.uint8)))
 
     def render_top_view(self, render_agent=True):
         """uint8[N,H,W,3] map views (render_top_view, miniworld.py:1088-1175) of every env."""

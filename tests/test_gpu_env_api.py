@@ -721,11 +721,12 @@ def test_two_engines_are_independent():
         v.close()
 
 
-@pytest.mark.parametrize("case", ["sidewalk_s0", "sidewalk_s3", "sign_s0", "sign_green_key_s1"])
+@pytest.mark.parametrize("case", ["sidewalk_s0", "sidewalk_s3", "sign_s0", "sign_green_key_s1", "collecthealth_s13"])
 def test_vec_env_host_rule_families_follow_reference_trajectory(case):
-    """Sidewalk and Sign in the batched API: device physics + rendering, reward / termination evaluated on the host
-    after the step (forbidden street area; touch table and the extra end-of-episode action).  Env 0, generated
-    from the fixture's seed, reproduces the reference's rewards, flags and poses."""
+    """Sidewalk, Sign and CollectHealth in the batched API: device physics + rendering, reward / termination
+    evaluated on the host after the step (forbidden street area; touch table and the extra end-of-episode action;
+    health bookkeeping with kits respawning through the env's own numpy stream).  Env 0, generated from the
+    fixture's seed, reproduces the reference's rewards, flags, frames and poses."""
     import torch
     from miniworld_amd.vec_env import MiniWorldVecEnv
     s0, tr, meta, obs = helpers.load_case(case)
