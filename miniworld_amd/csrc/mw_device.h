@@ -45,6 +45,18 @@ struct MwGenTables {
     int32_t room_no_ceiling, pad2;
 };
 
+// The pre-generated next world of every env ("spare"): same layouts as the live arrays.  With a device generator
+// and no domain randomisation an episode's end only copies the spare into place; a low-priority kernel beside the
+// raster kernel regenerates the spare (generate_world with the state pointers redirected here).  The random stream
+// is consumed in the same order — worlds only — so seed-exactness is unaffected; with domain randomisation the
+// per-step draws interleave with the worlds in the stream, and the generator stays inline.
+struct MwSpare {
+    double *ax, *ay, *az, *adir, *cam, *light, *extent;
+    int32_t *ekind, *emesh, *estatic;
+    double *epos, *edir, *egeom;
+    mw_poly *polys; int32_t *npolys; double *segs; int32_t *nsegs;     // per-env geometry sets only
+};
+
 // Everything the kernels need; passed by value (kernarg).
 struct MwArgs {
     int32_t N, W, H, E;
@@ -92,6 +104,8 @@ struct MwArgs {
     uint16_t *rec_order;    // [N][max_vis + 1] big scenes only: [0] sorted flag, then list indices by ascending depth bound
     float *envhdr;          // [N][MW_ENVHDR]
     uint32_t *status;
+    const MwSpare *spare;   // device copy of the spare pointers, null = generator inline
+    uint8_t *refill_mask;   // [N] 1 = the env's spare was consumed and must be regenerated
     // mesh kernel scheduling (longest processing time first): K1 leaves each env's mesh triangles in view,
     // mw_mesh_order_kernel turns them into the order in which the mesh kernel's blocks take the envs
     int32_t *k3_cost;       // [N]

@@ -20,7 +20,7 @@ extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, int view_
                                                 float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                     float *reward, uint8_t *term, uint8_t *trunc);
-extern "C" __global__ void mw_reset_pcg_kernel(MwArgs a, const uint8_t *mask, int force_all);
+extern "C" __global__ void mw_reset_pcg_kernel(MwArgs a, uint8_t *mask, int force_all, int clear_mask);
 extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                      float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
@@ -46,7 +46,8 @@ extern "C" __global__ void mw_raster_big_wrap_kernel(int N, int W, int H, int ma
                                                      const float *rec_shade, const float *rec_cull, const int32_t *nvis,
                                                      const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
                                                      uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
-extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all);
+extern "C" __global__ void mw_reset_kernel(MwArgs a, uint8_t *mask, int force_all, int clear_mask);
+extern "C" __global__ void mw_take_spare_kernel(MwArgs a, const uint8_t *mask, int force_all);
 extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, const float *hdr, const float *mesh_pos, uint32_t *keys);
 extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
                                                  const float *rec_shade, const int32_t *nvis, const float *envhdr,
@@ -72,6 +73,11 @@ thread_local std::string g_create_error;
 struct mw_engine {
     mw_config cfg{};
     MwArgs args{};
+    MwArgs spare_args{};        // args with the state pointers redirected to the spare world (spare mode)
+    bool spare_mode = false;
+    bool join_pending = false;
+    MwSpare spare_host{};
+    int32_t *d_spare_dummy = nullptr;   // carry / step / picked written by the generator in spare mode go nowhere
     int n_sets = 1;
     std::string err;
     // device allocations (freed in destroy)
@@ -385,6 +391,18 @@ mw_engine::Ev get_events(mw_engine *e)
     return ev;
 }
 
+// second, low-priority stream for work that runs beside the raster kernel (spare refill, K2 beside the mesh kernel)
+int ensure_side_stream(mw_engine *e)
+{
+    if (e->side_stream) return MW_OK;
+    int prio_least = 0, prio_greatest = 0;      // the filler work must not keep the main kernels' workgroups out
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    HIP_TRY(e, hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, prio_least));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+    return MW_OK;
+}
+
 int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_actions, uint8_t *d_obs, float *d_depth,
                  float *d_reward, uint8_t *d_term, uint8_t *d_trunc, hipStream_t st)
 {
@@ -392,6 +410,10 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     MwArgs a = e->args;
     a.step_override = e->use_step_override ? e->d_step_override : nullptr;
     const int N = e->cfg.num_envs;
+    if (e->join_pending) {      // spares regenerated beside the previous raster pass
+        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));
+        e->join_pending = false;
+    }
     mw_engine::Ev ev{};
     // kernel durations are sampled: three event records on every launch cost ~4 % of the step rate,
     // on one launch in MW_TIMING_STRIDE they cost nothing measurable
@@ -404,6 +426,17 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                        d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
                        d_trunc ? d_trunc : e->d_flag_scratch + N);
     if (timed) (void)hipEventRecord(ev.b, st);
+    bool forked = false;
+    if (e->spare_mode && do_step && e->cfg.autoreset == MW_AUTORESET_SAME_STEP) {
+        // envs whose episode just ended took their spare world inside K1: regenerate those spares beside the raster pass
+        if (ensure_side_stream(e) != MW_OK) return MW_E_HIP;
+        HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+        HIP_TRY(e, hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+        forked = true;
+        hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel,
+                           dim3(e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64), dim3(64), 0, e->side_stream,
+                           e->spare_args, a.refill_mask, 0, 1);
+    }
     if (e->have_meshes) {
         // envs may contain mesh entities: one 1024-thread workgroup per env, sample keys in LDS
         const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * 192;
@@ -417,15 +450,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         // records-from-global variant of K2 (192 B of LDS per wave) on a second stream; both kernels run over all
         // envs with flag 16 and each workgroup checks its env's mesh count first.
         const int kflags = e->dbg_flags | (e->obs_layout << 8) | 16;
-        if (!e->side_stream) {
-            int prio_least = 0, prio_greatest = 0;      // the filler kernel must not keep the mesh kernel's workgroups out
-            (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-            HIP_TRY(e, hipStreamCreateWithPriority(&e->side_stream, hipStreamNonBlocking, prio_least));
-            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-            HIP_TRY(e, hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
+        if (!forked) {
+            if (ensure_side_stream(e) != MW_OK) return MW_E_HIP;
+            HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+            HIP_TRY(e, hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+            forked = true;
         }
-        HIP_TRY(e, hipEventRecord(e->ev_fork, st));
-        HIP_TRY(e, hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
         {
             const int wpe = e->waves_per_env;
             const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -436,14 +466,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                                (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, kflags, e->texel_bytes,
                                (const uint16_t *)nullptr);
         }
-        HIP_TRY(e, hipEventRecord(e->ev_join, e->side_stream));
         hipLaunchKernelGGL(mw_mesh_order_kernel, dim3(1), dim3(1024), 0, st, N, (const int32_t *)a.k3_cost, a.k3_order);
         hipLaunchKernelGGL(mw_raster_mesh_kernel, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
                            a.mesh_rgb, a.mesh_uv, d_obs, d_depth, kflags, e->texel_bytes, e->d_k3prof,
                            (const int32_t *)a.k3_order);
-        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));
     } else {
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -457,6 +485,11 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                            (const int32_t *)a.nvis,
                            (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes,
                            (const uint16_t *)a.rec_order);
+    }
+    if (forked) {
+        HIP_TRY(e, hipEventRecord(e->ev_join, e->side_stream));
+        if (e->have_meshes) HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));      // the frame itself was produced there
+        else e->join_pending = true;            // only the spare refill: the next K1 is what has to wait for it
     }
     if (timed) {
         (void)hipEventRecord(ev.c, st);
@@ -536,6 +569,27 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(polys, (size_t)e->n_sets * cfg->max_polys); ALLOC(npolys, e->n_sets);
     ALLOC(segs, (size_t)e->n_sets * cfg->max_segs * 4); ALLOC(nsegs, e->n_sets);
     a.polys = polys; a.npolys = npolys; a.segs = segs; a.nsegs = nsegs;
+    // spare mode: a pre-generated next world per env (mw_device.h::MwSpare)
+    MwSpare sp{};
+    // Off by default: measured on the headline config the refill hides K1's 9 us generator tail, but the event that
+    // forks the side stream between K1 and K2 costs 11 us (13.99 M vs 14.5 M env-steps/s).  MW_SPARE=1 switches it on.
+    e->spare_mode = cfg->generator != MW_GEN_NONE && !cfg->domain_rand && getenv("MW_SPARE") != nullptr;
+    if (e->spare_mode) {
+        ALLOC(sp.ax, N); ALLOC(sp.ay, N); ALLOC(sp.az, N); ALLOC(sp.adir, N);
+        ALLOC(sp.cam, 4 * (size_t)N); ALLOC(sp.light, 12 * (size_t)N); ALLOC(sp.extent, 4 * (size_t)N);
+        ALLOC(sp.ekind, (size_t)E * N); ALLOC(sp.emesh, (size_t)E * N); ALLOC(sp.estatic, (size_t)E * N);
+        ALLOC(sp.epos, 3 * (size_t)E * N); ALLOC(sp.edir, (size_t)E * N); ALLOC(sp.egeom, 9 * (size_t)E * N);
+        if (!cfg->shared_geometry) {
+            ALLOC(sp.polys, (size_t)e->n_sets * cfg->max_polys); ALLOC(sp.npolys, e->n_sets);
+            ALLOC(sp.segs, (size_t)e->n_sets * cfg->max_segs * 4); ALLOC(sp.nsegs, e->n_sets);
+        }
+        MwSpare *d_sp = nullptr;
+        ALLOC(d_sp, 1);
+        ALLOC(a.refill_mask, N);
+        ALLOC(e->d_spare_dummy, 3 * (size_t)N);
+        e->spare_host = sp;
+        if (rc == MW_OK) { (void)hipMemcpy(d_sp, &sp, sizeof sp, hipMemcpyHostToDevice); a.spare = d_sp; }
+    }
     ALLOC(e->d_texdesc, MW_MAX_TEX); ALLOC(e->d_meshdesc, MW_MAX_MESH);
     a.tex = e->d_texdesc; a.mesh = e->d_meshdesc;
     ALLOC(a.rec_raster, (size_t)N * cfg->max_visible * MW_RASTER_REC);
@@ -563,6 +617,18 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
+    if (e->spare_mode) {
+        // the generator writes through these pointers: everything of the world goes to the spare arrays, the random
+        // stream (rng) and the status word stay the live ones
+        MwArgs &sa = e->spare_args;
+        sa = e->args;
+        const MwSpare &sp = e->spare_host;
+        sa.ax = sp.ax; sa.ay = sp.ay; sa.az = sp.az; sa.adir = sp.adir; sa.cam = sp.cam; sa.light = sp.light; sa.extent = sp.extent;
+        sa.ekind = sp.ekind; sa.emesh = sp.emesh; sa.estatic = sp.estatic; sa.epos = sp.epos; sa.edir = sp.edir; sa.egeom = sp.egeom;
+        sa.carry = e->d_spare_dummy; sa.step = e->d_spare_dummy + e->cfg.num_envs; sa.picked = e->d_spare_dummy + 2 * (size_t)e->cfg.num_envs;
+        if (!e->cfg.shared_geometry) { sa.polys = sp.polys; sa.npolys = sp.npolys; sa.segs = sp.segs; sa.nsegs = sp.nsegs; }
+        sa.spare = nullptr;
+    }
     if (getenv("MW_K1_PROF")) {
         if (dev_alloc(e, &e->args.k1_prof, (size_t)e->cfg.num_envs * 8) != MW_OK) e->args.k1_prof = nullptr;
     }
@@ -715,6 +781,10 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
     if (e->cfg.generator == MW_GEN_NONE) return fail(e, MW_E_INVALID, "engine was created without a device-side generator");
     const int N = e->cfg.num_envs;
     hipStream_t st = (hipStream_t)stream;
+    if (e->join_pending) {      // a spare refill may still be drawing from the random streams on the side stream
+        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));
+        e->join_pending = false;
+    }
     if (seeds) {
         std::vector<uint64_t> cur(5 * (size_t)N);
         HIP_TRY(e, hipStreamSynchronize(st));
@@ -724,8 +794,18 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
         HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 40 * (size_t)N, hipMemcpyHostToDevice));
     }
     if (mask) HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, N, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel,
-                       dim3(e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64), dim3(64), 0, st, e->args, e->d_mask, mask ? 0 : 1);
+    auto gen = e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel;
+    const dim3 grid(e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64);
+    const int all = mask ? 0 : 1;
+    if (!e->spare_mode) {
+        hipLaunchKernelGGL(gen, grid, dim3(64), 0, st, e->args, e->d_mask, all, 0);
+    } else {
+        // spare mode: a fresh seed generates the live world directly; without seeds the env's pre-generated world is
+        // taken (what the same-step auto-reset does); either way the spare is then (re)generated from the stream
+        if (seeds) hipLaunchKernelGGL(gen, grid, dim3(64), 0, st, e->args, e->d_mask, all, 0);
+        else hipLaunchKernelGGL(mw_take_spare_kernel, dim3(N), dim3(64), 0, st, e->args, (const uint8_t *)e->d_mask, all);
+        hipLaunchKernelGGL(gen, grid, dim3(64), 0, st, e->spare_args, e->d_mask, all, 0);
+    }
     HIP_TRY(e, hipGetLastError());
     return MW_OK;
 }

@@ -443,4 +443,36 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     rng_store(a.rng, a.N, env, r);
 }
 
+// An episode ends in spare mode: the env's pre-generated world becomes the live one (64 lanes of one wavefront).
+__device__ inline void take_spare(const MwArgs &a, int env, int lane)
+{
+    const MwSpare &sp = *a.spare;
+    const size_t N = a.N, E = a.E;
+    if (lane == 0) {
+        a.ax[env] = sp.ax[env]; a.ay[env] = sp.ay[env]; a.az[env] = sp.az[env]; a.adir[env] = sp.adir[env];
+        for (int k = 0; k < 4; ++k) a.cam[(size_t)k * N + env] = sp.cam[(size_t)k * N + env];
+        for (int k = 0; k < 12; ++k) a.light[(size_t)k * N + env] = sp.light[(size_t)k * N + env];
+        for (int k = 0; k < 4; ++k) a.extent[(size_t)k * N + env] = sp.extent[(size_t)k * N + env];
+        a.carry[env] = -1; a.step[env] = 0; a.picked[env] = 0;
+    }
+    for (int s = lane; s < (int)E; s += 64) {
+        a.ekind[(size_t)s * N + env] = sp.ekind[(size_t)s * N + env];
+        a.emesh[(size_t)s * N + env] = sp.emesh[(size_t)s * N + env];
+        a.estatic[(size_t)s * N + env] = sp.estatic[(size_t)s * N + env];
+        a.edir[(size_t)s * N + env] = sp.edir[(size_t)s * N + env];
+        for (int k = 0; k < 3; ++k) a.epos[((size_t)k * E + s) * N + env] = sp.epos[((size_t)k * E + s) * N + env];
+        for (int k = 0; k < 9; ++k) a.egeom[((size_t)k * E + s) * N + env] = sp.egeom[((size_t)k * E + s) * N + env];
+    }
+    if (!a.shared_geom) {
+        const int np = sp.npolys[env], ns = sp.nsegs[env];
+        const float4 *ps = reinterpret_cast<const float4 *>(sp.polys + (size_t)env * a.max_polys);
+        float4 *pd = reinterpret_cast<float4 *>(const_cast<mw_poly *>(a.polys) + (size_t)env * a.max_polys);
+        for (int i = lane; i < np * (int)(sizeof(mw_poly) / 16); i += 64) pd[i] = ps[i];
+        const double *ss = sp.segs + (size_t)env * a.max_segs * 4;
+        double *sd = const_cast<double *>(a.segs) + (size_t)env * a.max_segs * 4;
+        for (int i = lane; i < ns * 4; i += 64) sd[i] = ss[i];
+        if (lane == 0) { const_cast<int32_t *>(a.npolys)[env] = np; const_cast<int32_t *>(a.nsegs)[env] = ns; }
+    }
+}
+
 }  // namespace mw

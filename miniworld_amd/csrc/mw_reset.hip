@@ -5,7 +5,7 @@
 #ifndef MW_RESET_KERNEL_NAME
 #define MW_RESET_KERNEL_NAME mw_reset_kernel
 #endif
-extern "C" __global__ __launch_bounds__(64) void MW_RESET_KERNEL_NAME(MwArgs a, const uint8_t *__restrict__ mask, int force_all)
+extern "C" __global__ __launch_bounds__(64) void MW_RESET_KERNEL_NAME(MwArgs a, uint8_t *__restrict__ mask, int force_all, int clear_mask)
 {
     __shared__ unsigned char ws[64][MW_GEN_WS_BYTES];
     const bool wave_per_env = a.generator == MW_GEN_MAZE;
@@ -13,4 +13,16 @@ extern "C" __global__ __launch_bounds__(64) void MW_RESET_KERNEL_NAME(MwArgs a, 
     if (env >= a.N) return;
     if (!force_all && !mask[env]) return;
     mw::generate_world(a, env, wave_per_env ? ws[0] : ws[threadIdx.x], wave_per_env ? (int)threadIdx.x : 0);
+    if (clear_mask && (!wave_per_env || threadIdx.x == 0)) mask[env] = 0;      // spare regenerated
 }
+
+#if MW_RNG_KIND == 0
+// mw_reset without seeds in spare mode: the masked envs take their pre-generated world (one wavefront per env)
+extern "C" __global__ __launch_bounds__(64) void mw_take_spare_kernel(MwArgs a, const uint8_t *__restrict__ mask, int force_all)
+{
+    const int env = blockIdx.x;
+    if (env >= a.N) return;
+    if (!force_all && !mask[env]) return;
+    mw::take_spare(a, env, (int)threadIdx.x);
+}
+#endif

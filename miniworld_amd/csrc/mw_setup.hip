@@ -629,7 +629,13 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         // next episode (the reference leaves the reset to the caller, scripts/benchmark.py:36-37)
         regenerated = (tm | tr) != 0;
         if (regenerated) {
-            if (wave == 0) mw::generate_world(a, env, gen_ws, lane);
+            if (wave == 0) {
+                if (a.spare) {          // the world was generated ahead, beside an earlier raster pass
+                    mw::take_spare(a, env, lane);
+                    if (lane == 0) a.refill_mask[env] = 1;      // ... and the next one will be, beside this one
+                }
+                else mw::generate_world(a, env, gen_ws, lane);
+            }
             __syncthreads();
             c.px = a.ax[env]; c.py = a.ay[env]; c.pz = a.az[env]; c.dir = a.adir[env];
             c.carry = -1; c.live = -1;

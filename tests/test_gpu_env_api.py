@@ -745,3 +745,47 @@ def test_vec_env_host_rule_families_follow_reference_trajectory(case):
     st = vec.engine.get_state()
     assert np.abs(st["agent_pos"][0] - tr["pos"][-1]).max() < 1e-12
     vec.close()
+
+
+@pytest.mark.parametrize("env_id,cls_name", [("MiniWorld-Hallway-v0", "Hallway"), ("MiniWorld-MazeS3-v0", "MazeS3")])
+def test_spare_world_mode_keeps_the_reference_stream(env_id, cls_name, monkeypatch):
+    """MW_SPARE=1 (off by default): episodes end by copying a pre-generated world into place,
+    a side-stream kernel regenerates it beside the raster pass.  The random stream is consumed in the same order,
+    so explicit resets and auto-resets still produce the reference's worlds."""
+    import torch
+    from miniworld_amd import envs
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    monkeypatch.setenv("MW_SPARE", "1")
+    n, s = 48, 300
+    vec = MiniWorldVecEnv(env_id, n, seed=s)
+    vec.reset()
+    hosts = [getattr(envs, cls_name)(host_only=True) for _ in range(n)]
+    for i, h in enumerate(hosts):
+        h.reset(seed=s + i)
+    st = vec.engine.get_state()
+    for i, h in enumerate(hosts):
+        _assert_same_world(vec, st, i, h, "episode 1")
+    for h in hosts:
+        h.reset()
+    vec.engine.reset(None, None)
+    st = vec.engine.get_state()
+    for i, h in enumerate(hosts):
+        _assert_same_world(vec, st, i, h, "episode 2")
+    g = torch.Generator(device="cuda").manual_seed(4)
+    episodes = np.full(n, 2)
+    for t in range(300):
+        act = torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32)
+        act[torch.rand(n, generator=g, device="cuda") < 0.6] = 2
+        _, _, term, trunc = vec.step(act)
+        d = (term | trunc).bool().cpu().numpy()
+        if d.any():
+            st = vec.engine.get_state()
+            for i in np.nonzero(d)[0]:
+                hosts[i].reset()
+                episodes[i] += 1
+                _assert_same_world(vec, st, i, hosts[i], f"auto-reset at step {t} (episode {episodes[i]})")
+        if episodes.max() >= 5 and (episodes > 2).sum() > n // 4:
+            break
+    assert (episodes > 2).any()
+    vec.engine.check()
+    vec.close()
