@@ -46,8 +46,8 @@ struct MwGenTables {
 };
 
 // The pre-generated next world of every env ("spare"): same layouts as the live arrays.  With a device generator
-// and no domain randomisation an episode's end only copies the spare into place; a low-priority kernel beside the
-// raster kernel regenerates the spare (generate_world with the state pointers redirected here).  The random stream
+// and no domain randomisation an episode's end only copies the spare into place; extra blocks of the NEXT step's K1
+// regenerate it while the regular blocks step (generate_world with the state pointers redirected here).  The random stream
 // is consumed in the same order — worlds only — so seed-exactness is unaffected; with domain randomisation the
 // per-step draws interleave with the worlds in the stream, and the generator stays inline.
 struct MwSpare {
@@ -105,7 +105,9 @@ struct MwArgs {
     float *envhdr;          // [N][MW_ENVHDR]
     uint32_t *status;
     const MwSpare *spare;   // device copy of the spare pointers, null = generator inline
-    uint8_t *refill_mask;   // [N] 1 = the env's spare was consumed and must be regenerated
+    uint32_t *refill_mask;  // [N] 0 spare ready, 1 consumed (refill pending), 2 refill running, 3 env regenerating inline
+    const MwArgs *gen_live; // device copies of this struct for the generators (live state / spare state): they index
+    const MwArgs *gen_spare;//   it dynamically, which a by-value kernarg would turn into a scratch copy
     // mesh kernel scheduling (longest processing time first): K1 leaves each env's mesh triangles in view,
     // mw_mesh_order_kernel turns them into the order in which the mesh kernel's blocks take the envs
     int32_t *k3_cost;       // [N]

@@ -20,7 +20,7 @@ extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, int view_
                                                 float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                     float *reward, uint8_t *term, uint8_t *trunc);
-extern "C" __global__ void mw_reset_pcg_kernel(MwArgs a, uint8_t *mask, int force_all, int clear_mask);
+extern "C" __global__ void mw_reset_pcg_kernel(MwArgs a, const uint8_t *mask, int force_all, int mark_refill);
 extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                      float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
@@ -46,7 +46,9 @@ extern "C" __global__ void mw_raster_big_wrap_kernel(int N, int W, int H, int ma
                                                      const float *rec_shade, const float *rec_cull, const int32_t *nvis,
                                                      const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
                                                      uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
-extern "C" __global__ void mw_reset_kernel(MwArgs a, uint8_t *mask, int force_all, int clear_mask);
+extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all, int mark_refill);
+extern "C" __global__ void mw_refill_kernel(MwArgs a);
+extern "C" __global__ void mw_refill_pcg_kernel(MwArgs a);
 extern "C" __global__ void mw_take_spare_kernel(MwArgs a, const uint8_t *mask, int force_all);
 extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, const float *hdr, const float *mesh_pos, uint32_t *keys);
 extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
@@ -73,9 +75,8 @@ thread_local std::string g_create_error;
 struct mw_engine {
     mw_config cfg{};
     MwArgs args{};
-    MwArgs spare_args{};        // args with the state pointers redirected to the spare world (spare mode)
+    MwArgs *d_gen_live = nullptr, *d_gen_spare = nullptr;   // device copies of the argument block for the generators
     bool spare_mode = false;
-    bool join_pending = false;
     MwSpare spare_host{};
     int32_t *d_spare_dummy = nullptr;   // carry / step / picked written by the generator in spare mode go nowhere
     int n_sets = 1;
@@ -261,6 +262,8 @@ void build_pyramid(const uint8_t *rgb, int w, int h, std::vector<uint32_t> &out,
     }
 }
 
+int sync_gen_args(mw_engine *e);
+
 int upload_textures(mw_engine *e)
 {
     size_t total = 0;
@@ -279,6 +282,7 @@ int upload_textures(mw_engine *e)
     }
     HIP_TRY(e, hipMemcpy(e->d_texdesc, descs.data(), descs.size() * sizeof(MwTexDesc), hipMemcpyHostToDevice));
     e->args.texels = e->d_texels;
+    if (e->d_gen_live && sync_gen_args(e) != MW_OK) return MW_E_HIP;
     e->texel_bytes = (int)(std::max<size_t>(total, 1) * 4);
     return MW_OK;
 }
@@ -391,6 +395,37 @@ mw_engine::Ev get_events(mw_engine *e)
     return ev;
 }
 
+// Device copies of the argument block for the generators (live state; spare state with the world pointers
+// redirected): generate_world indexes the block dynamically, which a by-value kernarg would turn into a scratch copy.
+int sync_gen_args(mw_engine *e)
+{
+    if (e->cfg.generator == MW_GEN_NONE) return MW_OK;
+    if (!e->d_gen_live) {
+        HIP_TRY(e, hipMalloc((void **)&e->d_gen_live, sizeof(MwArgs)));
+        e->allocs.push_back(e->d_gen_live);
+        e->args.gen_live = e->d_gen_live;
+        if (e->spare_mode) {
+            HIP_TRY(e, hipMalloc((void **)&e->d_gen_spare, sizeof(MwArgs)));
+            e->allocs.push_back(e->d_gen_spare);
+            e->args.gen_spare = e->d_gen_spare;
+        }
+    }
+    MwArgs live = e->args;
+    HIP_TRY(e, hipMemcpy(e->d_gen_live, &live, sizeof live, hipMemcpyHostToDevice));
+    if (e->spare_mode) {
+        // everything of the world goes to the spare arrays; the random stream (rng) and the status word stay the live ones
+        MwArgs sa = e->args;
+        const MwSpare &sp = e->spare_host;
+        sa.ax = sp.ax; sa.ay = sp.ay; sa.az = sp.az; sa.adir = sp.adir; sa.cam = sp.cam; sa.light = sp.light; sa.extent = sp.extent;
+        sa.ekind = sp.ekind; sa.emesh = sp.emesh; sa.estatic = sp.estatic; sa.epos = sp.epos; sa.edir = sp.edir; sa.egeom = sp.egeom;
+        sa.carry = e->d_spare_dummy; sa.step = e->d_spare_dummy + e->cfg.num_envs; sa.picked = e->d_spare_dummy + 2 * (size_t)e->cfg.num_envs;
+        if (!e->cfg.shared_geometry) { sa.polys = sp.polys; sa.npolys = sp.npolys; sa.segs = sp.segs; sa.nsegs = sp.nsegs; }
+        sa.spare = nullptr;
+        HIP_TRY(e, hipMemcpy(e->d_gen_spare, &sa, sizeof sa, hipMemcpyHostToDevice));
+    }
+    return MW_OK;
+}
+
 // second, low-priority stream for work that runs beside the raster kernel (spare refill, K2 beside the mesh kernel)
 int ensure_side_stream(mw_engine *e)
 {
@@ -410,10 +445,6 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     MwArgs a = e->args;
     a.step_override = e->use_step_override ? e->d_step_override : nullptr;
     const int N = e->cfg.num_envs;
-    if (e->join_pending) {      // spares regenerated beside the previous raster pass
-        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));
-        e->join_pending = false;
-    }
     mw_engine::Ev ev{};
     // kernel durations are sampled: three event records on every launch cost ~4 % of the step rate,
     // on one launch in MW_TIMING_STRIDE they cost nothing measurable
@@ -422,21 +453,13 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         ev = get_events(e);
         (void)hipEventRecord(ev.a, st);
     }
-    hipLaunchKernelGGL(k1_of(e), dim3(N), dim3(k1_threads(e)), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
+    // spare mode: blocks appended to the grid regenerate the spare worlds consumed in earlier steps, beside the step itself
+    const int refill_blocks = (e->spare_mode && do_step) ? (e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64) : 0;
+    hipLaunchKernelGGL(k1_of(e), dim3(N + refill_blocks), dim3(k1_threads(e)), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
                        d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
                        d_trunc ? d_trunc : e->d_flag_scratch + N);
     if (timed) (void)hipEventRecord(ev.b, st);
     bool forked = false;
-    if (e->spare_mode && do_step && e->cfg.autoreset == MW_AUTORESET_SAME_STEP) {
-        // envs whose episode just ended took their spare world inside K1: regenerate those spares beside the raster pass
-        if (ensure_side_stream(e) != MW_OK) return MW_E_HIP;
-        HIP_TRY(e, hipEventRecord(e->ev_fork, st));
-        HIP_TRY(e, hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-        forked = true;
-        hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel,
-                           dim3(e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64), dim3(64), 0, e->side_stream,
-                           e->spare_args, a.refill_mask, 0, 1);
-    }
     if (e->have_meshes) {
         // envs may contain mesh entities: one 1024-thread workgroup per env, sample keys in LDS
         const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * 192;
@@ -488,8 +511,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     }
     if (forked) {
         HIP_TRY(e, hipEventRecord(e->ev_join, e->side_stream));
-        if (e->have_meshes) HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));      // the frame itself was produced there
-        else e->join_pending = true;            // only the spare refill: the next K1 is what has to wait for it
+        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));
     }
     if (timed) {
         (void)hipEventRecord(ev.c, st);
@@ -571,8 +593,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.polys = polys; a.npolys = npolys; a.segs = segs; a.nsegs = nsegs;
     // spare mode: a pre-generated next world per env (mw_device.h::MwSpare)
     MwSpare sp{};
-    // Off by default: measured on the headline config the refill hides K1's 9 us generator tail, but the event that
-    // forks the side stream between K1 and K2 costs 11 us (13.99 M vs 14.5 M env-steps/s).  MW_SPARE=1 switches it on.
+    // Off by default: on the headline config it shortens K1 by 2 us of 51 (the episode-end blocks are not what bounds
+    // the kernel), inside the run-to-run noise of the step rate.  MW_SPARE=1 switches it on.
     e->spare_mode = cfg->generator != MW_GEN_NONE && !cfg->domain_rand && getenv("MW_SPARE") != nullptr;
     if (e->spare_mode) {
         ALLOC(sp.ax, N); ALLOC(sp.ay, N); ALLOC(sp.az, N); ALLOC(sp.adir, N);
@@ -588,6 +610,10 @@ int mw_create(const mw_config *cfg, mw_engine **out)
         ALLOC(a.refill_mask, N);
         ALLOC(e->d_spare_dummy, 3 * (size_t)N);
         e->spare_host = sp;
+        if (rc == MW_OK) {      // every spare starts out consumed: the first reset generates it
+            std::vector<uint32_t> ones((size_t)N, 1u);
+            (void)hipMemcpy(a.refill_mask, ones.data(), 4 * (size_t)N, hipMemcpyHostToDevice);
+        }
         if (rc == MW_OK) { (void)hipMemcpy(d_sp, &sp, sizeof sp, hipMemcpyHostToDevice); a.spare = d_sp; }
     }
     ALLOC(e->d_texdesc, MW_MAX_TEX); ALLOC(e->d_meshdesc, MW_MAX_MESH);
@@ -617,24 +643,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
-    if (e->spare_mode) {
-        // the generator writes through these pointers: everything of the world goes to the spare arrays, the random
-        // stream (rng) and the status word stay the live ones
-        MwArgs &sa = e->spare_args;
-        sa = e->args;
-        const MwSpare &sp = e->spare_host;
-        sa.ax = sp.ax; sa.ay = sp.ay; sa.az = sp.az; sa.adir = sp.adir; sa.cam = sp.cam; sa.light = sp.light; sa.extent = sp.extent;
-        sa.ekind = sp.ekind; sa.emesh = sp.emesh; sa.estatic = sp.estatic; sa.epos = sp.epos; sa.edir = sp.edir; sa.egeom = sp.egeom;
-        sa.carry = e->d_spare_dummy; sa.step = e->d_spare_dummy + e->cfg.num_envs; sa.picked = e->d_spare_dummy + 2 * (size_t)e->cfg.num_envs;
-        if (!e->cfg.shared_geometry) { sa.polys = sp.polys; sa.npolys = sp.npolys; sa.segs = sp.segs; sa.nsegs = sp.nsegs; }
-        sa.spare = nullptr;
-    }
-    if (getenv("MW_K1_PROF")) {
-        if (dev_alloc(e, &e->args.k1_prof, (size_t)e->cfg.num_envs * 8) != MW_OK) e->args.k1_prof = nullptr;
-    }
-    if (getenv("MW_K3_PROF")) {
-        if (dev_alloc(e, &e->d_k3prof, (size_t)e->cfg.num_envs * 4) != MW_OK) e->d_k3prof = nullptr;
-    }
+    if (sync_gen_args(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     *out = e;
     return MW_OK;
 }
@@ -713,6 +722,7 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
     }
     HIP_TRY(e, hipMemcpy(e->d_meshdesc, e->mesh_desc.data(), sizeof(MwMeshDesc) * MW_MAX_MESH, hipMemcpyHostToDevice));
     e->args.mesh_pos = e->d_mesh_pos; e->args.mesh_nrm = e->d_mesh_nrm; e->args.mesh_rgb = e->d_mesh_rgb; e->args.mesh_uv = e->d_mesh_uv;
+    if (e->d_gen_live && sync_gen_args(e) != MW_OK) return MW_E_HIP;
     e->have_meshes = true;
     return MW_OK;
 }
@@ -781,10 +791,6 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
     if (e->cfg.generator == MW_GEN_NONE) return fail(e, MW_E_INVALID, "engine was created without a device-side generator");
     const int N = e->cfg.num_envs;
     hipStream_t st = (hipStream_t)stream;
-    if (e->join_pending) {      // a spare refill may still be drawing from the random streams on the side stream
-        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));
-        e->join_pending = false;
-    }
     if (seeds) {
         std::vector<uint64_t> cur(5 * (size_t)N);
         HIP_TRY(e, hipStreamSynchronize(st));
@@ -794,17 +800,24 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
         HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 40 * (size_t)N, hipMemcpyHostToDevice));
     }
     if (mask) HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, N, hipMemcpyHostToDevice, st));
-    auto gen = e->cfg.rng_mode == MW_RNG_PCG64 ? mw_reset_pcg_kernel : mw_reset_kernel;
+    const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
+    auto gen = pcg ? mw_reset_pcg_kernel : mw_reset_kernel;
     const dim3 grid(e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64);
     const int all = mask ? 0 : 1;
     if (!e->spare_mode) {
-        hipLaunchKernelGGL(gen, grid, dim3(64), 0, st, e->args, e->d_mask, all, 0);
+        hipLaunchKernelGGL(gen, grid, dim3(64), 0, st, e->args, (const uint8_t *)e->d_mask, all, 0);
     } else {
         // spare mode: a fresh seed generates the live world directly; without seeds the env's pre-generated world is
-        // taken (what the same-step auto-reset does); either way the spare is then (re)generated from the stream
-        if (seeds) hipLaunchKernelGGL(gen, grid, dim3(64), 0, st, e->args, e->d_mask, all, 0);
-        else hipLaunchKernelGGL(mw_take_spare_kernel, dim3(N), dim3(64), 0, st, e->args, (const uint8_t *)e->d_mask, all);
-        hipLaunchKernelGGL(gen, grid, dim3(64), 0, st, e->spare_args, e->d_mask, all, 0);
+        // taken (what the same-step auto-reset does, after the pending refills have been run); either way the spare
+        // of a reset env is then regenerated from its stream
+        auto refill = pcg ? mw_refill_pcg_kernel : mw_refill_kernel;
+        if (seeds) {
+            hipLaunchKernelGGL(gen, grid, dim3(64), 0, st, e->args, (const uint8_t *)e->d_mask, all, 1);
+        } else {
+            hipLaunchKernelGGL(refill, grid, dim3(64), 0, st, e->args);
+            hipLaunchKernelGGL(mw_take_spare_kernel, dim3(N), dim3(64), 0, st, e->args, (const uint8_t *)e->d_mask, all);
+        }
+        hipLaunchKernelGGL(refill, grid, dim3(64), 0, st, e->args);
     }
     HIP_TRY(e, hipGetLastError());
     return MW_OK;

@@ -475,4 +475,22 @@ __device__ inline void take_spare(const MwArgs &a, int env, int lane)
     }
 }
 
+// Spare refill, executed by extra blocks appended to K1's grid (and by mw_refill_kernel when mw_reset needs the
+// spares current): block r handles 64 envs, one per thread — or one env with all 64 lanes for the Maze generator.
+// An env is claimed with a compare-and-swap on its refill state, so that its own K1 block, should the new episode
+// end at once, either regenerates inline (claim won: state 3) or waits for this block (state 2).
+__device__ inline void refill_spares(const MwArgs &a, int r, int tid, unsigned char *ws)
+{
+    if (tid >= 64) return;
+    const bool wpe = a.generator == MW_GEN_MAZE;
+    const int env = wpe ? r : r * 64 + tid, lane = wpe ? tid : 0;
+    int got = 0;
+    if (env < a.N && lane == 0) got = atomicCAS(a.refill_mask + env, 1u, 2u) == 1u;
+    if (wpe) got = __shfl(got, 0);
+    if (!got) return;
+    generate_world(*a.gen_spare, env, ws, lane);       // the workspace is the Maze generator's (one env per block there)
+    __threadfence();
+    if (lane == 0) atomicExch(a.refill_mask + env, 0u);
+}
+
 }  // namespace mw

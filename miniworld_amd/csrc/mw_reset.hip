@@ -5,15 +5,25 @@
 #ifndef MW_RESET_KERNEL_NAME
 #define MW_RESET_KERNEL_NAME mw_reset_kernel
 #endif
-extern "C" __global__ __launch_bounds__(64) void MW_RESET_KERNEL_NAME(MwArgs a, uint8_t *__restrict__ mask, int force_all, int clear_mask)
+extern "C" __global__ __launch_bounds__(64) void MW_RESET_KERNEL_NAME(MwArgs a, const uint8_t *__restrict__ mask, int force_all, int mark_refill)
 {
     __shared__ unsigned char ws[64][MW_GEN_WS_BYTES];
     const bool wave_per_env = a.generator == MW_GEN_MAZE;
     const int env = wave_per_env ? (int)blockIdx.x : (int)(blockIdx.x * 64 + threadIdx.x);
     if (env >= a.N) return;
     if (!force_all && !mask[env]) return;
-    mw::generate_world(a, env, wave_per_env ? ws[0] : ws[threadIdx.x], wave_per_env ? (int)threadIdx.x : 0);
-    if (clear_mask && (!wave_per_env || threadIdx.x == 0)) mask[env] = 0;      // spare regenerated
+    mw::generate_world(*a.gen_live, env, wave_per_env ? ws[0] : ws[threadIdx.x], wave_per_env ? (int)threadIdx.x : 0);
+    if (mark_refill && (!wave_per_env || threadIdx.x == 0)) a.refill_mask[env] = 1u;      // spare mode: its spare is stale now
+}
+
+#ifndef MW_REFILL_KERNEL_NAME
+#define MW_REFILL_KERNEL_NAME mw_refill_kernel
+#endif
+// spare mode: regenerate every consumed spare now (mw_reset needs them current); grid like K1's refill blocks
+extern "C" __global__ __launch_bounds__(64) void MW_REFILL_KERNEL_NAME(MwArgs a)
+{
+    __shared__ unsigned char refill_ws[MW_GEN_WS_BYTES];
+    mw::refill_spares(a, (int)blockIdx.x, (int)threadIdx.x, refill_ws);
 }
 
 #if MW_RNG_KIND == 0
@@ -24,5 +34,6 @@ extern "C" __global__ __launch_bounds__(64) void mw_take_spare_kernel(MwArgs a, 
     if (env >= a.N) return;
     if (!force_all && !mask[env]) return;
     mw::take_spare(a, env, (int)threadIdx.x);
+    if (threadIdx.x == 0) a.refill_mask[env] = 1u;
 }
 #endif

@@ -493,6 +493,12 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
     constexpr int KW = MW_K1_WAVES;
     __shared__ int s_cnt[2][KW];
     __shared__ unsigned char gen_ws[MW_GEN_WS_BYTES];
+    // spare mode: blocks appended to the grid regenerate the spare worlds consumed in earlier steps, beside the step
+    // itself (measured both ways: at the head of the grid they delay the env blocks more than they hide)
+    if ((int)blockIdx.x >= a.N) {
+        mw::refill_spares(a, (int)blockIdx.x - a.N, (int)threadIdx.x, gen_ws);
+        return;
+    }
 #if MW_SORT_VIS
     __shared__ unsigned long long s_zmin_buf[MW_SORT_CAP];
     unsigned long long *s_zmin = s_zmin_buf;
@@ -629,12 +635,26 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         // next episode (the reference leaves the reset to the caller, scripts/benchmark.py:36-37)
         regenerated = (tm | tr) != 0;
         if (regenerated) {
-            if (wave == 0) {
-                if (a.spare) {          // the world was generated ahead, beside an earlier raster pass
-                    mw::take_spare(a, env, lane);
-                    if (lane == 0) a.refill_mask[env] = 1;      // ... and the next one will be, beside this one
+            if (a.spare) {
+                // the next world was generated ahead (by a refill block of an earlier launch): claim it
+                if (writer) s_cnt[0][0] = (int)atomicCAS(a.refill_mask + env, 1u, 3u);
+                __syncthreads();
+                const int old = s_cnt[0][0];
+                if (old == 1) {
+                    // the previous episode lasted one step and the refill has not run yet: generate in place
+                    if (wave == 0) mw::generate_world(*a.gen_live, env, gen_ws, lane);
+                } else {
+                    if (old == 2) {     // a refill block of this very launch is on it
+                        if (writer) while (__hip_atomic_load(a.refill_mask + env, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != 0u) __builtin_amdgcn_s_sleep(16);
+                        __syncthreads();
+                    }
+                    if (wave == 0) mw::take_spare(a, env, lane);
                 }
-                else mw::generate_world(a, env, gen_ws, lane);
+                __threadfence();
+                __syncthreads();
+                if (writer) atomicExch(a.refill_mask + env, 1u);        // the spare is missing again
+            } else if (wave == 0) {
+                mw::generate_world(*a.gen_live, env, gen_ws, lane);
             }
             __syncthreads();
             c.px = a.ax[env]; c.py = a.ay[env]; c.pz = a.az[env]; c.dir = a.adir[env];
