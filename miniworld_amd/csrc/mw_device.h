@@ -23,7 +23,15 @@
 
 struct MwTexDesc {
     uint32_t w, h, nlevels, pad;
-    uint32_t off[MW_MAX_LEVELS];   // first texel (dword index into the texel pool) of each level
+    // per mip level, everything a bilinear fetch needs, so that a lane gets it with two 16-byte loads instead of
+    // shifting / clamping / converting the level-0 size itself (8 VALU instructions per level and fetch)
+    struct Level {
+        uint32_t off;              // first texel (dword index into the texel pool)
+        uint32_t w;                // row length in texels
+        uint32_t wmask, hmask;     // w - 1, h - 1 (wrap masks of power-of-two levels)
+        float fw, fh;              // (float)w, (float)h
+        uint32_t h, pad;
+    } lvl[MW_MAX_LEVELS];
 };
 
 struct MwMeshDesc {

@@ -31,6 +31,11 @@ extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, in
                                             const float *envhdr,
                                             const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth, int dbg,
                                             int texel_bytes, const uint16_t *rec_order);
+extern "C" __global__ void mw_raster_depth_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                                  int waves_per_env, int tiles_per_wave, const float *rec_raster,
+                                                  const float *rec_shade, const float *rec_cull, const int32_t *nvis,
+                                                  const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
+                                                  uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
 extern "C" __global__ void mw_raster_big_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                                 int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                                 const float *rec_shade, const float *rec_cull, const int32_t *nvis,
@@ -237,7 +242,7 @@ void build_pyramid(const uint8_t *rgb, int w, int h, std::vector<uint32_t> &out,
     desc.w = (uint32_t)w; desc.h = (uint32_t)h; desc.nlevels = 0; desc.pad = 0;
     out.clear();
     for (;;) {
-        desc.off[desc.nlevels++] = (uint32_t)out.size();
+        desc.lvl[desc.nlevels++] = MwTexDesc::Level{(uint32_t)out.size(), (uint32_t)w, (uint32_t)w - 1u, (uint32_t)h - 1u, (float)w, (float)h, (uint32_t)h, 0u};
         for (size_t i = 0; i < (size_t)w * h; ++i)
             out.push_back((uint32_t)cur[i * 3] | ((uint32_t)cur[i * 3 + 1] << 8) | ((uint32_t)cur[i * 3 + 2] << 16) | 0xFF000000u);
         if ((w == 1 && h == 1) || desc.nlevels == MW_MAX_LEVELS) break;
@@ -264,17 +269,21 @@ void build_pyramid(const uint8_t *rgb, int w, int h, std::vector<uint32_t> &out,
 
 int sync_gen_args(mw_engine *e);
 
+// One device block holds the descriptor table followed by the texels of every level: the raster kernels reach
+// both through a single buffer resource (4 SGPRs instead of 8), texel offsets count dwords from the block's start.
 int upload_textures(mw_engine *e)
 {
-    size_t total = 0;
+    const size_t table = (size_t)MW_MAX_TEX * sizeof(MwTexDesc) / 4;       // dwords
+    size_t total = table;
     std::vector<MwTexDesc> descs = e->tex_desc;
     for (size_t i = 0; i < descs.size(); ++i) {
-        for (uint32_t l = 0; l < descs[i].nlevels; ++l) descs[i].off[l] += (uint32_t)total;
+        for (uint32_t l = 0; l < descs[i].nlevels; ++l) descs[i].lvl[l].off += (uint32_t)total;
         total += e->tex_data[i].size();
     }
-    if (e->d_texels) { (void)hipFree(e->d_texels); e->d_texels = nullptr; }
-    HIP_TRY(e, hipMalloc((void **)&e->d_texels, std::max<size_t>(total, 1) * 4));
-    size_t off = 0;
+    if (e->d_texels) { (void)hipFree(e->d_texels); e->d_texels = nullptr; e->d_texdesc = nullptr; }
+    HIP_TRY(e, hipMalloc((void **)&e->d_texels, total * 4));
+    e->d_texdesc = reinterpret_cast<MwTexDesc *>(e->d_texels);
+    size_t off = table;
     for (size_t i = 0; i < descs.size(); ++i) {
         if (!e->tex_data[i].empty())
             HIP_TRY(e, hipMemcpy(e->d_texels + off, e->tex_data[i].data(), e->tex_data[i].size() * 4, hipMemcpyHostToDevice));
@@ -282,8 +291,9 @@ int upload_textures(mw_engine *e)
     }
     HIP_TRY(e, hipMemcpy(e->d_texdesc, descs.data(), descs.size() * sizeof(MwTexDesc), hipMemcpyHostToDevice));
     e->args.texels = e->d_texels;
+    e->args.tex = e->d_texdesc;
+    e->texel_bytes = (int)(total * 4);
     if (e->d_gen_live && sync_gen_args(e) != MW_OK) return MW_E_HIP;
-    e->texel_bytes = (int)(std::max<size_t>(total, 1) * 4);
     return MW_OK;
 }
 
@@ -501,8 +511,10 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const int groups = (N + 7) / 8;
         const bool big = e->cfg.max_visible > 64;      // records stay in global memory
         const size_t lds = big ? 192 : (size_t)e->cfg.max_visible * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
-        auto k2 = big ? mw_raster_big_kernel : mw_raster_kernel;
-        if (e->obs_layout != MW_OBS_HWC_U8) k2 = big ? mw_raster_big_wrap_kernel : mw_raster_wrap_kernel;
+        // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
+        // anything else goes to the general kernel
+        auto k2 = big ? mw_raster_big_kernel : (d_depth ? mw_raster_depth_kernel : mw_raster_kernel);
+        if (e->obs_layout != MW_OBS_HWC_U8 || (!big && e->dbg_flags != 0)) k2 = big ? mw_raster_big_wrap_kernel : mw_raster_wrap_kernel;
         hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                            a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis,
@@ -616,8 +628,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
         }
         if (rc == MW_OK) { (void)hipMemcpy(d_sp, &sp, sizeof sp, hipMemcpyHostToDevice); a.spare = d_sp; }
     }
-    ALLOC(e->d_texdesc, MW_MAX_TEX); ALLOC(e->d_meshdesc, MW_MAX_MESH);
-    a.tex = e->d_texdesc; a.mesh = e->d_meshdesc;
+    ALLOC(e->d_meshdesc, MW_MAX_MESH);
+    a.mesh = e->d_meshdesc;      // a.tex / a.texels: upload_textures
     ALLOC(a.rec_raster, (size_t)N * cfg->max_visible * MW_RASTER_REC);
     ALLOC(a.rec_shade, (size_t)N * cfg->max_visible * MW_SHADE_REC);
     ALLOC(a.rec_cull, (size_t)N * cfg->max_visible * MW_CULL_REC);

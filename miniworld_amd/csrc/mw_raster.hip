@@ -30,7 +30,7 @@ __device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc,
 // LDS_RECS = true : the env's shade / classification records are staged in LDS (small scenes);
 // LDS_RECS = false: they are read in place from global memory (L1/L2) — scenes with hundreds of
 //                   visible primitives (Maze) would not leave room for enough resident waves.
-template <bool LDS_RECS, int FMT>
+template <bool LDS_RECS, int FMT, int HOT = 0>
 __device__ inline void raster_kernel_body(
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave,
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
@@ -67,9 +67,9 @@ __device__ inline void raster_kernel_body(
                 sky_b = envhdr[(size_t)env * MW_ENVHDR + 2];
     TexEnv te;
     te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
-    te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);
-    te.texd = texd;
-    te.flat = dbg & 1;
+    te.td = te.tx;      // the descriptor table is the head of the texel block (upload_textures): texd == texels
+    te.texd = reinterpret_cast<const MwTexDesc *>(texels);
+    te.flat = HOT ? 0 : (dbg & 1);
 
     TileCtx cx;
     cx.s_shade = LDS_RECS ? s_shade : g_shade; cx.s_cull = LDS_RECS ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = nullptr;
@@ -82,10 +82,12 @@ __device__ inline void raster_kernel_body(
     const int t_end = min(t_begin + tiles_per_wave, n_tiles);
     int tx = t_begin % tiles_x, ty = t_begin / tiles_x;
     // small scenes: classify (tile, primitive) pairs for as many tiles as fit in the 64 lanes at once
-    const bool pairs = LDS_RECS && nvis > 0 && nvis <= 32 && !(dbg & 2);
+    const bool pairs = LDS_RECS && nvis > 0 && nvis <= 32 && (HOT || !(dbg & 2));
     const int per_group = pairs ? 64 / nvis : 0;
     const uint64_t prim_mask = pairs ? ((1ull << nvis) - 1ull) : 0ull;
-    uint64_t T = 0ull, F = 0ull, Cl = 0ull;
+    // the masks of the g-th tile of the current group live in lane g of three VGPRs (<= 32 primitives: 32 bits each);
+    // a tile fetches its three with v_readlane instead of carrying 64-bit group masks through the tile loop in SGPRs
+    uint32_t vT = 0u, vF = 0u, vCl = 0u;
     int gi = 0, G = 0;
     cx.have_pre = pairs ? 1 : 0;
     cx.order = (!LDS_RECS && rec_order) ? rec_order + (size_t)env * (max_vis + 1) : nullptr;
@@ -95,14 +97,18 @@ __device__ inline void raster_kernel_body(
             if (gi == G) {
                 G = min(per_group, t_end - tile);
                 gi = 0;
+                uint64_t T, F, Cl;
                 classify_group(s_cull, lane, nvis, tile, G, tiles_x, T, F, Cl);
+                const int sh = lane < G ? lane * nvis : 0;
+                vT = (uint32_t)((T >> sh) & prim_mask); vF = (uint32_t)((F >> sh) & prim_mask); vCl = (uint32_t)((Cl >> sh) & prim_mask);
             }
-            const int sh = gi * nvis;
-            cx.pre_touch = (T >> sh) & prim_mask; cx.pre_full = (F >> sh) & prim_mask; cx.pre_clip = (Cl >> sh) & prim_mask;
+            cx.pre_touch = (uint32_t)__builtin_amdgcn_readlane((int)vT, gi);
+            cx.pre_full = (uint32_t)__builtin_amdgcn_readlane((int)vF, gi);
+            cx.pre_clip = (uint32_t)__builtin_amdgcn_readlane((int)vCl, gi);
             ++gi;
         }
         if (!LDS_RECS && rec_order) raster_tile_fmt<false, FMT, true>(cx, tx, ty, nullptr);
-        else raster_tile_fmt<false, FMT>(cx, tx, ty, nullptr);
+        else raster_tile_fmt<false, FMT, false, HOT>(cx, tx, ty, nullptr);
     }
 }
 
@@ -115,9 +121,16 @@ __device__ inline void raster_kernel_body(
 #define MW_RASTER_FWD N, W, H, max_vis, tiles_x, n_tiles, waves_per_env, tiles_per_wave, rec_raster, rec_shade, rec_cull, \
     nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order
 
+// the production kernels of small scenes: no debug flags (mw_engine.hip launches the general kernel below when
+// MW_DEBUG_FLAGS asks for any), RGB only / RGB + depth
 extern "C" __global__ __launch_bounds__(64) void mw_raster_kernel(MW_RASTER_ARGS)
 {
-    raster_kernel_body<true, 0>(MW_RASTER_FWD);
+    raster_kernel_body<true, 0, 1>(MW_RASTER_FWD);
+}
+
+extern "C" __global__ __launch_bounds__(64) void mw_raster_depth_kernel(MW_RASTER_ARGS)
+{
+    raster_kernel_body<true, 0, 2>(MW_RASTER_FWD);
 }
 
 extern "C" __global__ __launch_bounds__(64) void mw_raster_big_kernel(MW_RASTER_ARGS)
@@ -125,7 +138,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_raster_big_kernel(MW_RASTER_
     raster_kernel_body<false, 0>(MW_RASTER_FWD);
 }
 
-// the same kernels storing the frame in a wrapper layout (mw_set_obs_layout; layout in dbg bits 8-9)
+// the general kernels: output layout (mw_set_obs_layout; dbg bits 8-9), debug flags and depth read from the launch
 extern "C" __global__ __launch_bounds__(64) void mw_raster_wrap_kernel(MW_RASTER_ARGS)
 {
     raster_kernel_body<true, -1>(MW_RASTER_FWD);

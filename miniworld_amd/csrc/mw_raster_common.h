@@ -39,25 +39,33 @@ __device__ inline float ub0(uint32_t t) { float f; asm("v_cvt_f32_ubyte0 %0, %1"
 __device__ inline float ub1(uint32_t t) { float f; asm("v_cvt_f32_ubyte1 %0, %1" : "=v"(f) : "v"(t)); return f; }
 __device__ inline float ub2(uint32_t t) { float f; asm("v_cvt_f32_ubyte2 %0, %1" : "=v"(f) : "v"(t)); return f; }
 
-// R8: GL_LINEAR fetch on one mip level (first texel `off`, dims w x h), GL_REPEAT, centres at +0.5.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// R8: GL_LINEAR fetch on mip level `l` of the texture whose descriptor starts at dword `desc` of the table,
+// GL_REPEAT, centres at +0.5.  The level record (MwTexDesc::Level) arrives with two 16-byte loads.
 // POT: both dims are powers of two (wave-uniform property of the texture): wrap with a mask.
 template <bool POT>
-__device__ inline RGB bilinear(rsrc_t tx, uint32_t off, int w, int h, float uu, float vv)
+__device__ inline RGB bilinear(rsrc_t td, rsrc_t tx, uint32_t desc, int l, float uu, float vv)
 {
-    const float x = fmaf(uu, (float)w, -0.5f), y = fmaf(vv, (float)h, -0.5f);
+    const uint32_t rec = (desc + 4u + (uint32_t)l * 8u) << 2;        // byte offset of lvl[l]
+    const u32x4 a4 = __builtin_amdgcn_raw_buffer_load_b128(td, rec, 0, 0);         // off, w, wmask, hmask
+    const u32x4 b4 = __builtin_amdgcn_raw_buffer_load_b128(td, rec + 16u, 0, 0);   // fw, fh, h, -
+    const uint32_t off = a4.x, w = a4.y;
+    const float x = fmaf(uu, __uint_as_float(b4.x), -0.5f), y = fmaf(vv, __uint_as_float(b4.y), -0.5f);
     const float x0f = floorf(x), y0f = floorf(y);
     const float fx = x - x0f, fy = y - y0f;
     int i0 = (int)x0f, j0 = (int)y0f;
     int i1 = i0 + 1, j1 = j0 + 1;
     if (POT) {
-        i0 &= w - 1; i1 &= w - 1; j0 &= h - 1; j1 &= h - 1;
+        i0 &= (int)a4.z; i1 &= (int)a4.z; j0 &= (int)a4.w; j1 &= (int)a4.w;
     } else {
-        if (i0 < 0) i0 += w;
-        if (i1 >= w) i1 -= w;
-        if (j0 < 0) j0 += h;
-        if (j1 >= h) j1 -= h;
+        const int wi = (int)w, hi = (int)b4.z;
+        if (i0 < 0) i0 += wi;
+        if (i1 >= wi) i1 -= wi;
+        if (j0 < 0) j0 += hi;
+        if (j1 >= hi) j1 -= hi;
     }
-    const uint32_t r0 = off + __umul24((uint32_t)j0, (uint32_t)w), r1 = off + __umul24((uint32_t)j1, (uint32_t)w);
+    const uint32_t r0 = off + __umul24((uint32_t)j0, w), r1 = off + __umul24((uint32_t)j1, w);
     const uint32_t t00 = ldw(tx, r0 + i0), t10 = ldw(tx, r0 + i1);
     const uint32_t t01 = ldw(tx, r1 + i0), t11 = ldw(tx, r1 + i1);
     RGB o;
@@ -79,17 +87,15 @@ __device__ inline RGB bilinear(rsrc_t tx, uint32_t off, int w, int h, float uu, 
     return o;
 }
 
-__device__ inline int level_dim(int d, int l) { const int s = d >> l; return s > 0 ? s : 1; }
-
 // Textured fragment colour (R7-R9) for the lanes whose primitive uses texture `tex` (wave-uniform:
 // dims and level count live in SGPRs); the attribute planes come from the lane's shade record.
 template <bool POT>
 __device__ inline RGB shade_tex(const float4 q0, const float4 q1, const float4 q2, rsrc_t td, rsrc_t tx, int tex,
-                                int tw, int th, int q, float Xc, float Yc)
+                                float ftw, float fth, int q, float Xc, float Yc)
 {
     const float Ua = q0.x, Ub = q0.y, Uc = q0.z, Va = q0.w, Vb = q1.x, Vc = q1.y;
     const float Wa = q1.z, Wb = q1.w, Wc = q2.x;
-    const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4) + 4u;     // &texd[tex].off[0], in dwords
+    const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4);          // &texd[tex], in dwords
     const float Wq = fmaf(Wa, Xc, fmaf(Wb, Yc, Wc));
     RGB texel;
     // level selection first (all lanes), then at most two bilinear fetches
@@ -102,7 +108,6 @@ __device__ inline RGB shade_tex(const float4 q0, const float4 q1, const float4 q
         u = Uq * iw; v = Vq * iw;
         const float ux = (Ua - u * Wa) * iw, uy = (Ub - u * Wb) * iw;
         const float vx = (Va - v * Wa) * iw, vy = (Vb - v * Wb) * iw;
-        const float ftw = (float)tw, fth = (float)th;
         const float sx = ux * ftw, tx_ = vx * fth, sy = uy * ftw, ty_ = vy * fth;
         const float r2x = fmaf(sx, sx, tx_ * tx_), r2y = fmaf(sy, sy, ty_ * ty_);
         const float rho2 = r2x > r2y ? r2x : r2y;
@@ -116,12 +121,10 @@ __device__ inline RGB shade_tex(const float4 q0, const float4 q1, const float4 q
         }
     }
     const float uu = u - floorf(u), vv = v - floorf(v);        // GL_REPEAT, shared by both levels
-    const uint32_t off0 = ldw(td, desc + (uint32_t)l0);
-    const RGB c0 = bilinear<POT>(tx, off0, level_dim(tw, l0), level_dim(th, l0), uu, vv);
+    const RGB c0 = bilinear<POT>(td, tx, desc, l0, uu, vv);
     texel = c0;
     if (l1 >= 0) {
-        const uint32_t off1 = ldw(td, desc + (uint32_t)l1);
-        const RGB c1 = bilinear<POT>(tx, off1, level_dim(tw, l1), level_dim(th, l1), uu, vv);
+        const RGB c1 = bilinear<POT>(td, tx, desc, l1, uu, vv);
         texel.r = fmaf(fr, c1.r - c0.r, c0.r);
         texel.g = fmaf(fr, c1.g - c0.g, c0.g);
         texel.b = fmaf(fr, c1.b - c0.b, c0.b);
@@ -173,8 +176,9 @@ __device__ inline RGB apply_texture(const float4 q0, const float4 q1, const floa
         const bool mine = tex == t0;
         if (mine) {
             const int tw = (int)d->w, th = (int)d->h, q = (int)d->nlevels - 1;
-            if (((tw & (tw - 1)) | (th & (th - 1))) == 0) c = shade_tex<true>(q0, q1, q2, te.td, te.tx, t0, tw, th, q, Xc, Yc);
-            else c = shade_tex<false>(q0, q1, q2, te.td, te.tx, t0, tw, th, q, Xc, Yc);
+            const float ftw = d->lvl[0].fw, fth = d->lvl[0].fh;
+            if (((tw & (tw - 1)) | (th & (th - 1))) == 0) c = shade_tex<true>(q0, q1, q2, te.td, te.tx, t0, ftw, fth, q, Xc, Yc);
+            else c = shade_tex<false>(q0, q1, q2, te.td, te.tx, t0, ftw, fth, q, Xc, Yc);
         }
         pending &= ~__ballot(mine);
     }
@@ -189,6 +193,20 @@ __device__ inline RGB shade_prim(const float4 *sr, const TexEnv &te, float Xc, f
     const int tex = te.flat ? -1 : __float_as_int(sr[3].x);
     if (!__any(tex >= 0)) return RGB{q2.y, q2.z, q2.w};
     return apply_texture(sr[0], sr[1], q2, tex, te, Xc, Yc);
+}
+
+// the same for a wave-uniform primitive (pass A visits one primitive at a time): its texture id is a scalar, no
+// waterfall over the lanes' ids
+__device__ inline RGB shade_prim_uniform(const float4 *sr, const TexEnv &te, float Xc, float Yc)
+{
+    const float4 q2 = sr[2];
+    const int tex = te.flat ? -1 : __builtin_amdgcn_readfirstlane(__float_as_int(sr[3].x));
+    if (tex < 0) return RGB{q2.y, q2.z, q2.w};
+    const MwTexDesc *__restrict__ d = te.texd + tex;
+    const int tw = (int)d->w, th = (int)d->h, q = (int)d->nlevels - 1;
+    const float ftw = d->lvl[0].fw, fth = d->lvl[0].fh;
+    if (((tw & (tw - 1)) | (th & (th - 1))) == 0) return shade_tex<true>(sr[0], sr[1], q2, te.td, te.tx, tex, ftw, fth, q, Xc, Yc);
+    return shade_tex<false>(sr[0], sr[1], q2, te.td, te.tx, tex, ftw, fth, q, Xc, Yc);
 }
 
 struct TileCtx;
@@ -264,15 +282,19 @@ __device__ inline void classify_group(const float4 *s_cull, int lane, int nvis, 
 // go straight to the exact pass, walk the polygons front to back and stop as soon as every sample of the tile
 // holds something nearer than the next polygon's bound — in a maze that is after a handful of the dozens of
 // polygons stacked behind each other in the view.  Keys, winners and colours do not depend on the visiting order.
-template <bool MESH, int FMT, bool SORTED = false>
+// HOT: 0 = everything read from the launch (debug flags, depth or not); 1 / 2 = the production instantiations
+// without debug flags, RGB only / RGB + depth: the flag tests, the depth bookkeeping (HOT 1) and the SGPRs that keep
+// them alive leave the kernel (the general one spills 69 SGPRs to VGPR lanes, ~9 % of its VALU instructions).
+template <bool MESH, int FMT, bool SORTED = false, int HOT = 0>
 __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const uint32_t *mesh_key)
 {
-    const int lane = cx.lane, nvis = cx.nvis, dbg = cx.dbg, env = cx.env, W = cx.W, H = cx.H;
+    const int lane = cx.lane, nvis = cx.nvis, dbg = HOT ? 0 : cx.dbg, env = cx.env, W = cx.W, H = cx.H;
     const float4 *s_shade = cx.s_shade, *s_cull = cx.s_cull;
     const float *__restrict__ rr_env = cx.rr_env;
     uint8_t *s_pack = cx.s_pack;
     uint8_t *__restrict__ obs = cx.obs;
-    float *__restrict__ depth = cx.depth;
+    float *__restrict__ depth = HOT == 1 ? nullptr : cx.depth;
+    const bool has_depth = HOT == 2 ? true : (HOT == 1 ? false : depth != nullptr);
     const TexEnv &te = cx.te;
     const float sky_r = cx.sky_r, sky_g = cx.sky_g, sky_b = cx.sky_b;
     const int px = tx * MW_TILE_W + (lane & 15), py = ty * MW_TILE_H + (lane >> 4);
@@ -357,19 +379,21 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
                         cov_m[s] |= in_m[s];
-                        cnt += __builtin_amdgcn_inverse_ballot_w64(in_m[s]) ? 1u : 0u;
+                        // cnt += this lane's bit of in_m[s]: the mask goes in as the carry of an add-with-carry
+                        // (one VALU instruction per sample; select + add would be 12 for the eight)
+                        asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(cnt) : "s"(in_m[s]) : "vcc");
                     }
                     anycov_m |= any_m;
                     in0 = __builtin_amdgcn_inverse_ballot_w64(in_m[0]);
                 }
                 ncov += cnt;
                 if (cnt != 0u) {
-                    const RGB c = shade_prim(s_shade + p * (MW_SHADE_REC / 4), te, Xc, Yc);
+                    const RGB c = shade_prim_uniform(s_shade + p * (MW_SHADE_REC / 4), te, Xc, Yc);
                     const float fc = (float)cnt;
                     acc_r = fmaf(fc, c.r, acc_r);
                     acc_g = fmaf(fc, c.g, acc_g);
                     acc_b = fmaf(fc, c.b, acc_b);
-                    if (depth && in0) z16 = lazy_key(s_shade, (uint32_t)p, 0, Xc, Yc) >> 16;
+                    if (has_depth && in0) z16 = lazy_key(s_shade, (uint32_t)p, 0, Xc, Yc) >> 16;
                 }
             }
         }
@@ -477,6 +501,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             }
         }
     }
+#ifdef MW_VALU_PROBE
     if (dbg & 32) {
         // MW_DEBUG_FLAGS bit 5, perf experiments only: 64 extra dependent-free VALU instructions per tile
         // (is the kernel bound by VALU issue or by latency?)
@@ -487,6 +512,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                          : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
         if (t0 + t1 + t2 + t3 == 12345.678f) acc_r = t0;      // keeps the chain alive, never true in practice
     }
+#endif
     const uint32_t R = to_u8(acc_r), G = to_u8(acc_g), B = to_u8(acc_b);
 
     // ---- pack.  Output layout (mw_set_obs_layout; the reference's wrappers.py folded into the store):
@@ -530,7 +556,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
     }
-    if (depth) {
+    if (has_depth) {
         // R13 / R14: resolved depth = sample 0; get_depth_map in float32 as numpy evaluates it
         const float z = (float)z16;
         const float d = z / 65535.0f;

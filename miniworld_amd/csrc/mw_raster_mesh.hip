@@ -315,7 +315,7 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     cx.obs = obs; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3);
     cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
-    cx.te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);
+    cx.te.td = cx.te.tx;    // the descriptor table is the head of the texel block (upload_textures)
     cx.te.texd = texd;
     cx.te.flat = dbg & 1;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
@@ -484,7 +484,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.obs = out; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, H * W * 3, MW_RSRC_WORD3);
     cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
-    cx.te.td = __builtin_amdgcn_make_buffer_rsrc((void *)texd, 0, MW_MAX_TEX * (int)sizeof(MwTexDesc), MW_RSRC_WORD3);
+    cx.te.td = cx.te.tx;    // the descriptor table is the head of the texel block (upload_textures)
     cx.te.texd = texd;
     cx.te.flat = 0;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
