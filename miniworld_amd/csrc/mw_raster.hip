@@ -85,30 +85,42 @@ __device__ inline void raster_kernel_body(
     const bool pairs = LDS_RECS && nvis > 0 && nvis <= 32 && (HOT || !(dbg & 2));
     const int per_group = pairs ? 64 / nvis : 0;
     const uint64_t prim_mask = pairs ? ((1ull << nvis) - 1ull) : 0ull;
-    // the masks of the g-th tile of the current group live in lane g of three VGPRs (<= 32 primitives: 32 bits each);
-    // a tile fetches its three with v_readlane instead of carrying 64-bit group masks through the tile loop in SGPRs
-    uint32_t vT = 0u, vF = 0u, vCl = 0u;
-    int gi = 0, G = 0;
-    cx.have_pre = pairs ? 1 : 0;
     cx.order = (!LDS_RECS && rec_order) ? rec_order + (size_t)env * (max_vis + 1) : nullptr;
-    cx.pre_touch = cx.pre_full = cx.pre_clip = 0ull;
-    for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
-        if (pairs) {
+    cx.pre_touch = cx.pre_full = cx.pre_clip = cx.pre_edges = 0ull;
+    cx.have_pre = 0;
+    if (pairs) {
+        // the masks of the g-th tile of the current group live in lane g of three VGPRs (<= 32 primitives: 32 bits
+        // each); a tile fetches its three with v_readlane instead of carrying 64-bit group masks through the tile
+        // loop in SGPRs
+        uint32_t vT = 0u, vF = 0u, vCl = 0u, vE01 = 0u, vE23 = 0u;     // vE..: per-edge "needs a test" masks, 16 bits each
+        int gi = 0, G = 0;
+        cx.have_pre = 1;
+        for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
             if (gi == G) {
                 G = min(per_group, t_end - tile);
                 gi = 0;
-                uint64_t T, F, Cl;
-                classify_group(s_cull, lane, nvis, tile, G, tiles_x, T, F, Cl);
+                uint64_t T, F, Cl, Eo[4];
+                classify_group(s_cull, lane, nvis, tile, G, tiles_x, T, F, Cl, Eo);
                 const int sh = lane < G ? lane * nvis : 0;
                 vT = (uint32_t)((T >> sh) & prim_mask); vF = (uint32_t)((F >> sh) & prim_mask); vCl = (uint32_t)((Cl >> sh) & prim_mask);
+                if (nvis <= 16) {
+                    vE01 = (uint32_t)((Eo[0] >> sh) & prim_mask) | ((uint32_t)((Eo[1] >> sh) & prim_mask) << 16);
+                    vE23 = (uint32_t)((Eo[2] >> sh) & prim_mask) | ((uint32_t)((Eo[3] >> sh) & prim_mask) << 16);
+                }
             }
+            cx.pre_edges = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)vE01, gi) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)vE23, gi) << 32);
             cx.pre_touch = (uint32_t)__builtin_amdgcn_readlane((int)vT, gi);
             cx.pre_full = (uint32_t)__builtin_amdgcn_readlane((int)vF, gi);
             cx.pre_clip = (uint32_t)__builtin_amdgcn_readlane((int)vCl, gi);
             ++gi;
+            raster_tile_fmt<false, FMT, false, HOT, 1>(cx, tx, ty, nullptr);
         }
-        if (!LDS_RECS && rec_order) raster_tile_fmt<false, FMT, true>(cx, tx, ty, nullptr);
-        else raster_tile_fmt<false, FMT, false, HOT>(cx, tx, ty, nullptr);
+        return;
+    }
+    for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
+        if (!LDS_RECS && rec_order) raster_tile_fmt<false, FMT, true, 0, 0>(cx, tx, ty, nullptr);
+        else raster_tile_fmt<false, FMT, false, HOT, 0>(cx, tx, ty, nullptr);
     }
 }
 

@@ -2,6 +2,7 @@
 // texture LOD + trilinear fetch (R7, R8), fragment shading (R9), resolve conversion (R12).
 #pragma once
 #include "mw_device.h"
+#include <type_traits>
 
 namespace {
 
@@ -228,6 +229,7 @@ struct TileCtx {
     int env, nvis, W, H, dbg, lane;
     // tile classification done ahead for a group of tiles (classify_group): valid when have_pre
     uint64_t pre_touch, pre_full, pre_clip;
+    uint64_t pre_edges;             // bit 16 k + p: primitive p needs its edge k tested on this tile (PRE 1, <= 16 primitives)
     int have_pre;
     const uint16_t *order;          // SORTED kernels: [0] sorted flag, [1 + k] list index of the k-th nearest polygon
 };
@@ -236,8 +238,9 @@ struct TileCtx {
 // The edge function is monotone in X and Y (rounding included), so its extremes over the tile's
 // pixel centres sit at corners:  touch = every edge's maximum exceeds its smallest sample threshold,
 //                                full  = every edge's minimum exceeds its largest sample threshold.
+// edge_open: bit k set unless the whole tile lies strictly inside edge k (full == no bit set)
 __device__ inline void classify_prim(const float4 *s_cull, int lp, float Xlo, float Xhi, float Ylo, float Yhi,
-                                     bool &touch, bool &full, bool &clipf)
+                                     bool &touch, bool &full, bool &clipf, uint32_t *edge_open = nullptr)
 {
     const float4 A = s_cull[lp * 6 + 0], B = s_cull[lp * 6 + 1], C = s_cull[lp * 6 + 2];
     const float4 TMIN = s_cull[lp * 6 + 3], TMAX = s_cull[lp * 6 + 4];
@@ -249,7 +252,9 @@ __device__ inline void classify_prim(const float4 *s_cull, int lp, float Xlo, fl
         const float emax = fmaf(ea[k], ea[k] > 0.0f ? Xhi : Xlo, fmaf(eb[k], eb[k] > 0.0f ? Yhi : Ylo, ec[k]));
         const float emin = fmaf(ea[k], ea[k] > 0.0f ? Xlo : Xhi, fmaf(eb[k], eb[k] > 0.0f ? Ylo : Yhi, ec[k]));
         touch &= emax > tmn[k];
-        full &= emin > tmx[k];
+        const bool inside = emin > tmx[k];
+        full &= inside;
+        if (edge_open) *edge_open |= inside ? 0u : (1u << k);
     }
     clipf = __float_as_uint(s_cull[lp * 6 + 5].x) != 0u;
 }
@@ -258,22 +263,26 @@ __device__ inline void classify_prim(const float4 *s_cull, int lp, float Xlo, fl
 // with the dozen primitives of a typical indoor frame a per-tile pass would leave most lanes idle.
 // Lane l < G * nvis handles tile (tile0 + l / nvis), primitive l % nvis; the three ballots hold,
 // for the g-th tile of the group, its masks in bits [g * nvis, (g + 1) * nvis).
+// Eo[k]: the pairs whose tile is not strictly inside edge k of the primitive (the others need no test of that edge)
 __device__ inline void classify_group(const float4 *s_cull, int lane, int nvis, int tile0, int G, int tiles_x,
-                                      uint64_t &T, uint64_t &F, uint64_t &Cl)
+                                      uint64_t &T, uint64_t &F, uint64_t &Cl, uint64_t (&Eo)[4])
 {
     const uint32_t inv_n = (65536u + (uint32_t)nvis - 1u) / (uint32_t)nvis;      // lane / nvis, exact for lane < 64
     const int g = (int)(((uint32_t)lane * inv_n) >> 16);
     const int p = lane - g * nvis;
     bool touch = false, full = false, clipf = false;
+    uint32_t eo = 0u;
     if (g < G) {
         const uint32_t idx = (uint32_t)(tile0 + g);
         const uint32_t ty = __umulhi(idx, 0xFFFFFFFFu / (uint32_t)tiles_x + 1u);  // idx / tiles_x, exact for idx < 2^16
         const uint32_t tx = idx - ty * (uint32_t)tiles_x;
         const float Xlo = (float)(tx * MW_TILE_W) + 0.5f, Xhi = Xlo + (float)(MW_TILE_W - 1);
         const float Ylo = (float)(ty * MW_TILE_H) + 0.5f, Yhi = Ylo + (float)(MW_TILE_H - 1);
-        classify_prim(s_cull, p, Xlo, Xhi, Ylo, Yhi, touch, full, clipf);
+        classify_prim(s_cull, p, Xlo, Xhi, Ylo, Yhi, touch, full, clipf, &eo);
     }
     T = __ballot(touch); F = __ballot(full); Cl = __ballot(clipf);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) Eo[k] = __ballot((eo >> k) & 1u);
 }
 
 // FMT: output layout fixed at compile time (0: the plain observation, the hot path) or -1: read from
@@ -285,9 +294,17 @@ __device__ inline void classify_group(const float4 *s_cull, int lane, int nvis, 
 // HOT: 0 = everything read from the launch (debug flags, depth or not); 1 / 2 = the production instantiations
 // without debug flags, RGB only / RGB + depth: the flag tests, the depth bookkeeping (HOT 1) and the SGPRs that keep
 // them alive leave the kernel (the general one spills 69 SGPRs to VGPR lanes, ~9 % of its VALU instructions).
-template <bool MESH, int FMT, bool SORTED = false, int HOT = 0>
+// PRE: 1 = the tile's classification masks come from classify_group (cx.pre_*; at most 32 primitives, so the
+// masks are 32-bit and there is a single chunk), 0 = classified here, -1 = cx.have_pre decides
+__device__ inline int ffs_mask(uint32_t m) { return __ffs((int)m); }
+__device__ inline int ffs_mask(uint64_t m) { return __ffsll((unsigned long long)m); }
+
+template <bool MESH, int FMT, bool SORTED = false, int HOT = 0, int PRE = -1>
 __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const uint32_t *mesh_key)
 {
+    typedef typename std::conditional<PRE == 1, uint32_t, uint64_t>::type pmask_t;      // one bit per primitive of a chunk
+    const bool have_pre = PRE < 0 ? cx.have_pre != 0 : PRE == 1;
+    const bool use_edges = PRE == 1 && cx.nvis <= 16;
     const int lane = cx.lane, nvis = cx.nvis, dbg = HOT ? 0 : cx.dbg, env = cx.env, W = cx.W, H = cx.H;
     const float4 *s_shade = cx.s_shade, *s_cull = cx.s_cull;
     const float *__restrict__ rr_env = cx.rr_env;
@@ -326,24 +343,24 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         for (int s = 0; s < 8; ++s) cov_m[s] = 0ull;
         uint64_t anycov_m = 0ull;
         uint32_t ncov = 0;                           // covered samples of this lane's pixel
-        for (int chunk = 0; chunk < ((dbg & 2) ? 0 : nvis) && !exact; chunk += 64) {
+        for (int chunk = 0; chunk < (PRE == 1 ? 1 : ((dbg & 2) ? 0 : nvis)) && !exact; chunk += 64) {
             // Tile classification, one primitive per lane.  The edge function is monotone in X
             // and Y (rounding included), so its extremes over the tile's pixel centres sit at
             // corners:  touch = every edge's maximum exceeds its smallest sample threshold,
             //           full  = every edge's minimum exceeds its largest sample threshold.
-            uint64_t todo, fullm, clipm;
-            if (cx.have_pre) {
-                todo = cx.pre_touch; fullm = cx.pre_full; clipm = cx.pre_clip;
+            pmask_t todo, fullm, clipm;
+            if (have_pre) {
+                todo = (pmask_t)cx.pre_touch; fullm = (pmask_t)cx.pre_full; clipm = (pmask_t)cx.pre_clip;
             } else {
                 const int lp = chunk + lane;
                 bool touch = lp < nvis, full = touch, clipf = false;
                 if (touch) classify_prim(s_cull, lp, Xlo, Xhi, Ylo, Yhi, touch, full, clipf);
-                todo = __ballot(touch);
-                fullm = __ballot(full); clipm = __ballot(clipf);
+                todo = (pmask_t)__ballot(touch);
+                fullm = (pmask_t)__ballot(full); clipm = (pmask_t)__ballot(clipf);
             }
             if (todo & clipm) { exact = true; break; }
             while (todo) {
-                const int bit = __ffsll((unsigned long long)todo) - 1;
+                const int bit = ffs_mask(todo) - 1;
                 const int p = chunk + bit;
                 todo &= todo - 1;
                 uint32_t cnt;
@@ -362,6 +379,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     for (int s = 0; s < 8; ++s) in_m[s] = ~0ull;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
+                        if (PRE == 1 && use_edges && !((cx.pre_edges >> (16 * k + bit)) & 1ull)) continue;   // known from the classification
                         const float E = fmaf(rr[k], Xc, fmaf(rr[4 + k], Yc, rr[8 + k]));
                         if (__all(E > rr[57 + k])) continue;        // tile strictly inside edge k
 #pragma unroll
@@ -413,12 +431,12 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         for (int s = 0; s < 8; ++s) key[s] = MESH ? mesh_key[s] : 0xFFFFFFFFu;
         bool done = false;
         uint32_t far16 = 0xFFFFu;        // SORTED: the farthest depth stored in the tile (0xFFFF while a sample is empty)
-        for (int chunk = 0; chunk < nvis && !done; chunk += 64) {
-            uint64_t todo;
+        for (int chunk = 0; chunk < (PRE == 1 ? 1 : nvis) && !done; chunk += 64) {
+            pmask_t todo;
             int pidx = chunk + lane;        // list index of the polygon this lane classifies
             uint32_t zlo = 0u;              // SORTED: conservative 16-bit lower bound of its depth
-            if (cx.have_pre) {
-                todo = cx.pre_touch;
+            if (have_pre) {
+                todo = (pmask_t)cx.pre_touch;
             } else {
                 const int lp = chunk + lane;
                 bool touch = lp < nvis, full = false, clipf = false;
@@ -430,10 +448,10 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                         zlo = zb >= 2.0f ? (uint32_t)zb - 2u : 0u;                          // 2 LSB of slack for rounding
                     }
                 }
-                todo = __ballot(touch);
+                todo = (pmask_t)__ballot(touch);
             }
             while (todo) {
-                const int bit = __ffsll((unsigned long long)todo) - 1;
+                const int bit = ffs_mask(todo) - 1;
                 const int p = (SORTED && sorted) ? __builtin_amdgcn_readlane(pidx, bit) : chunk + bit;
                 todo &= todo - 1;
                 if (SORTED && sorted) {
@@ -445,6 +463,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 for (int s = 0; s < 8; ++s) in[s] = true;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
+                    if (PRE == 1 && use_edges && !((cx.pre_edges >> (16 * k + bit)) & 1ull)) continue;
                     const float E = fmaf(rr[k], Xc, fmaf(rr[4 + k], Yc, rr[8 + k]));
                     if (__all(E > rr[57 + k])) continue;
 #pragma unroll
