@@ -135,7 +135,9 @@ def main():
     if rank == 0:
         steps_per_s = world * n * args.steps / elapsed
         achieved = algo_bytes * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
-        dominant = "mw_raster_mesh_kernel" if vec.mesh_ids else "mw_raster_kernel"
+        dominant = "mw_raster_mesh_kernel" if vec.mesh_ids else ("mw_raster_depth_kernel" if want_depth else "mw_raster_kernel")
+        if env_id == "MiniWorld-Maze-v0":
+            dominant = "mw_raster_big_kernel"
         traffic, traffic_src = pmc_traffic(dominant, args.config, n)
         out = {
             "metric": "env-steps/s (batched, 80x60 RGB)",

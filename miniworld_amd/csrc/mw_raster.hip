@@ -92,7 +92,8 @@ __device__ inline void raster_kernel_body(
         // the masks of the g-th tile of the current group live in lane g of three VGPRs (<= 32 primitives: 32 bits
         // each); a tile fetches its three with v_readlane instead of carrying 64-bit group masks through the tile
         // loop in SGPRs
-        uint32_t vT = 0u, vF = 0u, vCl = 0u, vE01 = 0u, vE23 = 0u;     // vE..: per-edge "needs a test" masks, 16 bits each
+        uint32_t vT = 0u, vF = 0u, vCl = 0u;
+        uint32_t vE01 = ~0u, vE23 = ~0u;    // per-edge "needs a test" masks, 16 bits each (more than 16 primitives: test all)
         int gi = 0, G = 0;
         cx.have_pre = 1;
         for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {

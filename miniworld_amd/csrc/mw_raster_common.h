@@ -229,7 +229,7 @@ struct TileCtx {
     int env, nvis, W, H, dbg, lane;
     // tile classification done ahead for a group of tiles (classify_group): valid when have_pre
     uint64_t pre_touch, pre_full, pre_clip;
-    uint64_t pre_edges;             // bit 16 k + p: primitive p needs its edge k tested on this tile (PRE 1, <= 16 primitives)
+    uint64_t pre_edges;             // bit 16 k + p: primitive p needs its edge k tested on this tile (PRE 1; all ones with > 16 primitives)
     int have_pre;
     const uint16_t *order;          // SORTED kernels: [0] sorted flag, [1 + k] list index of the k-th nearest polygon
 };
@@ -304,7 +304,6 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 {
     typedef typename std::conditional<PRE == 1, uint32_t, uint64_t>::type pmask_t;      // one bit per primitive of a chunk
     const bool have_pre = PRE < 0 ? cx.have_pre != 0 : PRE == 1;
-    const bool use_edges = PRE == 1 && cx.nvis <= 16;
     const int lane = cx.lane, nvis = cx.nvis, dbg = HOT ? 0 : cx.dbg, env = cx.env, W = cx.W, H = cx.H;
     const float4 *s_shade = cx.s_shade, *s_cull = cx.s_cull;
     const float *__restrict__ rr_env = cx.rr_env;
@@ -379,7 +378,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     for (int s = 0; s < 8; ++s) in_m[s] = ~0ull;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        if (PRE == 1 && use_edges && !((cx.pre_edges >> (16 * k + bit)) & 1ull)) continue;   // known from the classification
+                        if (PRE == 1 && !((cx.pre_edges >> (16 * k + (bit & 15))) & 1ull)) continue;   // known from the classification
                         const float E = fmaf(rr[k], Xc, fmaf(rr[4 + k], Yc, rr[8 + k]));
                         if (__all(E > rr[57 + k])) continue;        // tile strictly inside edge k
 #pragma unroll
@@ -463,7 +462,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 for (int s = 0; s < 8; ++s) in[s] = true;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (PRE == 1 && use_edges && !((cx.pre_edges >> (16 * k + bit)) & 1ull)) continue;
+                    if (PRE == 1 && !((cx.pre_edges >> (16 * k + (bit & 15))) & 1ull)) continue;
                     const float E = fmaf(rr[k], Xc, fmaf(rr[4 + k], Yc, rr[8 + k]));
                     if (__all(E > rr[57 + k])) continue;
 #pragma unroll
