@@ -36,6 +36,11 @@ extern "C" __global__ void mw_raster_depth_kernel(int N, int W, int H, int max_v
                                                   const float *rec_shade, const float *rec_cull, const int32_t *nvis,
                                                   const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
                                                   uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
+extern "C" __global__ void mw_raster_big_depth_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                                      int waves_per_env, int tiles_per_wave, const float *rec_raster,
+                                                      const float *rec_shade, const float *rec_cull, const int32_t *nvis,
+                                                      const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
+                                                      uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
 extern "C" __global__ void mw_raster_big_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                                 int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                                 const float *rec_shade, const float *rec_cull, const int32_t *nvis,
@@ -493,7 +498,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             const int wpe = e->waves_per_env;
             const int tpw = (a.n_tiles + wpe - 1) / wpe;
             const int groups = (N + 7) / 8;
-            auto k2 = e->obs_layout != MW_OBS_HWC_U8 ? mw_raster_big_wrap_kernel : mw_raster_big_kernel;
+            auto k2 = d_depth ? mw_raster_big_depth_kernel : mw_raster_big_kernel;
+            if (e->obs_layout != MW_OBS_HWC_U8 || e->dbg_flags != 0) k2 = mw_raster_big_wrap_kernel;
             hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), 192, e->side_stream, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                                a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                                (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, kflags, e->texel_bytes,
@@ -513,8 +519,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const size_t lds = big ? 192 : (size_t)e->cfg.max_visible * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
         // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
         // anything else goes to the general kernel
-        auto k2 = big ? mw_raster_big_kernel : (d_depth ? mw_raster_depth_kernel : mw_raster_kernel);
-        if (e->obs_layout != MW_OBS_HWC_U8 || (!big && e->dbg_flags != 0)) k2 = big ? mw_raster_big_wrap_kernel : mw_raster_wrap_kernel;
+        auto k2 = big ? (d_depth ? mw_raster_big_depth_kernel : mw_raster_big_kernel) : (d_depth ? mw_raster_depth_kernel : mw_raster_kernel);
+        if (e->obs_layout != MW_OBS_HWC_U8 || e->dbg_flags != 0) k2 = big ? mw_raster_big_wrap_kernel : mw_raster_wrap_kernel;
         hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                            a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis,

@@ -120,7 +120,7 @@ __device__ inline void raster_kernel_body(
         return;
     }
     for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
-        if (!LDS_RECS && rec_order) raster_tile_fmt<false, FMT, true, 0, 0>(cx, tx, ty, nullptr);
+        if (!LDS_RECS && rec_order) raster_tile_fmt<false, FMT, true, HOT, 0>(cx, tx, ty, nullptr);
         else raster_tile_fmt<false, FMT, false, HOT, 0>(cx, tx, ty, nullptr);
     }
 }
@@ -148,7 +148,12 @@ extern "C" __global__ __launch_bounds__(64) void mw_raster_depth_kernel(MW_RASTE
 
 extern "C" __global__ __launch_bounds__(64) void mw_raster_big_kernel(MW_RASTER_ARGS)
 {
-    raster_kernel_body<false, 0>(MW_RASTER_FWD);
+    raster_kernel_body<false, 0, 1>(MW_RASTER_FWD);
+}
+
+extern "C" __global__ __launch_bounds__(64) void mw_raster_big_depth_kernel(MW_RASTER_ARGS)
+{
+    raster_kernel_body<false, 0, 2>(MW_RASTER_FWD);
 }
 
 // the general kernels: output layout (mw_set_obs_layout; dbg bits 8-9), debug flags and depth read from the launch
