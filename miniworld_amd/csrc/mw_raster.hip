@@ -125,6 +125,8 @@ __device__ inline void raster_kernel_body(
     }
 }
 
+// (texd == texels: the descriptor table is the head of the texel block, mw_engine.hip::upload_textures; the kernels
+// use `texels` for both)
 #define MW_RASTER_ARGS \
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave, \
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull, \

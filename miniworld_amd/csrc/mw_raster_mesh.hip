@@ -382,7 +382,7 @@ extern "C" __global__ __launch_bounds__(256) void mw_view_mesh_kernel(int W, int
 template <int S>
 __device__ inline void view_tile_body(TileCtx &cx, int tiles_x, const uint32_t *mesh_keys)
 {
-    const int lane = cx.lane, W = cx.W, H = cx.H, nvis = cx.nvis;
+    const int lane = cx.lane, W = cx.W, nvis = cx.nvis;
     const int tile = blockIdx.x;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int px = tx * MW_TILE_W + (lane & 15), py = ty * MW_TILE_H + (lane >> 4);
