@@ -316,8 +316,10 @@ __device__ __forceinline__ bool cull_poly(const MwArgs &a, const HV h[4], int nv
     edge_coef(h[0], h[1], g.ga[2], g.gb[2], g.gc[2]);
     g.D = fmaf(h[0].hx, g.ga[0], fmaf(h[0].hy, g.gb[0], h[0].hw * g.gc[0]));
     if (!(g.D > 0.0f)) return false;          // back-face cull (miniworld.py:512)
-    // conservative screen bounds -> tile range.  The polygon is clipped against w >= 0.01 (well in
-    // front of the 0.04 near plane) only to bound its projection; coverage itself never clips (R4).
+    // conservative screen bounds: is anything of the polygon on the screen at all?  The polygon is clipped against
+    // w >= 0.01 (well in front of the 0.04 near plane) only to bound its projection; coverage itself never clips
+    // (R4).  The bounds feed this yes / no and a tile range, both with a margin of a pixel, so the perspective
+    // divides are hardware reciprocals (1 ulp) instead of IEEE divisions (a dozen dependent instructions each).
     const float wc = 0.01f;
     float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
     bool some = false;
@@ -328,13 +330,14 @@ __device__ __forceinline__ bool cull_poly(const MwArgs &a, const HV h[4], int nv
             const HV q = (k + 1 == nv || k == 3) ? h[0] : h[k < 3 ? k + 1 : 0];
             const bool pin = p.hw >= wc, qin = q.hw >= wc;
             if (pin) {
-                const float X = p.hx / p.hw, Y = p.hy / p.hw;
+                const float iw = __builtin_amdgcn_rcpf(p.hw);
+                const float X = p.hx * iw, Y = p.hy * iw;
                 xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
                 some = true;
             }
             if (pin != qin) {
-                const float t = (wc - p.hw) / (q.hw - p.hw);
-                const float X = fmaf(t, q.hx - p.hx, p.hx) / wc, Y = fmaf(t, q.hy - p.hy, p.hy) / wc;
+                const float t = (wc - p.hw) * __builtin_amdgcn_rcpf(q.hw - p.hw);
+                const float X = fmaf(t, q.hx - p.hx, p.hx) * 100.0f, Y = fmaf(t, q.hy - p.hy, p.hy) * 100.0f;
                 xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
                 some = true;
             }
@@ -342,8 +345,9 @@ __device__ __forceinline__ bool cull_poly(const MwArgs &a, const HV h[4], int nv
     }
     if (!some) return false;                         // entirely behind the eye
     // generous margin: the clipped outline is computed in float and huge coordinates lose precision
-    const float mx = 1.0f + 1e-4f * fmaxf(fabsf(xmin), fabsf(xmax)), my = 1.0f + 1e-4f * fmaxf(fabsf(ymin), fabsf(ymax));
+    const float mx = 1.0f + 1e-3f * fmaxf(fabsf(xmin), fabsf(xmax)), my = 1.0f + 1e-3f * fmaxf(fabsf(ymin), fabsf(ymax));
     if (xmax + mx < 0.0f || ymax + my < 0.0f || xmin - mx > (float)a.W || ymin - my > (float)a.H) return false;
+    // tile range for the large views (mw_raster_mesh.hip::view_tile_body skips primitives by it)
     const float fx0 = fminf(fmaxf(floorf(xmin - mx), 0.0f), (float)(a.W - 1));
     const float fx1 = fminf(fmaxf(floorf(xmax + mx), 0.0f), (float)(a.W - 1));
     const float fy0 = fminf(fmaxf(floorf(ymin - my), 0.0f), (float)(a.H - 1));
