@@ -323,6 +323,42 @@ class MiniWorldEnv(gym.Env):
             ent1 = self.agent
         return np.linalg.norm(ent0.pos - ent1.pos) < ent0.radius + ent1.radius + 1.1 * self.max_forward_step
 
+    # Host-side counterparts of the two motion primitives (miniworld.py:606-668).  step() runs them on the GPU; these
+    # are for callers that move the agent themselves — the next step / render pushes the host state to the engine.
+    def _get_carry_pos(self, agent_pos, ent):
+        dist = self.agent.radius + ent.radius + self.max_forward_step
+        pos = agent_pos + self.agent.dir_vec * 1.05 * dist
+        lift = max(self.agent.cam_height - ent.height - 0.3, 0)      # keeps the carried object in view
+        return pos + np.array([0.0, 1.0, 0.0]) * lift
+
+    def move_agent(self, fwd_dist, fwd_drift):
+        """Forward by fwd_dist, sideways by fwd_drift; blocked (no sliding) by walls and entities.  True if moved."""
+        target = self.agent.pos + self.agent.dir_vec * fwd_dist + self.agent.right_vec * fwd_drift
+        if self.intersect(self.agent, target, self.agent.radius):
+            return False
+        held = self.agent.carrying
+        if held:
+            held_target = self._get_carry_pos(target, held)
+            if self.intersect(held, held_target, held.radius):
+                return False
+            held.pos = held_target
+        self.agent.pos = target
+        return True
+
+    def turn_agent(self, turn_angle):
+        """Turn by turn_angle degrees (positive = left); undone if the carried object would collide.  True if turned."""
+        before = self.agent.dir
+        self.agent.dir += turn_angle * (math.pi / 180)
+        held = self.agent.carrying
+        if held:
+            held_target = self._get_carry_pos(self.agent.pos, held)
+            if self.intersect(held, held_target, held.radius):
+                self.agent.dir = before
+                return False
+            held.pos = held_target
+            held.dir = self.agent.dir
+        return True
+
     def _gen_static_data(self):
         rng = self.np_random if self.domain_rand else None
         for room in self.rooms:

@@ -158,3 +158,33 @@ def test_pcg64_stream_of_the_engine_is_numpys():
         g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
         want = [g.random() if b == 0 else (g.integers(0, b) if i % 2 else g.choice(int(b))) for i, b in enumerate(bounds)]
         assert np.array_equal(out, np.array(want, np.float64)), seed
+
+
+@pytest.mark.parametrize("case", ["hallway_s0", "hallway_dr_s3", "oneroom_s0", "fourrooms_s0", "maze_s0"])
+def test_host_move_and_turn_follow_the_reference_trajectory(case):
+    """MiniWorldEnv.move_agent / turn_agent on the host (miniworld.py:620-668): replaying the fixture's actions with
+    its per-step parameters reproduces the reference's agent positions and headings bit for bit (float64)."""
+    from miniworld_amd import envs
+    s0, tr, meta, obs = helpers.load_case(case)
+    env = getattr(envs, str(meta["env"]))(host_only=True, **helpers.env_kwargs_of(meta))
+    env.reset(seed=int(meta["seed"]))
+    assert np.array_equal(np.asarray(env.agent.pos, np.float64), s0["agent_pos"])
+    n = 0
+    for t, action in enumerate(tr["action"]):
+        fwd, drift, turn = float(tr["fwd_step"][t]), float(tr["fwd_drift"][t]), float(tr["turn_step"][t])
+        if action == 2:
+            env.move_agent(fwd, drift)
+        elif action == 3:
+            env.move_agent(-fwd, drift)
+        elif action == 0:
+            env.turn_agent(turn)
+        elif action == 1:
+            env.turn_agent(-turn)
+        else:
+            break                                   # pickup / drop / toggle are the engine's
+        assert np.array_equal(np.asarray(env.agent.pos, np.float64), tr["pos"][t]), (case, t)
+        assert float(env.agent.dir) == float(tr["dir"][t]), (case, t)
+        n += 1
+        if tr["term"][t] or tr["trunc"][t]:
+            break                                   # the fixture resets the episode here
+    assert n >= 20
