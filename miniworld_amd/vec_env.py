@@ -24,9 +24,11 @@ _KIND = {
     "MiniWorld-Hallway-v0": ("Hallway", eng.GEN_HALLWAY, eng.TASK_GOTO, 3),
     "MiniWorld-OneRoom-v0": ("OneRoom", eng.GEN_ONEROOM, eng.TASK_GOTO, 3),
     "MiniWorld-OneRoomS6-v0": ("OneRoomS6", eng.GEN_ONEROOM, eng.TASK_GOTO, 3),
+    "MiniWorld-OneRoomS6Fast-v0": ("OneRoomS6Fast", eng.GEN_ONEROOM, eng.TASK_GOTO, 3),     # S6 + its own step / turn sizes
     "MiniWorld-Maze-v0": ("Maze", eng.GEN_MAZE, eng.TASK_GOTO, 3),
     "MiniWorld-MazeS2-v0": ("MazeS2", eng.GEN_MAZE, eng.TASK_GOTO, 3),
     "MiniWorld-MazeS3-v0": ("MazeS3", eng.GEN_MAZE, eng.TASK_GOTO, 3),
+    "MiniWorld-MazeS3Fast-v0": ("MazeS3Fast", eng.GEN_MAZE, eng.TASK_GOTO, 3),
     "MiniWorld-PickupObjects-v0": ("PickupObjects", eng.GEN_PICKUP, eng.TASK_PICKUP, 5),
     # host-generated worlds (reference-compatible numpy stream), device stepping / rendering
     "MiniWorld-FourRooms-v0": ("FourRooms", eng.GEN_NONE, eng.TASK_GOTO, 3),

@@ -188,3 +188,28 @@ def test_host_move_and_turn_follow_the_reference_trajectory(case):
         if tr["term"][t] or tr["trunc"][t]:
             break                                   # the fixture resets the episode here
     assert n >= 20
+
+
+REFERENCE_IDS = [          # miniworld/envs/__init__.py:43-157 (gym.register calls)
+    "CollectHealth", "FourRooms", "Hallway", "Maze", "MazeS2", "MazeS3", "MazeS3Fast", "OneRoom", "OneRoomS6",
+    "OneRoomS6Fast", "PickupObjects", "PutNext", "RoomObjects", "Sidewalk", "Sign", "ThreeRooms", "TMaze", "TMazeLeft",
+    "TMazeRight", "WallGap", "YMaze", "YMazeLeft", "YMazeRight",
+]
+
+
+def test_every_reference_env_id_is_registered_and_batched():
+    """Each `MiniWorld-<name>-v0` the reference registers exists as a single-env class, as a gym id and in the
+    batched engine's table, and its template world generates on the host."""
+    from miniworld_amd import envs
+    from miniworld_amd.vec_env import _KIND
+    for name in REFERENCE_IDS:
+        env_id = f"MiniWorld-{name}-v0"
+        assert env_id in _KIND, env_id
+        assert envs.ENV_IDS[env_id] == name if hasattr(envs, "ENV_IDS") else hasattr(envs, name)
+        cls = getattr(envs, _KIND[env_id][0])
+        env = cls(host_only=True)
+        env.reset(seed=1)
+        assert env.max_episode_steps > 0 and len(env.rooms) >= 1
+    fast = envs.MazeS3Fast(host_only=True)
+    assert fast.params.get_max("forward_step") == 0.7 and fast.max_episode_steps == 300      # maze.py:75-95
+    assert envs.OneRoomS6Fast(host_only=True).max_episode_steps == 50                        # oneroom.py:83-97
