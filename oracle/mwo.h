@@ -17,6 +17,8 @@
  *                              file restates the OpenGL 2.1 fixed-function semantics of
  *                              the call sites cited per function, with every
  *                              implementation-defined choice written down.
+ *                              External anchor: the reference's own screenshots, compared per surface
+ *                              in tests/test_oracle_vs_reference_screenshots.py (oracle/README.md).
  */
 #ifndef MWO_H
 #define MWO_H

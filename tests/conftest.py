@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f != "meshes.npz")
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("meshes.npz", "screenshots.npz"))
 
 
 @pytest.fixture(scope="session")

@@ -1,0 +1,179 @@
+"""The external anchor of the pixel oracle: the reference's own screenshots.
+
+The reference holds no golden images and no GL context can be created in the build container, so every
+RGB assertion elsewhere is HIP engine vs oracle/mwo_render.c ("parity unpinned").  The only pixels under
+/root/reference that a real OpenGL driver produced are the JPEG screenshots of the manual_control window
+(images/hallway_0.jpg, oneroom_0.jpg, pickupobjs_0.jpg): the 800x600x16spp vis_fb view, the 80x60 observation
+as an inset, and the printed pose (miniworld.py:1340-1443).  tools/gen_screenshot_fixtures.py box-filtered them
+into tests/golden/screenshots.npz; here the oracle renders the same room from the printed pose and must agree
+region by region — the reference's own L3-style check (tests/test_miniworld.py:26-31, |d mean| < 5) made
+much tighter and per surface.  A systematic error shared by oracle and engine (handedness, the directional-light
+quirk of miniworld.py:1031, per-wall shading, texture orientation / scale, sky colour, perspective, box faces)
+would show here.  What the JPEGs cannot pin: the last bit of filtering / sample positions (they are lossy).
+"""
+import numpy as np
+import pytest
+
+import pyoracle
+
+SHOTS = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "screenshots.npz"))
+NAMES = sorted({k.split("/")[0] for k in SHOTS.files})
+
+
+def _down(a, f):
+    h, w, _ = a.shape
+    return a.reshape(h // f, f, w // f, f, 3).astype(np.float32).mean(axis=(1, 3))
+
+
+def _dilate(m, r):
+    out = m.copy()
+    for dy in range(-r, r + 1):
+        for dx in range(-r, r + 1):
+            out |= np.roll(np.roll(m, dy, 0), dx, 1)
+    return out
+
+
+def _room_scene(name):
+    """The env's room (fixed floorplan and textures, domain_rand off) seen from the printed pose, entities removed
+    (their placement in the screenshot is random and unseeded)."""
+    from miniworld_amd import envs
+    from miniworld_amd.scene import scene_from_env
+    env = getattr(envs, str(SHOTS[name + "/env"]))(host_only=True)
+    env.reset(seed=0)
+    sc = scene_from_env(env)
+    for k in list(sc):
+        if k.startswith("ents_"):
+            sc[k] = sc[k][:0]
+    sc["mesh_names"], sc["mesh_tex"] = np.array([]), np.zeros(0, np.int32)
+    sc["agent_pos"] = SHOTS[name + "/pos"].astype(np.float64)
+    return sc
+
+
+def _entity_mask(shot):
+    """Pixels of the screenshot that belong to the (randomly placed) objects: pure, saturated colours — the room
+    textures are greys and brick browns, the sky (0.25, 0.82, 1.0) has saturation 0.75."""
+    mx, mn = shot.max(-1), shot.min(-1)
+    sat = (mx - mn) / np.maximum(mx, 1)
+    return _dilate((sat > 0.82) & (mx > 60), 3)
+
+
+def _register(sc, name, main):
+    """The label prints the heading in whole degrees (truncated): find the tenth of a degree that fits best."""
+    ang = int(SHOTS[name + "/angle_deg"])
+    best = None
+    for k in range(10):
+        sc["agent_dir"] = np.deg2rad(ang + k / 10 + 0.05)
+        err = np.abs(_down(pyoracle.render(sc, 800, 600, 16)["rgb"], 4) - main)[~_entity_mask(main)].mean()
+        if best is None or err < best[0]:
+            best = (err, sc["agent_dir"])
+    sc["agent_dir"] = best[1]
+    return best[0]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_matches_reference_screenshot_surfaces(name):
+    sc = _room_scene(name)
+    main = SHOTS[name + "/main"].astype(np.float32)
+    inset = SHOTS[name + "/inset"].astype(np.float32)
+    ents = _entity_mask(main)
+    err = _register(sc, name, main)
+    # whole frame outside the objects: mean |difference| of the 4x4-filtered 800x600 views (JPEG noise included)
+    assert err < 4.0, (name, err)
+    r = pyoracle.render(sc, 800, 600, 16, want_prim=True)
+    full = _down(r["rgb"], 4)
+    pb = r["prim"][:, :, 0].reshape(150, 4, 200, 4).transpose(0, 2, 1, 3).reshape(150, 200, 16)
+    uniform, pid = pb.min(-1) == pb.max(-1), pb[:, :, 0]
+    shades = {}
+    checked = 0
+    for p in np.unique(pid):
+        m = uniform & (pid == p) & ~ents
+        if m.sum() < 400:
+            continue
+        want, got = main[m].mean(0), full[m].mean(0)
+        # per-surface mean colour: sky, floor, ceiling and every wall within 2.5 of 255 per channel
+        assert np.abs(want - got).max() < 2.5, (name, int(p), want, got)
+        if p >= 0 and abs(float(sc["polys_n"][p][1])) < 0.5:
+            shades[int(p)] = (tuple(np.sign(np.round(sc["polys_n"][p], 3))), want.mean(), got.mean())
+        checked += 1
+    assert checked >= 4, (name, checked)
+    # walls facing +x / +z are lit by the (light_pos + 1) directional light, those facing -x / -z only by the ambient
+    # term (0.8354 vs 0.65 of the texture): same ordering in the screenshot and the oracle
+    lit = [v for v in shades.values() if v[0][0] > 0 or v[0][2] > 0]
+    unlit = [v for v in shades.values() if v[0][0] < 0 or v[0][2] < 0]
+    assert (lit and unlit) or name == "pickupobjs_0", (name, shades)      # that view only shows two ambient-lit walls
+    for a in lit:
+        for b in unlit:
+            assert a[1] > b[1] + 15 and a[2] > b[2] + 15, (name, a, b)
+    # the 80x60x8spp observation against the inset (the obs blown up 3.2x with GL_LINEAR and filtered back: blurrier
+    # than the original, hence the looser bound)
+    obs = pyoracle.render(sc)["rgb"].astype(np.float32)
+    small = _dilate(_entity_mask(inset), 1)
+    small[0], small[-1], small[:, 0], small[:, -1] = True, True, True, True      # the blit's border texels blend with the window
+    assert np.abs(obs - inset)[~small].mean() < 7.0, (name, np.abs(obs - inset)[~small].mean())
+    assert abs(obs[~small].mean() - inset[~small].mean()) < 1.5
+
+
+def _fit_box(sc, main, region, x0):
+    """Least-squares fit of the box pose (x, z, dir) inside `region` of the 200x150 view (Nelder-Mead on oracle renders)."""
+    from scipy.optimize import minimize
+
+    def cost(p):
+        sc["ents_pos"] = np.array([[p[0], 0.0, p[1]]])
+        sc["ents_dir"] = np.array([p[2]])
+        r = pyoracle.render(sc, 400, 300, 8)["rgb"]
+        return float(np.abs(_down(r, 2) - main)[region].mean())
+    best = None
+    for d0 in (0.3, 1.1):          # two starts: a box looks the same every 90 degrees, but the simplex can stall
+        res = minimize(cost, np.array([x0[0], x0[1], d0]), method="Nelder-Mead",
+                       options={"xatol": 2e-3, "fatol": 1e-3, "maxfev": 260, "initial_simplex": None})
+        if best is None or res.fun < best.fun:
+            best = res
+        if best.fun < 5.0:
+            break
+    cost(best.x)
+    return best
+
+
+@pytest.mark.parametrize("name", [n for n in NAMES if n in ("hallway_0", "oneroom_0")])
+def test_oracle_box_matches_reference_screenshot(name):
+    """Box.render / drawBox (entity.py:409-432, opengl.py:460-503): with the room registered, a red Box(size 0.8) placed
+    by a 3-parameter pose fit must reproduce the screenshot's box — silhouette, perspective size, and the three face
+    shades the lighting model gives (top 1.0, sides between 0.65 and 0.84 of pure red)."""
+    from miniworld_amd import envs
+    from miniworld_amd.scene import scene_from_env
+    main = SHOTS[name + "/main"].astype(np.float32)
+    sc = _room_scene(name)
+    _register(sc, name, main)
+    env = getattr(envs, str(SHOTS[name + "/env"]))(host_only=True)
+    env.reset(seed=0)
+    full = scene_from_env(env)
+    for k in list(full):
+        if k.startswith("ents_"):
+            sc[k] = full[k][:1].copy()
+    red = (main[..., 0] > 120) & (main[..., 1] < 70) & (main[..., 2] < 70)
+    assert 150 < red.sum() < 4000
+    region = _dilate(red, 4)
+    # first guess: the ray through the bottom centre of the red blob, intersected with the floor
+    ys, xs = np.nonzero(red)
+    u, v = xs.mean() + 0.5, ys.max() + 1.0
+    fov = np.deg2rad(float(sc["cam_fov_y"]))
+    ry = (1 - 2 * v / 150) * np.tan(fov / 2)
+    rx = (2 * u / 200 - 1) * np.tan(fov / 2) * 4 / 3
+    dist = float(sc["cam_height"]) / -ry
+    a = float(sc["agent_dir"])
+    fwd, right = np.array([np.cos(a), -np.sin(a)]), np.array([np.sin(a), np.cos(a)])
+    ground = sc["agent_pos"][[0, 2]] + dist * (fwd + rx * right)
+    res = _fit_box(sc, main, region, ground + 0.4 * fwd)
+    got = _down(pyoracle.render(sc, 800, 600, 16)["rgb"], 4)
+    err = np.abs(got - main)[region].mean()
+    assert err < 6.0, (name, err, res.x)
+    # silhouette: the fitted box covers the same pixels
+    red_o = (got[..., 0] > 120) & (got[..., 1] < 70) & (got[..., 2] < 70)
+    inter, union = (red & red_o).sum(), (red | red_o).sum()
+    assert inter / union > 0.9, (name, inter / union)
+    # hue and shading: pure red, top face saturated, side faces within the model's range
+    core = red & red_o & ~_dilate(~(red & red_o), 1)
+    assert main[core][:, 1:].mean() < 25 and got[core][:, 1:].max() == 0
+    assert abs(main[core][:, 0].mean() - got[core][:, 0].mean()) < 6
+    # no face is darker than the ambient-only shade 0.2 + 0.45 (hallway_0's visible face is exactly that: 166 = 0.65 * 255)
+    assert main[core][:, 0].min() > 0.65 * 255 - 8 and np.abs(main[core][:, 0] - got[core][:, 0]).mean() < 6
