@@ -186,7 +186,9 @@ int mw_set_state(mw_engine *e, int32_t first_env, int32_t count, const mw_state_
 int mw_set_step_params(mw_engine *e, const double *host_params);
 int mw_get_state(mw_engine *e, int32_t first_env, int32_t count, mw_state_view *host);
 /* device-side MiniWorldEnv.reset (miniworld.py:544-604) for the configured generator.
- * mask: host uint8[num_envs] or NULL (= all); seeds: host uint64[num_envs] or NULL. */
+ * mask: host uint8[num_envs] or NULL (= all); seeds: host uint64[num_envs] or NULL.
+ * With MW_GEN_NONE (host-generated worlds) only the re-seeding happens: seeds[i] (masked) re-seeds env i's device
+ * stream, which serves the per-step domain-randomisation draws (miniworld.py:677-680); seeds == NULL is an error. */
 int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *stream);
 
 /* ---- the hot path ------------------------------------------------------------ */
@@ -235,9 +237,10 @@ int mw_check(mw_engine *e, void *stream);
 
 /* ---- measurement ------------------------------------------------------------- */
 /* average duration (ms) of the dominant (raster) kernel and of the setup kernel over the launches since
- * the last call, measured with HIP events on the stream the kernels ran on; enables timing on first use
- * (reset < 0 switches it off).  One launch in 8 is bracketed with events (recording on every launch costs
- * ~4 % of the step rate); `launches` is the number of launches measured.  Returns <0 on error. */
+ * the last call, measured with HIP events on the stream the kernels ran on; enables timing on first use.
+ * reset > 0: from now on one launch in `reset` is bracketed with events (1 = every launch; recording on every
+ * launch costs a few percent of the step rate); reset = 0: the default, one in 8; reset < 0 switches timing off.
+ * `launches` is the number of launches measured.  Returns <0 on error. */
 int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *setup_ms, int64_t *launches);
 
 #ifdef __cplusplus

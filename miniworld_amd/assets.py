@@ -6,7 +6,7 @@ Replaces ``miniworld.utils.get_file_path`` + the file probing in ``Texture.get``
      configs, produced by tools/pack_assets.py from the reference's Apache-2.0 data files);
   2. directories listed in ``$MINIWORLD_ASSET_PATH`` (``:``-separated), each laid out like the
      reference package (``textures/<name>_<i>.png``, ``meshes/<name>.obj|mtl``);
-  3. an installed ``miniworld`` package or a reference checkout, if present.
+  3. an installed ``miniworld`` package, if present.
 """
 from __future__ import annotations
 
@@ -28,9 +28,6 @@ def _pack_file():
 
 def _asset_dirs():
     dirs = [d for d in os.environ.get("MINIWORLD_ASSET_PATH", "").split(":") if d]
-    for cand in ("/root/reference/miniworld",):
-        if os.path.isdir(cand):
-            dirs.append(cand)
     try:
         import importlib.util
         spec = importlib.util.find_spec("miniworld")

@@ -120,6 +120,7 @@ struct mw_engine {
     bool use_step_override = false;
     // timing
     bool timing = false;
+    int timing_stride = MW_TIMING_STRIDE;
     uint64_t frame_count = 0;
     struct Ev { hipEvent_t a, b, c; };
     std::vector<Ev> ev_used, ev_free;
@@ -396,6 +397,11 @@ int state_xfer(mw_engine *e, int first, int count, const mw_state_view *h, bool 
     return MW_OK;
 }
 
+// every entry point runs on the engine's device, whatever the calling thread's current device is (two engines
+// on different GPUs in one process; torch's current device != cfg.device_id)
+#define ON_DEVICE(e) do { hipError_t sd_ = hipSetDevice((e)->cfg.device_id); \
+        if (sd_ != hipSuccess) return fail((e), MW_E_HIP, "hipSetDevice(%d): %s", (e)->cfg.device_id, hipGetErrorString(sd_)); } while (0)
+
 mw_engine::Ev get_events(mw_engine *e)
 {
     if (!e->ev_free.empty()) {
@@ -463,7 +469,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     mw_engine::Ev ev{};
     // kernel durations are sampled: three event records on every launch cost ~4 % of the step rate,
     // on one launch in MW_TIMING_STRIDE they cost nothing measurable
-    const bool timed = e->timing && (e->frame_count++ % MW_TIMING_STRIDE) == 0;
+    const bool timed = e->timing && (e->frame_count++ % (uint64_t)e->timing_stride) == 0;
     if (timed) {
         ev = get_events(e);
         (void)hipEventRecord(ev.a, st);
@@ -694,6 +700,7 @@ void mw_destroy(mw_engine *e)
 int mw_upload_texture(mw_engine *e, int32_t tex_id, const uint8_t *rgb, int32_t w, int32_t h)
 {
     if (!e || !rgb) return fail(e, MW_E_INVALID, "null argument");
+    ON_DEVICE(e);
     if (tex_id < 0 || tex_id >= MW_MAX_TEX) return fail(e, MW_E_CAPACITY, "texture id %d out of range (max %d)", tex_id, MW_MAX_TEX);
     if (w <= 0 || h <= 0 || w > 16384 || h > 16384) return fail(e, MW_E_INVALID, "bad texture size %dx%d", w, h);
     build_pyramid(rgb, w, h, e->tex_data[tex_id], e->tex_desc[tex_id]);
@@ -704,6 +711,7 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
                    const float *rgb, int32_t ntris, int32_t tex_id)
 {
     if (!e || !pos || !nrm || !rgb) return fail(e, MW_E_INVALID, "null argument");
+    ON_DEVICE(e);
     if (tex_id >= MW_MAX_TEX || (tex_id >= 0 && !uv)) return fail(e, MW_E_INVALID, "textured mesh needs texcoords and a valid texture id");
     if (mesh_id < 0 || mesh_id >= MW_MAX_MESH) return fail(e, MW_E_CAPACITY, "mesh id %d out of range (max %d)", mesh_id, MW_MAX_MESH);
     if (ntris <= 0 || ntris > 60000) return fail(e, MW_E_CAPACITY, "mesh with %d triangles (1..60000 supported: 16-bit draw ids)", ntris);
@@ -748,6 +756,7 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
 int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_polys, const double *segs, int32_t n_segs)
 {
     if (!e || (n_polys > 0 && !polys) || (n_segs > 0 && !segs)) return fail(e, MW_E_INVALID, "null argument");
+    ON_DEVICE(e);
     if (n_polys < 0 || n_polys > e->cfg.max_polys) return fail(e, MW_E_CAPACITY, "%d polygons > max_polys %d", n_polys, e->cfg.max_polys);
     if (n_segs < 0 || n_segs > e->cfg.max_segs) return fail(e, MW_E_CAPACITY, "%d segments > max_segs %d", n_segs, e->cfg.max_segs);
     int set = 0;
@@ -773,6 +782,7 @@ int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_p
 int mw_get_geometry(mw_engine *e, int32_t env, mw_poly *polys, int32_t *n_polys, double *segs, int32_t *n_segs)
 {
     if (!e || !polys || !n_polys || !segs || !n_segs) return fail(e, MW_E_INVALID, "null argument");
+    ON_DEVICE(e);
     const int set = e->cfg.shared_geometry ? 0 : env;
     if (set < 0 || set >= e->n_sets) return fail(e, MW_E_INVALID, "env out of range");
     HIP_TRY(e, hipDeviceSynchronize());
@@ -785,12 +795,16 @@ int mw_get_geometry(mw_engine *e, int32_t env, mw_poly *polys, int32_t *n_polys,
 
 int mw_set_state(mw_engine *e, int32_t first_env, int32_t count, const mw_state_view *host)
 {
+    if (!e) return MW_E_INVALID;
+    ON_DEVICE(e);
     return state_xfer(e, first_env, count, host, true);
 }
 
 int mw_get_state(mw_engine *e, int32_t first_env, int32_t count, mw_state_view *host)
 {
-    if (e) (void)hipDeviceSynchronize();
+    if (!e) return MW_E_INVALID;
+    ON_DEVICE(e);
+    (void)hipDeviceSynchronize();
     return state_xfer(e, first_env, count, host, false);
 }
 
@@ -798,6 +812,7 @@ int mw_set_step_params(mw_engine *e, const double *host_params)
 {
     if (!e) return MW_E_INVALID;
     if (!host_params) { e->use_step_override = false; return MW_OK; }
+    ON_DEVICE(e);
     HIP_TRY(e, hipMemcpy(e->d_step_override, host_params, 24 * (size_t)e->cfg.num_envs, hipMemcpyHostToDevice));
     e->use_step_override = true;
     return MW_OK;
@@ -806,7 +821,8 @@ int mw_set_step_params(mw_engine *e, const double *host_params)
 int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *stream)
 {
     if (!e) return MW_E_INVALID;
-    if (e->cfg.generator == MW_GEN_NONE) return fail(e, MW_E_INVALID, "engine was created without a device-side generator");
+    ON_DEVICE(e);
+    if (e->cfg.generator == MW_GEN_NONE && !seeds) return fail(e, MW_E_INVALID, "engine was created without a device-side generator");
     const int N = e->cfg.num_envs;
     hipStream_t st = (hipStream_t)stream;
     if (seeds) {
@@ -817,6 +833,9 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
             if (!mask || mask[i]) seed_env(e, cur.data(), i, seeds[i]);
         HIP_TRY(e, hipMemcpy(e->args.rng, cur.data(), 40 * (size_t)N, hipMemcpyHostToDevice));
     }
+    // host-generated worlds (MW_GEN_NONE): seeds only re-seed the env's device stream, which then serves the per-step
+    // domain-randomisation draws (miniworld.py:677-680); the world itself comes through mw_set_state / mw_set_geometry
+    if (e->cfg.generator == MW_GEN_NONE) return MW_OK;
     if (mask) HIP_TRY(e, hipMemcpyAsync(e->d_mask, mask, N, hipMemcpyHostToDevice, st));
     const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
     auto gen = pcg ? mw_reset_pcg_kernel : mw_reset_kernel;
@@ -845,6 +864,7 @@ int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_dep
             uint8_t *d_term, uint8_t *d_trunc, void *stream)
 {
     if (!e) return MW_E_INVALID;
+    ON_DEVICE(e);
     if (!d_actions) return fail(e, MW_E_INVALID, "d_actions is null");
     return launch_frame(e, true, 0, d_actions, d_obs, d_depth, d_reward, d_term, d_trunc, (hipStream_t)stream);
 }
@@ -852,12 +872,14 @@ int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_dep
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream)
 {
     if (!e) return MW_E_INVALID;
+    ON_DEVICE(e);
     return launch_frame(e, false, 0, e->d_action_scratch, d_obs, d_depth, nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int mw_render_top(mw_engine *e, uint8_t *d_obs, float *d_depth, int32_t render_agent, void *stream)
 {
     if (!e) return MW_E_INVALID;
+    ON_DEVICE(e);
     return launch_frame(e, false, 1 | (render_agent ? 2 : 0), e->d_action_scratch, d_obs, d_depth, nullptr, nullptr, nullptr,
                         (hipStream_t)stream);
 }
@@ -866,6 +888,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
                    uint8_t *d_out, float *d_depth, void *stream)
 {
     if (!e || !d_out) return fail(e, MW_E_INVALID, "null argument");
+    ON_DEVICE(e);
     if (env < 0 || env >= e->cfg.num_envs) return fail(e, MW_E_INVALID, "env %d out of range", env);
     if (msaa != 8 && msaa != 16) return fail(e, MW_E_INVALID, "msaa must be 8 or 16");
     if (width <= 0 || height <= 0 || width % MW_TILE_W || height % MW_TILE_H || width > 255 * MW_TILE_W || height > 255 * MW_TILE_H)
@@ -922,6 +945,7 @@ int mw_set_obs_layout(mw_engine *e, int32_t layout)
 int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_vis, void *stream)
 {
     if (!e || !d_vis) return fail(e, MW_E_INVALID, "null argument");
+    ON_DEVICE(e);
     if (first_env < 0 || count <= 0 || first_env + count > e->cfg.num_envs) return fail(e, MW_E_INVALID, "env range out of bounds");
     const size_t lds = (size_t)e->cfg.obs_width * e->cfg.obs_height * 8 * 4;
     if (lds + 1024 > 160 * 1024) return fail(e, MW_E_CAPACITY, "obs frame too large for the in-LDS depth buffer of mw_visible_ents");
@@ -945,6 +969,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
 int mw_check(mw_engine *e, void *stream)
 {
     if (!e) return MW_E_INVALID;
+    ON_DEVICE(e);
     HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
     uint32_t st = 0;
     HIP_TRY(e, hipMemcpy(&st, e->args.status, 4, hipMemcpyDeviceToHost));
@@ -956,6 +981,7 @@ int mw_check(mw_engine *e, void *stream)
 int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *setup_ms, int64_t *launches)
 {
     if (!e) return MW_E_INVALID;
+    ON_DEVICE(e);
     double r = 0, s = 0;
     int64_t n = 0;
     for (auto &ev : e->ev_used) {
@@ -972,6 +998,7 @@ int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *se
     if (launches) *launches = n;
     e->timing = true;
     e->frame_count = 0;
+    e->timing_stride = reset > 0 ? reset : MW_TIMING_STRIDE;
     if (reset < 0) e->timing = false;
     return MW_OK;
 }

@@ -157,9 +157,10 @@ def load_library():
     return L
 
 
-def _stream_ptr():
+def _stream_ptr(device=None):
+    """torch's current stream ON THE ENGINE'S DEVICE (not on torch's current device)."""
     import torch
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
 class Engine:
@@ -260,22 +261,45 @@ class Engine:
         m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
         s = None if seeds is None else np.ascontiguousarray(seeds, np.uint64)
         self._check(self.lib.mw_reset(self.h, None if m is None else m.ctypes.data,
-                                      None if s is None else s.ctypes.data, _stream_ptr()), "mw_reset")
+                                      None if s is None else s.ctypes.data, _stream_ptr(self.device)), "mw_reset")
 
     # -- hot path ---------------------------------------------------------------------
+    def _dev_tensor(self, t, name, dtype, numel):
+        """The kernels read raw pointers: a tensor of another dtype / device / stride pattern would be read as garbage
+        (an int64 action tensor as int32 pairs, a CPU tensor as a fault).  Outputs must already be right; see step()."""
+        if t is None:
+            return None
+        if t.device != self.device or t.dtype != dtype or not t.is_contiguous() or t.numel() != numel:
+            raise EngineError(f"{name}: need a contiguous {dtype} tensor of {numel} elements on {self.device}, got "
+                              f"{t.dtype} {tuple(t.shape)} on {t.device}{'' if t.is_contiguous() else ' (non-contiguous)'}")
+        return t
+
     def step(self, actions, obs, depth=None, reward=None, term=None, trunc=None):
-        """All arguments are torch tensors on this engine's device (depth may be None)."""
+        """All arguments are torch tensors on this engine's device (depth may be None).  `actions` is converted to a
+        contiguous int32 tensor on the device if it is not one already (torch.randint / argmax / Categorical.sample
+        give int64; a column of a [N, T] tensor is strided); the output tensors are checked, never converted."""
+        import torch
+        if actions.device != self.device or actions.dtype != torch.int32 or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if actions.numel() != self.N:
+            raise EngineError(f"actions: {actions.numel()} elements for {self.N} envs")
+        obs_numel = self.N * self.H * self.W * (1 if self.obs_layout == OBS_GREY_F64 else 3)
+        self._dev_tensor(obs, "obs", torch.float64 if self.obs_layout == OBS_GREY_F64 else torch.uint8, obs_numel)
+        self._dev_tensor(depth, "depth", torch.float32, self.N * self.H * self.W)
+        self._dev_tensor(reward, "reward", torch.float32, self.N)
+        self._dev_tensor(term, "terminated", torch.uint8, self.N)
+        self._dev_tensor(trunc, "truncated", torch.uint8, self.N)
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
         self._check(self.lib.mw_step(self.h, ptr(actions), ptr(obs), ptr(depth), ptr(reward), ptr(term),
-                                     ptr(trunc), _stream_ptr()), "mw_step")
+                                     ptr(trunc), _stream_ptr(self.device)), "mw_step")
 
     def render(self, obs, depth=None):
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        self._check(self.lib.mw_render(self.h, ptr(obs), ptr(depth), _stream_ptr()), "mw_render")
+        self._check(self.lib.mw_render(self.h, ptr(obs), ptr(depth), _stream_ptr(self.device)), "mw_render")
 
     def render_top(self, obs, depth=None, render_agent=True):
         ptr = lambda t: None if t is None else C.c_void_p(t.data_ptr())
-        self._check(self.lib.mw_render_top(self.h, ptr(obs), ptr(depth), int(render_agent), _stream_ptr()), "mw_render_top")
+        self._check(self.lib.mw_render_top(self.h, ptr(obs), ptr(depth), int(render_agent), _stream_ptr(self.device)), "mw_render_top")
 
     def render_view(self, env: int, width: int, height: int, msaa: int = 16, top: bool = False,
                     render_agent: bool = False, want_depth: bool = False):
@@ -285,7 +309,7 @@ class Engine:
         dep = torch.zeros((height, width, 1), dtype=torch.float32, device=self.device) if want_depth else None
         flags = (1 if top else 0) | (2 if render_agent else 0)
         self._check(self.lib.mw_render_view(self.h, env, flags, width, height, msaa, C.c_void_p(out.data_ptr()),
-                                            None if dep is None else C.c_void_p(dep.data_ptr()), _stream_ptr()),
+                                            None if dep is None else C.c_void_p(dep.data_ptr()), _stream_ptr(self.device)),
                     "mw_render_view")
         return (out, dep) if want_depth else out
 
@@ -310,14 +334,16 @@ class Engine:
         import torch
         count = self.N - first_env if count is None else count
         vis = torch.zeros((count, self.E), dtype=torch.uint8, device=self.device)
-        self._check(self.lib.mw_visible_ents(self.h, first_env, count, C.c_void_p(vis.data_ptr()), _stream_ptr()),
+        self._check(self.lib.mw_visible_ents(self.h, first_env, count, C.c_void_p(vis.data_ptr()), _stream_ptr(self.device)),
                     "mw_visible_ents")
         return vis
 
     def check(self):
-        self._check(self.lib.mw_check(self.h, _stream_ptr()), "mw_check")
+        self._check(self.lib.mw_check(self.h, _stream_ptr(self.device)), "mw_check")
 
     def kernel_time_ms(self, reset=0):
+        """(raster ms, setup ms, launches measured) since the last call; reset = k > 0: time one launch in k from now
+        on (1 = every launch), 0: the default one in 8, < 0: switch timing off."""
         r, s, n = C.c_double(), C.c_double(), C.c_int64()
         self._check(self.lib.mw_kernel_time_ms(self.h, reset, C.byref(r), C.byref(s), C.byref(n)), "mw_kernel_time_ms")
         return r.value, s.value, n.value

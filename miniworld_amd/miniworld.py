@@ -436,6 +436,12 @@ class MiniWorldEnv(gym.Env):
         return img, {"x_scale": xs, "z_scale": zs, "x_offset": int(0 - min_x * xs), "z_offset": int(0 - min_z * zs)}
 
     def render_depth(self, frame_buffer=None):
+        """Depth map in metres at the frame buffer's size and sample count (miniworld.py:1223-1236)."""
+        if not self._is_obs_fb(frame_buffer):
+            self._engine.push_state(self)
+            msaa = 16 if frame_buffer.num_samples > 8 else 8
+            _, dep = self._engine.engine.render_view(0, frame_buffer.width, frame_buffer.height, msaa, want_depth=True)
+            return dep.cpu().numpy()
         return self._engine.render(self, want_depth=True)["depth"]
 
     def get_visible_ents(self):

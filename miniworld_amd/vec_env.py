@@ -7,8 +7,9 @@ Episodes auto-reset on the device (same-step semantics: the observation returned
 with ``terminated|truncated`` is the first one of the next episode; the reference leaves the
 reset to the caller, scripts/benchmark.py:36-37).
 
-Envs whose generator is not on the device yet (Maze, PickupObjects) are generated on the host
-with the reference-compatible world generator and injected; their auto-reset is host-driven.
+Hallway, OneRoom*, Maze* and PickupObjects (the BASELINE configs) are generated and auto-reset on the device, on
+the reference's own numpy PCG64 stream.  The other env families are generated on the host with the
+reference-compatible world generator and injected (`_host_generate`); their auto-reset is host-driven.
 """
 from __future__ import annotations
 
@@ -209,11 +210,26 @@ class MiniWorldVecEnv:
             env.reset(seed=int(s))
             self._health[i] = 100
             sc = scene_from_env(env)
+            # with domain randomisation a world may draw a texture variant no earlier world used (concrete_2 ...):
+            # upload it on first sight
+            for v in [str(v) for v in sc["tex_names"]]:
+                if v not in self.tex_ids:
+                    from . import assets
+                    self.tex_ids[v] = len(self.tex_ids)
+                    self.engine.upload_texture(self.tex_ids[v], assets.texture_rgb_bottom_up(v))
             if not self.engine.cfg.shared_geometry:
                 tex_map = {k: self.tex_ids[str(v)] for k, v in enumerate(sc["tex_names"])}
                 self.engine.set_geometry(i, polys_array(sc, tex_map), sc["wall_segs"])
             mm = upload_scene_meshes(self.engine, sc, self.mesh_ids, self.tex_ids)
             self.engine.set_state(state_arrays([sc], self.engine.E, [mm]), first=i, count=1)
+        if self.domain_rand:
+            # the per-step forward_step / drift / turn_step draws (miniworld.py:677-680) come from the env's device
+            # stream: seed it with the env's seed (not with the env index it got at creation)
+            mask = np.zeros(self.num_envs, np.uint8)
+            full = np.zeros(self.num_envs, np.uint64)
+            for i, s_ in zip(indices, seeds):
+                mask[i], full[i] = 1, int(s_)
+            self.engine.reset(mask, full)
 
     # ------------------------------------------------------------------ API
     def reset(self, seed: int | None = None):
@@ -230,7 +246,7 @@ class MiniWorldVecEnv:
         return self.obs
 
     def step(self, actions):
-        """actions: int32 torch tensor [N] on the engine's device."""
+        """actions: integer torch tensor [N] (converted to contiguous int32 on the engine's device if needed)."""
         self.engine.step(actions, self.obs, self.depth, self.reward, self.terminated, self.truncated)
         if self._host_rule is not None:
             self._host_rule(actions)

@@ -191,6 +191,9 @@ double mwo_bench_loop(mwo_scene *sc, mwo_agent_state *ag, mwo_phys_ent *ents, co
 {
     struct timespec t0, t1;
     mwo_agent_state ag0 = *ag;
+    mwo_phys_ent ents0[64];
+    int ne = ag->n_ents < 64 ? ag->n_ents : 64;
+    memcpy(ents0, ents, (size_t)ne * sizeof(mwo_phys_ent));
     uint32_t lcg = 12345u;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int i = 0; i < steps; ++i) {
@@ -199,7 +202,7 @@ double mwo_bench_loop(mwo_scene *sc, mwo_agent_state *ag, mwo_phys_ent *ents, co
         double rew;
         int32_t te, tr;
         mwo_step(ag, ents, 0, segs, n_segs, action, 0.15, 0.0, 15.0, &rew, &te, &tr);
-        if (te || tr) *ag = ag0;
+        if (te || tr) { *ag = ag0; memcpy(ents, ents0, (size_t)ne * sizeof(mwo_phys_ent)); }   /* episode restart */
         sc->agent_pos[0] = ag->pos[0]; sc->agent_pos[1] = ag->pos[1]; sc->agent_pos[2] = ag->pos[2];
         sc->agent_dir = ag->dir;
         mwo_render_obs(sc, rgb, 0, 0, 0);

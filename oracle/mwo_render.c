@@ -254,8 +254,11 @@ static int setup_prim(const mwo_scene *sc, const hvert *h, int nv, const float (
     }
     /* pixel bounds: conservative for polygons (an optimisation that never changes their coverage in
      * practice), exact and part of the semantics for mesh triangles (R4m below) */
-    int allpos = 1;
-    for (int k = 0; k < nv; ++k) allpos &= (h[k].hw > 0.0f);
+    int allpos = 1, allneg = 1;
+    for (int k = 0; k < nv; ++k) { allpos &= (h[k].hw > 0.0f); allneg &= !(h[k].hw > 0.0f); }
+    /* a primitive with every vertex on or behind the eye plane is clipped away as a whole (GL clips geometrically;
+     * in 2DH terms every point inside it has w <= 0, i.e. z_ndc > 1, and fails R6's range test anyway) */
+    if (allneg) return 0;
     p->x0 = 0; p->y0 = 0; p->x1 = sc->width - 1; p->y1 = sc->height - 1;
     if (allpos) {
         float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;

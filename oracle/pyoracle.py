@@ -319,9 +319,10 @@ class Dynamics:
                                    self.segs.ctypes.data, self.segs.shape[0])
 
 
-def bench_loop(scene: dict, task: int, max_episode_steps: int, n_actions: int, steps: int) -> float:
+def bench_loop(scene: dict, task: int, max_episode_steps: int, n_actions: int, steps: int,
+               meshes: dict | None = None) -> float:
     """Seconds the C oracle needs for `steps` x [MiniWorldEnv.step + render_obs] on one env."""
-    sc, keep = pack_scene(scene)
+    sc, keep = pack_scene(scene, meshes=meshes)
     dyn = Dynamics(scene, task, max_episode_steps, num_objs=len(scene["ents_kind"]),
                    max_forward_step=float(scene["max_forward_step"]))
     rgb = np.zeros((60, 80, 3), np.uint8)

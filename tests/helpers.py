@@ -150,3 +150,110 @@ def depth_from_z16(z16):
     clip_z = (depth_map - 0.5) * 2.0
     world_z = -2 * z_far * z_near / (clip_z * (z_far - z_near) - (z_far + z_near))
     return world_z.astype(np.float32)
+
+
+# ------------------------------------------------------------------ batched env -> oracle scenes
+
+def vec_env_meshes(vec):
+    """mesh name -> arrays for pyoracle.render, for every mesh resident in the batched env's engine."""
+    from miniworld_amd.objmesh import ObjMesh
+    out = {}
+    for name in vec.mesh_ids:
+        m = ObjMesh.get(name)
+        out[name] = {"verts": m.verts, "norms": m.norms, "texcs": m.texcs, "colors": m.colors}
+    return out
+
+
+def scene_of_vec_env(vec, st, i, row=None):
+    """Neutral scene (oracle input) of env i of a MiniWorldVecEnv, from what the DEVICE holds: the state arrays `st`
+    (mw_get_state; `row` = env i's row in them, default i) and, for envs with their own geometry set (Maze, texture
+    domain randomisation), the polygons read back with mw_get_geometry."""
+    from miniworld_amd.scene import scene_from_env
+    row = i if row is None else row
+    sc = scene_from_env(vec.template)
+    names = sorted(vec.mesh_ids, key=vec.mesh_ids.get)
+    sc["agent_pos"], sc["agent_dir"] = st["agent_pos"][row], st["agent_dir"][row]
+    sc["cam_height"], sc["cam_fwd_disp"], sc["cam_pitch"], sc["cam_fov_y"] = st["cam"][row]
+    sc["sky"], sc["light_pos"] = st["light"][row, 0:3], st["light"][row, 3:6]
+    sc["light_color"], sc["light_ambient"] = st["light"][row, 6:9], st["light"][row, 9:12]
+    sc["ents_kind"], sc["ents_mesh"] = st["ent_kind"][row], st["ent_mesh"][row]
+    sc["ents_pos"], sc["ents_dir"] = st["ent_pos"][row], st["ent_dir"][row]
+    sc["ents_size"], sc["ents_color"] = st["ent_geom"][row, :, 0:3], st["ent_geom"][row, :, 3:6]
+    sc["ents_scale"], sc["ents_radius"], sc["ents_height"] = st["ent_geom"][row, :, 6], st["ent_geom"][row, :, 7], st["ent_geom"][row, :, 8]
+    sc["ents_static"] = st["ent_static"][row]
+    sc["mesh_names"] = np.array(names)
+    sc["mesh_tex"] = np.full(len(names), -1, np.int32)         # ball / key meshes are untextured
+    if not vec.engine.cfg.shared_geometry:
+        polys, segs = vec.engine.get_geometry(i)
+        sc["polys_v"], sc["polys_uv"], sc["polys_n"] = polys["v"], polys["uv"], polys["n"]
+        sc["polys_nv"], sc["polys_tex"], sc["polys_rgb"] = polys["nv"], polys["tex"], polys["rgb"]
+        sc["wall_segs"] = segs
+        ids = vec.tex_ids
+        sc["tex_names"] = np.array(sorted(ids, key=ids.get))
+    return sc
+
+
+class EpisodeMirror:
+    """One environment of a device batch replayed on the CPU from the same seed, with nothing of the engine in it:
+    worlds come from the host world generator (seed-exact with the reference's reset(), tests/test_host_logic_cpu.py),
+    steps from the C oracle's dynamics (pyoracle.Dynamics, pinned on the reference's trajectories), the three per-step
+    domain-randomisation draws from the env's own numpy stream in the reference's order (miniworld.py:677-680), and an
+    episode's end continues that stream with reset() exactly like the device's same-step auto-reset."""
+
+    def __init__(self, cls, seed, domain_rand, task, **env_kwargs):
+        self.h = cls(host_only=True, domain_rand=domain_rand, **env_kwargs)
+        self.h.reset(seed=int(seed))
+        self.dr, self.task = domain_rand, task
+        self.episodes = 0
+        self._new_episode()
+
+    def _new_episode(self):
+        import pyoracle
+        from miniworld_amd.scene import scene_from_env
+        h = self.h
+        self.sc = scene_from_env(h)
+        self.dyn = pyoracle.Dynamics(self.sc, self.task, int(min(float(h.max_episode_steps), 2 ** 30)),
+                                     num_objs=len(self.sc["ents_kind"]), max_forward_step=float(h.max_forward_step),
+                                     agent_radius=float(h.agent.radius))
+        self.fresh = True
+        self.episodes += 1
+
+    def step(self, action):
+        h = self.h
+        rand = h.np_random if self.dr else None
+        p = [h.params.sample(rand, k) for k in ("forward_step", "forward_drift", "turn_step")]
+        r, te, tr = self.dyn.step(int(action), *p)
+        self.fresh = False
+        if te or tr:
+            h.reset()
+            self._new_episode()
+        return r, te, tr
+
+    def state(self):
+        """(agent_pos, agent_dir, carrying, step_count, alive[E], ent_pos[E,3], ent_dir[E]) after the last step."""
+        E = len(self.sc["ents_kind"])
+        ag, ents = self.dyn.ag, self.dyn.ents
+        return (np.array(ag.pos[:]), float(ag.dir), int(ag.carrying), int(ag.step_count),
+                np.array([bool(ents[k].alive) for k in range(E)]),
+                np.array([ents[k].pos[:] for k in range(E)]).reshape(E, 3), np.array([ents[k].dir for k in range(E)]))
+
+    def frame_scene(self):
+        """The scene the observation returned by the last step shows: a fresh episode's initial world, or the state
+        at render time — rendering happens before PickupObjects removes what was picked up (pickupobjects.py:86-88)."""
+        sc = dict(self.sc)
+        if not self.fresh:
+            E = len(sc["ents_kind"])
+            ag, ents = self.dyn.ag, self.dyn.render_ents
+            sc["agent_pos"], sc["agent_dir"] = np.array(ag.pos[:]), np.float64(ag.dir)
+            sc["ents_pos"] = np.array([ents[k].pos[:] for k in range(E)]).reshape(E, 3)
+            sc["ents_dir"] = np.array([ents[k].dir for k in range(E)])
+            sc["ents_kind"] = np.where([bool(ents[k].alive) for k in range(E)], sc["ents_kind"], 0).astype(np.int32)
+        return sc
+
+    def meshes(self):
+        from miniworld_amd.objmesh import ObjMesh
+        out = {}
+        for name in [str(m) for m in self.sc["mesh_names"]]:
+            m = ObjMesh.get(name)
+            out[name] = {"verts": m.verts, "norms": m.norms, "texcs": m.texcs, "colors": m.colors}
+        return out

@@ -789,3 +789,74 @@ def test_spare_world_mode_keeps_the_reference_stream(env_id, cls_name, monkeypat
     assert (episodes > 2).any()
     vec.engine.check()
     vec.close()
+
+
+def test_vec_env_host_generated_family_with_domain_rand():
+    """A host-generated family with domain_rand=True in the batched API: every world draws its own texture variants
+    (some never seen by the template: they are uploaded on first sight), sky / light / camera parameters; env 2 of a
+    batch seeded with 0 is the reference's FourRooms(domain_rand=True).reset(seed=2) (fixture fourrooms_dr_s2), and
+    every frame equals the oracle's render of the host world."""
+    import torch
+    import pyoracle
+    from miniworld_amd.scene import scene_from_env
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    s0, tr, meta, obs = helpers.load_case("fourrooms_dr_s2")
+    n = 6
+    vec = MiniWorldVecEnv("MiniWorld-FourRooms-v0", n, domain_rand=True, seed=0)
+    o = vec.reset()
+    assert np.array_equal(o[2].cpu().numpy(), obs[0]["rgb"])
+    variants = set()
+    for i in range(n):
+        sc = scene_from_env(vec._host_envs[i])
+        variants |= {str(v) for v in sc["tex_names"]}
+        assert np.array_equal(o[i].cpu().numpy(), pyoracle.render(sc)["rgb"]), i
+    assert len(variants) > len({str(v) for v in scene_from_env(vec.template)["tex_names"]})       # variants beyond the template's
+    # steps draw forward_step / drift / turn_step from the env's device stream, re-seeded with the env's own seed
+    act = torch.full((n,), 2, dtype=torch.int32, device="cuda")
+    p0 = vec.engine.get_state()["agent_pos"].copy()
+    for _ in range(3):
+        vec.step(act)
+    vec.engine.check()
+    moved = np.linalg.norm(vec.engine.get_state()["agent_pos"] - p0, axis=1)
+    assert (moved <= 3 * 0.17 * 1.05 + 1e-9).all() and len(np.unique(np.round(moved[moved > 0], 9))) > 1
+    vec.close()
+
+
+def test_step_accepts_int64_and_strided_actions_and_rejects_bad_outputs():
+    """torch.randint / argmax / Categorical.sample give int64, a column of a [N, T] plan is strided: step() converts
+    such action tensors instead of reading them as raw int32 words; output tensors of the wrong dtype are an error."""
+    import torch
+    from miniworld_amd.engine import EngineError
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n, T = 64, 12
+    plan = torch.randint(0, 3, (n, T), generator=torch.Generator(device="cuda").manual_seed(4), device="cuda")     # int64 [N, T]
+    a = MiniWorldVecEnv("MiniWorld-Hallway-v0", n, seed=3)
+    b = MiniWorldVecEnv("MiniWorld-Hallway-v0", n, seed=3)
+    a.reset(); b.reset()
+    for t in range(T):
+        a.step(plan[:, t].to(torch.int32).contiguous())
+        if t % 3 == 0:
+            b.step(plan[:, t])                      # int64, stride T
+        elif t % 3 == 1:
+            b.step(plan[:, t].cpu())                # on the host
+        else:
+            b.step(plan[:, t].to(torch.int16))
+    assert torch.equal(a.obs, b.obs) and torch.equal(a.reward, b.reward)
+    with pytest.raises(EngineError):
+        a.engine.step(plan[:, 0], a.obs, None, a.reward.double(), a.terminated, a.truncated)
+    with pytest.raises(EngineError):
+        a.engine.step(plan[:8, 0], a.obs, None, a.reward, a.terminated, a.truncated)
+    a.close(); b.close()
+
+
+def test_render_depth_honours_the_frame_buffer():
+    """render_depth(frame_buffer) renders at that buffer's size and sample count (miniworld.py:1223-1236)."""
+    import pyoracle
+    from miniworld_amd import envs
+    env = envs.OneRoom()
+    env.reset(seed=3)
+    d = env.render_depth(env.vis_fb)
+    assert d.shape[:2] == (600, 800) and d.dtype == np.float32
+    want = pyoracle.render(env.scene(), 800, 600, 16)["depth"]
+    assert np.array_equal(d.reshape(600, 800), want.reshape(600, 800))
+    env.close()
