@@ -326,7 +326,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     // visiting the primitives in ascending draw index IS the resolve order of R12.  Each
     // visit shades immediately.  Any contention abandons the tile to pass B (exact keys).
     bool exact = (dbg & 4) != 0;
-    const bool sorted = SORTED && cx.order[0] != 0;
+    const bool sorted = SORTED && cx.order[0] != 0 && !(dbg & 64);     // MW_DEBUG_FLAGS bit 6: ignore the visiting order
     if (SORTED && sorted) exact = true;
     if (MESH) {
         bool m = false;
@@ -443,8 +443,10 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     if (SORTED && sorted) pidx = (int)cx.order[1 + lp];
                     classify_prim(s_cull, pidx, Xlo, Xhi, Ylo, Yhi, touch, full, clipf);
                     if (SORTED && sorted) {
-                        const float zb = fmaf(s_cull[pidx * 6 + 5].y, 65535.0f, 0.5f);     // the key formula of R6 on the bound
-                        zlo = zb >= 2.0f ? (uint32_t)zb - 2u : 0u;                          // 2 LSB of slack for rounding
+                        // the key formula of R6 on K1's bound (itself the smallest value the plane + offset expression
+                        // takes over the polygon's tiles): no key of this polygon is below it
+                        const float zb = fmaf(s_cull[pidx * 6 + 5].y, 65535.0f, 0.5f);
+                        zlo = zb >= 1.0f ? (uint32_t)zb : 0u;
                     }
                 }
                 todo = (pmask_t)__ballot(touch);

@@ -428,16 +428,26 @@ __device__ __forceinline__ void write_poly(const MwArgs &a, int env, int idx, ui
     float zmin = 0.0f;
 #if MW_SORT_VIS
     {
-        // lower bound of the polygon's window depth (its depth plane is linear on screen, so the minimum over
-        // the covered samples is no smaller than the minimum over the vertices); 0 = nearest possible when a
-        // vertex is behind the eye.  The raster kernel visits polygons in ascending order of this bound and
-        // stops once a tile's farthest stored sample is nearer than the next bound.
+        // Lower bound of every depth KEY the raster kernel can compute for this polygon: its depth plane, evaluated
+        // exactly like there (R6: fmaf(zx, Xc, fmaf(zy, Yc, zc)) + zo[s], every step monotone in Xc and Yc, rounding
+        // included), at the corner of the polygon's tile bounds where it is smallest, plus the smallest sample offset.
+        // (The minimum over the VERTEX depths is not such a bound: the plane coefficients of a thin or grazing
+        // polygon carry rounding error, and the key computed at a sample can fall below the depth of every vertex —
+        // the full-size parity test caught single samples of far polygons, seen through cracks, lost that way.)
+        // 0 = nearest possible when a vertex is behind the eye (bounds are the whole screen then).
+        // The raster kernel visits polygons in ascending order of this bound and stops once a tile's farthest
+        // stored sample is nearer than the next bound.
         bool allpos = true;
-        float m = 1e30f;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (k < nv) { allpos &= h[k].hw > 0.0f; m = fminf(m, h[k].cz / h[k].hw); }
-        zmin = allpos ? fmaf(m, 0.5f, 0.5f) : 0.0f;
+            if (k < nv) allpos &= h[k].hw > 0.0f;
+        const float Xlo = (float)((g.bbox & 255u) * MW_TILE_W) + 0.5f, Xhi = (float)(((g.bbox >> 8) & 255u) * MW_TILE_W + (MW_TILE_W - 1)) + 0.5f;
+        const float Ylo = (float)(((g.bbox >> 16) & 255u) * MW_TILE_H) + 0.5f, Yhi = (float)((g.bbox >> 24) * MW_TILE_H + (MW_TILE_H - 1)) + 0.5f;
+        const float zcmin = fmaf(zx, zx > 0.0f ? Xlo : Xhi, fmaf(zy, zy > 0.0f ? Ylo : Yhi, zc));
+        float zomin = zo[0];
+#pragma unroll
+        for (int s = 1; s < 8; ++s) zomin = fminf(zomin, zo[s]);
+        zmin = allpos ? zcmin + zomin : 0.0f;
         if (!(zmin >= 0.0f)) zmin = 0.0f;
         // sort key: the bound's bit pattern (monotone for non-negative floats), ties broken by the list index
         if (idx < MW_SORT_CAP) s_zmin[idx] = ((unsigned long long)__float_as_uint(zmin) << 16) | (unsigned long long)idx;
