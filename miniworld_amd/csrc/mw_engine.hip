@@ -21,6 +21,10 @@ extern "C" __global__ void mw_step_setup_kernel(MwArgs a, int do_step, int view_
 extern "C" __global__ void mw_step_setup_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                     float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_reset_pcg_kernel(MwArgs a, const uint8_t *mask, int force_all, int mark_refill);
+extern "C" __global__ void mw_step_setup_dense_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
+                                                       float *reward, uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_step_setup_dense_pcg_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
+                                                           float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                      float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
@@ -125,6 +129,7 @@ struct mw_engine {
     struct Ev { hipEvent_t a, b, c; };
     std::vector<Ev> ev_used, ev_free;
     int waves_per_env = 0;
+    bool k1_dense = true;    // MW_K1_DENSE=0: always the wave-per-env K1
     int texel_bytes = 4;
     int dbg_flags = 0;       // MW_DEBUG_FLAGS: perf experiments only (bit0: flat shading)
 };
@@ -175,6 +180,16 @@ auto k1_of(const mw_engine *e) -> decltype(&mw_step_setup_kernel)
 }
 
 int k1_threads(const mw_engine *e) { return e->args.rec_order ? 256 : 64; }     // MW_K1_WAVES of the variant (mw_setup.hip)
+
+// Lanes per env of the dense K1 (mw_setup_dense.hip: one lane per room polygon + six per entity slot), or 0 when the
+// frame has to go through the wave-per-env kernel: big scenes, mesh entities, spare-world mode, other views,
+// K1 profiling, or simply too many primitive slots for a wavefront.  MW_K1_DENSE=0 switches it off (A/B runs).
+int k1_dense_lanes(const mw_engine *e, int view_flags)
+{
+    if (e->args.rec_order || e->have_meshes || view_flags != 0 || !e->k1_dense) return 0;
+    const int lanes = e->cfg.max_polys + 6 * e->cfg.max_ents;
+    return lanes <= 64 ? lanes : 0;
+}
 
 // numpy.random.SeedSequence(seed).generate_state(4, uint64) for a non-negative integer seed (the
 // published SeedSequence algorithm: 4-word pool, hashmix / mix with the constants below), then PCG64's
@@ -476,9 +491,19 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     }
     // spare mode: blocks appended to the grid regenerate the spare worlds consumed in earlier steps, beside the step itself
     const int refill_blocks = (e->spare_mode && do_step) ? (e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64) : 0;
-    hipLaunchKernelGGL(k1_of(e), dim3(N + refill_blocks), dim3(k1_threads(e)), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
-                       d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
-                       d_trunc ? d_trunc : e->d_flag_scratch + N);
+    if (const int lanes = k1_dense_lanes(e, view_flags)) {
+        const int epw = 64 / lanes;
+        auto k1d = e->cfg.rng_mode == MW_RNG_PCG64 ? mw_step_setup_dense_pcg_kernel : mw_step_setup_dense_kernel;
+        // spare mode: blocks appended to the grid regenerate the spare worlds consumed in earlier steps (64 envs each)
+        const int refill = (e->spare_mode && do_step) ? (N + 63) / 64 : 0;
+        hipLaunchKernelGGL(k1d, dim3((N + epw - 1) / epw + refill), dim3(64), 0, st, a, do_step ? 1 : 0, lanes, d_actions,
+                           d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
+                           d_trunc ? d_trunc : e->d_flag_scratch + N);
+    } else {
+        hipLaunchKernelGGL(k1_of(e), dim3(N + refill_blocks), dim3(k1_threads(e)), 0, st, a, do_step ? 1 : 0, view_flags, d_actions,
+                           d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
+                           d_trunc ? d_trunc : e->d_flag_scratch + N);
+    }
     if (timed) (void)hipEventRecord(ev.b, st);
     bool forked = false;
     if (e->have_meshes) {
@@ -617,9 +642,16 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.polys = polys; a.npolys = npolys; a.segs = segs; a.nsegs = nsegs;
     // spare mode: a pre-generated next world per env (mw_device.h::MwSpare)
     MwSpare sp{};
-    // Off by default: on the headline config it shortens K1 by 2 us of 51 (the episode-end blocks are not what bounds
-    // the kernel), inside the run-to-run noise of the step rate.  MW_SPARE=1 switches it on.
-    e->spare_mode = cfg->generator != MW_GEN_NONE && !cfg->domain_rand && getenv("MW_SPARE") != nullptr;
+    // Spare worlds pay where the inline generator is the launch's tail: in the dense K1 of small scenes (a wave with a
+    // finished env takes 26 us instead of 12, profiles/r02a) they are on by default; in the wave-per-env K1 they bought
+    // 2 us of 51 (Hallway) and nothing on Maze, where they stay off.  MW_SPARE=1 / 0 forces either.  Not with domain
+    // randomisation: the per-step draws interleave with the worlds in the env's stream.
+    {
+        const bool small_scene = cfg->max_visible <= 64 && cfg->max_polys + 6 * std::max(cfg->max_ents, 1) <= 64;
+        bool want = small_scene && cfg->generator != MW_GEN_MAZE;
+        if (const char *s = getenv("MW_SPARE")) want = atoi(s) != 0;
+        e->spare_mode = cfg->generator != MW_GEN_NONE && !cfg->domain_rand && want;
+    }
     if (e->spare_mode) {
         ALLOC(sp.ax, N); ALLOC(sp.ay, N); ALLOC(sp.az, N); ALLOC(sp.adir, N);
         ALLOC(sp.cam, 4 * (size_t)N); ALLOC(sp.light, 12 * (size_t)N); ALLOC(sp.extent, 4 * (size_t)N);
@@ -650,6 +682,10 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
+    if (getenv("MW_K1_PROF")) {     // perf experiments only: per-env cycle stamps of K1's phases, dumped by mw_destroy
+        ALLOC(a.k1_prof, 8 * (size_t)N);
+        if (rc == MW_OK) (void)hipMemset(a.k1_prof, 0, 64 * (size_t)N);
+    }
 #undef ALLOC
     if (rc != MW_OK) { g_create_error = e->err; mw_destroy(e); return rc; }
     // carrying = -1 everywhere; default seeds = env index
@@ -667,6 +703,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
+    if (const char *s = getenv("MW_K1_DENSE")) e->k1_dense = atoi(s) != 0;
     if (sync_gen_args(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     *out = e;
     return MW_OK;

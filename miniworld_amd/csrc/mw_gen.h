@@ -475,6 +475,67 @@ __device__ inline void take_spare(const MwArgs &a, int env, int lane)
     }
 }
 
+// The same by ONE lane (mw_setup_dense.hip: the env's leading lane; a wavefront holds several envs there).
+// Every group of values is loaded into registers first and stored afterwards: source and destination may alias as
+// far as the compiler knows, and a load -> store -> load chain would pay one memory round trip per value.
+__device__ inline void take_spare_lane(const MwArgs &a, int env)
+{
+    const MwSpare &sp = *a.spare;
+    const size_t N = a.N, E = a.E;
+    {
+        double v[24];
+        v[0] = sp.ax[env]; v[1] = sp.ay[env]; v[2] = sp.az[env]; v[3] = sp.adir[env];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[4 + k] = sp.cam[(size_t)k * N + env];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) v[8 + k] = sp.light[(size_t)k * N + env];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[20 + k] = sp.extent[(size_t)k * N + env];
+        a.ax[env] = v[0]; a.ay[env] = v[1]; a.az[env] = v[2]; a.adir[env] = v[3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.cam[(size_t)k * N + env] = v[4 + k];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) a.light[(size_t)k * N + env] = v[8 + k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a.extent[(size_t)k * N + env] = v[20 + k];
+        a.carry[env] = -1; a.step[env] = 0; a.picked[env] = 0;
+    }
+    for (int s = 0; s < (int)E; ++s) {
+        const int32_t kind = sp.ekind[(size_t)s * N + env], mesh = sp.emesh[(size_t)s * N + env], stat = sp.estatic[(size_t)s * N + env];
+        double v[13];
+        v[0] = sp.edir[(size_t)s * N + env];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v[1 + k] = sp.epos[((size_t)k * E + s) * N + env];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) v[4 + k] = sp.egeom[((size_t)k * E + s) * N + env];
+        a.ekind[(size_t)s * N + env] = kind; a.emesh[(size_t)s * N + env] = mesh; a.estatic[(size_t)s * N + env] = stat;
+        a.edir[(size_t)s * N + env] = v[0];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) a.epos[((size_t)k * E + s) * N + env] = v[1 + k];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.egeom[((size_t)k * E + s) * N + env] = v[4 + k];
+    }
+    if (!a.shared_geom) {
+        const int np = sp.npolys[env], ns = sp.nsegs[env];
+        const float4 *ps = reinterpret_cast<const float4 *>(sp.polys + (size_t)env * a.max_polys);
+        float4 *pd = reinterpret_cast<float4 *>(const_cast<mw_poly *>(a.polys) + (size_t)env * a.max_polys);
+        for (int i = 0; i < np; ++i) {
+            float4 q[sizeof(mw_poly) / 16];
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(mw_poly) / 16); ++k) q[k] = ps[i * (int)(sizeof(mw_poly) / 16) + k];
+#pragma unroll
+            for (int k = 0; k < (int)(sizeof(mw_poly) / 16); ++k) pd[i * (int)(sizeof(mw_poly) / 16) + k] = q[k];
+        }
+        const double *ss = sp.segs + (size_t)env * a.max_segs * 4;
+        double *sd = const_cast<double *>(a.segs) + (size_t)env * a.max_segs * 4;
+        for (int i = 0; i < ns; ++i) {
+            const double s0 = ss[i * 4], s1 = ss[i * 4 + 1], s2 = ss[i * 4 + 2], s3 = ss[i * 4 + 3];
+            sd[i * 4] = s0; sd[i * 4 + 1] = s1; sd[i * 4 + 2] = s2; sd[i * 4 + 3] = s3;
+        }
+        const_cast<int32_t *>(a.npolys)[env] = np; const_cast<int32_t *>(a.nsegs)[env] = ns;
+    }
+}
+
 // Spare refill, executed by extra blocks appended to K1's grid (and by mw_refill_kernel when mw_reset needs the
 // spares current): block r handles 64 envs, one per thread — or one env with all 64 lanes for the Maze generator.
 // An env is claimed with a compare-and-swap on its refill state, so that its own K1 block, should the new episode
