@@ -99,7 +99,7 @@ struct mw_engine {
     std::vector<void *> allocs;
     // textures
     std::vector<MwTexDesc> tex_desc;
-    std::vector<std::vector<uint32_t>> tex_data;   // RGBA8 pyramid per texture
+    std::vector<std::vector<uint32_t>> tex_data;   // per texture: every level as 16-byte footprint records (build_pyramid)
     uint32_t *d_texels = nullptr;
     MwTexDesc *d_texdesc = nullptr;
     MwMeshDesc *d_meshdesc = nullptr;
@@ -263,9 +263,20 @@ void build_pyramid(const uint8_t *rgb, int w, int h, std::vector<uint32_t> &out,
     desc.w = (uint32_t)w; desc.h = (uint32_t)h; desc.nlevels = 0; desc.pad = 0;
     out.clear();
     for (;;) {
-        desc.lvl[desc.nlevels++] = MwTexDesc::Level{(uint32_t)out.size(), (uint32_t)w, (uint32_t)w - 1u, (uint32_t)h - 1u, (float)w, (float)h, (uint32_t)h, 0u};
-        for (size_t i = 0; i < (size_t)w * h; ++i)
-            out.push_back((uint32_t)cur[i * 3] | ((uint32_t)cur[i * 3 + 1] << 8) | ((uint32_t)cur[i * 3 + 2] << 16) | 0xFF000000u);
+        // a level is stored as one 16-byte record per texel (i, j): the four texels of its GL_LINEAR footprint
+        // (i, j), (i+1, j), (i, j+1), (i+1, j+1), GL_REPEAT applied — a bilinear tap is ONE 16-byte load and needs
+        // neither the neighbour indices nor their wrap (4x the memory: the coarse levels an 80x60 frame samples stay
+        // cache resident all the same).  Level::off counts these records from the start of the texture.
+        desc.lvl[desc.nlevels++] = MwTexDesc::Level{(uint32_t)(out.size() / 4), (uint32_t)w, (uint32_t)w - 1u, (uint32_t)h - 1u, (float)w, (float)h, (uint32_t)h, 0u};
+        auto texel = [&](int i, int j) {
+            const size_t k = ((size_t)(j % h) * w + (size_t)(i % w)) * 3;
+            return (uint32_t)cur[k] | ((uint32_t)cur[k + 1] << 8) | ((uint32_t)cur[k + 2] << 16) | 0xFF000000u;
+        };
+        for (int j = 0; j < h; ++j)
+            for (int i = 0; i < w; ++i) {
+                out.push_back(texel(i, j)); out.push_back(texel(i + 1, j));
+                out.push_back(texel(i, j + 1)); out.push_back(texel(i + 1, j + 1));
+            }
         if ((w == 1 && h == 1) || desc.nlevels == MW_MAX_LEVELS) break;
         const int nw = std::max(1, w / 2), nh = std::max(1, h / 2);
         nxt.assign((size_t)nw * nh * 3, 0);
@@ -297,10 +308,12 @@ int upload_textures(mw_engine *e)
     const size_t table = (size_t)MW_MAX_TEX * sizeof(MwTexDesc) / 4;       // dwords
     size_t total = table;
     std::vector<MwTexDesc> descs = e->tex_desc;
+    static_assert((MW_MAX_TEX * sizeof(MwTexDesc)) % 16 == 0, "footprint records are 16-byte aligned behind the table");
     for (size_t i = 0; i < descs.size(); ++i) {
-        for (uint32_t l = 0; l < descs[i].nlevels; ++l) descs[i].lvl[l].off += (uint32_t)total;
+        for (uint32_t l = 0; l < descs[i].nlevels; ++l) descs[i].lvl[l].off += (uint32_t)(total / 4);      // in 16-byte records
         total += e->tex_data[i].size();
     }
+    if (total * 4 > 0xFFFFFFF0ull) return fail(e, MW_E_CAPACITY, "texture pool of %zu bytes exceeds one buffer resource", total * 4);
     if (e->d_texels) { (void)hipFree(e->d_texels); e->d_texels = nullptr; e->d_texdesc = nullptr; }
     HIP_TRY(e, hipMalloc((void **)&e->d_texels, total * 4));
     e->d_texdesc = reinterpret_cast<MwTexDesc *>(e->d_texels);

@@ -56,19 +56,16 @@ __device__ inline RGB bilinear(rsrc_t td, rsrc_t tx, uint32_t desc, int l, float
     const float x0f = floorf(x), y0f = floorf(y);
     const float fx = x - x0f, fy = y - y0f;
     int i0 = (int)x0f, j0 = (int)y0f;
-    int i1 = i0 + 1, j1 = j0 + 1;
     if (POT) {
-        i0 &= (int)a4.z; i1 &= (int)a4.z; j0 &= (int)a4.w; j1 &= (int)a4.w;
+        i0 &= (int)a4.z; j0 &= (int)a4.w;
     } else {
-        const int wi = (int)w, hi = (int)b4.z;
-        if (i0 < 0) i0 += wi;
-        if (i1 >= wi) i1 -= wi;
-        if (j0 < 0) j0 += hi;
-        if (j1 >= hi) j1 -= hi;
+        if (i0 < 0) i0 += (int)w;
+        if (j0 < 0) j0 += (int)b4.z;
     }
-    const uint32_t r0 = off + __umul24((uint32_t)j0, w), r1 = off + __umul24((uint32_t)j1, w);
-    const uint32_t t00 = ldw(tx, r0 + i0), t10 = ldw(tx, r0 + i1);
-    const uint32_t t01 = ldw(tx, r1 + i0), t11 = ldw(tx, r1 + i1);
+    // the pool holds, per texel (i, j) of a level, its whole GL_LINEAR footprint: (i, j), (i+1, j), (i, j+1), (i+1, j+1)
+    // with GL_REPEAT applied (mw_engine.hip::build_pyramid) — one 16-byte load, no neighbour indices, no second wrap
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(tx, (off + __umul24((uint32_t)j0, w) + (uint32_t)i0) << 4, 0, 0);
+    const uint32_t t00 = q.x, t10 = q.y, t01 = q.z, t11 = q.w;
     RGB o;
     {
         const float a = ub0(t00), b = ub0(t10), c = ub0(t01), d = ub0(t11);
