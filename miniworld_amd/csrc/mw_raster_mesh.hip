@@ -122,8 +122,8 @@ __device__ inline void mesh_tri_fragment(const TileCtx &cx, const MeshEnt &e, in
     const float Wa = (ga[0] + ga[1]) + ga[2], Wb = (gb[0] + gb[1]) + gb[2], Wc = (gc[0] + gc[1]) + gc[2];
     const float Wq = fmaf(Wa, Xc, fmaf(Wb, Yc, Wc));
     float out[3] = {col[0][0], col[0][1], col[0][2]};
-    if (Wq > 0.0f) {
-        const float iw = 1.0f / Wq;
+    if (rcp_domain(Wq)) {
+        const float iw = rcp_exact(Wq);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const float Ca = fmaf(col[2][i], ga[2], fmaf(col[1][i], ga[1], col[0][i] * ga[0]));

@@ -1,0 +1,43 @@
+// Test hooks that need the GPU but no engine (tests/test_gpu_numerics.py).
+//
+// mw_selftest_rcp: the raster kernels take 1 / W of the perspective-correct interpolation (R7) with rcp_exact()
+// (mw_raster_common.h: hardware reciprocal estimate + one fused Newton step) instead of the compiler's IEEE division
+// sequence (11 instructions).  "Same result as the oracle's 1.0f / x" is a claim about every float: this kernel
+// evaluates both for ALL 2^32 bit patterns and counts where they differ, per binade, so that the guard range inside
+// rcp_exact() is measured, not assumed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mw_raster_common.h"
+
+extern "C" __global__ void mw_selftest_rcp_kernel(unsigned long long *bad_per_exp, uint32_t *examples, unsigned int *n_examples)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint64_t b = tid; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float want = 1.0f / x;                 // correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
+        const float got = rcp_domain(x) ? rcp_exact(x) : want;      // the callers' guard (R7)
+        const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got);
+        if (!same) {
+            atomicAdd(&bad_per_exp[(b >> 23) & 511u], 1ull);           // sign | exponent
+            const unsigned int k = atomicAdd(n_examples, 1u);
+            if (k < 64u) examples[k] = (uint32_t)b;
+        }
+    }
+}
+
+extern "C" int mw_selftest_rcp(unsigned long long *host_bad_per_exp /*[512]*/, uint32_t *host_examples /*[64]*/, uint32_t *host_n)
+{
+    unsigned long long *d_bad = nullptr;
+    uint32_t *d_ex = nullptr;
+    unsigned int *d_n = nullptr;
+    if (hipMalloc((void **)&d_bad, 512 * 8) != hipSuccess || hipMalloc((void **)&d_ex, 64 * 4) != hipSuccess ||
+        hipMalloc((void **)&d_n, 4) != hipSuccess) return -1;
+    (void)hipMemset(d_bad, 0, 512 * 8); (void)hipMemset(d_ex, 0, 64 * 4); (void)hipMemset(d_n, 0, 4);
+    hipLaunchKernelGGL(mw_selftest_rcp_kernel, dim3(256 * 32), dim3(256), 0, 0, d_bad, d_ex, d_n);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    (void)hipMemcpy(host_bad_per_exp, d_bad, 512 * 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host_examples, d_ex, 64 * 4, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host_n, d_n, 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad); (void)hipFree(d_ex); (void)hipFree(d_n);
+    return 0;
+}

@@ -351,7 +351,7 @@ static void bilinear(const mwo_tex *t, int level, float u, float v, float out[3]
 static void shade(const mwo_scene *sc, const prim *p, float Xc, float Yc, float out[3])
 {
     float Wq = fmaf(p->Wa, Xc, fmaf(p->Wb, Yc, p->Wc));
-    int wok = Wq > 0.0f;
+    int wok = Wq >= 1e-30f && Wq <= 1e30f;      /* R7: W <= 0 (or absurdly small / large) = degenerate */
     float iw = wok ? 1.0f / Wq : 0.0f;
     float base[3];
     if (p->gouraud && wok) {
