@@ -78,6 +78,18 @@ extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vi
                                                  const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
                                                  const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes,
                                                  unsigned long long *prof, const int32_t *env_order);
+extern "C" __global__ void mw_raster_mesh_depth_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                                 const float *rec_raster, const float *rec_shade, const float *rec_cull,
+                                                 const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
+                                                 const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
+                                                 const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes,
+                                                 unsigned long long *prof, const int32_t *env_order);
+extern "C" __global__ void mw_raster_mesh_wrap_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+                                                 const float *rec_raster, const float *rec_shade, const float *rec_cull,
+                                                 const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
+                                                 const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
+                                                 const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes,
+                                                 unsigned long long *prof, const int32_t *env_order);
 extern "C" __global__ void mw_mesh_order_kernel(int N, const int32_t *cost, int32_t *order);
 
 #define MW_TIMING_STRIDE 8
@@ -524,7 +536,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * 192;
         if (lds > 160 * 1024) return fail(e, MW_E_CAPACITY, "mesh entities need the env's sample keys in LDS: %dx%d is too large", a.W, a.H);
         if (!e->mesh_lds_ready) {
-            HIP_TRY(e, hipFuncSetAttribute((const void *)mw_raster_mesh_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            for (auto k : {mw_raster_mesh_kernel, mw_raster_mesh_depth_kernel, mw_raster_mesh_wrap_kernel})
+                HIP_TRY(e, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             e->mesh_lds_ready = true;
         }
         // Co-run: the mesh kernel holds one workgroup per CU (its key buffer fills the LDS) but only 352 of a
@@ -550,7 +563,9 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                                (const uint16_t *)nullptr);
         }
         hipLaunchKernelGGL(mw_mesh_order_kernel, dim3(1), dim3(1024), 0, st, N, (const int32_t *)a.k3_cost, a.k3_order);
-        hipLaunchKernelGGL(mw_raster_mesh_kernel, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
+        auto k3 = d_depth ? mw_raster_mesh_depth_kernel : mw_raster_mesh_kernel;
+        if (e->obs_layout != MW_OBS_HWC_U8 || e->dbg_flags != 0) k3 = mw_raster_mesh_wrap_kernel;
+        hipLaunchKernelGGL(k3, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
                            a.mesh_rgb, a.mesh_uv, d_obs, d_depth, kflags, e->texel_bytes, e->d_k3prof,
@@ -695,6 +710,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
+    if (getenv("MW_K3_PROF")) ALLOC(e->d_k3prof, 4 * (size_t)N);      // perf experiments only: dumped by mw_destroy
     if (getenv("MW_K1_PROF")) {     // perf experiments only: per-env cycle stamps of K1's phases, dumped by mw_destroy
         ALLOC(a.k1_prof, 8 * (size_t)N);
         if (rc == MW_OK) (void)hipMemset(a.k1_prof, 0, 64 * (size_t)N);

@@ -37,6 +37,22 @@ __device__ inline float rcp_exact(float x)
     return fmaf(fmaf(-x, y, 1.0f), y, y);
 }
 
+// a / b, correctly rounded like the IEEE division, given y = rcp_exact(b) = RN(1 / b): q = RN(a y) is within an ulp of
+// a / b, its residual r = a - b q is exact in an fma, and q + r y rounds to RN(a / b) (Markstein 1990: the theorem for a
+// correctly rounded reciprocal).  3 instructions per quotient once the reciprocal is there (quotients by one divisor
+// share it) instead of the 11 of the compiler's sequence.  Domain (nothing may overflow or go denormal on the way):
+// b in [MW_DIV_LO, MW_DIV_HI] and a == 0 or |a| in [1e-25, 1e25].  The callers guard b — eye-space w of a vertex, a
+// mesh scale; R4m / R11 treat values outside like the oracle does — and rely on world coordinates below 1e6 m for a.
+// mw_selftest_div compares it with a / b on 2^32 pseudo-random pairs of the domain (tests/test_gpu_numerics.py).
+#define MW_DIV_LO 1e-10f
+#define MW_DIV_HI 1e10f
+__device__ inline bool div_domain(float b) { return b >= MW_DIV_LO && b <= MW_DIV_HI; }
+__device__ inline float div_exact(float a, float y, float b)
+{
+    const float q = a * y;
+    return fmaf(fmaf(-b, q, a), y, q);
+}
+
 // Texel pool and descriptor table are read through raw buffer loads: 32-bit offsets (no 64-bit
 // address arithmetic per texel), hardware bounds check, descriptor in SGPRs.
 typedef __amdgpu_buffer_rsrc_t rsrc_t;

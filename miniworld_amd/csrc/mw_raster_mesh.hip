@@ -106,10 +106,19 @@ __device__ inline void mesh_tri_fragment(const TileCtx &cx, const MeshEnt &e, in
     const float *L = cx.hdr + 20, *amb = cx.hdr + 24, *lcol = cx.hdr + 28;
     const float *nrm = cx.mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = cx.mesh_rgb + (size_t)(e.first + tri) * 9;
     float col[3][3];
+    // R11: normal through the inverse transpose, R_y n / scale, three exact quotients per vertex by one divisor
+    const bool fast_div = div_domain(e.scale);
+    const float inv_scale = fast_div ? rcp_exact(e.scale) : 0.0f;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float nx0 = nrm[k * 3 + 0], ny0 = nrm[k * 3 + 1], nz0 = nrm[k * 3 + 2];
-        const float n[3] = {fmaf(e.c, nx0, e.s * nz0) / e.scale, ny0 / e.scale, fmaf(e.c, nz0, -(e.s * nx0)) / e.scale};
+        const float rnx = fmaf(e.c, nx0, e.s * nz0), rnz = fmaf(e.c, nz0, -(e.s * nx0));
+        float n[3];
+        if (fast_div) {
+            n[0] = div_exact(rnx, inv_scale, e.scale); n[1] = div_exact(ny0, inv_scale, e.scale); n[2] = div_exact(rnz, inv_scale, e.scale);
+        } else {
+            n[0] = rnx / e.scale; n[1] = ny0 / e.scale; n[2] = rnz / e.scale;
+        }
         const float ndl = fmaf(n[2], L[2], fmaf(n[1], L[1], n[0] * L[0]));
         const float d = ndl > 0.0f ? ndl : 0.0f;
 #pragma unroll
@@ -200,11 +209,12 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
     // claim samples away from it.  A triangle reaching behind the eye is bounded loosely instead, by the
     // part in front of w = 0.01 plus a pixel (coverage itself never clips, R4).
     int x0, y0, x1, y1;
-    if (h[0].hw > 0.0f && h[1].hw > 0.0f && h[2].hw > 0.0f) {
+    if (div_domain(h[0].hw) && div_domain(h[1].hw) && div_domain(h[2].hw)) {     // R4m: every w in [1e-10, 1e10]
         float xmin = 1e30f, xmax = -1e30f, ymin = 1e30f, ymax = -1e30f;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            const float X = h[k].hx / h[k].hw, Y = h[k].hy / h[k].hw;
+            const float iw = rcp_exact(h[k].hw);            // the oracle's hx / hw, hy / hw (exact quotients, mw_raster_common.h)
+            const float X = div_exact(h[k].hx, iw, h[k].hw), Y = div_exact(h[k].hy, iw, h[k].hw);
             xmin = fminf(xmin, X); xmax = fmaxf(xmax, X); ymin = fminf(ymin, Y); ymax = fmaxf(ymax, Y);
         }
         const float fx0 = floorf(xmin), fx1 = floorf(xmax), fy0 = floorf(ymin), fy1 = floorf(ymax);
@@ -251,7 +261,7 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
             thr[k][s] = tl ? below(t) : t;
         }
     }
-    const float invD = 1.0f / D;
+    const float invD = rcp_domain(D) ? rcp_exact(D) : 1.0f / D;
     const float ta = fmaf(h[2].cz, ga[2], fmaf(h[1].cz, ga[1], h[0].cz * ga[0]));
     const float tb = fmaf(h[2].cz, gb[2], fmaf(h[1].cz, gb[1], h[0].cz * gb[0]));
     const float tc = fmaf(h[2].cz, gc[2], fmaf(h[1].cz, gc[1], h[0].cz * gc[0]));
@@ -280,13 +290,20 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
 
 }  // namespace
 
-extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
-    int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-    const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
-    const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
-    const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
-    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes,
-    unsigned long long *__restrict__ prof, const int32_t *__restrict__ env_order)
+#define MW_MESH_ARGS \
+    int N, int W, int H, int max_vis, int tiles_x, int n_tiles, \
+    const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull, \
+    const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd, \
+    const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm, \
+    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, \
+    unsigned long long *__restrict__ prof, const int32_t *__restrict__ env_order
+#define MW_MESH_FWD N, W, H, max_vis, tiles_x, n_tiles, rec_raster, rec_shade, rec_cull, nvis_arr, envhdr, texd, texels, mesh_pos, \
+    mesh_nrm, mesh_rgb, mesh_uv, obs, depth, dbg, texel_bytes, prof, env_order
+
+// FMT / HOT as in mw_raster.hip: the production kernels (plain observation layout, RGB or RGB-D) carry no debug flags
+// and no run-time depth / layout switches in their tile loop; the general one reads all of that from `dbg`.
+template <int FMT, int HOT>
+__device__ inline void mesh_kernel_body(MW_MESH_ARGS)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                     // [H][W][8]
@@ -302,7 +319,10 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     // mw_raster_big_kernel on a second stream (they come last in the block order, so these blocks retire at once)
     if ((dbg & 16) && __float_as_int(envhdr[(size_t)env * MW_ENVHDR + 3]) == 0) return;
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
-    for (int i = tid; i < nkeys; i += 1024) keys[i] = 0xFFFFFFFFu;
+    {
+        uint4 *k4 = reinterpret_cast<uint4 *>(keys);
+        for (int i = tid; i < nkeys / 4; i += 1024) k4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    }
     __syncthreads();
 
     TileCtx cx;
@@ -317,12 +337,12 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
     cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
     cx.te.td = cx.te.tx;    // the descriptor table is the head of the texel block (upload_textures)
     cx.te.texd = texd;
-    cx.te.flat = dbg & 1;
+    cx.te.flat = HOT ? 0 : (dbg & 1);
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
     cx.env = env; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane; cx.have_pre = 0; cx.order = nullptr;
 
     // ---- phase 1: every mesh triangle -> LDS keys, one triangle per lane -------------------
-    const int n_mesh = (dbg & 8) ? 0 : __float_as_int(hdr[3]);       // MW_DEBUG_FLAGS bit 3: perf experiments only
+    const int n_mesh = (!HOT && (dbg & 8)) ? 0 : __float_as_int(hdr[3]);       // MW_DEBUG_FLAGS bit 3: perf experiments only
     for (int j = 0; j < n_mesh; ++j) {
         const MeshEnt e = load_ment(hdr, j);
         for (int t = tid; t < e.ntris; t += 1024) raster_tri<8>(cx, e, t, keys);
@@ -338,7 +358,7 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
         const uint4 k0 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8);
         const uint4 k1 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8 + 4);
         mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
-        raster_tile_fmt<true, -1>(cx, tx, ty, mk);
+        raster_tile_fmt<true, FMT, false, HOT, 0>(cx, tx, ty, mk);
     }
     if (prof) {     // MW_K3_PROF: per-env cycle counts (perf experiments only)
         __syncthreads();
@@ -353,6 +373,10 @@ extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(
         }
     }
 }
+
+extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(MW_MESH_ARGS) { mesh_kernel_body<0, 1>(MW_MESH_FWD); }
+extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_depth_kernel(MW_MESH_ARGS) { mesh_kernel_body<0, 2>(MW_MESH_FWD); }
+extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_wrap_kernel(MW_MESH_ARGS) { mesh_kernel_body<-1, 0>(MW_MESH_FWD); }
 
 // ======================================================================================
 // Generic-resolution path: render()/vis_fb 800x600x16 (miniworld.py:518, 1340-1362) and any other

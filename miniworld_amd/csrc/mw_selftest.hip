@@ -41,3 +41,43 @@ extern "C" int mw_selftest_rcp(unsigned long long *host_bad_per_exp /*[512]*/, u
     (void)hipFree(d_bad); (void)hipFree(d_ex); (void)hipFree(d_n);
     return 0;
 }
+
+// mw_selftest_div: div_exact(a, rcp_exact(b), b) against a / b for 2^32 pseudo-random pairs of its domain
+// (b in [1e-10, 1e10], |a| in [1e-25, 1e25] or zero; both signs of a), the mantissas drawn from a 64-bit mixer.
+extern "C" __global__ void mw_selftest_div_kernel(unsigned long long *n_bad, uint32_t *examples)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint64_t i = tid; i < (1ull << 32); i += stride) {
+        uint64_t z = i * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;       // splitmix64
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        // exponents: b in 2^-33 .. 2^33 (inside [1e-10, 1e10]), a in 2^-83 .. 2^83 (inside [1e-25, 1e25])
+        const uint32_t mb = (uint32_t)z & 0x7FFFFFu, ma = (uint32_t)(z >> 23) & 0x7FFFFFu;
+        const uint32_t eb = 127u - 33u + (uint32_t)((z >> 46) % 67u), ea = 127u - 83u + (uint32_t)((z >> 53) % 167u);
+        const float b = __uint_as_float((eb << 23) | mb);
+        float a = __uint_as_float((((uint32_t)(z >> 63)) << 31) | (ea << 23) | ma);
+        if ((i & 0xFFFFull) == 0ull) a = 0.0f;
+        if (!div_domain(b)) continue;
+        const float want = a / b;
+        const float got = div_exact(a, rcp_exact(b), b);
+        if (__float_as_uint(want) != __float_as_uint(got)) {
+            const unsigned long long k = atomicAdd(n_bad, 1ull);
+            if (k < 32ull) { examples[2 * k] = __float_as_uint(a); examples[2 * k + 1] = __float_as_uint(b); }
+        }
+    }
+}
+
+extern "C" int mw_selftest_div(unsigned long long *host_n_bad, uint32_t *host_examples /*[64]*/)
+{
+    unsigned long long *d_n = nullptr;
+    uint32_t *d_ex = nullptr;
+    if (hipMalloc((void **)&d_n, 8) != hipSuccess || hipMalloc((void **)&d_ex, 64 * 4) != hipSuccess) return -1;
+    (void)hipMemset(d_n, 0, 8); (void)hipMemset(d_ex, 0, 64 * 4);
+    hipLaunchKernelGGL(mw_selftest_div_kernel, dim3(256 * 32), dim3(256), 0, 0, d_n, d_ex);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    (void)hipMemcpy(host_n_bad, d_n, 8, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host_examples, d_ex, 64 * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_n); (void)hipFree(d_ex);
+    return 0;
+}

@@ -256,6 +256,9 @@ static int setup_prim(const mwo_scene *sc, const hvert *h, int nv, const float (
      * practice), exact and part of the semantics for mesh triangles (R4m below) */
     int allpos = 1, allneg = 1;
     for (int k = 0; k < nv; ++k) { allpos &= (h[k].hw > 0.0f); allneg &= !(h[k].hw > 0.0f); }
+    /* R4m applies to a mesh triangle whose every w lies in [1e-10, 1e10] (a vertex closer to the eye plane than that
+     * is treated like one behind it: no box) */
+    if (gouraud) for (int k = 0; k < nv; ++k) allpos &= (h[k].hw >= 1e-10f && h[k].hw <= 1e10f);
     /* a primitive with every vertex on or behind the eye plane is clipped away as a whole (GL clips geometrically;
      * in 2DH terms every point inside it has w <= 0, i.e. z_ndc > 1, and fails R6's range test anyway) */
     if (allneg) return 0;

@@ -20,3 +20,15 @@ def test_fast_reciprocal_equals_ieee_division_for_every_float():
     examples = np.array(ex[:min(n.value, 64)], np.uint32).view(np.float32)
     assert n.value == 0, (f"{n.value} inputs differ; binades (sign|exponent): {np.nonzero(bad)[0].tolist()[:40]}; "
                           f"examples: {examples[:8].tolist()}")
+
+
+def test_fast_division_equals_ieee_division_on_its_domain():
+    """div_exact(a, rcp_exact(b), b) == a / b for 2^32 pseudo-random pairs of the domain the kernels use it on."""
+    from miniworld_amd import engine
+    lib = engine.load_library()
+    n = C.c_uint64()
+    ex = (C.c_uint32 * 64)()
+    lib.mw_selftest_div.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.mw_selftest_div(C.byref(n), ex) == 0
+    pairs = np.array(ex[:], np.uint32).view(np.float32).reshape(-1, 2)[:min(int(n.value), 32)]
+    assert n.value == 0, f"{n.value} quotients differ, e.g. (a, b) = {pairs[:6].tolist()}"
