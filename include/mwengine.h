@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MW_ABI_VERSION 2
+#define MW_ABI_VERSION 3
 
 enum {
     MW_OK = 0,
@@ -45,7 +45,11 @@ enum {
     MW_TASK_NONE = 0,
     MW_TASK_GOTO = 1,       /* hallway.py:67-74, oneroom.py:64-71, maze.py:155-162 */
     MW_TASK_PICKUP = 2,     /* pickupobjects.py:83-95                            */
-    MW_TASK_PUTNEXT = 3     /* putnext.py:71-80: goal_ent next to goal_ent2, not carrying */
+    MW_TASK_PUTNEXT = 3,    /* putnext.py:71-80: goal_ent next to goal_ent2, not carrying */
+    MW_TASK_SIDEWALK = 4,   /* sidewalk.py:93-104: the street ends the episode with reward 0, the box like GOTO
+                             * (mw_gen_program.street, goal_ent) */
+    MW_TASK_SIGN = 5        /* sign.py:152-170: action move_forward + 1 ends the episode; touching an object of the
+                             * table ends it with +-1, the last one touched wins (mw_gen_program.sign_*) */
 };
 
 /* device-side world generators for mw_reset / auto-reset (the env's _gen_world) */
@@ -54,7 +58,10 @@ enum {
     MW_GEN_HALLWAY = 1,     /* hallway.py:55-65                               */
     MW_GEN_ONEROOM = 2,     /* oneroom.py:59-62                               */
     MW_GEN_PICKUP = 3,      /* pickupobjects.py:55-81                         */
-    MW_GEN_MAZE = 4         /* maze.py:73-153 (needs shared_geometry = 0)     */
+    MW_GEN_MAZE = 4,        /* maze.py:73-153 (needs shared_geometry = 0)     */
+    MW_GEN_PROGRAM = 5      /* a fixed floorplan whose _gen_world is a list of draws and placements: the placement
+                             * program of mw_set_gen_program (FourRooms, TMaze*, YMaze*, WallGap, ThreeRooms, PutNext,
+                             * RoomObjects, Sidewalk, Sign, ...) */
 };
 
 /* Random stream of device-side resets.  MW_RNG_PHILOX: Philox4x32-10 keyed by the env's seed (same
@@ -63,7 +70,8 @@ enum {
  * reference's call order (miniworld.py:551, 872-905; hallway.py:59-65, oneroom.py:61-62), so that env i
  * reset with seed s is the world of the reference's env.reset(seed=s), and later episodes continue that
  * stream like env.reset() does (with domain randomisation the per-step parameters come from it too,
- * miniworld.py:677-680).  Every device generator; not Maze with domain_rand (no per-room texture variants). */
+ * miniworld.py:677-680).  Every device generator, with and without domain_rand (the Maze's room textures exist in one
+ * variant each in the reference, so Room._gen_static_data's variant draws consume nothing there, opengl.py:134-138). */
 enum { MW_RNG_PHILOX = 0, MW_RNG_PCG64 = 1 };
 enum { MW_AUTORESET_OFF = 0, MW_AUTORESET_SAME_STEP = 1 };
 
@@ -155,6 +163,82 @@ typedef struct {
     double *extent;             /* [count][4] env.min_x, max_x, min_z, max_z (miniworld.py:588-591); top view only */
 } mw_state_view;
 
+/* ---- placement programs (MW_GEN_PROGRAM) --------------------------------------------------------------------
+ * The env families beyond the four BASELINE configs have a FIXED floorplan; their _gen_world only draws a few
+ * numbers and places entities (fourrooms.py:46-73, tmaze.py:54-81, ymaze.py:56-108, wallgap.py:48-77, threerooms.py:47-73,
+ * putnext.py:45-65, roomobjects.py:44-80, sidewalk.py:51-91, sign.py:101-150).  The host compiles that method into
+ * the table below; the device generator executes it on the env's random stream (MW_RNG_PCG64: numpy's own, so env i
+ * is the reference's reset(seed + i)), for mw_reset and for the same-step auto-reset:
+ *   1. the entity table is initialised from the template (ent_*: what the constructors give before placement);
+ *   2. the ops run in order; the first placement op also runs Room._gen_static_data for every room (miniworld.py:856-857):
+ *      with domain_rand three texture-variant draws per room, wall / floor / ceiling (opengl.py:134-138), after which
+ *      the room polygons of the template are re-emitted into the env's own geometry set with the variants' texture ids
+ *      and texture coordinates (metres * TEX_DENSITY / size, miniworld.py:82-119);
+ *   3. the per-episode parameters, Box.randomize for every box in slot order, Agent.randomize (miniworld.py:576-585). */
+#define MW_PROG_MAX_ROOMS 16
+#define MW_PROG_MAX_TEX 8
+#define MW_PROG_MAX_OPS 48
+#define MW_PROG_MAX_ENTS 64
+
+enum {
+    MW_OP_COIN = 1,         /* reg = np_random.integers(0, n)              n in `slot`                          */
+    MW_OP_DRAW_DIR = 2,     /* dir_reg = np_random.uniform(-dir, dir)      (an argument evaluated before place_entity) */
+    MW_OP_PLACE = 3,        /* place_entity(ent, room=..., min_x=... ) by rejection sampling (miniworld.py:839-909)  */
+    MW_OP_FIXED = 4,        /* place_entity(ent, pos=(lx, a, lz), dir=...)                                       */
+    MW_OP_BOX_SIZE = 5,     /* Box(size=np_random.uniform(a, b)): size, radius, height of box `slot`             */
+    MW_OP_COLOR = 6,        /* colour index = np_random.choice(6) for `slot`: room = 0 box (colour vector),
+                             * 1 / 2 ball / key (mesh id = flags + index)                                        */
+    MW_OP_APPEND = 7        /* self.entities.append(ent): in the list from here on (no draw, no static data)     */
+};
+
+typedef struct {
+    int32_t nverts;             /* 3 or 4 outline corners, counter-clockwise seen from above (miniworld.py:127-176) */
+    int32_t wall_tex, floor_tex, ceil_tex;      /* indices into mw_gen_program.tex_* (texture NAMES)             */
+    double ox[4], oz[4];        /* Room.outline                                                                   */
+    double nx[4], nz[4];        /* Room.edge_norms (for point_inside, miniworld.py:272-284)                       */
+    double min_x, max_x, min_z, max_z;
+    double cdf;                 /* cumulative room probability: np_random.choice(len(rooms), p=room_probs) picks
+                                 * searchsorted(cdf, u, side="right") (miniworld.py:873-875)                      */
+} mw_prog_room;
+
+typedef struct {
+    int32_t op;                 /* MW_OP_*                                                                         */
+    int32_t slot;               /* entity slot; -1 = the agent                                                     */
+    int32_t room;               /* PLACE: room index, -1 = choice over all rooms                                   */
+    int32_t cond;               /* run only if the coin register == cond (-1: always)                              */
+    int32_t dir_mode;           /* 0: uniform(-pi, pi) drawn after the position; 1: `dir`; 2: the DRAW_DIR register */
+    int32_t flags;              /* PLACE: bit 0..3 = min_x, max_x, min_z, max_z given (lx, hx, lz, hz)             */
+    double lx, hx, lz, hz;
+    double dir;
+    double a, b;
+} mw_prog_op;
+
+typedef struct {
+    int32_t n_rooms, n_tex, n_ops, n_ents;
+    mw_prog_room rooms[MW_PROG_MAX_ROOMS];
+    int32_t tex_nvar[MW_PROG_MAX_TEX];          /* variants of each texture name (Texture.get, opengl.py:124-140) */
+    int32_t tex_var_id[MW_PROG_MAX_TEX][9];     /* their texture ids (mw_upload_texture)                           */
+    double tex_var_scale[MW_PROG_MAX_TEX][9][2];/* TEX_DENSITY / (width, height)                                   */
+    mw_prog_op ops[MW_PROG_MAX_OPS];
+    int32_t ent_kind[MW_PROG_MAX_ENTS], ent_mesh[MW_PROG_MAX_ENTS], ent_static[MW_PROG_MAX_ENTS];
+    double ent_pos[MW_PROG_MAX_ENTS][3], ent_dir[MW_PROG_MAX_ENTS], ent_geom[MW_PROG_MAX_ENTS][9];
+    double colors[6][3];        /* COLORS of the six sorted colour names (entity.py:30-43), for MW_OP_COLOR         */
+    double extent[4];           /* env.min_x, max_x, min_z, max_z                                                  */
+    double street[4];           /* MW_TASK_SIDEWALK: min_x, max_x, min_z, max_z of the forbidden room              */
+    int32_t sign_n, pad;        /* MW_TASK_SIGN: objects in the order sign.py:160-169 visits them                  */
+    int32_t sign_slot[8];
+    double sign_reward[8];
+} mw_gen_program;
+
+/* Installs the placement program of an engine created with MW_GEN_PROGRAM.  The template geometry (what
+ * mw_set_geometry would receive for domain_rand = 0) comes with, per polygon, the room it belongs to (-1: not a room
+ * polygon, copied as it is), its surface (0 wall, 1 floor, 2 ceiling) and the metre coordinates its texture
+ * coordinates are computed from (poly_m[p][k] = the two factors of vertex k), so that a texture-variant draw can
+ * re-emit it.  With shared_geometry = 1 (no texture randomisation) the template is installed as the shared set. */
+int mw_set_gen_program(mw_engine *e, const mw_gen_program *prog, const mw_poly *polys, const int32_t *poly_room,
+                       const int32_t *poly_surf, const double *poly_m /* [n_polys][4][2] */, int32_t n_polys,
+                       const double *segs, int32_t n_segs);
+
 /* ---- lifetime --------------------------------------------------------------- */
 /* replaces MiniWorldEnv.__init__'s GL setup (shadow window, FrameBuffer) miniworld.py:504-518 */
 int mw_create(const mw_config *cfg, mw_engine **out);
@@ -214,6 +298,13 @@ int mw_set_obs_layout(mw_engine *e, int32_t layout);
  * Generator(PCG64(SeedSequence(seed))).random(); bounds[i] = k > 0: an integer in [0, k), i.e. Generator.integers(0, k)
  * / Generator.choice(k), returned as a double. */
 int mw_pcg64_draws(uint64_t seed, int32_t n, const int32_t *bounds, double *out);
+
+/* Test hooks, GPU only, no engine (tests/test_gpu_numerics.py): the kernels' 3-instruction reciprocal / quotient
+ * (hardware estimate + fused Newton / Markstein steps, mw_raster_common.h) against the IEEE division the oracle
+ * performs — mw_selftest_rcp over all 2^32 floats (bad_per_exp[512]: mismatches per sign|exponent, examples[64],
+ * *n = their total), mw_selftest_div over 2^32 pseudo-random pairs of its domain. */
+int mw_selftest_rcp(unsigned long long *bad_per_exp, uint32_t *examples, uint32_t *n);
+int mw_selftest_div(unsigned long long *n_bad, uint32_t *examples);
 
 /* render_obs / render_depth only (miniworld.py:1177-1236) */
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);

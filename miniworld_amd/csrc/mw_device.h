@@ -65,6 +65,17 @@ struct MwSpare {
     mw_poly *polys; int32_t *npolys; double *segs; int32_t *nsegs;     // per-env geometry sets only
 };
 
+// Device side of a placement program (mw_set_gen_program): the table itself plus the template geometry.
+struct MwProgram {
+    mw_gen_program p;
+    const mw_poly *polys;       // [n_polys] template polygons
+    const int32_t *poly_room;   // [n_polys]
+    const int32_t *poly_surf;   // [n_polys]
+    const double *poly_m;       // [n_polys][4][2]
+    const double *segs;         // [n_segs][4]
+    int32_t n_polys, n_segs;
+};
+
 // Everything the kernels need; passed by value (kernarg).
 struct MwArgs {
     int32_t N, W, H, E;
@@ -79,6 +90,7 @@ struct MwArgs {
     mw_range cam_height, cam_fwd_disp, cam_pitch, cam_fov_y;
     double gen_args[8];
     const MwGenTables *gt;  // generator tables (device memory: they are indexed dynamically)
+    const MwProgram *prog;  // MW_GEN_PROGRAM / MW_TASK_SIDEWALK / MW_TASK_SIGN tables, else null
     // --- world state, SoA over envs -------------------------------------------------
     double *ax, *ay, *az, *adir;
     double *cam;        // [4][N]

@@ -142,6 +142,7 @@ struct mw_engine {
     std::vector<Ev> ev_used, ev_free;
     int waves_per_env = 0;
     bool k1_dense = true;    // MW_K1_DENSE=0: always the wave-per-env K1
+    MwProgram *d_prog = nullptr;        // placement program (mw_set_gen_program)
     int texel_bytes = 4;
     int dbg_flags = 0;       // MW_DEBUG_FLAGS: perf experiments only (bit0: flat shading)
 };
@@ -611,8 +612,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (cfg->num_envs <= 0 || cfg->max_ents < 0 || cfg->max_polys <= 0 || cfg->max_segs <= 0 || cfg->max_visible <= 0)
         return fail(nullptr, MW_E_INVALID, "bad capacities");
     if (cfg->rng_mode != MW_RNG_PHILOX && cfg->rng_mode != MW_RNG_PCG64) return fail(nullptr, MW_E_INVALID, "unknown rng_mode %d", cfg->rng_mode);
-    if (cfg->rng_mode == MW_RNG_PCG64 && (cfg->generator == MW_GEN_NONE || (cfg->generator == MW_GEN_MAZE && cfg->domain_rand)))
-        return fail(nullptr, MW_E_INVALID, "MW_RNG_PCG64 (the reference's own numpy stream) needs a device generator; the Maze generator has no per-room texture randomisation");
+    if (cfg->rng_mode == MW_RNG_PCG64 && cfg->generator == MW_GEN_NONE)
+        return fail(nullptr, MW_E_INVALID, "MW_RNG_PCG64 (the reference's own numpy stream) needs a device generator");
     if (cfg->max_ents > 64) return fail(nullptr, MW_E_CAPACITY, "max_ents > 64 (one entity slot per lane of the env's wavefront)");
     if (cfg->msaa != 8) return fail(nullptr, MW_E_INVALID, "only msaa = 8 is implemented");
     if (cfg->obs_width % MW_TILE_W || cfg->obs_height % MW_TILE_H || cfg->obs_width > 255 * MW_TILE_W || cfg->obs_height > 255 * MW_TILE_H)
@@ -874,6 +875,55 @@ int mw_get_state(mw_engine *e, int32_t first_env, int32_t count, mw_state_view *
     return state_xfer(e, first_env, count, host, false);
 }
 
+int mw_set_gen_program(mw_engine *e, const mw_gen_program *prog, const mw_poly *polys, const int32_t *poly_room,
+                       const int32_t *poly_surf, const double *poly_m, int32_t n_polys, const double *segs, int32_t n_segs)
+{
+    if (!e || !prog) return fail(e, MW_E_INVALID, "null argument");
+    ON_DEVICE(e);
+    if (prog->n_rooms < 1 || prog->n_rooms > MW_PROG_MAX_ROOMS || prog->n_tex < 0 || prog->n_tex > MW_PROG_MAX_TEX ||
+        prog->n_ops < 0 || prog->n_ops > MW_PROG_MAX_OPS || prog->n_ents < 0 || prog->n_ents > MW_PROG_MAX_ENTS ||
+        prog->n_ents > e->cfg.max_ents || prog->sign_n < 0 || prog->sign_n > 8)
+        return fail(e, MW_E_CAPACITY, "placement program exceeds the table sizes");
+    if (n_polys < 0 || n_polys > e->cfg.max_polys || n_segs < 0 || n_segs > e->cfg.max_segs)
+        return fail(e, MW_E_CAPACITY, "template geometry exceeds max_polys / max_segs");
+    if (n_polys > 0 && (!polys || !poly_room || !poly_surf || !poly_m)) return fail(e, MW_E_INVALID, "null template geometry");
+    for (int i = 0; i < prog->n_ops; ++i) {
+        const mw_prog_op &op = prog->ops[i];
+        const bool needs_slot = op.op == MW_OP_PLACE || op.op == MW_OP_FIXED || op.op == MW_OP_BOX_SIZE || op.op == MW_OP_COLOR || op.op == MW_OP_APPEND;
+        if (op.op < MW_OP_COIN || op.op > MW_OP_APPEND) return fail(e, MW_E_INVALID, "op %d: unknown opcode %d", i, op.op);
+        if (needs_slot && (op.slot >= prog->n_ents || (op.slot < 0 && !(op.op == MW_OP_PLACE || op.op == MW_OP_FIXED))))
+            return fail(e, MW_E_INVALID, "op %d: bad entity slot %d", i, op.slot);
+        if (op.op == MW_OP_PLACE && op.room >= prog->n_rooms) return fail(e, MW_E_INVALID, "op %d: bad room %d", i, op.room);
+    }
+    MwProgram hp{};
+    hp.p = *prog;
+    hp.n_polys = n_polys; hp.n_segs = n_segs;
+    mw_poly *d_polys = nullptr; int32_t *d_room = nullptr, *d_surf = nullptr; double *d_m = nullptr, *d_segs = nullptr;
+    int rc = MW_OK;
+    if (rc == MW_OK) rc = dev_alloc(e, &d_polys, (size_t)n_polys);
+    if (rc == MW_OK) rc = dev_alloc(e, &d_room, (size_t)n_polys);
+    if (rc == MW_OK) rc = dev_alloc(e, &d_surf, (size_t)n_polys);
+    if (rc == MW_OK) rc = dev_alloc(e, &d_m, (size_t)n_polys * 8);
+    if (rc == MW_OK) rc = dev_alloc(e, &d_segs, (size_t)n_segs * 4);
+    if (rc == MW_OK && !e->d_prog) rc = dev_alloc(e, &e->d_prog, 1);
+    if (rc != MW_OK) return rc;
+    if (n_polys > 0) {
+        HIP_TRY(e, hipMemcpy(d_polys, polys, sizeof(mw_poly) * (size_t)n_polys, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(d_room, poly_room, 4 * (size_t)n_polys, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(d_surf, poly_surf, 4 * (size_t)n_polys, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(d_m, poly_m, 64 * (size_t)n_polys, hipMemcpyHostToDevice));
+    }
+    if (n_segs > 0) HIP_TRY(e, hipMemcpy(d_segs, segs, 32 * (size_t)n_segs, hipMemcpyHostToDevice));
+    hp.polys = d_polys; hp.poly_room = d_room; hp.poly_surf = d_surf; hp.poly_m = d_m; hp.segs = d_segs;
+    HIP_TRY(e, hipMemcpy(e->d_prog, &hp, sizeof hp, hipMemcpyHostToDevice));
+    e->args.prog = e->d_prog;
+    if (e->cfg.shared_geometry && n_polys > 0) {        // no texture randomisation: the template IS the geometry
+        const int r2 = mw_set_geometry(e, -1, polys, n_polys, segs, n_segs);
+        if (r2 != MW_OK) return r2;
+    }
+    return sync_gen_args(e);
+}
+
 int mw_set_step_params(mw_engine *e, const double *host_params)
 {
     if (!e) return MW_E_INVALID;
@@ -889,6 +939,7 @@ int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *str
     if (!e) return MW_E_INVALID;
     ON_DEVICE(e);
     if (e->cfg.generator == MW_GEN_NONE && !seeds) return fail(e, MW_E_INVALID, "engine was created without a device-side generator");
+    if (e->cfg.generator == MW_GEN_PROGRAM && !e->args.prog) return fail(e, MW_E_INVALID, "MW_GEN_PROGRAM: no placement program installed (mw_set_gen_program)");
     const int N = e->cfg.num_envs;
     hipStream_t st = (hipStream_t)stream;
     if (seeds) {
@@ -932,6 +983,8 @@ int mw_step(mw_engine *e, const int32_t *d_actions, uint8_t *d_obs, float *d_dep
     if (!e) return MW_E_INVALID;
     ON_DEVICE(e);
     if (!d_actions) return fail(e, MW_E_INVALID, "d_actions is null");
+    if ((e->cfg.generator == MW_GEN_PROGRAM || e->cfg.task >= MW_TASK_SIDEWALK) && !e->args.prog)
+        return fail(e, MW_E_INVALID, "no placement program installed (mw_set_gen_program)");
     return launch_frame(e, true, 0, d_actions, d_obs, d_depth, d_reward, d_term, d_trunc, (hipStream_t)stream);
 }
 

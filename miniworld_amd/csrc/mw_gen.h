@@ -313,6 +313,166 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
     bx = out[0][0]; bz = out[0][1]; ax = out[1][0]; az = out[1][1];
 }
 
+// ---------------------------------------------------------------- placement programs (MW_GEN_PROGRAM)
+// include/mwengine.h: mw_gen_program.  One lane runs the env's program on its random stream.
+
+// Room.point_inside (miniworld.py:272-284): np.sum(edge_norms * (p - outline), axis=1) > 0 for every edge; the y terms
+// are +-0 * 0, so a row's sum is nx * dx + nz * dz (two rounded products, one rounded sum: no fma)
+__device__ inline bool prog_point_inside(const mw_prog_room &rm, double x, double z)
+{
+    bool in = true;
+    for (int k = 0; k < rm.nverts; ++k) {
+        const double t = rm.nx[k] * (x - rm.ox[k]) + rm.nz[k] * (z - rm.oz[k]);
+        in &= t > 0.0;
+    }
+    return in;
+}
+
+// MiniWorldEnv.intersect as place_entity uses it (miniworld.py:937-963): walls, then every entity already in the list
+__device__ inline bool prog_blocked(const MwArgs &a, int env, int set, unsigned long long placed, bool agent_placed,
+                                    double agent_x, double agent_z, double x, double z, double radius)
+{
+    if (gen_hits_wall(a, set, x, z, radius)) return true;
+    for (int s = 0; s < a.E; ++s) {
+        if (!((placed >> s) & 1ull)) continue;
+        const double dx = a.epos[((size_t)0 * a.E + s) * a.N + env] - x;
+        const double dz = a.epos[((size_t)2 * a.E + s) * a.N + env] - z;
+        if (sqrt(dx * dx + dz * dz) < radius + a.egeom[((size_t)7 * a.E + s) * a.N + env]) return true;
+    }
+    if (agent_placed) {
+        const double dx = agent_x - x, dz = agent_z - z;
+        if (sqrt(dx * dx + dz * dz) < radius + a.agent_radius) return true;
+    }
+    return false;
+}
+
+// Room._gen_static_data of every room with an rng (miniworld.py:295-297, opengl.py:134-138): per room the wall, floor
+// and ceiling variants are drawn in that order; the template polygons are then re-emitted into the env's own set
+// with the variants' ids and texture coordinates = (float)(metres * TEX_DENSITY / size) (miniworld.py:82-119)
+__device__ inline void prog_static_data(const MwArgs &a, int env, int set, Rng &r)
+{
+    const MwProgram &P = *a.prog;
+    if (!a.domain_rand || a.shared_geom) return;
+    unsigned char pick[MW_PROG_MAX_ROOMS][3];
+    for (int i = 0; i < P.p.n_rooms; ++i) {
+        const mw_prog_room &rm = P.p.rooms[i];
+        const int t[3] = {rm.wall_tex, rm.floor_tex, rm.ceil_tex};
+        for (int k = 0; k < 3; ++k) pick[i][k] = (unsigned char)(P.p.tex_nvar[t[k]] > 1 ? rng_below(r, (uint32_t)P.p.tex_nvar[t[k]]) : 0u);
+    }
+    mw_poly *dst = const_cast<mw_poly *>(a.polys) + (size_t)set * a.max_polys;
+    for (int p = 0; p < P.n_polys; ++p) {
+        mw_poly q = P.polys[p];
+        const int room = P.poly_room[p];
+        if (room >= 0) {
+            const mw_prog_room &rm = P.p.rooms[room];
+            const int surf = P.poly_surf[p];
+            const int t = surf == 0 ? rm.wall_tex : (surf == 1 ? rm.floor_tex : rm.ceil_tex);
+            const int v = pick[room][surf];
+            q.tex = P.p.tex_var_id[t][v];
+            const double ku = P.p.tex_var_scale[t][v][0], kv = P.p.tex_var_scale[t][v][1];
+            const int nv = q.nv & 0xFF;
+            for (int k = 0; k < nv; ++k) {
+                q.uv[k][0] = (float)(P.poly_m[((size_t)p * 4 + k) * 2 + 0] * ku);
+                q.uv[k][1] = (float)(P.poly_m[((size_t)p * 4 + k) * 2 + 1] * kv);
+            }
+        }
+        dst[p] = q;
+    }
+    double *sd = const_cast<double *>(a.segs) + (size_t)set * a.max_segs * 4;
+    for (int i = 0; i < P.n_segs * 4; ++i) sd[i] = P.segs[i];
+    const_cast<int32_t *>(a.npolys)[set] = P.n_polys;
+    const_cast<int32_t *>(a.nsegs)[set] = P.n_segs;
+    __threadfence();        // the placements below test against these segments
+}
+
+__device__ inline void gen_program(const MwArgs &a, int env, int set, Rng &r, double &ax, double &az, double &adir)
+{
+    const MwProgram &P = *a.prog;
+    const mw_gen_program &g = P.p;
+    const size_t N = a.N, E = a.E;
+    // the entity table as the constructors leave it
+    for (int s = 0; s < (int)E; ++s) {
+        const bool have = s < g.n_ents;
+        a.ekind[(size_t)s * N + env] = have ? g.ent_kind[s] : MW_ENT_NONE;
+        a.emesh[(size_t)s * N + env] = have ? g.ent_mesh[s] : -1;
+        a.estatic[(size_t)s * N + env] = have ? g.ent_static[s] : 0;
+        a.edir[(size_t)s * N + env] = have ? g.ent_dir[s] : 0.0;
+        for (int k = 0; k < 3; ++k) a.epos[((size_t)k * E + s) * N + env] = have ? g.ent_pos[s][k] : 0.0;
+        for (int k = 0; k < 9; ++k) a.egeom[((size_t)k * E + s) * N + env] = have ? g.ent_geom[s][k] : 0.0;
+    }
+    unsigned long long placed = 0ull;
+    bool agent_placed = false, static_done = false;
+    int coin = -1;
+    double dir_reg = 0.0;
+    for (int i = 0; i < g.n_ops; ++i) {
+        const mw_prog_op &op = g.ops[i];
+        if (op.cond >= 0 && op.cond != coin) continue;
+        switch (op.op) {
+        case MW_OP_COIN: coin = (int)rng_below(r, (uint32_t)op.slot); break;
+        case MW_OP_DRAW_DIR: dir_reg = rng_uniform(r, -op.dir, op.dir); break;
+        case MW_OP_BOX_SIZE: {
+            const double size = rng_uniform(r, op.a, op.b);
+            for (int k = 0; k < 3; ++k) a.egeom[((size_t)k * E + op.slot) * N + env] = size;
+            a.egeom[((size_t)7 * E + op.slot) * N + env] = sqrt(size * size + size * size) / 2.0;      // Box.radius entity.py:401
+            a.egeom[((size_t)8 * E + op.slot) * N + env] = size;
+            break;
+        }
+        case MW_OP_COLOR: {
+            const int c = (int)rng_below(r, 6u);
+            if (op.room == 0) for (int k = 0; k < 3; ++k) a.egeom[((size_t)(3 + k) * E + op.slot) * N + env] = g.colors[c][k];
+            else a.emesh[(size_t)op.slot * N + env] = op.flags + c;
+            break;
+        }
+        case MW_OP_APPEND: placed |= 1ull << op.slot; break;
+        case MW_OP_FIXED:
+        case MW_OP_PLACE: {
+            if (!static_done) { prog_static_data(a, env, set, r); static_done = true; }
+            const bool agent = op.slot < 0;
+            const double rad = agent ? a.agent_radius : a.egeom[((size_t)7 * E + op.slot) * N + env];
+            double x = op.lx, z = op.lz, y = 0.0;
+            if (op.op == MW_OP_FIXED) {
+                y = op.a;
+            } else {
+                bool ok = false;
+                for (int attempt = 0; attempt < 100000 && !ok; ++attempt) {
+                    int ri = op.room;
+                    if (ri < 0) {       // np_random.choice(len(rooms), p=room_probs): one double, searchsorted right
+                        ri = 0;
+                        if (rng_is_pcg(r) || g.n_rooms > 1) {
+                            const double u = rng_double(r);
+                            while (ri < g.n_rooms - 1 && !(u < g.rooms[ri].cdf)) ++ri;
+                        }
+                    }
+                    const mw_prog_room &rm = g.rooms[ri];
+                    const double lx = (op.flags & 1) ? op.lx : rm.min_x, hx = (op.flags & 2) ? op.hx : rm.max_x;
+                    const double lz = (op.flags & 4) ? op.lz : rm.min_z, hz = (op.flags & 8) ? op.hz : rm.max_z;
+                    x = rng_uniform(r, lx - rad, hx + rad);
+                    if (rng_is_pcg(r)) (void)rng_uniform(r, 0.0, 0.0);        // the y component of the 3-vector draw
+                    z = rng_uniform(r, lz - rad, hz + rad);
+                    if (!prog_point_inside(rm, x, z)) continue;
+                    if (prog_blocked(a, env, set, placed, agent_placed, ax, az, x, z, rad)) continue;
+                    ok = true;
+                }
+                if (!ok) atomicOr(a.status, MW_ST_PLACEMENT_FAIL);
+            }
+            const double dir = op.dir_mode == 1 ? op.dir : (op.dir_mode == 2 ? dir_reg : rng_uniform(r, -kGenPi, kGenPi));
+            if (agent) {
+                ax = x; az = z; adir = dir; agent_placed = true;
+            } else {
+                a.epos[((size_t)0 * E + op.slot) * N + env] = x;
+                a.epos[((size_t)1 * E + op.slot) * N + env] = y;
+                a.epos[((size_t)2 * E + op.slot) * N + env] = z;
+                a.edir[(size_t)op.slot * N + env] = dir;
+                placed |= 1ull << op.slot;
+            }
+            break;
+        }
+        default: break;
+        }
+    }
+    if (!static_done) prog_static_data(a, env, set, r);
+}
+
 // One full reset of env `env`.  Writes every per-env state array.
 // Called by the 64 lanes of one wavefront; everything but the Maze's room emission runs on lane 0.
 __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *ws, int lane)
@@ -385,6 +545,25 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
         a.cam[(size_t)2 * N + env] = gen_param(r, a.cam_pitch, dr);
         a.cam[(size_t)3 * N + env] = gen_param(r, a.cam_fov_y, dr);
     }
+    if (a.generator == MW_GEN_PROGRAM) {
+        gen_program(a, env, set, r, ax, az, adir);
+        const bool dr_ = dr;
+        for (int k = 0; k < 3; ++k) a.light[(size_t)(0 + k) * N + env] = gen_param(r, a.sky[k], dr_);
+        for (int k = 0; k < 3; ++k) a.light[(size_t)(3 + k) * N + env] = gen_param(r, a.light_pos[k], dr_);
+        for (int k = 0; k < 3; ++k) a.light[(size_t)(6 + k) * N + env] = gen_param(r, a.light_color[k], dr_);
+        for (int k = 0; k < 3; ++k) a.light[(size_t)(9 + k) * N + env] = gen_param(r, a.light_ambient[k], dr_);
+        for (int s = 0; s < a.E; ++s)               // Box.randomize in entity order: colour bias (entity.py:405-407)
+            if (a.ekind[(size_t)s * N + env] == MW_ENT_BOX)
+                for (int k = 0; k < 3; ++k) {
+                    const size_t gi = ((size_t)(3 + k) * a.E + s) * N + env;
+                    const double v = a.egeom[gi] + gen_param(r, a.color_bias[k], dr_);
+                    a.egeom[gi] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+                }
+        a.cam[(size_t)0 * N + env] = gen_param(r, a.cam_height, dr_);          // Agent.randomize entity.py:505-515
+        a.cam[(size_t)1 * N + env] = gen_param(r, a.cam_fwd_disp, dr_);
+        a.cam[(size_t)2 * N + env] = gen_param(r, a.cam_pitch, dr_);
+        a.cam[(size_t)3 * N + env] = gen_param(r, a.cam_fov_y, dr_);
+    }
     if (a.generator == MW_GEN_PICKUP) {
         // pickupobjects.py:55-81: num_objs objects of random kind (Ball, Box, Key) and colour, placed
         // one after the other, then the agent; gen_tab holds the per-kind constants computed by the
@@ -433,7 +612,9 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     }
     a.ax[env] = ax; a.ay[env] = 0.0; a.az[env] = az; a.adir[env] = adir;
     a.carry[env] = -1; a.step[env] = 0; a.picked[env] = 0;
-    if (a.generator == MW_GEN_MAZE) {
+    if (a.generator == MW_GEN_PROGRAM) {
+        for (int k = 0; k < 4; ++k) a.extent[(size_t)k * N + env] = a.prog->p.extent[k];
+    } else if (a.generator == MW_GEN_MAZE) {
         const double pitch = a.gt->gen_tab[2] + a.gt->gen_tab[3];
         a.extent[(size_t)0 * N + env] = 0.0; a.extent[(size_t)1 * N + env] = ((int)a.gt->gen_tab[1] - 1) * pitch + a.gt->gen_tab[2];
         a.extent[(size_t)2 * N + env] = 0.0; a.extent[(size_t)3 * N + env] = ((int)a.gt->gen_tab[0] - 1) * pitch + a.gt->gen_tab[2];

@@ -152,6 +152,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
                 if (picked == a.num_objs) tm = 1;
             }
         }
+        if (a.task >= MW_TASK_SIDEWALK) program_rules(c, action, step_count, rew, tm);
         if (KW > 1) __syncthreads();        // every wave has read the state it needs: thread 0 may now overwrite it
         if (writer) {
             if (drew) mw::rng_store(a.rng, a.N, env, rng);

@@ -163,6 +163,34 @@ __device__ inline void carry_pos(const StepCtx &c, int slot, double ax, double a
     out[1] = out[1] + 1.0 * (y > 0.0 ? y : 0.0);
 }
 
+// near(ent) (miniworld.py:965-975): 3D distance agent - entity below the two radii + 1.1 * max_forward_step
+__device__ inline bool near_agent(const StepCtx &c, int slot)
+{
+    const double dx = ent_pos(c, slot, 0) - c.px, dy = ent_pos(c, slot, 1) - c.py, dz = ent_pos(c, slot, 2) - c.pz;
+    return sqrt(dx * dx + dy * dy + dz * dz) < ent_geom(c.a, c.env, slot, 7) + c.a.agent_radius + 1.1 * c.a.max_forward_step;
+}
+
+// The env rules that live in the placement program's tables (include/mwengine.h):
+// Sidewalk.step (sidewalk.py:93-104): the street ends the episode and zeroes the reward, the box adds the GOTO reward;
+// Sign.step (sign.py:152-170): action move_forward + 1 ends the episode, touching an object ends it with +-1.
+__device__ inline void program_rules(const StepCtx &c, int action, int step_count, double &rew, int &tm)
+{
+    const MwArgs &a = c.a;
+    if (a.task == MW_TASK_SIDEWALK) {
+        const double *st = a.prog->p.street;
+        if (c.px > st[0] && c.px < st[1] && c.pz > st[2] && c.pz < st[3]) { rew = 0.0; tm = 1; }     // Room.point_inside
+        if (near_agent(c, a.goal_ent)) {
+            rew += 1.0 - 0.2 * ((double)step_count / (double)a.max_steps);
+            tm = 1;
+        }
+    } else if (a.task == MW_TASK_SIGN) {
+        if (action == 3) tm = 1;                    // actions.move_forward + 1: the custom end-of-episode action
+        const mw_gen_program &g = a.prog->p;
+        for (int k = 0; k < g.sign_n; ++k)
+            if (near_agent(c, g.sign_slot[k])) { tm = 1; rew = g.sign_reward[k]; }
+    }
+}
+
 template <bool PER_LANE>
 __device__ void move_agent(StepCtx &c, double fwd_dist, double fwd_drift)
 {

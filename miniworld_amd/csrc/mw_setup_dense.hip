@@ -140,6 +140,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1
                 if (picked == a.num_objs) tm = 1;
             }
         }
+        if (a.task >= MW_TASK_SIDEWALK) program_rules(c, action, step_count, rew, tm);
         // every lane of the env has read the old state (the lanes of a wavefront run in lockstep, and each lane only
         // reads its own env): the leading lane writes the new one
         __builtin_amdgcn_wave_barrier();

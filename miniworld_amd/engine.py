@@ -16,11 +16,13 @@ import numpy as np
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ENT_NONE, ENT_BOX, ENT_MESH, ENT_FRAME = 0, 1, 2, 3
 POLY_ENTITY = 0x100          # mw_poly.nv flag: quad of a static entity, not a room
-TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT = 0, 1, 2, 3
-GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE = 0, 1, 2, 3, 4
+TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT, TASK_SIDEWALK, TASK_SIGN = 0, 1, 2, 3, 4, 5
+GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE, GEN_PROGRAM = 0, 1, 2, 3, 4, 5
+OP_COIN, OP_DRAW_DIR, OP_PLACE, OP_FIXED, OP_BOX_SIZE, OP_COLOR, OP_APPEND = 1, 2, 3, 4, 5, 6, 7
+PROG_MAX_ROOMS, PROG_MAX_TEX, PROG_MAX_OPS, PROG_MAX_ENTS = 16, 8, 48, 64
 AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
 OBS_HWC_U8, OBS_CWH_U8, OBS_GREY_F64 = 0, 1, 2
 RNG_PHILOX, RNG_PCG64 = 0, 1
@@ -29,6 +31,7 @@ EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
     "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms",
+    "mw_set_gen_program", "mw_selftest_rcp", "mw_selftest_div",
 ]
 
 
@@ -70,6 +73,31 @@ class MwPoly(C.Structure):
 POLY_DTYPE = np.dtype([("v", np.float32, (4, 3)), ("uv", np.float32, (4, 2)), ("n", np.float32, (3,)),
                        ("nv", np.int32), ("tex", np.int32), ("rgb", np.float32, (3,))])
 assert POLY_DTYPE.itemsize == C.sizeof(MwPoly) == 112
+
+
+class MwProgRoom(C.Structure):
+    _fields_ = [("nverts", C.c_int32), ("wall_tex", C.c_int32), ("floor_tex", C.c_int32), ("ceil_tex", C.c_int32),
+                ("ox", C.c_double * 4), ("oz", C.c_double * 4), ("nx", C.c_double * 4), ("nz", C.c_double * 4),
+                ("min_x", C.c_double), ("max_x", C.c_double), ("min_z", C.c_double), ("max_z", C.c_double), ("cdf", C.c_double)]
+
+
+class MwProgOp(C.Structure):
+    _fields_ = [("op", C.c_int32), ("slot", C.c_int32), ("room", C.c_int32), ("cond", C.c_int32), ("dir_mode", C.c_int32),
+                ("flags", C.c_int32), ("lx", C.c_double), ("hx", C.c_double), ("lz", C.c_double), ("hz", C.c_double),
+                ("dir", C.c_double), ("a", C.c_double), ("b", C.c_double)]
+
+
+class MwGenProgram(C.Structure):
+    _fields_ = [("n_rooms", C.c_int32), ("n_tex", C.c_int32), ("n_ops", C.c_int32), ("n_ents", C.c_int32),
+                ("rooms", MwProgRoom * PROG_MAX_ROOMS),
+                ("tex_nvar", C.c_int32 * PROG_MAX_TEX), ("tex_var_id", (C.c_int32 * 9) * PROG_MAX_TEX),
+                ("tex_var_scale", ((C.c_double * 2) * 9) * PROG_MAX_TEX),
+                ("ops", MwProgOp * PROG_MAX_OPS),
+                ("ent_kind", C.c_int32 * PROG_MAX_ENTS), ("ent_mesh", C.c_int32 * PROG_MAX_ENTS), ("ent_static", C.c_int32 * PROG_MAX_ENTS),
+                ("ent_pos", (C.c_double * 3) * PROG_MAX_ENTS), ("ent_dir", C.c_double * PROG_MAX_ENTS),
+                ("ent_geom", (C.c_double * 9) * PROG_MAX_ENTS),
+                ("colors", (C.c_double * 3) * 6), ("extent", C.c_double * 4), ("street", C.c_double * 4),
+                ("sign_n", C.c_int32), ("pad", C.c_int32), ("sign_slot", C.c_int32 * 8), ("sign_reward", C.c_double * 8)]
 
 
 class MwStateView(C.Structure):
@@ -143,6 +171,7 @@ def load_library():
     L.mw_set_state.argtypes = [vp, i32, i32, C.POINTER(MwStateView)]
     L.mw_get_state.argtypes = [vp, i32, i32, C.POINTER(MwStateView)]
     L.mw_set_step_params.argtypes = [vp, vp]
+    L.mw_set_gen_program.argtypes = [vp, C.POINTER(MwGenProgram), vp, vp, vp, vp, i32, vp, i32]
     L.mw_reset.argtypes = [vp, vp, vp, vp]
     L.mw_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     L.mw_render.argtypes = [vp, vp, vp, vp]
@@ -249,6 +278,16 @@ class Engine:
         view, keep = self._view({}, count, alloc=True)
         self._check(self.lib.mw_get_state(self.h, first, count, C.byref(view)), "mw_get_state")
         return keep
+
+    def set_gen_program(self, prog: MwGenProgram, polys: np.ndarray, poly_room, poly_surf, poly_m, segs: np.ndarray):
+        """Installs the placement program of an MW_GEN_PROGRAM engine (include/mwengine.h: mw_set_gen_program)."""
+        p = np.ascontiguousarray(polys, POLY_DTYPE)
+        room = np.ascontiguousarray(poly_room, np.int32)
+        surf = np.ascontiguousarray(poly_surf, np.int32)
+        m = np.ascontiguousarray(poly_m, np.float64).reshape(len(p), 4, 2)
+        sg = np.ascontiguousarray(segs, np.float64).reshape(-1, 4)
+        self._check(self.lib.mw_set_gen_program(self.h, C.byref(prog), p.ctypes.data, room.ctypes.data, surf.ctypes.data,
+                                                m.ctypes.data, len(p), sg.ctypes.data, len(sg)), "mw_set_gen_program")
 
     def set_step_params(self, params: np.ndarray | None):
         if params is None:

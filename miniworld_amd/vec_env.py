@@ -31,23 +31,24 @@ _KIND = {
     "MiniWorld-MazeS3-v0": ("MazeS3", eng.GEN_MAZE, eng.TASK_GOTO, 3),
     "MiniWorld-MazeS3Fast-v0": ("MazeS3Fast", eng.GEN_MAZE, eng.TASK_GOTO, 3),
     "MiniWorld-PickupObjects-v0": ("PickupObjects", eng.GEN_PICKUP, eng.TASK_PICKUP, 5),
-    # host-generated worlds (reference-compatible numpy stream), device stepping / rendering
-    "MiniWorld-FourRooms-v0": ("FourRooms", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-TMaze-v0": ("TMaze", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-TMazeLeft-v0": ("TMazeLeft", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-TMazeRight-v0": ("TMazeRight", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-YMaze-v0": ("YMaze", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-YMazeLeft-v0": ("YMazeLeft", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-YMazeRight-v0": ("YMazeRight", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-WallGap-v0": ("WallGap", eng.GEN_NONE, eng.TASK_GOTO, 3),
-    "MiniWorld-ThreeRooms-v0": ("ThreeRooms", eng.GEN_NONE, eng.TASK_NONE, 3),
-    # reward / termination rule evaluated on the host after the device step (_host_rule below): the engine's
-    # task rules are GOTO / PICKUP / PUTNEXT; these two envs add a forbidden area resp. a touch table
-    "MiniWorld-Sidewalk-v0": ("Sidewalk", eng.GEN_NONE, eng.TASK_NONE, 3),
-    "MiniWorld-Sign-v0": ("Sign", eng.GEN_NONE, eng.TASK_NONE, 4),
+    # fixed floorplans: _gen_world compiled into a placement program the device generator runs (genprog.py)
+    "MiniWorld-FourRooms-v0": ("FourRooms", eng.GEN_PROGRAM, eng.TASK_GOTO, 3),
+    "MiniWorld-TMaze-v0": ("TMaze", eng.GEN_PROGRAM, eng.TASK_GOTO, 3),
+    "MiniWorld-TMazeLeft-v0": ("TMazeLeft", eng.GEN_PROGRAM, eng.TASK_GOTO, 3),
+    "MiniWorld-TMazeRight-v0": ("TMazeRight", eng.GEN_PROGRAM, eng.TASK_GOTO, 3),
+    "MiniWorld-YMaze-v0": ("YMaze", eng.GEN_PROGRAM, eng.TASK_GOTO, 3),
+    "MiniWorld-YMazeLeft-v0": ("YMazeLeft", eng.GEN_PROGRAM, eng.TASK_GOTO, 3),
+    "MiniWorld-YMazeRight-v0": ("YMazeRight", eng.GEN_PROGRAM, eng.TASK_GOTO, 3),
+    "MiniWorld-WallGap-v0": ("WallGap", eng.GEN_PROGRAM, eng.TASK_GOTO, 3),
+    "MiniWorld-ThreeRooms-v0": ("ThreeRooms", eng.GEN_PROGRAM, eng.TASK_NONE, 3),
+    # the forbidden street / the touch table + end-of-episode action are K1 task rules fed by the program's tables
+    "MiniWorld-Sidewalk-v0": ("Sidewalk", eng.GEN_PROGRAM, eng.TASK_SIDEWALK, 3),
+    "MiniWorld-Sign-v0": ("Sign", eng.GEN_PROGRAM, eng.TASK_SIGN, 4),
+    "MiniWorld-PutNext-v0": ("PutNext", eng.GEN_PROGRAM, eng.TASK_PUTNEXT, 8),
+    "MiniWorld-RoomObjects-v0": ("RoomObjects", eng.GEN_PROGRAM, eng.TASK_NONE, 8),
+    # host-generated worlds (reference-compatible numpy stream) with the rule on the host: a consumed kit respawns through
+    # place_entity at the END of the entity list (collecthealth.py:86-90), which reorders the slots
     "MiniWorld-CollectHealth-v0": ("CollectHealth", eng.GEN_NONE, eng.TASK_NONE, 8),
-    "MiniWorld-PutNext-v0": ("PutNext", eng.GEN_NONE, eng.TASK_PUTNEXT, 8),
-    "MiniWorld-RoomObjects-v0": ("RoomObjects", eng.GEN_NONE, eng.TASK_NONE, 8),
 }
 
 
@@ -60,8 +61,8 @@ class MiniWorldVecEnv:
         the raster kernel stores the frame in that layout, there is no extra pass.
         rng: stream of the device-side resets. "pcg64" = numpy's own Generator(PCG64(SeedSequence(seed + i))) drawn in
         the reference's call order, so that env i IS the reference's env.reset(seed=seed + i) and its later episodes
-        continue like env.reset(), per-step domain-randomisation draws included (every device generator; not
-        Maze with domain_rand); "philox" = the engine's counter-based stream; "auto" = pcg64 where implemented."""
+        continue like env.reset(), per-step domain-randomisation draws included (every device generator);
+        "philox" = the engine's counter-based stream; "auto" = pcg64 where implemented."""
         import torch
         self.torch = torch
         if obs_layout not in ("hwc", "cwh", "grey"):
@@ -70,6 +71,8 @@ class MiniWorldVecEnv:
         if env_id not in _KIND:
             raise KeyError(f"{env_id!r} is not available in the batched engine yet; have {sorted(_KIND)}")
         cls_name, generator, task, n_actions = _KIND[env_id]
+        if cls_name == "Sign":
+            domain_rand = False             # sign.py:92-98 fixes it
         self.env_id, self.num_envs, self.n_actions = env_id, num_envs, n_actions
         self.domain_rand, self.want_depth = domain_rand, want_depth
         self.generator = generator
@@ -87,7 +90,10 @@ class MiniWorldVecEnv:
         tex_slots = [room0.wall_tex_name, room0.floor_tex_name, room0.ceil_tex_name]
         variants = [_assets.texture_variants(t) for t in tex_slots]
         tex_dr = bool(domain_rand) and generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM, eng.GEN_PICKUP) and any(len(v) > 1 for v in variants)
-        shared = generator not in (eng.GEN_NONE, eng.GEN_MAZE) and not tex_dr
+        # placement programs: every room may name its own textures
+        prog_names = sorted({n for r in self.template.rooms for n in (r.wall_tex_name, r.floor_tex_name, r.ceil_tex_name)})
+        prog_tex_dr = bool(domain_rand) and generator == eng.GEN_PROGRAM and any(len(_assets.texture_variants(n)) > 1 for n in prog_names)
+        shared = generator not in (eng.GEN_NONE, eng.GEN_MAZE) and not tex_dr and not prog_tex_dr
         P, S, E = len(sc["polys_nv"]), len(sc["wall_segs"]), max(1, len(sc["ents_kind"]))
         pickup_meshes = None
         if cls_name == "PickupObjects":
@@ -103,8 +109,10 @@ class MiniWorldVecEnv:
                           params_ranges=self.template.params.as_ranges(), device_id=device_id)
         cfg.shared_geometry = int(shared)
         cfg.task, cfg.goal_ent, cfg.num_objs = task, 0, len(sc["ents_kind"])
+        ents = [e for e in self.template.entities if e is not self.template.agent]
+        if task in (eng.TASK_GOTO, eng.TASK_SIDEWALK) and hasattr(self.template, "box"):
+            cfg.goal_ent = ents.index(self.template.box)
         if task == eng.TASK_PUTNEXT:
-            ents = [e for e in self.template.entities if e is not self.template.agent]
             cfg.goal_ent, cfg.goal_ent2 = ents.index(self.template.red_box), ents.index(self.template.yellow_box)
         cfg.max_episode_steps = int(min(float(self.template.max_episode_steps), 2 ** 30))
         cfg.domain_rand = int(domain_rand)
@@ -143,6 +151,11 @@ class MiniWorldVecEnv:
                 for j in range(3):
                     cfg.gen_colors[ci * 3 + j] = float(COLORS[cname][j])
         self._tex_dr_variants = None
+        if prog_tex_dr:     # every variant of every room texture is resident; the program's tables name them
+            names = [str(v) for v in sc["tex_names"]]
+            for n in prog_names:
+                names += [v for v in _assets.texture_variants(n) if v not in names]
+            self._tex_dr_variants = names
         if tex_dr:
             order, nid = [], len(sc["tex_names"])
             names = [str(v) for v in sc["tex_names"]]
@@ -157,23 +170,40 @@ class MiniWorldVecEnv:
             self._tex_dr_variants = names
             cfg.room_wall_height = float(room0.wall_height)
             cfg.room_no_ceiling = int(bool(room0.no_ceiling))
-        pcg_ok = generator != eng.GEN_NONE and not (generator == eng.GEN_MAZE and domain_rand)
+        if generator == eng.GEN_MAZE and domain_rand and any(len(v) > 1 for v in variants):
+            # the reference's Maze textures (brick_wall, floor_tiles_bw, concrete_tiles) exist in one variant each, so
+            # Room._gen_static_data's three rng.integers(0, 1) per room draw nothing (opengl.py:134-138) and the device
+            # generator is stream-exact as it is; an asset directory with more variants would need per-room picks
+            raise NotImplementedError("Maze with domain_rand and several variants of a room texture is not implemented on the device")
+        pcg_ok = generator != eng.GEN_NONE
         if rng not in ("auto", "pcg64", "philox") or (rng == "pcg64" and not pcg_ok):
             raise ValueError(f"rng={rng!r} is not available for {env_id} (domain_rand={domain_rand})")
         cfg.rng_mode = eng.RNG_PCG64 if (pcg_ok and rng != "philox") else eng.RNG_PHILOX
         self.rng_mode = "pcg64" if cfg.rng_mode == eng.RNG_PCG64 else "philox"
         self.engine = eng.Engine(cfg)
         self.host_autoreset = autoreset and generator == eng.GEN_NONE
-        self._host_rule = {"Sidewalk": self._rule_sidewalk, "Sign": self._rule_sign,
-                           "CollectHealth": self._rule_collecthealth}.get(cls_name)
+        self._host_rule = {"CollectHealth": self._rule_collecthealth}.get(cls_name)
         self._health = np.full(num_envs, 100, np.int64)
         self._upload_assets(sc)
+        if cls_name == "RoomObjects":       # any colour of ball / key can be drawn: all twelve meshes are resident
+            from .entity import COLOR_NAMES
+            pickup_meshes = [f"ball_{c}" for c in COLOR_NAMES] + [f"key_{c}" for c in COLOR_NAMES]
         if pickup_meshes:
             from .objmesh import ObjMesh
             for name in pickup_meshes:
                 self.mesh_ids[name] = len(self.mesh_ids)
                 m = ObjMesh.get(name)
                 self.engine.upload_mesh(self.mesh_ids[name], m.verts, m.norms, m.texcs, m.colors)
+        if generator == eng.GEN_PROGRAM:
+            from . import genprog
+            mesh_map = upload_scene_meshes(self.engine, sc, self.mesh_ids, self.tex_ids)
+            slot_of = lambda e: ents.index(e)                       # noqa: E731
+            room_of = lambda r: self.template.rooms.index(r)        # noqa: E731
+            if cls_name == "RoomObjects":
+                ops = genprog.room_objects_ops(0, 1, 2, self.mesh_ids["ball_" + COLOR_NAMES[0]], self.mesh_ids["key_" + COLOR_NAMES[0]])
+            else:
+                ops = genprog.family_ops(self.template, slot_of, room_of)
+            self.engine.set_gen_program(*genprog.compile_program(self.template, sc, self.tex_ids, mesh_map, ops))
         dev = self.engine.device
         H, W = self.template.obs_height, self.template.obs_width
         self.engine.set_obs_layout({"hwc": eng.OBS_HWC_U8, "cwh": eng.OBS_CWH_U8, "grey": eng.OBS_GREY_F64}[obs_layout])
@@ -264,36 +294,6 @@ class MiniWorldVecEnv:
         """MiniWorldEnv.near (miniworld.py:965-975) for every env: agent vs entity `slot`."""
         d = np.linalg.norm(st["agent_pos"] - st["ent_pos"][:, slot], axis=1)
         return d < self.template.agent.radius + st["ent_geom"][:, slot, 7] + 1.1 * self.template.max_forward_step
-
-    def _rule_sidewalk(self, actions):
-        """Sidewalk.step (sidewalk.py:93-104): entering the street zeroes the reward and ends the episode; reaching
-        the box adds the GOTO reward and ends it too."""
-        st = self.engine.get_state()
-        t = self.template
-        r = t.street
-        p = st["agent_pos"]
-        street = (p[:, 0] > r.min_x) & (p[:, 0] < r.max_x) & (p[:, 2] > r.min_z) & (p[:, 2] < r.max_z)    # Room.point_inside
-        ents = [e for e in t.entities if e is not t.agent]
-        near = self._near(st, ents.index(t.box))
-        reward = np.where(near, 1.0 - 0.2 * (st["step_count"] / float(t.max_episode_steps)), 0.0)
-        self.reward.copy_(self.torch.as_tensor(reward.astype(np.float32)))
-        self.terminated.copy_(self.torch.as_tensor((street | near).astype(np.uint8)))
-
-    def _rule_sign(self, actions):
-        """Sign.step (sign.py:152-170): the extra action ends the episode; touching any object ends it with +1 for
-        the object of the sign's colour and the goal's shape, -1 otherwise (a later object in the table wins)."""
-        st = self.engine.get_state()
-        t = self.template
-        ents = [e for e in t.entities if e is not t.agent]
-        term = (actions.cpu().numpy() == t.actions.move_forward + 1)
-        reward = np.zeros(self.num_envs)
-        for obj_index, pair in enumerate(t._objects):
-            for color_index, obj in enumerate(pair):
-                near = self._near(st, ents.index(obj))
-                term = term | near
-                reward = np.where(near, float(color_index == t._color_index and obj_index == t._goal) * 2 - 1, reward)
-        self.reward.copy_(self.torch.as_tensor(reward.astype(np.float32)))
-        self.terminated.copy_(self.torch.as_tensor(term.astype(np.uint8)))
 
     def _rule_collecthealth(self, actions):
         """CollectHealth.step (collecthealth.py:79-98): health drops by 2 per step; a kit that has just been

@@ -38,6 +38,8 @@ CASES = [
     ("mazes3_s0", "MazeS3", {}, 0, 3, 150, [0, 50, 149]),
     ("maze_s0", "Maze", {}, 0, 3, 200, [0, 100, 199]),
     ("maze_s2", "Maze", {}, 2, 3, 60, [0, 59]),
+    ("maze_dr_s3", "Maze", {"domain_rand": True}, 3, [0.2, 0.2, 0.6], 90, [0, 45, 89]),
+    ("mazes3_dr_s1", "MazeS3", {"domain_rand": True}, 1, [0.2, 0.2, 0.6], 120, [0, 119]),
     ("pickup_s0", "PickupObjects", {}, 0, 5, 200, [0, 60, 199]),
     ("pickup_dr_s1", "PickupObjects", {"domain_rand": True}, 1, 5, 300, [0, 100, 299]),
     ("pickup_dr_s4", "PickupObjects", {"domain_rand": True}, 4, 5, 300, [0, 150]),
