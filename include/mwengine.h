@@ -48,8 +48,11 @@ enum {
     MW_TASK_PUTNEXT = 3,    /* putnext.py:71-80: goal_ent next to goal_ent2, not carrying */
     MW_TASK_SIDEWALK = 4,   /* sidewalk.py:93-104: the street ends the episode with reward 0, the box like GOTO
                              * (mw_gen_program.street, goal_ent) */
-    MW_TASK_SIGN = 5        /* sign.py:152-170: action move_forward + 1 ends the episode; touching an object of the
+    MW_TASK_SIGN = 5,       /* sign.py:152-170: action move_forward + 1 ends the episode; touching an object of the
                              * table ends it with +-1, the last one touched wins (mw_gen_program.sign_*) */
+    MW_TASK_COLLECT = 6     /* collecthealth.py:79-98: health -2 per step, +2 reward while alive, -100 and the end at 0;
+                             * a kit picked up is consumed after the frame was drawn: health back to 100, the kit leaves
+                             * the entity list and is re-placed at its END with the env's own stream (place_entity) */
 };
 
 /* device-side world generators for mw_reset / auto-reset (the env's _gen_world) */

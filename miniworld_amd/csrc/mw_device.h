@@ -96,6 +96,7 @@ struct MwArgs {
     double *cam;        // [4][N]
     double *light;      // [12][N]
     int32_t *carry, *step, *picked;
+    int32_t *health;    // [N] MW_TASK_COLLECT (collecthealth.py:77, 83)
     int32_t *ekind, *emesh, *estatic;   // [E][N]
     double *epos;       // [3][E][N]
     double *edir;       // [E][N]

@@ -199,7 +199,7 @@ int k1_threads(const mw_engine *e) { return e->args.rec_order ? 256 : 64; }     
 // K1 profiling, or simply too many primitive slots for a wavefront.  MW_K1_DENSE=0 switches it off (A/B runs).
 int k1_dense_lanes(const mw_engine *e, int view_flags)
 {
-    if (e->args.rec_order || e->have_meshes || view_flags != 0 || !e->k1_dense) return 0;
+    if (e->args.rec_order || e->have_meshes || view_flags != 0 || !e->k1_dense || e->cfg.task == MW_TASK_COLLECT) return 0;
     const int lanes = e->cfg.max_polys + 6 * e->cfg.max_ents;
     return lanes <= 64 ? lanes : 0;
 }
@@ -659,6 +659,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.ax, N); ALLOC(a.ay, N); ALLOC(a.az, N); ALLOC(a.adir, N);
     ALLOC(a.cam, 4 * (size_t)N); ALLOC(a.light, 12 * (size_t)N);
     ALLOC(a.carry, N); ALLOC(a.step, N); ALLOC(a.picked, N);
+    if (cfg->task == MW_TASK_COLLECT) ALLOC(a.health, N);
     ALLOC(a.ekind, (size_t)E * N); ALLOC(a.emesh, (size_t)E * N); ALLOC(a.estatic, (size_t)E * N);
     ALLOC(a.epos, 3 * (size_t)E * N); ALLOC(a.edir, (size_t)E * N); ALLOC(a.egeom, 9 * (size_t)E * N);
     ALLOC(a.rng, 5 * (size_t)N); ALLOC(a.extent, 4 * (size_t)N);

@@ -385,6 +385,35 @@ __device__ inline void prog_static_data(const MwArgs &a, int env, int set, Rng &
     __threadfence();        // the placements below test against these segments
 }
 
+// place_entity's rejection sampling (miniworld.py:872-905) for one PLACE op: room (given or drawn by area), a 3-vector
+// draw whose y is thrown away, Room.point_inside, MiniWorldEnv.intersect against walls and the entities in the list
+__device__ inline void prog_sample_position(const MwArgs &a, int env, int set, Rng &r, const mw_prog_op &op, double rad,
+                                            unsigned long long placed, bool agent_placed, double agent_x, double agent_z,
+                                            double &x, double &z)
+{
+    const mw_gen_program &g = a.prog->p;
+    for (int attempt = 0; attempt < 100000; ++attempt) {
+        int ri = op.room;
+        if (ri < 0) {       // np_random.choice(len(rooms), p=room_probs): one double, searchsorted right
+            ri = 0;
+            if (rng_is_pcg(r) || g.n_rooms > 1) {
+                const double u = rng_double(r);
+                while (ri < g.n_rooms - 1 && !(u < g.rooms[ri].cdf)) ++ri;
+            }
+        }
+        const mw_prog_room &rm = g.rooms[ri];
+        const double lx = (op.flags & 1) ? op.lx : rm.min_x, hx = (op.flags & 2) ? op.hx : rm.max_x;
+        const double lz = (op.flags & 4) ? op.lz : rm.min_z, hz = (op.flags & 8) ? op.hz : rm.max_z;
+        x = rng_uniform(r, lx - rad, hx + rad);
+        if (rng_is_pcg(r)) (void)rng_uniform(r, 0.0, 0.0);        // the y component of the 3-vector draw
+        z = rng_uniform(r, lz - rad, hz + rad);
+        if (!prog_point_inside(rm, x, z)) continue;
+        if (prog_blocked(a, env, set, placed, agent_placed, agent_x, agent_z, x, z, rad)) continue;
+        return;
+    }
+    atomicOr(a.status, MW_ST_PLACEMENT_FAIL);
+}
+
 __device__ inline void gen_program(const MwArgs &a, int env, int set, Rng &r, double &ax, double &az, double &adir)
 {
     const MwProgram &P = *a.prog;
@@ -433,27 +462,7 @@ __device__ inline void gen_program(const MwArgs &a, int env, int set, Rng &r, do
             if (op.op == MW_OP_FIXED) {
                 y = op.a;
             } else {
-                bool ok = false;
-                for (int attempt = 0; attempt < 100000 && !ok; ++attempt) {
-                    int ri = op.room;
-                    if (ri < 0) {       // np_random.choice(len(rooms), p=room_probs): one double, searchsorted right
-                        ri = 0;
-                        if (rng_is_pcg(r) || g.n_rooms > 1) {
-                            const double u = rng_double(r);
-                            while (ri < g.n_rooms - 1 && !(u < g.rooms[ri].cdf)) ++ri;
-                        }
-                    }
-                    const mw_prog_room &rm = g.rooms[ri];
-                    const double lx = (op.flags & 1) ? op.lx : rm.min_x, hx = (op.flags & 2) ? op.hx : rm.max_x;
-                    const double lz = (op.flags & 4) ? op.lz : rm.min_z, hz = (op.flags & 8) ? op.hz : rm.max_z;
-                    x = rng_uniform(r, lx - rad, hx + rad);
-                    if (rng_is_pcg(r)) (void)rng_uniform(r, 0.0, 0.0);        // the y component of the 3-vector draw
-                    z = rng_uniform(r, lz - rad, hz + rad);
-                    if (!prog_point_inside(rm, x, z)) continue;
-                    if (prog_blocked(a, env, set, placed, agent_placed, ax, az, x, z, rad)) continue;
-                    ok = true;
-                }
-                if (!ok) atomicOr(a.status, MW_ST_PLACEMENT_FAIL);
+                prog_sample_position(a, env, set, r, op, rad, placed, agent_placed, ax, az, x, z);
             }
             const double dir = op.dir_mode == 1 ? op.dir : (op.dir_mode == 2 ? dir_reg : rng_uniform(r, -kGenPi, kGenPi));
             if (agent) {
@@ -471,6 +480,42 @@ __device__ inline void gen_program(const MwArgs &a, int env, int set, Rng &r, do
         }
     }
     if (!static_done) prog_static_data(a, env, set, r);
+}
+
+// CollectHealth (collecthealth.py:86-90): the consumed kit leaves the entity list and is placed again at its END —
+// slots are list positions, so the slots behind it move down by one and the new kit takes the last one — with
+// place_entity's draws from the env's stream.  One lane, after the frame's primitives were set up.
+__device__ inline void collect_respawn(const MwArgs &a, int env, int set, int k, double agent_x, double agent_z)
+{
+    const size_t N = a.N, E = a.E;
+    const int n = a.prog->p.n_ents, last = n - 1;
+    int32_t kind = a.ekind[(size_t)k * N + env], mesh = a.emesh[(size_t)k * N + env], stat = a.estatic[(size_t)k * N + env];
+    double geom[9];
+    for (int j = 0; j < 9; ++j) geom[j] = a.egeom[((size_t)j * E + k) * N + env];
+    for (int s = k; s < last; ++s) {
+        a.ekind[(size_t)s * N + env] = a.ekind[(size_t)(s + 1) * N + env];
+        a.emesh[(size_t)s * N + env] = a.emesh[(size_t)(s + 1) * N + env];
+        a.estatic[(size_t)s * N + env] = a.estatic[(size_t)(s + 1) * N + env];
+        a.edir[(size_t)s * N + env] = a.edir[(size_t)(s + 1) * N + env];
+        for (int j = 0; j < 3; ++j) a.epos[((size_t)j * E + s) * N + env] = a.epos[((size_t)j * E + s + 1) * N + env];
+        for (int j = 0; j < 9; ++j) a.egeom[((size_t)j * E + s) * N + env] = a.egeom[((size_t)j * E + s + 1) * N + env];
+    }
+    a.ekind[(size_t)last * N + env] = kind; a.emesh[(size_t)last * N + env] = mesh; a.estatic[(size_t)last * N + env] = stat;
+    for (int j = 0; j < 9; ++j) a.egeom[((size_t)j * E + last) * N + env] = geom[j];
+    __threadfence();
+    Rng r = rng_load(a.rng, a.N, env);
+    mw_prog_op op{};
+    op.op = MW_OP_PLACE; op.slot = last; op.room = -1; op.cond = -1; op.flags = 0;
+    unsigned long long placed = 0ull;
+    for (int s = 0; s < last; ++s)
+        if (a.ekind[(size_t)s * N + env] != MW_ENT_NONE) placed |= 1ull << s;
+    double x = 0.0, z = 0.0;
+    prog_sample_position(a, env, set, r, op, geom[7], placed, true, agent_x, agent_z, x, z);
+    a.epos[((size_t)0 * E + last) * N + env] = x;
+    a.epos[((size_t)1 * E + last) * N + env] = 0.0;
+    a.epos[((size_t)2 * E + last) * N + env] = z;
+    a.edir[(size_t)last * N + env] = rng_uniform(r, -kGenPi, kGenPi);
+    rng_store(a.rng, a.N, env, r);
 }
 
 // One full reset of env `env`.  Writes every per-env state array.
@@ -612,6 +657,7 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     }
     a.ax[env] = ax; a.ay[env] = 0.0; a.az[env] = az; a.adir[env] = adir;
     a.carry[env] = -1; a.step[env] = 0; a.picked[env] = 0;
+    if (a.health) a.health[env] = 100;          // CollectHealth._gen_world (collecthealth.py:77)
     if (a.generator == MW_GEN_PROGRAM) {
         for (int k = 0; k < 4; ++k) a.extent[(size_t)k * N + env] = a.prog->p.extent[k];
     } else if (a.generator == MW_GEN_MAZE) {
@@ -635,6 +681,7 @@ __device__ inline void take_spare(const MwArgs &a, int env, int lane)
         for (int k = 0; k < 12; ++k) a.light[(size_t)k * N + env] = sp.light[(size_t)k * N + env];
         for (int k = 0; k < 4; ++k) a.extent[(size_t)k * N + env] = sp.extent[(size_t)k * N + env];
         a.carry[env] = -1; a.step[env] = 0; a.picked[env] = 0;
+        if (a.health) a.health[env] = 100;
     }
     for (int s = lane; s < (int)E; s += 64) {
         a.ekind[(size_t)s * N + env] = sp.ekind[(size_t)s * N + env];

@@ -153,6 +153,15 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
             }
         }
         if (a.task >= MW_TASK_SIDEWALK) program_rules(c, action, step_count, rew, tm);
+        int health = 0;
+        if (a.task == MW_TASK_COLLECT) {        // collecthealth.py:79-98
+            health = a.health[env] - 2;
+            if (action == 4 && c.carry >= 0) {  // the kit in hand is consumed — after this frame was drawn (remove_slot)
+                remove_slot = c.carry;
+                health = 100;
+            }
+            if (health > 0) rew = 2.0; else { rew = -100.0; tm = 1; }
+        }
         if (KW > 1) __syncthreads();        // every wave has read the state it needs: thread 0 may now overwrite it
         if (writer) {
             if (drew) mw::rng_store(a.rng, a.N, env, rng);
@@ -161,6 +170,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
             trunc[env] = (uint8_t)tr;
             a.step[env] = step_count;
             a.picked[env] = picked;
+            if (a.task == MW_TASK_COLLECT) a.health[env] = health;
         }
     }
 
@@ -512,6 +522,9 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         }
         hdr[16] = cam.p00; hdr[17] = cam.p11; hdr[18] = cam.p22; hdr[19] = cam.p23;
         hdr[23] = __int_as_float(cam.ortho); hdr[27] = cam.p03; hdr[31] = cam.p13;
-        if (remove_slot >= 0) a.ekind[(size_t)remove_slot * a.N + env] = MW_ENT_NONE;
+        if (remove_slot >= 0) {
+            if (a.task == MW_TASK_COLLECT) mw::collect_respawn(a, env, c.set, remove_slot, c.px, c.pz);     // the kit respawns
+            else a.ekind[(size_t)remove_slot * a.N + env] = MW_ENT_NONE;
+        }
     }
 }

@@ -19,7 +19,7 @@ LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
 ABI_VERSION = 3
 ENT_NONE, ENT_BOX, ENT_MESH, ENT_FRAME = 0, 1, 2, 3
 POLY_ENTITY = 0x100          # mw_poly.nv flag: quad of a static entity, not a room
-TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT, TASK_SIDEWALK, TASK_SIGN = 0, 1, 2, 3, 4, 5
+TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT, TASK_SIDEWALK, TASK_SIGN, TASK_COLLECT = 0, 1, 2, 3, 4, 5, 6
 GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE, GEN_PROGRAM = 0, 1, 2, 3, 4, 5
 OP_COIN, OP_DRAW_DIR, OP_PLACE, OP_FIXED, OP_BOX_SIZE, OP_COLOR, OP_APPEND = 1, 2, 3, 4, 5, 6, 7
 PROG_MAX_ROOMS, PROG_MAX_TEX, PROG_MAX_OPS, PROG_MAX_ENTS = 16, 8, 48, 64

@@ -89,6 +89,8 @@ def family_ops(t, slot_of, room_of):
         for e in ents:
             ops.append(dict(op=eng.OP_APPEND, slot=slot_of(e)) if isinstance(e, _Frame) else _fixed(slot_of(e), e.pos))
         return ops + [_place(A, min_x=4.0, max_x=5.0, min_z=4.0, max_z=6.0)]
+    if name == "CollectHealth":
+        return [_place(slot_of(e)) for e in ents] + [_place(A)]
     raise KeyError(f"no placement program for {name}")
 
 

@@ -46,9 +46,9 @@ _KIND = {
     "MiniWorld-Sign-v0": ("Sign", eng.GEN_PROGRAM, eng.TASK_SIGN, 4),
     "MiniWorld-PutNext-v0": ("PutNext", eng.GEN_PROGRAM, eng.TASK_PUTNEXT, 8),
     "MiniWorld-RoomObjects-v0": ("RoomObjects", eng.GEN_PROGRAM, eng.TASK_NONE, 8),
-    # host-generated worlds (reference-compatible numpy stream) with the rule on the host: a consumed kit respawns through
-    # place_entity at the END of the entity list (collecthealth.py:86-90), which reorders the slots
-    "MiniWorld-CollectHealth-v0": ("CollectHealth", eng.GEN_NONE, eng.TASK_NONE, 8),
+    # health bookkeeping and the respawn of a consumed kit (place_entity at the END of the entity list,
+    # collecthealth.py:79-98) are a K1 task rule too
+    "MiniWorld-CollectHealth-v0": ("CollectHealth", eng.GEN_PROGRAM, eng.TASK_COLLECT, 8),
 }
 
 
@@ -182,8 +182,6 @@ class MiniWorldVecEnv:
         self.rng_mode = "pcg64" if cfg.rng_mode == eng.RNG_PCG64 else "philox"
         self.engine = eng.Engine(cfg)
         self.host_autoreset = autoreset and generator == eng.GEN_NONE
-        self._host_rule = {"CollectHealth": self._rule_collecthealth}.get(cls_name)
-        self._health = np.full(num_envs, 100, np.int64)
         self._upload_assets(sc)
         if cls_name == "RoomObjects":       # any colour of ball / key can be drawn: all twelve meshes are resident
             from .entity import COLOR_NAMES
@@ -238,7 +236,6 @@ class MiniWorldVecEnv:
                 env = self._cls(host_only=True, **self._dr_kw(self.domain_rand), **self._env_kwargs)
                 self._host_envs[i] = env
             env.reset(seed=int(s))
-            self._health[i] = 100
             sc = scene_from_env(env)
             # with domain randomisation a world may draw a texture variant no earlier world used (concrete_2 ...):
             # upload it on first sight
@@ -278,8 +275,6 @@ class MiniWorldVecEnv:
     def step(self, actions):
         """actions: integer torch tensor [N] (converted to contiguous int32 on the engine's device if needed)."""
         self.engine.step(actions, self.obs, self.depth, self.reward, self.terminated, self.truncated)
-        if self._host_rule is not None:
-            self._host_rule(actions)
         if self.host_autoreset:
             done = (self.terminated | self.truncated).nonzero().flatten().tolist()
             if done:
@@ -288,39 +283,6 @@ class MiniWorldVecEnv:
                 self._host_generate(done, seeds)
                 self.engine.render(self.obs, self.depth)
         return self.obs, self.reward, self.terminated, self.truncated
-
-    # ------------------------------------------------------------------ env rules evaluated on the host
-    def _near(self, st, slot):
-        """MiniWorldEnv.near (miniworld.py:965-975) for every env: agent vs entity `slot`."""
-        d = np.linalg.norm(st["agent_pos"] - st["ent_pos"][:, slot], axis=1)
-        return d < self.template.agent.radius + st["ent_geom"][:, slot, 7] + 1.1 * self.template.max_forward_step
-
-    def _rule_collecthealth(self, actions):
-        """CollectHealth.step (collecthealth.py:79-98): health drops by 2 per step; a kit that has just been
-        picked up is consumed (health back to 100) and re-placed with the env's own numpy stream — done on the
-        env's host object, whose entity list then has the kit at the end like the reference's, and pushed back;
-        +2 per step survived, -100 and termination when the health runs out."""
-        st = self.engine.get_state()
-        act = actions.cpu().numpy()
-        self._health -= 2
-        for i in np.nonzero((act == self.template.actions.pickup) & (st["carrying"] >= 0))[0]:
-            h = self._host_envs[i]
-            ents = [e for e in h.entities if e is not h.agent]
-            h.agent.pos, h.agent.dir = st["agent_pos"][i].copy(), float(st["agent_dir"][i])
-            for k, e in enumerate(ents):
-                e.pos, e.dir = st["ent_pos"][i, k].copy(), float(st["ent_dir"][i, k])
-            kit = ents[int(st["carrying"][i])]
-            h.entities.remove(kit)
-            h.place_entity(kit)
-            h.agent.carrying = None
-            h.step_count = int(st["step_count"][i])
-            sc = scene_from_env(h)
-            mm = upload_scene_meshes(self.engine, sc, self.mesh_ids, self.tex_ids)
-            self.engine.set_state(state_arrays([sc], self.engine.E, [mm]), first=int(i), count=1)
-            self._health[i] = 100
-        dead = self._health <= 0
-        self.reward.copy_(self.torch.as_tensor(np.where(dead, -100.0, 2.0).astype(np.float32)))
-        self.terminated.copy_(self.torch.as_tensor(dead.astype(np.uint8)))
 
     def render_top_view(self, render_agent=True):
         """uint8[N,H,W,3] map views (render_top_view, miniworld.py:1088-1175) of every env."""

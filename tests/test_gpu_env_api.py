@@ -442,7 +442,7 @@ def test_vec_env_fused_wrapper_layouts(env_id, kw):
 
 
 _PROGRAM_FAMILIES = ["FourRooms", "TMaze", "TMazeLeft", "TMazeRight", "YMaze", "YMazeLeft", "YMazeRight", "WallGap",
-                     "ThreeRooms", "PutNext", "RoomObjects", "Sidewalk", "Sign"]
+                     "ThreeRooms", "PutNext", "RoomObjects", "Sidewalk", "Sign", "CollectHealth"]
 
 
 def _host_scene_with_device_state(h, st, i):
@@ -672,7 +672,7 @@ _DEVICE_FAMILIES.update({c: f"MiniWorld-{c}-v0" for c in _PROGRAM_FAMILIES})
 
 
 # (putnext_poke teleports a box mid-trajectory: covered through the single-env API and the C-level step test)
-@pytest.mark.parametrize("case", [c for c in ALL_CASES if c.split("_")[0] not in ("collecthealth",) and "poke" not in c])
+@pytest.mark.parametrize("case", [c for c in ALL_CASES if "poke" not in c])
 def test_batched_env_reproduces_reference_trajectory_from_seed(case):
     """The whole path with nothing from the host classes in between: a batched env seeded like the reference run
     that produced the fixture (tools/gen_golden.py: the reference's own miniworld.py under GL stubs) generates
@@ -767,10 +767,10 @@ def test_two_engines_are_independent():
 
 @pytest.mark.parametrize("case", ["sidewalk_s0", "sidewalk_s3", "sign_s0", "sign_green_key_s1", "collecthealth_s13"])
 def test_vec_env_host_rule_families_follow_reference_trajectory(case):
-    """Sidewalk, Sign and CollectHealth in the batched API.  Sidewalk's forbidden street and Sign's touch table / extra
-    end-of-episode action are K1 task rules fed by the placement program; CollectHealth keeps its rule on the host
-    (health bookkeeping, kits respawning through the env's own numpy stream at the end of the entity list).  Env 0,
-    generated from the fixture's seed, reproduces the reference's rewards, flags, frames and poses."""
+    """Sidewalk, Sign and CollectHealth in the batched API: Sidewalk's forbidden street, Sign's touch table / extra
+    end-of-episode action and CollectHealth's health bookkeeping with kits respawning through the env's own numpy
+    stream at the end of the entity list are K1 task rules fed by the placement program.  Env 0, generated from
+    the fixture's seed on the device, reproduces the reference's rewards, flags, frames and poses."""
     import torch
     from miniworld_amd.vec_env import MiniWorldVecEnv
     s0, tr, meta, obs = helpers.load_case(case)

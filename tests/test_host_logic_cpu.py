@@ -210,6 +210,37 @@ def test_every_reference_env_id_is_registered_and_batched():
         env = cls(host_only=True)
         env.reset(seed=1)
         assert env.max_episode_steps > 0 and len(env.rooms) >= 1
+        # every id is generated, auto-reset and ruled on the device: none is left on the host path
+        from miniworld_amd import engine as eng
+        assert _KIND[env_id][1] != eng.GEN_NONE, env_id
     fast = envs.MazeS3Fast(host_only=True)
     assert fast.params.get_max("forward_step") == 0.7 and fast.max_episode_steps == 300      # maze.py:75-95
     assert envs.OneRoomS6Fast(host_only=True).max_episode_steps == 50                        # oneroom.py:83-97
+
+
+def test_placement_programs_compile_for_every_fixed_floorplan_family():
+    """genprog.compile_program: rooms, texture tables, ops and the template geometry's metre coordinates (which must
+    reproduce the template's own texture coordinates) for each family of the batched table with MW_GEN_PROGRAM."""
+    from miniworld_amd import assets, engine as eng, envs, genprog
+    from miniworld_amd.scene import scene_from_env
+    from miniworld_amd.vec_env import _KIND
+    n = 0
+    for env_id, (cls, gen, task, _) in _KIND.items():
+        if gen != eng.GEN_PROGRAM:
+            continue
+        t = getattr(envs, cls)(host_only=True)
+        t.reset(seed=0)
+        sc = scene_from_env(t)
+        names = [str(v) for v in sc["tex_names"]]
+        for r in t.rooms:
+            for nm in (r.wall_tex_name, r.floor_tex_name, r.ceil_tex_name):
+                names += [v for v in assets.texture_variants(nm) if v not in names]
+        ents = [e for e in t.entities if e is not t.agent]
+        ops = genprog.room_objects_ops(0, 1, 2, 0, 6) if cls == "RoomObjects" else genprog.family_ops(t, ents.index, t.rooms.index)
+        prog, polys, room, surf, m, segs = genprog.compile_program(t, sc, {v: i for i, v in enumerate(names)},
+                                                                   {i: i for i in range(len(sc["mesh_names"]))}, ops)
+        assert prog.n_rooms == len(t.rooms) and prog.n_ents == len(ents) and prog.n_ops == len(ops)
+        assert abs(prog.rooms[prog.n_rooms - 1].cdf - 1.0) < 1e-12
+        assert (room >= 0).sum() >= 5 and len(polys) == len(sc["polys_nv"]) and len(segs) == len(sc["wall_segs"])
+        n += 1
+    assert n == 14
