@@ -39,7 +39,16 @@ struct MwMeshDesc {
     int32_t tex;
     uint32_t first;                // first triangle in the mesh pools
     uint32_t bound_bits;           // float bits: max |vertex| (radius of the bounding sphere about the mesh origin)
+    float last_n[3];               // vertex normal of the LAST triangle's last vertex in drawing order (GL's current
+    uint32_t pad;                  //   normal after the mesh, for the top view's agent marker)
 };
+
+// Mesh pools: triangles are STORED sorted by the direction of their face normal (mw_upload_mesh), so that the 64
+// triangles of a wavefront face the same way and back-face culling retires whole waves instead of half the lanes of
+// each.  Drawing order (= draw ids, GL's first-drawn-wins on equal depth, the oracle's triangle indices) is the
+// original one: a position record is 9 floats + one word, (original index of stored triangle i) | (stored index of
+// original triangle i) << 16.
+#define MW_MESH_POS_STRIDE 10
 
 // Generator tables; kept in device memory because dynamic indexing into a by-value kernarg
 // struct would force a private (scratch) copy of the whole argument block.

@@ -534,7 +534,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     bool forked = false;
     if (e->have_meshes) {
         // envs may contain mesh entities: one 1024-thread workgroup per env, sample keys in LDS
-        const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * 192;
+        const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * 192 + 16;       // keys, 16 pack buffers, the tile counter
         if (lds > 160 * 1024) return fail(e, MW_E_CAPACITY, "mesh entities need the env's sample keys in LDS: %dx%d is too large", a.W, a.H);
         if (!e->mesh_lds_ready) {
             for (auto k : {mw_raster_mesh_kernel, mw_raster_mesh_depth_kernel, mw_raster_mesh_wrap_kernel})
@@ -783,11 +783,41 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
     if (tex_id >= MW_MAX_TEX || (tex_id >= 0 && !uv)) return fail(e, MW_E_INVALID, "textured mesh needs texcoords and a valid texture id");
     if (mesh_id < 0 || mesh_id >= MW_MAX_MESH) return fail(e, MW_E_CAPACITY, "mesh id %d out of range (max %d)", mesh_id, MW_MAX_MESH);
     if (ntris <= 0 || ntris > 60000) return fail(e, MW_E_CAPACITY, "mesh with %d triangles (1..60000 supported: 16-bit draw ids)", ntris);
-    e->mesh_pos[mesh_id].assign(pos, pos + (size_t)ntris * 9);
-    e->mesh_nrm[mesh_id].assign(nrm, nrm + (size_t)ntris * 9);
-    e->mesh_rgb[mesh_id].assign(rgb, rgb + (size_t)ntris * 9);
-    if (uv) e->mesh_uv[mesh_id].assign(uv, uv + (size_t)ntris * 6);
-    else e->mesh_uv[mesh_id].assign((size_t)ntris * 6, 0.0f);
+    // storage order: triangles sorted by the direction of their face normal (octahedral map, 6 + 6 bit Morton code,
+    // stable), mw_device.h: MW_MESH_POS_STRIDE
+    std::vector<uint32_t> order((size_t)ntris), key((size_t)ntris);
+    for (int t = 0; t < ntris; ++t) {
+        const float *p = pos + (size_t)t * 9;
+        const double ax = p[3] - p[0], ay = p[4] - p[1], az = p[5] - p[2], bx = p[6] - p[0], by = p[7] - p[1], bz = p[8] - p[2];
+        double nx = ay * bz - az * by, ny = az * bx - ax * bz, nz = ax * by - ay * bx;
+        double l1 = std::fabs(nx) + std::fabs(ny) + std::fabs(nz);
+        if (!(l1 > 0.0)) { nx = nrm[(size_t)t * 9]; ny = nrm[(size_t)t * 9 + 1]; nz = nrm[(size_t)t * 9 + 2]; l1 = std::fabs(nx) + std::fabs(ny) + std::fabs(nz); }
+        if (!(l1 > 0.0)) { nx = 0; ny = 1; nz = 0; l1 = 1; }
+        double u = nx / l1, v = nz / l1;
+        if (ny < 0.0) {     // lower hemisphere folded outwards
+            const double uu = (1.0 - std::fabs(v)) * (u >= 0 ? 1.0 : -1.0), vv = (1.0 - std::fabs(u)) * (v >= 0 ? 1.0 : -1.0);
+            u = uu; v = vv;
+        }
+        const uint32_t qu = (uint32_t)std::min(63.0, std::max(0.0, (u * 0.5 + 0.5) * 64.0)), qv = (uint32_t)std::min(63.0, std::max(0.0, (v * 0.5 + 0.5) * 64.0));
+        uint32_t m = 0;
+        for (int b = 0; b < 6; ++b) m |= ((qu >> b) & 1u) << (2 * b) | ((qv >> b) & 1u) << (2 * b + 1);
+        key[t] = m; order[t] = (uint32_t)t;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    std::vector<uint32_t> inv((size_t)ntris);
+    for (int s_ = 0; s_ < ntris; ++s_) inv[order[s_]] = (uint32_t)s_;
+    auto &P = e->mesh_pos[mesh_id]; auto &Nn = e->mesh_nrm[mesh_id]; auto &Cc = e->mesh_rgb[mesh_id]; auto &U = e->mesh_uv[mesh_id];
+    P.assign((size_t)ntris * MW_MESH_POS_STRIDE, 0.0f); Nn.assign((size_t)ntris * 9, 0.0f); Cc.assign((size_t)ntris * 9, 0.0f); U.assign((size_t)ntris * 6, 0.0f);
+    for (int s_ = 0; s_ < ntris; ++s_) {
+        const size_t o = order[s_];
+        memcpy(&P[(size_t)s_ * MW_MESH_POS_STRIDE], pos + o * 9, 36);
+        const uint32_t word = order[s_] | (inv[s_] << 16);
+        memcpy(&P[(size_t)s_ * MW_MESH_POS_STRIDE + 9], &word, 4);
+        memcpy(&Nn[(size_t)s_ * 9], nrm + o * 9, 36);
+        memcpy(&Cc[(size_t)s_ * 9], rgb + o * 9, 36);
+        if (uv) memcpy(&U[(size_t)s_ * 6], uv + o * 6, 24);
+    }
+    memcpy(e->mesh_desc[mesh_id].last_n, nrm + ((size_t)(ntris - 1) * 3 + 2) * 3, 12);
     e->mesh_desc[mesh_id].ntris = (uint32_t)ntris;
     e->mesh_desc[mesh_id].tex = tex_id;
     {
@@ -802,14 +832,14 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
     for (int i = 0; i < MW_MAX_MESH; ++i) { e->mesh_desc[i].first = (uint32_t)total; total += e->mesh_desc[i].ntris; }
     for (float **p : {&e->d_mesh_pos, &e->d_mesh_nrm, &e->d_mesh_rgb, &e->d_mesh_uv})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
-    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_pos, total * 36));
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_pos, total * 4 * MW_MESH_POS_STRIDE));
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_nrm, total * 36));
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_rgb, total * 36));
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_uv, total * 24));
     for (int i = 0; i < MW_MAX_MESH; ++i) {
         const size_t n = e->mesh_desc[i].ntris, off = (size_t)e->mesh_desc[i].first * 9;
         if (!n) continue;
-        HIP_TRY(e, hipMemcpy(e->d_mesh_pos + off, e->mesh_pos[i].data(), n * 36, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->d_mesh_pos + (size_t)e->mesh_desc[i].first * MW_MESH_POS_STRIDE, e->mesh_pos[i].data(), n * 4 * MW_MESH_POS_STRIDE, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_nrm + off, e->mesh_nrm[i].data(), n * 36, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_rgb + off, e->mesh_rgb[i].data(), n * 36, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_uv + (size_t)e->mesh_desc[i].first * 6, e->mesh_uv[i].data(), n * 24, hipMemcpyHostToDevice));

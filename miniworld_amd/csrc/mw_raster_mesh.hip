@@ -78,10 +78,20 @@ __constant__ float kDy16[16] = {0.0625f, -0.1875f, 0.125f, -0.0625f, -0.125f, 0.
 template <int S> __device__ inline float sample_dx(int s) { return S == 16 ? kDx16[s] : kDx[s]; }
 template <int S> __device__ inline float sample_dy(int s) { return S == 16 ? kDy16[s] : kDy[s]; }
 
-// world-space vertices of triangle `tri` of mesh entity e (R11: pos + scale * R_y(dir) * v)
+// stored triangle -> original (drawing order) index and back (mw_device.h: MW_MESH_POS_STRIDE)
+__device__ inline int tri_original(const TileCtx &cx, const MeshEnt &e, int stored)
+{
+    return (int)(__float_as_uint(cx.mesh_pos[(size_t)(e.first + stored) * MW_MESH_POS_STRIDE + 9]) & 0xFFFFu);
+}
+__device__ inline int tri_stored(const TileCtx &cx, const MeshEnt &e, int original)
+{
+    return (int)(__float_as_uint(cx.mesh_pos[(size_t)(e.first + original) * MW_MESH_POS_STRIDE + 9]) >> 16);
+}
+
+// world-space vertices of STORED triangle `tri` of mesh entity e (R11: pos + scale * R_y(dir) * v)
 __device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, int tri, float halfw, float halfh, HV h[3])
 {
-    const float *p = cx.mesh_pos + (size_t)(e.first + tri) * 9;
+    const float *p = cx.mesh_pos + (size_t)(e.first + tri) * MW_MESH_POS_STRIDE;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float lx = p[k * 3 + 0], ly = p[k * 3 + 1], lz = p[k * 3 + 2];
@@ -93,9 +103,10 @@ __device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, int tri, f
 
 // Mesh triangle (e, tri) at the pixel centre (R9-R11): Gouraud colour in q2.yzw and, for a textured
 // mesh (objmesh.py:209-216), the texcoord / 1/w planes in q0, q1, q2.x for apply_texture
-__device__ inline void mesh_tri_fragment(const TileCtx &cx, const MeshEnt &e, int tri, float Xc, float Yc,
+__device__ inline void mesh_tri_fragment(const TileCtx &cx, const MeshEnt &e, int tri_drawn, float Xc, float Yc,
                                          float4 &q0, float4 &q1, float4 &q2)
 {
+    const int tri = tri_stored(cx, e, tri_drawn);       // the draw id names the triangle in drawing order
     const float halfw = (float)cx.W * 0.5f, halfh = (float)cx.H * 0.5f;
     HV h[3];
     tri_verts(cx, e, tri, halfw, halfh, h);
@@ -269,7 +280,7 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
     float zo[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) zo[s] = fmaf(zx, sample_dx<S>(s), zy * sample_dy<S>(s));
-    const uint32_t id = (uint32_t)(e.start + tri);
+    const uint32_t id = (uint32_t)(e.start + tri_original(cx, e, tri));      // draw id = position in drawing order
     for (int py = y0; py <= y1; ++py)
         for (int px = x0; px <= x1; ++px) {
             const float Xc = (float)px + 0.5f, Yc = (float)py + 0.5f;
@@ -322,6 +333,7 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
     {
         uint4 *k4 = reinterpret_cast<uint4 *>(keys);
         for (int i = tid; i < nkeys / 4; i += 1024) k4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+        if (tid == 0) *reinterpret_cast<int *>(smem + (size_t)nkeys * 4 + 16 * 192) = 0;       // the tile counter of phase 2
     }
     __syncthreads();
 
@@ -350,8 +362,15 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
     __syncthreads();
     const unsigned long long t_mesh = prof ? __builtin_readcyclecounter() : 0ull;
 
-    // ---- phase 2: tiles, 16 wavefronts round-robin --------------------------------------------
-    for (int tile = wave; tile < n_tiles; tile += 16) {
+    // ---- phase 2: tiles, taken by the 16 wavefronts from a shared counter --------------------------------------
+    // (a tile under a ball costs several times a plain one: with a static round-robin the waves that drew the mesh
+    // tiles decide the workgroup's duration while the others idle — and nothing else fits on the CU beside its LDS)
+    int *s_next = reinterpret_cast<int *>(smem + (size_t)nkeys * 4 + 16 * 192);
+    for (;;) {
+        int tile = 0;
+        if (lane == 0) tile = atomicAdd(s_next, 1);
+        tile = __builtin_amdgcn_readfirstlane(tile);
+        if (tile >= n_tiles) break;
         const int tx = tile % tiles_x, ty = tile / tiles_x;
         const int px = tx * MW_TILE_W + (lane & 15), py = ty * MW_TILE_H + (lane >> 4);
         uint32_t mk[8];

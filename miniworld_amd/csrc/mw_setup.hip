@@ -358,8 +358,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
                     atomicOr(a.status, MW_ST_VIS_OVERFLOW);
                 }
                 if (md_ntris > 0) {     // the mesh's last vertex normal stays current
-                    const float *ln = a.mesh_nrm + ((size_t)(md_first + md_ntris - 1) * 3 + 2) * 3;
-                    stale_n[0] = uni(ln[0]); stale_n[1] = uni(ln[1]); stale_n[2] = uni(ln[2]);
+                    stale_n[0] = uni(mdp->last_n[0]); stale_n[1] = uni(mdp->last_n[1]); stale_n[2] = uni(mdp->last_n[2]);
                 }
                 ++s0;
                 continue;
