@@ -362,11 +362,12 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         exact |= __any(m) != 0;
     }
     if (!exact) {
-        // Per-sample coverage lives in wave-uniform 64-bit lane masks (SGPR pairs): every test
-        // below is a v_cmp producing a mask, every combination is SALU work.
-        uint64_t cov_m[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) cov_m[s] = 0ull;
+        // The samples claimed so far live in ONE VGPR per lane (bit s = sample s of this lane's pixel) plus a
+        // wave-level "anything covered" mask; a primitive's own coverage is computed in wave-uniform lane masks
+        // (one v_cmp per edge and sample, combined on the SALU) and folded into the lane's bits with add-with-carry.
+        // (Eight 64-bit "covered" masks in SGPRs cost 16 scalar registers the tile loop does not have: they were
+        // spilled to VGPR lanes, every v_readlane / v_writelane a VALU instruction.)
+        uint32_t covbits = 0u;
         uint64_t anycov_m = 0ull;
         uint32_t ncov = 0;                           // covered samples of this lane's pixel
         for (int chunk = 0; chunk < (PRE == 1 ? 1 : ((dbg & 2) ? 0 : nvis)) && !exact; chunk += 64) {
@@ -395,8 +396,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     // the whole tile lies strictly inside primitive p
                     if (anycov_m) { exact = true; break; }
                     cnt = 8u; in0 = true;
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) cov_m[s] = ~0ull;
+                    covbits = 0xFFu;
                     anycov_m = ~0ull;
                 } else {
                     const float *__restrict__ rr = rr_env + (size_t)p * MW_RASTER_REC;
@@ -411,24 +411,21 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 #pragma unroll
                         for (int s = 0; s < 8; ++s) in_m[s] &= __ballot(E > rr[16 + k * 8 + s]);
                     }
-                    uint64_t any_m = 0ull, clash_m = 0ull;
+                    uint64_t any_m = 0ull;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        any_m |= in_m[s];
-                        clash_m |= in_m[s] & cov_m[s];
-                    }
-                    if (clash_m) { exact = true; break; }
+                    for (int s = 0; s < 8; ++s) any_m |= in_m[s];
                     if (!any_m) continue;
-                    cnt = 0u;
+                    // this lane's eight bits: bits = 2 * bits + (lane's bit of in_m[s]), the mask going in as the carry
+                    // of an add-with-carry, sample 7 first so that sample s ends up in bit s
+                    uint32_t bits = 0u;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) {
-                        cov_m[s] |= in_m[s];
-                        // cnt += this lane's bit of in_m[s]: the mask goes in as the carry of an add-with-carry
-                        // (one VALU instruction per sample; select + add would be 12 for the eight)
-                        asm("v_addc_co_u32_e64 %0, vcc, 0, %0, %1" : "+v"(cnt) : "s"(in_m[s]) : "vcc");
-                    }
+                    for (int s = 7; s >= 0; --s)
+                        asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(in_m[s]) : "vcc");
+                    if (__any((bits & covbits) != 0u)) { exact = true; break; }      // a sample claimed twice
+                    covbits |= bits;
+                    cnt = (uint32_t)__popc(bits);
                     anycov_m |= any_m;
-                    in0 = __builtin_amdgcn_inverse_ballot_w64(in_m[0]);
+                    in0 = (bits & 1u) != 0u;
                 }
                 ncov += cnt;
                 if (cnt != 0u) {

@@ -1,43 +1,47 @@
-"""Turns gpurun_out/prof_<tag> (tools/perf/profile_round.sh) into the committed profiles/<tag>/:
-kernel_stats.csv, kernel_trace.csv (mw_* dispatches only), pmc_all_summary.json (mean of every counter per
-kernel), pmc_hbm_summary.json (FETCH_SIZE / WRITE_SIZE, KiB per launch — read by bench.py for roofline.traffic),
-bench_line*.json.   usage: python tools/perf/summarize_profile.py r01f"""
+"""Turns gpurun_out/prof_<tag>_<config> (tools/perf/profile_round.sh) into the committed profiles/<tag>/:
+kernel_stats[_<config>].csv, kernel_trace.csv (mw_* dispatches of the headline config only), pmc_all_summary.json (mean of
+every counter per kernel, headline), pmc_hbm_summary[_<config>].json (FETCH_SIZE / WRITE_SIZE, KiB per launch — read by
+bench.py for roofline.traffic), bench_line[_<config>].json.   usage: python tools/perf/summarize_profile.py r02b"""
 import collections, csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-src, dst = os.path.join(root, "gpurun_out", "prof_" + tag), os.path.join(root, "profiles", tag)
+dst = os.path.join(root, "profiles", tag)
 os.makedirs(dst, exist_ok=True)
-shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, "kernel_stats.csv"))
-with open(os.path.join(src, "trace", "bench_kernel_trace.csv")) as f, open(os.path.join(dst, "kernel_trace.csv"), "w") as g:
-    rows = list(csv.reader(f))
-    w = csv.writer(g)
-    w.writerow(rows[0])
-    name = rows[0].index("Kernel_Name")
-    for r in [r for r in rows[1:] if r[name].startswith("mw_")][:200]:
-        w.writerow(r)
-agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for f in glob.glob(os.path.join(src, "pmc_*", "bench_counter_collection.csv")):
-    for r in csv.DictReader(open(f)):
-        if r["Kernel_Name"].startswith("mw_"):
-            agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
-allc, hbm = {}, {}
-for k, cs in agg.items():
-    allc[k], hbm[k] = {}, {}
-    for c, v in cs.items():
-        key = c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")
-        allc[k][key + "_mean"] = sum(v) / len(v)
-        allc[k][c + "_n"] = len(v)
-        if c in ("FETCH_SIZE", "WRITE_SIZE"):
-            hbm[k][key + "_mean"] = sum(v) / len(v)
-            hbm[k][c + "_n"] = len(v)
-json.dump(allc, open(os.path.join(dst, "pmc_all_summary.json"), "w"), indent=1)
-json.dump(hbm, open(os.path.join(dst, "pmc_hbm_summary.json"), "w"), indent=1)
-line = open(src + ".bench.json").read().strip().splitlines()[-1]
-open(os.path.join(dst, "bench_line.json"), "w").write(line + "\n")
-for cfg in ("oneroom_rgbd", "maze", "pickup_dr"):       # bench.py --config lines of the same call, if present
-    f = os.path.join(root, "gpurun_out", "bench_%s.json" % cfg)
-    if os.path.exists(f):
-        shutil.copy(f, os.path.join(dst, "bench_line_%s.json" % cfg))
-print(open(os.path.join(dst, "kernel_stats.csv")).read()[:600])
-print(json.dumps(allc.get("mw_raster_kernel"), indent=1))
+for cfg in ("hallway", "oneroom_rgbd", "maze", "pickup_dr"):
+    src = os.path.join(root, "gpurun_out", f"prof_{tag}_{cfg}")
+    if not os.path.isdir(src):
+        continue
+    suffix = "" if cfg == "hallway" else "_" + cfg
+    shutil.copy(os.path.join(src, "trace", "bench_kernel_stats.csv"), os.path.join(dst, f"kernel_stats{suffix}.csv"))
+    if cfg == "hallway":
+        with open(os.path.join(src, "trace", "bench_kernel_trace.csv")) as f, open(os.path.join(dst, "kernel_trace.csv"), "w") as g:
+            rows = list(csv.reader(f))
+            w = csv.writer(g)
+            w.writerow(rows[0])
+            name = rows[0].index("Kernel_Name")
+            for r in [r for r in rows[1:] if r[name].startswith("mw_")][-200:]:
+                w.writerow(r)
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(os.path.join(src, "pmc_*", "bench_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith("mw_"):
+                agg[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    allc, hbm = {}, {}
+    for k, cs in agg.items():
+        allc[k], hbm[k] = {}, {}
+        for c, v in cs.items():
+            key = c + ("_KiB" if c in ("FETCH_SIZE", "WRITE_SIZE") else "")
+            allc[k][key + "_mean"] = sum(v) / len(v)
+            allc[k][c + "_n"] = len(v)
+            if c in ("FETCH_SIZE", "WRITE_SIZE"):
+                hbm[k][key + "_mean"] = sum(v) / len(v)
+                hbm[k][c + "_n"] = len(v)
+    if cfg == "hallway":
+        json.dump(allc, open(os.path.join(dst, "pmc_all_summary.json"), "w"), indent=1)
+    json.dump(hbm, open(os.path.join(dst, f"pmc_hbm_summary{suffix}.json"), "w"), indent=1)
+    line = open(src + ".bench.json").read().strip().splitlines()[-1]
+    open(os.path.join(dst, f"bench_line{suffix}.json"), "w").write(line + "\n")
+    print("==", cfg)
+    print(open(os.path.join(dst, f"kernel_stats{suffix}.csv")).read()[:420])
+    print(json.dumps({k: {kk: round(vv) for kk, vv in v.items() if kk.endswith("_mean")} for k, v in hbm.items()}))
