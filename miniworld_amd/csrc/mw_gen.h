@@ -33,6 +33,24 @@ __device__ inline bool gen_hits_wall(const MwArgs &a, int set, double x, double 
     return false;
 }
 
+// the same test by the 64 lanes of a wavefront that all hold the same (x, z): segments dealt to the lanes, one ballot
+// (the Maze's 256 segments cost one lane ~100 us per placement attempt)
+__device__ inline bool gen_hits_wall_wave(const MwArgs &a, int set, double x, double z, double radius, int lane)
+{
+    const double *segs = a.segs + (size_t)set * a.max_segs * 4;
+    const int ns = a.nsegs[set];
+    bool hit = false;
+    for (int i = lane; i < ns; i += 64) {
+        const double sax = segs[i * 4 + 0], saz = segs[i * 4 + 1], sbx = segs[i * 4 + 2], sbz = segs[i * 4 + 3];
+        const double abx = sbx - sax, abz = sbz - saz, apx = x - sax, apz = z - saz;
+        double t = (apx * abx + apz * abz) / (abx * abx + abz * abz);
+        t = t < 0.0 ? 0.0 : (t > 1.0 ? 1.0 : t);
+        const double dx = sax + t * abx - x, dz = saz + t * abz - z;
+        hit |= sqrt(dx * dx + dz * dz) < radius;
+    }
+    return __any(hit) != 0;
+}
+
 // place_entity in the rectangular room gen_args[0..3] (miniworld.py:872-905); lx/hx narrow
 // the sampled x range like the min_x / max_x keyword arguments do.
 __device__ inline bool gen_place(const MwArgs &a, int env, int set, Rng &r, double radius, int n_placed,
@@ -266,10 +284,18 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
             const_cast<int32_t *>(a.nsegs)[set] = ns_base;
         }
     }
-    __threadfence();                // lane 0 tests the placement against the segments the other lanes wrote
+    __threadfence();                // the placement is tested against the segments the lanes just wrote
     __builtin_amdgcn_wave_barrier();
-    if (lane != 0) return;
     // ---- placement: box then agent, room drawn with probability ~ area (miniworld.py:872-905) --
+    // All 64 lanes run it: the random stream is a pure function of its state, so after lane 0 (which alone advanced
+    // it while carving) has handed its state over, every lane draws the same candidates and takes the same decisions,
+    // and the one expensive step — the candidate against the env's 256 wall segments — is shared out (ballot).
+    {
+        const uint32_t a_lo = (uint32_t)__shfl((int)(uint32_t)r.a, 0), a_hi = (uint32_t)__shfl((int)(uint32_t)(r.a >> 32), 0);
+        const uint32_t b_lo = (uint32_t)__shfl((int)(uint32_t)r.b, 0), b_hi = (uint32_t)__shfl((int)(uint32_t)(r.b >> 32), 0);
+        r.a = ((uint64_t)a_hi << 32) | a_lo; r.b = ((uint64_t)b_hi << 32) | b_lo;
+        r.has32 = (uint32_t)__shfl((int)r.has32, 0); r.buf32 = (uint32_t)__shfl((int)r.buf32, 0);
+    }
     const double cell_area = a.gt->gen_tab[2] * a.gt->gen_tab[2], link_area = a.gt->gen_tab[2] * a.gt->gen_tab[3];
     const double total = ncell * cell_area + nlink * link_area;
     const double radii[2] = {sqrt(0.8 * 0.8 + 0.8 * 0.8) / 2.0, a.agent_radius};
@@ -299,7 +325,7 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
             if (rng_is_pcg(r)) (void)rng_uniform(r, 0.0, 0.0);       // the y component of the 3-vector draw
             const double z = rng_uniform(r, rr.z0 - rad, rr.z1 + rad);
             if (!(x > rr.x0 && x < rr.x1 && z > rr.z0 && z < rr.z1)) continue;        // Room.point_inside
-            if (gen_hits_wall(a, set, x, z, rad)) continue;
+            if (gen_hits_wall_wave(a, set, x, z, rad, lane)) continue;
             if (who == 1) {
                 const double dx = out[0][0] - x, dz = out[0][1] - z;
                 if (sqrt(dx * dx + dz * dz) < rad + radii[0]) continue;
