@@ -88,7 +88,9 @@ typedef struct {
     int32_t device_id;
     int32_t num_envs;
     int32_t obs_width, obs_height;  /* MiniWorldEnv(obs_width=80, obs_height=60) miniworld.py:473-474 */
-    int32_t msaa;               /* FrameBuffer(..., num_samples=8) miniworld.py:515; 8 only for now */
+    int32_t msaa;               /* FrameBuffer(..., num_samples=8) miniworld.py:515.  8 = the hot path; 4 or 1 = what the
+                                 * reference falls back to on a driver that clamps GL_MAX_SAMPLES (opengl.py:229-231):
+                                 * same semantics through the generic-resolution kernels, plain HWC layout only       */
     int32_t max_ents;           /* entity slots per env, agent excluded            */
     int32_t max_polys;          /* room polygons per geometry set                  */
     int32_t max_segs;           /* collision segments per geometry set             */
@@ -315,7 +317,7 @@ int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);
  * kind of buffers; render_agent != 0 also draws Agent.render's marker (entity.py:518-539) */
 int mw_render_top(mw_engine *e, uint8_t *d_obs, float *d_depth, int32_t render_agent, void *stream);
 /* render() / render_obs(vis_fb) / render_top_view(vis_fb) (miniworld.py:1340-1362): ONE env into a frame
- * buffer of any size (multiples of 16 x 4) with msaa = 8 or 16 samples (vis_fb = FrameBuffer(800, 600, 16),
+ * buffer of any size (multiples of 16 x 4) with msaa = 1, 4, 8 or 16 samples (vis_fb = FrameBuffer(800, 600, 16),
  * miniworld.py:518).  view_flags: bit 0 top view, bit 1 draw the agent marker.
  *   d_out uint8[height][width][3], d_depth float[height][width] or NULL.  Not the hot path. */
 int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width, int32_t height, int32_t msaa,

@@ -64,7 +64,7 @@ extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int fo
 extern "C" __global__ void mw_refill_kernel(MwArgs a);
 extern "C" __global__ void mw_refill_pcg_kernel(MwArgs a);
 extern "C" __global__ void mw_take_spare_kernel(MwArgs a, const uint8_t *mask, int force_all);
-extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, const float *hdr, const float *mesh_pos, uint32_t *keys);
+extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, int first_env, const float *envhdr, const float *mesh_pos, uint32_t *keys);
 extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
                                                  const float *rec_shade, const int32_t *nvis, const float *envhdr,
                                                  const MwTexDesc *texd, const uint32_t *texels, const float *mesh_pos,
@@ -532,7 +532,30 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     }
     if (timed) (void)hipEventRecord(ev.b, st);
     bool forked = false;
-    if (e->have_meshes) {
+    if (e->cfg.msaa != 8) {
+        // FrameBuffer's fallback sample counts (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES gets 4 or 1
+        // samples): not the hot path — the generic-resolution kernels, exact packed-key resolution, the whole batch
+        // in one grid (blockIdx.y = env)
+        if (e->obs_layout != MW_OBS_HWC_U8) return fail(e, MW_E_INVALID, "wrapper layouts need msaa = 8");
+        const int S = e->cfg.msaa;
+        uint32_t *keys = nullptr;
+        if (e->have_meshes) {
+            const size_t need = (size_t)N * a.W * a.H * S * 4;
+            if (need > e->view_keys_bytes) {
+                HIP_TRY(e, hipStreamSynchronize(st));
+                if (e->d_view_keys) (void)hipFree(e->d_view_keys);
+                e->d_view_keys = nullptr; e->view_keys_bytes = 0;
+                HIP_TRY(e, hipMalloc((void **)&e->d_view_keys, need));
+                e->view_keys_bytes = need;
+            }
+            keys = e->d_view_keys;
+            HIP_TRY(e, hipMemsetAsync(keys, 0xFF, need, st));
+            hipLaunchKernelGGL(mw_view_mesh_kernel, dim3(32, N), dim3(256), 0, st, a.W, a.H, S, 0, (const float *)a.envhdr, a.mesh_pos, keys);
+        }
+        hipLaunchKernelGGL(mw_view_raster_kernel, dim3(a.n_tiles, N), dim3(64), 0, st, 0, a.W, a.H, S, a.max_vis, a.tiles_x,
+                           (const float *)a.rec_raster, (const float *)a.rec_shade, (const int32_t *)a.nvis, (const float *)a.envhdr,
+                           a.tex, a.texels, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, (const uint32_t *)keys, d_obs, d_depth, e->texel_bytes);
+    } else if (e->have_meshes) {
         // envs may contain mesh entities: one 1024-thread workgroup per env, sample keys in LDS
         const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * 192 + 16;       // keys, 16 pack buffers, the tile counter
         if (lds > 160 * 1024) return fail(e, MW_E_CAPACITY, "mesh entities need the env's sample keys in LDS: %dx%d is too large", a.W, a.H);
@@ -615,7 +638,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (cfg->rng_mode == MW_RNG_PCG64 && cfg->generator == MW_GEN_NONE)
         return fail(nullptr, MW_E_INVALID, "MW_RNG_PCG64 (the reference's own numpy stream) needs a device generator");
     if (cfg->max_ents > 64) return fail(nullptr, MW_E_CAPACITY, "max_ents > 64 (one entity slot per lane of the env's wavefront)");
-    if (cfg->msaa != 8) return fail(nullptr, MW_E_INVALID, "only msaa = 8 is implemented");
+    if (cfg->msaa != 8 && cfg->msaa != 4 && cfg->msaa != 1) return fail(nullptr, MW_E_INVALID, "msaa must be 8, 4 or 1");
     if (cfg->obs_width % MW_TILE_W || cfg->obs_height % MW_TILE_H || cfg->obs_width > 255 * MW_TILE_W || cfg->obs_height > 255 * MW_TILE_H)
         return fail(nullptr, MW_E_INVALID, "obs size must be a multiple of %dx%d", MW_TILE_W, MW_TILE_H);
     if (cfg->max_visible > 60000) return fail(nullptr, MW_E_CAPACITY, "max_visible too large (16-bit draw ids)");
@@ -1040,7 +1063,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     if (!e || !d_out) return fail(e, MW_E_INVALID, "null argument");
     ON_DEVICE(e);
     if (env < 0 || env >= e->cfg.num_envs) return fail(e, MW_E_INVALID, "env %d out of range", env);
-    if (msaa != 8 && msaa != 16) return fail(e, MW_E_INVALID, "msaa must be 8 or 16");
+    if (msaa != 1 && msaa != 4 && msaa != 8 && msaa != 16) return fail(e, MW_E_INVALID, "msaa must be 1, 4, 8 or 16");
     if (width <= 0 || height <= 0 || width % MW_TILE_W || height % MW_TILE_H || width > 255 * MW_TILE_W || height > 255 * MW_TILE_H)
         return fail(e, MW_E_INVALID, "frame buffer size must be a multiple of %dx%d", MW_TILE_W, MW_TILE_H);
     hipStream_t st = (hipStream_t)stream;
@@ -1063,8 +1086,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
         }
         keys = e->d_view_keys;
         HIP_TRY(e, hipMemsetAsync(keys, 0xFF, need, st));
-        hipLaunchKernelGGL(mw_view_mesh_kernel, dim3(128), dim3(256), 0, st, width, height, msaa,
-                           (const float *)(b.envhdr + (size_t)env * MW_ENVHDR), b.mesh_pos, keys);
+        hipLaunchKernelGGL(mw_view_mesh_kernel, dim3(128), dim3(256), 0, st, width, height, msaa, env, (const float *)b.envhdr, b.mesh_pos, keys);
     }
     hipLaunchKernelGGL(mw_view_raster_kernel, dim3(b.n_tiles), dim3(64), 0, st, env, width, height, msaa, b.max_vis, b.tiles_x,
                        (const float *)b.rec_raster, (const float *)b.rec_shade, (const int32_t *)b.nvis, (const float *)b.envhdr,

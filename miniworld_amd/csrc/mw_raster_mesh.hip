@@ -75,8 +75,12 @@ __constant__ float kDx16[16] = {0.0625f, -0.0625f, -0.1875f, 0.25f, -0.3125f, 0.
                                 -0.125f, 0.0f, -0.25f, -0.375f, -0.5f, 0.4375f, 0.375f, -0.4375f};
 __constant__ float kDy16[16] = {0.0625f, -0.1875f, 0.125f, -0.0625f, -0.125f, 0.3125f, 0.1875f, -0.3125f,
                                 0.375f, -0.4375f, -0.375f, 0.25f, 0.0f, -0.25f, 0.4375f, -0.5f};
-template <int S> __device__ inline float sample_dx(int s) { return S == 16 ? kDx16[s] : kDx[s]; }
-template <int S> __device__ inline float sample_dy(int s) { return S == 16 ? kDy16[s] : kDy[s]; }
+// the fallback sample counts of FrameBuffer (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES): 4 = the D3D
+// standard 4x pattern (6,2)(14,6)(2,10)(10,14), 1 = the pixel centre
+__constant__ float kDx4[4] = {-0.125f, 0.375f, -0.375f, 0.125f};
+__constant__ float kDy4[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
+template <int S> __device__ inline float sample_dx(int s) { return S == 16 ? kDx16[s] : (S == 4 ? kDx4[s] : (S == 1 ? 0.0f : kDx[s])); }
+template <int S> __device__ inline float sample_dy(int s) { return S == 16 ? kDy16[s] : (S == 4 ? kDy4[s] : (S == 1 ? 0.0f : kDy[s])); }
 
 // stored triangle -> original (drawing order) index and back (mw_device.h: MW_MESH_POS_STRIDE)
 __device__ inline int tri_original(const TileCtx &cx, const MeshEnt &e, int stored)
@@ -415,10 +419,15 @@ __device__ inline void view_mesh_body(int W, int H, const float *hdr, const floa
     }
 }
 
-extern "C" __global__ __launch_bounds__(256) void mw_view_mesh_kernel(int W, int H, int S, const float *__restrict__ hdr,
+// grid (x, count): blockIdx.y = env first_env + y of the batch, its keys at keys + y * W * H * S
+extern "C" __global__ __launch_bounds__(256) void mw_view_mesh_kernel(int W, int H, int S, int first_env, const float *__restrict__ envhdr,
                                                                      const float *__restrict__ mesh_pos, uint32_t *keys)
 {
+    const float *hdr = envhdr + (size_t)(first_env + (int)blockIdx.y) * MW_ENVHDR;
+    keys += (size_t)blockIdx.y * W * H * S;
     if (S == 16) view_mesh_body<16>(W, H, hdr, mesh_pos, keys);
+    else if (S == 4) view_mesh_body<4>(W, H, hdr, mesh_pos, keys);
+    else if (S == 1) view_mesh_body<1>(W, H, hdr, mesh_pos, keys);
     else view_mesh_body<8>(W, H, hdr, mesh_pos, keys);
 }
 
@@ -509,13 +518,19 @@ __device__ inline void view_tile_body(TileCtx &cx, int tiles_x, const uint32_t *
     }
 }
 
+// grid (n_tiles, count): blockIdx.y = env first_env + y of the batch; its frame at out + y * H * W * 3, its mesh keys
+// at mesh_keys + y * W * H * S
 extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
-    int env, int W, int H, int S, int max_vis, int tiles_x, const float *__restrict__ rec_raster,
+    int first_env, int W, int H, int S, int max_vis, int tiles_x, const float *__restrict__ rec_raster,
     const float *__restrict__ rec_shade, const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr,
     const MwTexDesc *__restrict__ texd, const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos,
     const float *__restrict__ mesh_nrm, const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, const uint32_t *mesh_keys,
     uint8_t *__restrict__ out, float *__restrict__ depth, int texel_bytes)
 {
+    const int env = first_env + (int)blockIdx.y;
+    out += (size_t)blockIdx.y * H * W * 3;
+    if (depth) depth += (size_t)blockIdx.y * H * W;
+    if (mesh_keys) mesh_keys += (size_t)blockIdx.y * W * H * S;
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     TileCtx cx;
     cx.s_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
@@ -533,6 +548,8 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
     cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
+    else if (S == 4) view_tile_body<4>(cx, tiles_x, mesh_keys);
+    else if (S == 1) view_tile_body<1>(cx, tiles_x, mesh_keys);
     else view_tile_body<8>(cx, tiles_x, mesh_keys);
 }
 

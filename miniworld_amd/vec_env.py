@@ -55,10 +55,12 @@ _KIND = {
 class MiniWorldVecEnv:
     def __init__(self, env_id: str, num_envs: int, device_id: int = 0, domain_rand: bool = False,
                  want_depth: bool = False, seed: int = 0, autoreset: bool = True, obs_layout: str = "hwc",
-                 rng: str = "auto", **env_kwargs):
+                 rng: str = "auto", msaa: int = 8, **env_kwargs):
         """obs_layout: "hwc" uint8[N,H,W,3] (the env's observation), "cwh" uint8[N,3,W,H]
         (PyTorchObsWrapper, wrappers.py:24) or "grey" float64[N,H,W,1] (GreyscaleWrapper, wrappers.py:44):
         the raster kernel stores the frame in that layout, there is no extra pass.
+        msaa: samples per pixel, 8 like the reference's FrameBuffer(80, 60, 8) (miniworld.py:515); 4 or 1 reproduce what the
+        reference renders on a driver that clamps GL_MAX_SAMPLES (opengl.py:229-231) — same semantics, not the tuned path.
         rng: stream of the device-side resets. "pcg64" = numpy's own Generator(PCG64(SeedSequence(seed + i))) drawn in
         the reference's call order, so that env i IS the reference's env.reset(seed=seed + i) and its later episodes
         continue like env.reset(), per-step domain-randomisation draws included (every device generator);
@@ -108,6 +110,7 @@ class MiniWorldVecEnv:
                           max_visible=-(-(P + 6 * E) // 16) * 16,
                           params_ranges=self.template.params.as_ranges(), device_id=device_id)
         cfg.shared_geometry = int(shared)
+        cfg.msaa = int(msaa)
         cfg.task, cfg.goal_ent, cfg.num_objs = task, 0, len(sc["ents_kind"])
         ents = [e for e in self.template.entities if e is not self.template.agent]
         if task in (eng.TASK_GOTO, eng.TASK_SIDEWALK) and hasattr(self.template, "box"):

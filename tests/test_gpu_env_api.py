@@ -897,3 +897,28 @@ def test_render_depth_honours_the_frame_buffer():
     want = pyoracle.render(env.scene(), 800, 600, 16)["depth"]
     assert np.array_equal(d.reshape(600, 800), want.reshape(600, 800))
     env.close()
+
+
+@pytest.mark.parametrize("msaa", [4, 1])
+@pytest.mark.parametrize("env_id,kw", [("MiniWorld-Hallway-v0", {}), ("MiniWorld-PickupObjects-v0", {"domain_rand": True})])
+def test_vec_env_fallback_sample_counts_match_oracle(env_id, kw, msaa):
+    """FrameBuffer falls back to the driver's GL_MAX_SAMPLES when it is below 8 (opengl.py:229-231): mw_config.msaa = 4 / 1
+    renders the batch with the D3D 4x pattern / the pixel centre; frames and depth equal the oracle's at that count."""
+    import torch
+    import pyoracle
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n = 24
+    vec = MiniWorldVecEnv(env_id, n, seed=21, want_depth=True, msaa=msaa, **kw)
+    vec.reset()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for _ in range(10):
+        vec.step(torch.randint(0, vec.n_actions, (n,), generator=g, device="cuda", dtype=torch.int32))
+    vec.engine.render(vec.obs, vec.depth)         # the state after the steps (a pickup is removed after its frame)
+    vec.engine.check()
+    st = vec.engine.get_state()
+    meshes = helpers.vec_env_meshes(vec)
+    for i in (0, 5, n - 1):
+        want = pyoracle.render(helpers.scene_of_vec_env(vec, st, i), nsamples=msaa, meshes=meshes)
+        assert np.array_equal(vec.obs[i].cpu().numpy(), want["rgb"]), (env_id, msaa, i)
+        assert np.array_equal(vec.depth[i].cpu().numpy(), want["depth"]), (env_id, msaa, i)
+    vec.close()
