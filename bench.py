@@ -229,6 +229,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
     ap.add_argument("--config", default="hallway", choices=list(CONFIGS), help="hallway = the headline workload")
+    ap.add_argument("--prewarm-steps", type=int, default=0,
+                    help="pre-warm with exactly this many steps instead of PREWARM_S seconds (A/B runs: the timed region then "
+                         "covers the same episode phases in both)")
     ap.add_argument("--dry", action="store_true", help="CPU dry run of the multi-rank path (gloo, no engine)")
     ap.add_argument("--gather-obs", action="store_true",
                     help="also all-gather every rank's observations onto every rank each step (RCCL over xGMI, overlapped "
@@ -298,7 +301,7 @@ def main():
     # untimed and reported, separate from the W warm-up steps of the contract
     t_pre = time.perf_counter()
     k = 0
-    while not args.dry and time.perf_counter() - t_pre < PREWARM_S:
+    while not args.dry and (k < args.prewarm_steps if args.prewarm_steps else time.perf_counter() - t_pre < PREWARM_S):
         for _ in range(16):
             vec.step(actions[k % total])
             k += 1
