@@ -25,6 +25,10 @@ extern "C" __global__ void mw_step_setup_dense_kernel(MwArgs a, int do_step, int
                                                        float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_dense_pcg_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
                                                            float *reward, uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_step_setup_dense_mesh_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
+                                                            float *reward, uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_step_setup_dense_mesh_pcg_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
+                                                                float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                      float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
@@ -196,12 +200,14 @@ int k1_threads(const mw_engine *e) { return e->args.rec_order ? 256 : 64; }     
 
 // Lanes per env of the dense K1 (mw_setup_dense.hip: one lane per room polygon + six per entity slot), or 0 when the
 // frame has to go through the wave-per-env kernel: big scenes, mesh entities, spare-world mode, other views,
-// K1 profiling, or simply too many primitive slots for a wavefront.  MW_K1_DENSE=0 switches it off (A/B runs).
+// or too many primitive slots to pack two envs into a wavefront.  MW_K1_DENSE=0 switches it off (A/B runs).
 int k1_dense_lanes(const mw_engine *e, int view_flags)
 {
-    if (e->args.rec_order || e->have_meshes || view_flags != 0 || !e->k1_dense || e->cfg.task == MW_TASK_COLLECT) return 0;
+    if (e->args.rec_order || view_flags != 0 || !e->k1_dense || e->cfg.task == MW_TASK_COLLECT) return 0;
+    // at least two envs per wavefront: with one, every lane repeats the env's scalar work for nothing and the wave-per-env
+    // kernel's lane-cooperative collision tests win (PickupObjects, 35 slots: 62 us dense against 47 us)
     const int lanes = e->cfg.max_polys + 6 * e->cfg.max_ents;
-    return lanes <= 64 ? lanes : 0;
+    return lanes <= 32 ? lanes : 0;
 }
 
 // numpy.random.SeedSequence(seed).generate_state(4, uint64) for a non-negative integer seed (the
@@ -519,7 +525,9 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     const int refill_blocks = (e->spare_mode && do_step) ? (e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64) : 0;
     if (const int lanes = k1_dense_lanes(e, view_flags)) {
         const int epw = 64 / lanes;
-        auto k1d = e->cfg.rng_mode == MW_RNG_PCG64 ? mw_step_setup_dense_pcg_kernel : mw_step_setup_dense_kernel;
+        const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
+        auto k1d = e->have_meshes ? (pcg ? mw_step_setup_dense_mesh_pcg_kernel : mw_step_setup_dense_mesh_kernel)
+                                  : (pcg ? mw_step_setup_dense_pcg_kernel : mw_step_setup_dense_kernel);
         // spare mode: blocks appended to the grid regenerate the spare worlds consumed in earlier steps (64 envs each)
         const int refill = (e->spare_mode && do_step) ? (N + 63) / 64 : 0;
         hipLaunchKernelGGL(k1d, dim3((N + epw - 1) / epw + refill), dim3(64), 0, st, a, do_step ? 1 : 0, lanes, d_actions,
@@ -700,7 +708,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     // 2 us of 51 (Hallway) and nothing on Maze, where they stay off.  MW_SPARE=1 / 0 forces either.  Not with domain
     // randomisation: the per-step draws interleave with the worlds in the env's stream.
     {
-        const bool small_scene = cfg->max_visible <= 64 && cfg->max_polys + 6 * std::max(cfg->max_ents, 1) <= 64;
+        const bool small_scene = cfg->max_visible <= 64 && cfg->max_polys + 6 * std::max(cfg->max_ents, 1) <= 32;      // = the dense K1 (k1_dense_lanes)
         bool want = small_scene && cfg->generator != MW_GEN_MAZE;
         if (const char *s = getenv("MW_SPARE")) want = atoi(s) != 0;
         e->spare_mode = cfg->generator != MW_GEN_NONE && !cfg->domain_rand && want;

@@ -119,8 +119,8 @@ __device__ int intersect_lane(const StepCtx &c, int self_slot, double x, double 
     const double *segs = a.segs + (size_t)c.set * a.max_segs * 4;
     const int ns = a.nsegs[c.set];
     bool hit = false;
-#pragma unroll 4
-    for (int i = 0; i < ns; ++i) {      // independent iterations: four divisions / square roots in flight
+#pragma unroll 2
+    for (int i = 0; i < ns; ++i) {      // independent iterations: two divisions / square roots in flight
         const double sax = segs[i * 4 + 0], saz = segs[i * 4 + 1], sbx = segs[i * 4 + 2], sbz = segs[i * 4 + 3];
         const double abx = sbx - sax, abz = sbz - saz;
         const double apx = x - sax, apz = z - saz;

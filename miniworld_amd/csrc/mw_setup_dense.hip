@@ -12,13 +12,36 @@
 // of the waves, no cross-lane traffic and no spills (up to 256 VGPRs: with fewer waves than SIMDs occupancy is moot).
 // The leading lane of an env writes its state, flags, header and — on an episode's end — runs the generator.
 //
-// Not handled here (the engine launches mw_setup.hip instead): mesh entities, top / proxy views, spare-world mode,
-// scenes whose L exceeds 64, big scenes with a visiting order.
+// Mesh entities reserve their draw-id ranges and are described in the env header like in mw_setup.hip.
+// Not handled here (the engine launches mw_setup.hip instead): top / proxy views, scenes whose L exceeds 64, big scenes
+// with a visiting order, MW_TASK_COLLECT.
 #include "mw_setup_common.h"
 
+// MW_DENSE_MESH = 1: the instantiation for engines with meshes (mw_setup_dense_mesh*.hip): the two mesh walks are
+// compiled in and the camera comes first (the walk needs it, and the primitive's object-space data would otherwise be
+// live across it: 64 spilled dwords); the plain instantiation carries none of it (175 VGPRs, no scratch).
+#ifndef MW_DENSE_MESH
+#define MW_DENSE_MESH 0
+#endif
 #ifndef MW_DENSE_KERNEL_NAME
 #define MW_DENSE_KERNEL_NAME mw_step_setup_dense_kernel
 #endif
+
+namespace {
+// whole-entity frustum cull of a mesh entity: the bounding sphere of the scaled mesh about its origin against the near
+// and the four side planes, conservative — a skipped mesh has no pixel
+__device__ inline bool mesh_in_view(const MwArgs &a, const StepCtx &c, const Cam &cam, int env, int es, const MwMeshDesc *mdp)
+{
+    const float brad = __uint_as_float(mdp->bound_bits) * (float)ent_geom(a, env, es, 6) * 1.001f + 1e-3f;
+    const float wx = (float)ent_pos(c, es, 0), wy = (float)ent_pos(c, es, 1), wz = (float)ent_pos(c, es, 2);
+    const float ex = fmaf(cam.m[0][0], wx, fmaf(cam.m[0][1], wy, fmaf(cam.m[0][2], wz, cam.m[0][3])));
+    const float ey = fmaf(cam.m[1][0], wx, fmaf(cam.m[1][1], wy, fmaf(cam.m[1][2], wz, cam.m[1][3])));
+    const float ez = fmaf(cam.m[2][0], wx, fmaf(cam.m[2][1], wy, fmaf(cam.m[2][2], wz, cam.m[2][3])));
+    const float w = -ez;
+    const float lx = sqrtf(fmaf(cam.p00, cam.p00, 1.0f)), ly = sqrtf(fmaf(cam.p11, cam.p11, 1.0f));
+    return !(w + brad < 0.04f) && !(w - fabsf(cam.p00 * ex) < -(brad * lx)) && !(w - fabsf(cam.p11 * ey) < -(brad * ly));
+}
+}  // namespace
 
 extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void MW_DENSE_KERNEL_NAME(
     MwArgs a, int do_step, int lanes_per_env, const int32_t *__restrict__ actions, float *__restrict__ reward,
@@ -193,7 +216,60 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1
     }
 
     if (prof) pt[2] = __builtin_readcyclecounter();
-    // ---- this lane's primitive: object-space data first (the loads are in flight during the camera maths) ----
+    // ---- camera (per env, evaluated by each of its lanes) --------------------------------------
+    Cam cam;
+    float sky[3];
+    build_camera(a, env, c.px, c.py, c.pz, c.dir, cam, sky, false);
+
+#if MW_DENSE_MESH
+    // ---- mesh entities, first walk: each reserves a range of draw ids at its place in the drawing order (static
+    // entities first, then dynamic ones, each in slot order: miniworld.py:1058-1060, 1075-1077) and is described to the
+    // mesh raster kernel in the env header; a box drawn after it has its draw id shifted by the triangles before it.
+    // Every lane of the env walks the (few) slots; the leading lane writes the table.
+    int mesh_tris = 0, n_mesh = 0, mesh_before = 0;
+    float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
+    {
+        const int my_es = slot >= a.max_polys ? (slot - a.max_polys) / 6 : -1;
+        const int my_cls = (my_es >= 0 && my_es < a.E && a.ekind[(size_t)my_es * a.N + env] == MW_ENT_BOX)
+                               ? (a.estatic[(size_t)my_es * a.N + env] ? 1 : 2) : 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int es = 0; es < a.E; ++es) {
+                const int kind = a.ekind[(size_t)es * a.N + env];
+                if (kind == MW_ENT_NONE || (a.estatic[(size_t)es * a.N + env] != 0) != (pass == 0)) continue;
+                if (es == my_es && my_cls == 1 + pass) mesh_before = mesh_tris;         // this lane's box is drawn here
+                if (kind != MW_ENT_MESH) continue;
+                const MwMeshDesc *mdp = a.mesh + a.emesh[(size_t)es * a.N + env];
+                if (!mesh_in_view(a, c, cam, env, es, mdp)) continue;
+                const int md_ntris = (int)mdp->ntris;
+                if (n_mesh < MW_MAX_MESH_ENTS && L + mesh_tris + md_ntris < 0xFFF0) {
+                    const double edir = (es == c.live) ? c.cdir : a.edir[(size_t)es * a.N + env];
+                    const mw::SinCos sc = mw::sincos_det(edir);
+                    if (leader) {
+                        float *m = hdr + MW_HDR_MESH + 12 * n_mesh;     // m[1], the first draw id, follows in the second walk
+                        m[0] = __int_as_float(es);
+                        m[2] = __int_as_float(md_ntris);
+                        m[3] = __int_as_float((int)mdp->first);
+                        m[4] = (float)sc.c; m[5] = (float)sc.s;
+                        m[6] = (float)ent_geom(a, env, es, 6);
+                        m[7] = (float)ent_pos(c, es, 0); m[8] = (float)ent_pos(c, es, 1); m[9] = (float)ent_pos(c, es, 2);
+                        m[10] = __int_as_float((int)mdp->tex);
+                        m[11] = 0.0f;
+                    }
+                    mesh_tris += md_ntris;
+                    ++n_mesh;
+                } else {
+                    atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+                }
+            }
+        }
+    }
+
+#else
+    int mesh_tris = 0, n_mesh = 0, mesh_before = 0;
+    float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
+#endif
+
+    // ---- this lane's primitive: object-space data (after the camera: held across it, it cost 56 spilled dwords) ----
     const mw_poly *polys = a.polys + (size_t)c.set * a.max_polys;
     const int np = a.npolys[c.set];
     bool have = false;
@@ -246,11 +322,6 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1
     }
     if (prof) pt[3] = __builtin_readcyclecounter();
 
-    // ---- camera (per env, evaluated by each of its lanes) --------------------------------------
-    Cam cam;
-    float sky[3];
-    build_camera(a, env, c.px, c.py, c.pz, c.dir, cam, sky, false);
-
     // ---- transform, cull, light: once, whatever the lane holds ---------------------------------------------
     bool vis = false;
     HV h[4];
@@ -273,16 +344,37 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1
     else if (cls == 1) idx = __popcll((unsigned long long)(mv & m_room)) + __popcll((unsigned long long)(mv & m_sbox & below));
     else idx = __popcll((unsigned long long)(mv & (m_room | m_sbox))) + __popcll((unsigned long long)(mv & ~(m_room | m_sbox) & below));
     const int count = __popcll((unsigned long long)mv);
+    // ---- mesh entities, second walk: now that the visible primitives are counted, each mesh's first draw id =
+    // visible primitives drawn before it (the rooms; the static boxes — all of them for a dynamic mesh, those in lower
+    // slots for a static one; the dynamic boxes in lower slots) + mesh triangles before it
+    if (MW_DENSE_MESH && n_mesh > 0) {
+        int tris = 0, j = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int es = 0; es < a.E; ++es) {
+                const int kind = a.ekind[(size_t)es * a.N + env];
+                if (kind != MW_ENT_MESH || (a.estatic[(size_t)es * a.N + env] != 0) != (pass == 0)) continue;
+                const MwMeshDesc *mdp = a.mesh + a.emesh[(size_t)es * a.N + env];
+                if (!mesh_in_view(a, c, cam, env, es, mdp)) continue;
+                const int md_ntris = (int)mdp->ntris;
+                if (!(j < MW_MAX_MESH_ENTS && L + tris + md_ntris < 0xFFF0)) continue;
+                const uint64_t lower = ((1ull << (a.max_polys + 6 * es)) - 1ull) << (el * L);
+                const uint64_t m_dbox = ~(m_room | m_sbox);
+                const uint64_t before_m = pass == 0 ? (m_room | (m_sbox & lower)) : (m_room | m_sbox | (m_dbox & lower));
+                if (leader) hdr[MW_HDR_MESH + 12 * j + 1] = __int_as_float(__popcll((unsigned long long)(mv & before_m)) + tris);
+                tris += md_ntris;
+                ++j;
+            }
+        }
+    }
     if (vis) {
-        if (idx < a.max_vis) write_poly(a, env, idx, (uint32_t)idx, h, nv, g, uv, col, tex, nullptr);
+        if (idx < a.max_vis) write_poly(a, env, idx, (uint32_t)(idx + (cls == 0 ? 0 : mesh_before)), h, nv, g, uv, col, tex, nullptr);
         else atomicOr(a.status, MW_ST_VIS_OVERFLOW);
     }
     if (leader) {
-        float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
-        a.k3_cost[env] = 0;
+        a.k3_cost[env] = mesh_tris;             // mesh triangles in view: the mesh kernel's scheduling weight
         hdr[0] = sky[0]; hdr[1] = sky[1]; hdr[2] = sky[2];
-        hdr[3] = __int_as_float(0);             // no mesh entities in a scene this kernel is launched for
+        hdr[3] = __int_as_float(n_mesh);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             hdr[4 + 4 * i + 0] = cam.m[i][0]; hdr[4 + 4 * i + 1] = cam.m[i][1];
