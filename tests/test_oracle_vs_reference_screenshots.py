@@ -3,13 +3,13 @@
 The reference holds no golden images and no GL context can be created in the build container, so every
 RGB assertion elsewhere is HIP engine vs oracle/mwo_render.c ("parity unpinned").  The only pixels under
 /root/reference that a real OpenGL driver produced are the JPEG screenshots of the manual_control window
-(images/hallway_0.jpg, oneroom_0.jpg, pickupobjs_0.jpg): the 800x600x16spp vis_fb view, the 80x60 observation
+(images/hallway_0.jpg, oneroom_0.jpg, pickupobjs_0.jpg, sidewalk_0.jpg): the 800x600x16spp vis_fb view, the 80x60 observation
 as an inset, and the printed pose (miniworld.py:1340-1443).  tools/gen_screenshot_fixtures.py box-filtered them
 into tests/golden/screenshots.npz; here the oracle renders the same room from the printed pose and must agree
 region by region — the reference's own L3-style check (tests/test_miniworld.py:26-31, |d mean| < 5) made
 much tighter and per surface.  A systematic error shared by oracle and engine (handedness, the directional-light
-quirk of miniworld.py:1031, per-wall shading, texture orientation / scale, sky colour, perspective, box faces)
-would show here.  What the JPEGs cannot pin: the last bit of filtering / sample positions (they are lossy).
+quirk of miniworld.py:1031, per-wall shading, texture orientation / scale, sky colour, perspective, box faces, the
+textured building and cones of sidewalk_0) would show here.  What the JPEGs cannot pin: the last bit of filtering / sample positions (they are lossy).
 """
 import numpy as np
 import pytest
@@ -34,19 +34,28 @@ def _dilate(m, r):
 
 
 def _room_scene(name):
-    """The env's room (fixed floorplan and textures, domain_rand off) seen from the printed pose, entities removed
-    (their placement in the screenshot is random and unseeded)."""
+    """The env's room (fixed floorplan and textures, domain_rand off) seen from the printed pose.  Entities whose
+    placement in the screenshot is random and unseeded are removed; static meshes at fixed positions stay (Sidewalk's
+    textured building and cones — the cones' drawn heading only turns a rotationally symmetric mesh)."""
     from miniworld_amd import envs
+    from miniworld_amd.entity import MeshEnt
+    from miniworld_amd.objmesh import ObjMesh
     from miniworld_amd.scene import scene_from_env
     env = getattr(envs, str(SHOTS[name + "/env"]))(host_only=True)
     env.reset(seed=0)
+    env.entities = [e for e in env.entities if e is env.agent or (isinstance(e, MeshEnt) and e.is_static)]
     sc = scene_from_env(env)
-    for k in list(sc):
-        if k.startswith("ents_"):
-            sc[k] = sc[k][:0]
-    sc["mesh_names"], sc["mesh_tex"] = np.array([]), np.zeros(0, np.int32)
     sc["agent_pos"] = SHOTS[name + "/pos"].astype(np.float64)
+    meshes = {}
+    for n in [str(m) for m in sc["mesh_names"]]:
+        m = ObjMesh.get(n)
+        meshes[n] = {"verts": m.verts, "norms": m.norms, "texcs": m.texcs, "colors": m.colors}
+    sc["_meshes"] = meshes
     return sc
+
+
+def _render(sc, *args, **kw):
+    return pyoracle.render(sc, *args, meshes=sc["_meshes"], **kw)
 
 
 def _entity_mask(shot):
@@ -58,16 +67,17 @@ def _entity_mask(shot):
 
 
 def _register(sc, name, main):
-    """The label prints the heading in whole degrees (truncated): find the tenth of a degree that fits best."""
+    """The label prints int(degrees) % 360 — truncated towards zero BEFORE the modulo, so a negative heading is rounded
+    up (sidewalk_0's "298" is -62.7 degrees = 297.3): find the tenth of a degree within +-1 that fits best."""
     ang = int(SHOTS[name + "/angle_deg"])
     best = None
-    for k in range(10):
+    for k in range(-10, 10):
         sc["agent_dir"] = np.deg2rad(ang + k / 10 + 0.05)
-        err = np.abs(_down(pyoracle.render(sc, 800, 600, 16)["rgb"], 4) - main)[~_entity_mask(main)].mean()
+        err = np.abs(_down(_render(sc, 400, 300, 8)["rgb"], 2) - main)[~_entity_mask(main)].mean()
         if best is None or err < best[0]:
             best = (err, sc["agent_dir"])
     sc["agent_dir"] = best[1]
-    return best[0]
+    return np.abs(_down(_render(sc, 800, 600, 16)["rgb"], 4) - main)[~_entity_mask(main)].mean()
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -79,13 +89,25 @@ def test_oracle_matches_reference_screenshot_surfaces(name):
     err = _register(sc, name, main)
     # whole frame outside the objects: mean |difference| of the 4x4-filtered 800x600 views (JPEG noise included)
     assert err < 4.0, (name, err)
-    r = pyoracle.render(sc, 800, 600, 16, want_prim=True)
+    r = _render(sc, 800, 600, 16, want_prim=True)
     full = _down(r["rgb"], 4)
     pb = r["prim"][:, :, 0].reshape(150, 4, 200, 4).transpose(0, 2, 1, 3).reshape(150, 200, 16)
     uniform, pid = pb.min(-1) == pb.max(-1), pb[:, :, 0]
     shades = {}
     checked = 0
+    n_polys = len(sc["polys_nv"])
+    mesh_px = uniform & (pid >= n_polys) & ~ents
+    if mesh_px.sum() >= 400:
+        # textured static meshes (Sidewalk: the building's window grid, the cones' stripes; ObjMesh.render objmesh.py:280-292,
+        # MeshEnt.render entity.py:150-161): mean colour and pixel-wise agreement of the 4x4-filtered views
+        want, got = main[mesh_px].mean(0), full[mesh_px].mean(0)
+        assert np.abs(want - got).max() < 2.5, (name, "meshes", want, got)
+        assert np.abs(main[mesh_px] - full[mesh_px]).mean() < 4.0, (name, np.abs(main[mesh_px] - full[mesh_px]).mean())
+    elif name == "sidewalk_0":
+        raise AssertionError("the building should fill a good part of sidewalk_0")
     for p in np.unique(pid):
+        if p >= n_polys:
+            continue
         m = uniform & (pid == p) & ~ents
         if m.sum() < 400:
             continue
@@ -93,20 +115,21 @@ def test_oracle_matches_reference_screenshot_surfaces(name):
         # per-surface mean colour: sky, floor, ceiling and every wall within 2.5 of 255 per channel
         assert np.abs(want - got).max() < 2.5, (name, int(p), want, got)
         if p >= 0 and abs(float(sc["polys_n"][p][1])) < 0.5:
-            shades[int(p)] = (tuple(np.sign(np.round(sc["polys_n"][p], 3))), want.mean(), got.mean())
+            shades[int(p)] = (tuple(np.sign(np.round(sc["polys_n"][p], 3))), want.mean(), got.mean(), int(sc["polys_tex"][p]))
         checked += 1
     assert checked >= 4, (name, checked)
     # walls facing +x / +z are lit by the (light_pos + 1) directional light, those facing -x / -z only by the ambient
     # term (0.8354 vs 0.65 of the texture): same ordering in the screenshot and the oracle
     lit = [v for v in shades.values() if v[0][0] > 0 or v[0][2] > 0]
     unlit = [v for v in shades.values() if v[0][0] < 0 or v[0][2] < 0]
-    assert (lit and unlit) or name == "pickupobjs_0", (name, shades)      # that view only shows two ambient-lit walls
+    assert (lit and unlit) or name in ("pickupobjs_0", "sidewalk_0"), (name, shades)      # those views show ambient-lit walls only / one kind
     for a in lit:
         for b in unlit:
-            assert a[1] > b[1] + 15 and a[2] > b[2] + 15, (name, a, b)
+            if a[3] == b[3]:            # the same texture on both walls
+                assert a[1] > b[1] + 15 and a[2] > b[2] + 15, (name, a, b)
     # the 80x60x8spp observation against the inset (the obs blown up 3.2x with GL_LINEAR and filtered back: blurrier
     # than the original, hence the looser bound)
-    obs = pyoracle.render(sc)["rgb"].astype(np.float32)
+    obs = _render(sc)["rgb"].astype(np.float32)
     small = _dilate(_entity_mask(inset), 1)
     small[0], small[-1], small[:, 0], small[:, -1] = True, True, True, True      # the blit's border texels blend with the window
     assert np.abs(obs - inset)[~small].mean() < 7.0, (name, np.abs(obs - inset)[~small].mean())
@@ -120,7 +143,7 @@ def _fit_box(sc, main, region, x0):
     def cost(p):
         sc["ents_pos"] = np.array([[p[0], 0.0, p[1]]])
         sc["ents_dir"] = np.array([p[2]])
-        r = pyoracle.render(sc, 400, 300, 8)["rgb"]
+        r = _render(sc, 400, 300, 8)["rgb"]
         return float(np.abs(_down(r, 2) - main)[region].mean())
     best = None
     for d0 in (0.3, 1.1):          # two starts: a box looks the same every 90 degrees, but the simplex can stall
@@ -164,7 +187,7 @@ def test_oracle_box_matches_reference_screenshot(name):
     fwd, right = np.array([np.cos(a), -np.sin(a)]), np.array([np.sin(a), np.cos(a)])
     ground = sc["agent_pos"][[0, 2]] + dist * (fwd + rx * right)
     res = _fit_box(sc, main, region, ground + 0.4 * fwd)
-    got = _down(pyoracle.render(sc, 800, 600, 16)["rgb"], 4)
+    got = _down(_render(sc, 800, 600, 16)["rgb"], 4)
     err = np.abs(got - main)[region].mean()
     assert err < 6.0, (name, err, res.x)
     # silhouette: the fitted box covers the same pixels

@@ -28,6 +28,7 @@ SHOTS = {
     "hallway_0": ("Hallway", (-0.02, 0.00, -0.03), 1, 20),
     "oneroom_0": ("OneRoom", (0.63, 0.00, 8.42), 30, 10),
     "pickupobjs_0": ("PickupObjects", (3.03, 0.00, 4.12), 289, 0),
+    "sidewalk_0": ("Sidewalk", (-1.89, 0.00, 0.41), 298, 82),       # textured static meshes: the building and the cones
 }
 TITLE_BAR = 24        # rows of window decoration above the GL area (the JPEGs are 1058 x 625 = 800+1+257 x 24+601)
 
