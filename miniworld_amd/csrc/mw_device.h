@@ -15,6 +15,7 @@
 #define MW_SKY_PID 0xFFFFu
 #define MW_ENVHDR 288         // floats per env: sky, camera, light, mesh-entity table (K1 -> K2/K3)
 #define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
+#define MW_K3_WAVE_LDS 192     // LDS bytes per wave of the mesh kernel beside the key buffer: its pack buffer
 #define MW_HDR_MESH 32        // first float of the mesh-entity table; 12 floats per entry
 
 // status bits written by kernels, read by mw_check()
@@ -43,11 +44,11 @@ struct MwMeshDesc {
     uint32_t pad;                  //   normal after the mesh, for the top view's agent marker)
 };
 
-// Mesh pools: triangles are STORED sorted by the direction of their face normal (mw_upload_mesh), so that the 64
-// triangles of a wavefront face the same way and back-face culling retires whole waves instead of half the lanes of
-// each.  Drawing order (= draw ids, GL's first-drawn-wins on equal depth, the oracle's triangle indices) is the
-// original one: a position record is 9 floats + one word, (original index of stored triangle i) | (stored index of
-// original triangle i) << 16.
+// Mesh pools: per-face-vertex arrays in drawing order (= draw ids, GL's first-drawn-wins on equal depth, the oracle's
+// triangle indices).  The mesh kernels RASTERISE the triangles in another order — sorted by the direction of their face
+// normal (mw_upload_mesh), so that the 64 triangles of a wavefront face the same way and back-face culling retires whole
+// waves instead of half the lanes of each: a position record is 9 floats + one word, the index of the i-th triangle of
+// that order.  (Shading looks a triangle up by its draw id directly: no indirection on the tile phase's critical path.)
 #define MW_MESH_POS_STRIDE 10
 
 // Generator tables; kept in device memory because dynamic indexing into a by-value kernarg

@@ -565,7 +565,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                            a.tex, a.texels, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, (const uint32_t *)keys, d_obs, d_depth, e->texel_bytes);
     } else if (e->have_meshes) {
         // envs may contain mesh entities: one 1024-thread workgroup per env, sample keys in LDS
-        const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * 192 + 16;       // keys, 16 pack buffers, the tile counter
+        const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * MW_K3_WAVE_LDS + 16 + MW_MAX_MESH_ENTS * 48;   // keys, 16 pack buffers, the tile counter, the mesh table
         if (lds > 160 * 1024) return fail(e, MW_E_CAPACITY, "mesh entities need the env's sample keys in LDS: %dx%d is too large", a.W, a.H);
         if (!e->mesh_lds_ready) {
             for (auto k : {mw_raster_mesh_kernel, mw_raster_mesh_depth_kernel, mw_raster_mesh_wrap_kernel})
@@ -743,7 +743,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
-    if (getenv("MW_K3_PROF")) ALLOC(e->d_k3prof, 4 * (size_t)N);      // perf experiments only: dumped by mw_destroy
+    if (getenv("MW_K3_PROF")) ALLOC(e->d_k3prof, 8 * (size_t)N);      // perf experiments only: dumped by mw_destroy
     if (getenv("MW_K1_PROF")) {     // perf experiments only: per-env cycle stamps of K1's phases, dumped by mw_destroy
         ALLOC(a.k1_prof, 8 * (size_t)N);
         if (rc == MW_OK) (void)hipMemset(a.k1_prof, 0, 64 * (size_t)N);
@@ -782,7 +782,7 @@ void mw_destroy(mw_engine *e)
             if (FILE *f = fopen(getenv("MW_K1_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
     if (e->d_k3prof) {      // dump the last frame's per-env cycle counts: [env][mesh phase, tile phase, meshes, triangles]
-        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 4);
+        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 8);
         if (hipMemcpy(h.data(), e->d_k3prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(getenv("MW_K3_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
@@ -835,18 +835,13 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
         key[t] = m; order[t] = (uint32_t)t;
     }
     std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
-    std::vector<uint32_t> inv((size_t)ntris);
-    for (int s_ = 0; s_ < ntris; ++s_) inv[order[s_]] = (uint32_t)s_;
     auto &P = e->mesh_pos[mesh_id]; auto &Nn = e->mesh_nrm[mesh_id]; auto &Cc = e->mesh_rgb[mesh_id]; auto &U = e->mesh_uv[mesh_id];
-    P.assign((size_t)ntris * MW_MESH_POS_STRIDE, 0.0f); Nn.assign((size_t)ntris * 9, 0.0f); Cc.assign((size_t)ntris * 9, 0.0f); U.assign((size_t)ntris * 6, 0.0f);
-    for (int s_ = 0; s_ < ntris; ++s_) {
-        const size_t o = order[s_];
-        memcpy(&P[(size_t)s_ * MW_MESH_POS_STRIDE], pos + o * 9, 36);
-        const uint32_t word = order[s_] | (inv[s_] << 16);
-        memcpy(&P[(size_t)s_ * MW_MESH_POS_STRIDE + 9], &word, 4);
-        memcpy(&Nn[(size_t)s_ * 9], nrm + o * 9, 36);
-        memcpy(&Cc[(size_t)s_ * 9], rgb + o * 9, 36);
-        if (uv) memcpy(&U[(size_t)s_ * 6], uv + o * 6, 24);
+    P.assign((size_t)ntris * MW_MESH_POS_STRIDE, 0.0f);
+    Nn.assign(nrm, nrm + (size_t)ntris * 9); Cc.assign(rgb, rgb + (size_t)ntris * 9);
+    if (uv) U.assign(uv, uv + (size_t)ntris * 6); else U.assign((size_t)ntris * 6, 0.0f);
+    for (int i = 0; i < ntris; ++i) {
+        memcpy(&P[(size_t)i * MW_MESH_POS_STRIDE], pos + (size_t)i * 9, 36);
+        memcpy(&P[(size_t)i * MW_MESH_POS_STRIDE + 9], &order[i], 4);      // the i-th triangle of the rasterisation order
     }
     memcpy(e->mesh_desc[mesh_id].last_n, nrm + ((size_t)(ntris - 1) * 3 + 2) * 3, 12);
     e->mesh_desc[mesh_id].ntris = (uint32_t)ntris;

@@ -72,7 +72,7 @@ __device__ inline void raster_kernel_body(
     te.flat = HOT ? 0 : (dbg & 1);
 
     TileCtx cx;
-    cx.s_shade = LDS_RECS ? s_shade : g_shade; cx.s_cull = LDS_RECS ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = nullptr;
+    cx.s_shade = LDS_RECS ? s_shade : g_shade; cx.s_cull = LDS_RECS ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = nullptr; cx.ment = nullptr; cx.tprof = nullptr;
     cx.mesh_pos = cx.mesh_nrm = cx.mesh_rgb = cx.mesh_uv = nullptr;
     cx.obs = obs; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3); cx.te = te;

@@ -247,6 +247,8 @@ struct TileCtx {
     const float *__restrict__ rr_env;   // [nvis][64] raster records (scalar loads)
     uint8_t *s_pack;                // 192 B of LDS per wavefront
     const float *hdr;               // env header (mesh kernel only)
+    const float *ment;              // the env's mesh-entity table, 12 floats per entry (mesh kernel: a copy in LDS — the
+                                    // per-winner lookups of the tile phase are on its critical path; else hdr + MW_HDR_MESH)
     const float *mesh_pos, *mesh_nrm, *mesh_rgb, *mesh_uv;
     uint8_t *__restrict__ obs;
     float *__restrict__ depth;
@@ -258,6 +260,7 @@ struct TileCtx {
     uint64_t pre_touch, pre_full, pre_clip;
     uint64_t pre_edges;             // bit 16 k + p: primitive p needs its edge k tested on this tile (PRE 1; all ones with > 16 primitives)
     int have_pre;
+    unsigned long long *tprof;      // MW_K3_PROF (general mesh kernel only): [4] cycles in pass B coverage, in deferred shading, iterations, tiles
     const uint16_t *order;          // SORTED kernels: [0] sorted flag, [1 + k] list index of the k-th nearest polygon
 };
 
@@ -448,6 +451,8 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 
     // ============ pass B: exact packed-key resolution =================================
     if (exact) {
+        const bool tp = MESH && !HOT && cx.tprof != nullptr;
+        const unsigned long long tp0 = tp ? __builtin_readcyclecounter() : 0ull;
         acc_r = acc_g = acc_b = 0.0f;
         uint32_t key[8];
 #pragma unroll
@@ -521,10 +526,13 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 #pragma unroll
         for (int s = 0; s < 8; ++s) pid[s] = key[s] & 0xFFFFu;
         // deferred shading: each distinct winner once, ascending draw index, sky last (R9, R12)
+        const unsigned long long tp1 = tp ? __builtin_readcyclecounter() : 0ull;
+        int tp_it = 0;
         for (;;) {
             const uint32_t sel = min(min(min(pid[0], pid[1]), min(pid[2], pid[3])), min(min(pid[4], pid[5]), min(pid[6], pid[7])));
             const bool active = sel != 0x10000u;
             if (!__any(active)) break;
+            ++tp_it;
             if (active) {
                 uint32_t cnt = 0;
 #pragma unroll
@@ -543,6 +551,11 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 acc_g = fmaf(fc, c.g, acc_g);
                 acc_b = fmaf(fc, c.b, acc_b);
             }
+        }
+        if (tp && lane == 0) {
+            const unsigned long long tp2 = __builtin_readcyclecounter();
+            atomicAdd(cx.tprof + 0, tp1 - tp0); atomicAdd(cx.tprof + 1, tp2 - tp1);
+            atomicAdd(cx.tprof + 2, (unsigned long long)tp_it); atomicAdd(cx.tprof + 3, 1ull);
         }
     }
 #ifdef MW_VALU_PROBE

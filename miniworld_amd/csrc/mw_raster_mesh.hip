@@ -22,9 +22,9 @@ struct MeshEnt {            // one entry of the env header's mesh table (written
     float c, s, scale, px, py, pz;
 };
 
-__device__ inline MeshEnt load_ment(const float *hdr, int j)
+__device__ inline MeshEnt load_ment(const float *table, int j)
 {
-    const float *m = hdr + MW_HDR_MESH + 12 * j;
+    const float *m = table + 12 * j;
     MeshEnt e;
     e.slot = __float_as_int(m[0]); e.start = __float_as_int(m[1]); e.ntris = __float_as_int(m[2]);
     e.first = __float_as_int(m[3]);
@@ -82,17 +82,13 @@ __constant__ float kDy4[4] = {-0.375f, -0.125f, 0.125f, 0.375f};
 template <int S> __device__ inline float sample_dx(int s) { return S == 16 ? kDx16[s] : (S == 4 ? kDx4[s] : (S == 1 ? 0.0f : kDx[s])); }
 template <int S> __device__ inline float sample_dy(int s) { return S == 16 ? kDy16[s] : (S == 4 ? kDy4[s] : (S == 1 ? 0.0f : kDy[s])); }
 
-// stored triangle -> original (drawing order) index and back (mw_device.h: MW_MESH_POS_STRIDE)
-__device__ inline int tri_original(const TileCtx &cx, const MeshEnt &e, int stored)
+// the i-th triangle of the rasterisation order (sorted by face-normal direction; mw_device.h: MW_MESH_POS_STRIDE)
+__device__ inline int tri_sorted(const TileCtx &cx, const MeshEnt &e, int i)
 {
-    return (int)(__float_as_uint(cx.mesh_pos[(size_t)(e.first + stored) * MW_MESH_POS_STRIDE + 9]) & 0xFFFFu);
-}
-__device__ inline int tri_stored(const TileCtx &cx, const MeshEnt &e, int original)
-{
-    return (int)(__float_as_uint(cx.mesh_pos[(size_t)(e.first + original) * MW_MESH_POS_STRIDE + 9]) >> 16);
+    return (int)__float_as_uint(cx.mesh_pos[(size_t)(e.first + i) * MW_MESH_POS_STRIDE + 9]);
 }
 
-// world-space vertices of STORED triangle `tri` of mesh entity e (R11: pos + scale * R_y(dir) * v)
+// world-space vertices of triangle `tri` (drawing order) of mesh entity e (R11: pos + scale * R_y(dir) * v)
 __device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, int tri, float halfw, float halfh, HV h[3])
 {
     const float *p = cx.mesh_pos + (size_t)(e.first + tri) * MW_MESH_POS_STRIDE;
@@ -107,10 +103,9 @@ __device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, int tri, f
 
 // Mesh triangle (e, tri) at the pixel centre (R9-R11): Gouraud colour in q2.yzw and, for a textured
 // mesh (objmesh.py:209-216), the texcoord / 1/w planes in q0, q1, q2.x for apply_texture
-__device__ inline void mesh_tri_fragment(const TileCtx &cx, const MeshEnt &e, int tri_drawn, float Xc, float Yc,
+__device__ inline void mesh_tri_fragment(const TileCtx &cx, const MeshEnt &e, int tri, float Xc, float Yc,
                                          float4 &q0, float4 &q1, float4 &q2)
 {
-    const int tri = tri_stored(cx, e, tri_drawn);       // the draw id names the triangle in drawing order
     const float halfw = (float)cx.W * 0.5f, halfh = (float)cx.H * 0.5f;
     HV h[3];
     tri_verts(cx, e, tri, halfw, halfh, h);
@@ -181,12 +176,12 @@ __device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc,
     int tex = -1;
     bool is_tri = false;
     for (int j = 0; j < n_mesh; ++j) {
-        const int start = __float_as_int(cx.hdr[MW_HDR_MESH + 12 * j + 1]);
-        const int nt = __float_as_int(cx.hdr[MW_HDR_MESH + 12 * j + 2]);
+        const int start = __float_as_int(cx.ment[12 * j + 1]);
+        const int nt = __float_as_int(cx.ment[12 * j + 2]);
         if ((int)id >= start + nt) {
             vis -= nt;
         } else if ((int)id >= start) {
-            const MeshEnt e = load_ment(cx.hdr, j);
+            const MeshEnt e = load_ment(cx.ment, j);
             mesh_tri_fragment(cx, e, (int)id - start, Xc, Yc, q0, q1, q2);
             tex = e.tex;
             is_tri = true;
@@ -284,7 +279,7 @@ __device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, 
     float zo[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) zo[s] = fmaf(zx, sample_dx<S>(s), zy * sample_dy<S>(s));
-    const uint32_t id = (uint32_t)(e.start + tri_original(cx, e, tri));      // draw id = position in drawing order
+    const uint32_t id = (uint32_t)(e.start + tri);      // draw id = position in drawing order
     for (int py = y0; py <= y1; ++py)
         for (int px = x0; px <= x1; ++px) {
             const float Xc = (float)px + 0.5f, Yc = (float)py + 0.5f;
@@ -329,7 +324,7 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
     // first and the light ones fill the gaps at the end
     const int env = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint8_t *s_pack = smem + (size_t)nkeys * 4 + wave * 192;
+    uint8_t *s_pack = smem + (size_t)nkeys * 4 + wave * MW_K3_WAVE_LDS;
     // co-run mode (flag 16): the envs without a mesh in view are being drawn at the same time by
     // mw_raster_big_kernel on a second stream (they come last in the block order, so these blocks retire at once)
     if ((dbg & 16) && __float_as_int(envhdr[(size_t)env * MW_ENVHDR + 3]) == 0) return;
@@ -337,7 +332,9 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
     {
         uint4 *k4 = reinterpret_cast<uint4 *>(keys);
         for (int i = tid; i < nkeys / 4; i += 1024) k4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (tid == 0) *reinterpret_cast<int *>(smem + (size_t)nkeys * 4 + 16 * 192) = 0;       // the tile counter of phase 2
+        if (tid == 0) *reinterpret_cast<int *>(smem + (size_t)nkeys * 4 + 16 * MW_K3_WAVE_LDS) = 0;       // the tile counter of phase 2
+        float *s_ment = reinterpret_cast<float *>(smem + (size_t)nkeys * 4 + 16 * MW_K3_WAVE_LDS + 16);       // [MW_MAX_MESH_ENTS][12]
+        if (tid < MW_MAX_MESH_ENTS * 12) s_ment[tid] = hdr[MW_HDR_MESH + tid];
     }
     __syncthreads();
 
@@ -347,6 +344,7 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
     cx.rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     cx.s_pack = s_pack;
     cx.hdr = hdr;
+    cx.ment = reinterpret_cast<const float *>(smem + (size_t)nkeys * 4 + 16 * MW_K3_WAVE_LDS + 16);
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.obs = obs; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3);
@@ -356,12 +354,13 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
     cx.te.flat = HOT ? 0 : (dbg & 1);
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
     cx.env = env; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane; cx.have_pre = 0; cx.order = nullptr;
+    cx.tprof = prof ? prof + (size_t)N * 4 + (size_t)env * 4 : nullptr;        // MW_K3_PROF: second half of the buffer
 
     // ---- phase 1: every mesh triangle -> LDS keys, one triangle per lane -------------------
     const int n_mesh = (!HOT && (dbg & 8)) ? 0 : __float_as_int(hdr[3]);       // MW_DEBUG_FLAGS bit 3: perf experiments only
     for (int j = 0; j < n_mesh; ++j) {
-        const MeshEnt e = load_ment(hdr, j);
-        for (int t = tid; t < e.ntris; t += 1024) raster_tri<8>(cx, e, t, keys);
+        const MeshEnt e = load_ment(cx.ment, j);
+        for (int t = tid; t < e.ntris; t += 1024) raster_tri<8>(cx, e, tri_sorted(cx, e, t), keys);
     }
     __syncthreads();
     const unsigned long long t_mesh = prof ? __builtin_readcyclecounter() : 0ull;
@@ -369,7 +368,7 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
     // ---- phase 2: tiles, taken by the 16 wavefronts from a shared counter --------------------------------------
     // (a tile under a ball costs several times a plain one: with a static round-robin the waves that drew the mesh
     // tiles decide the workgroup's duration while the others idle — and nothing else fits on the CU beside its LDS)
-    int *s_next = reinterpret_cast<int *>(smem + (size_t)nkeys * 4 + 16 * 192);
+    int *s_next = reinterpret_cast<int *>(smem + (size_t)nkeys * 4 + 16 * MW_K3_WAVE_LDS);
     for (;;) {
         int tile = 0;
         if (lane == 0) tile = atomicAdd(s_next, 1);
@@ -410,12 +409,13 @@ template <int S>
 __device__ inline void view_mesh_body(int W, int H, const float *hdr, const float *mesh_pos, uint32_t *keys)
 {
     TileCtx cx{};
-    cx.hdr = hdr; cx.mesh_pos = mesh_pos; cx.W = W; cx.H = H;
+    cx.tprof = nullptr;
+    cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH; cx.mesh_pos = mesh_pos; cx.W = W; cx.H = H;
     const int n_mesh = __float_as_int(hdr[3]);
     const int stride = gridDim.x * blockDim.x;
     for (int j = 0; j < n_mesh; ++j) {
-        const MeshEnt e = load_ment(hdr, j);
-        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e.ntris; t += stride) raster_tri<S>(cx, e, t, keys);
+        const MeshEnt e = load_ment(cx.ment, j);
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e.ntris; t += stride) raster_tri<S>(cx, e, tri_sorted(cx, e, t), keys);
     }
 }
 
@@ -537,7 +537,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.s_cull = nullptr;
     cx.rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     cx.s_pack = nullptr;
-    cx.hdr = hdr;
+    cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH;
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.obs = out; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)out, 0, H * W * 3, MW_RSRC_WORD3);
@@ -546,7 +546,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.te.texd = texd;
     cx.te.flat = 0;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
-    cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr;
+    cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr; cx.tprof = nullptr;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
     else if (S == 4) view_tile_body<4>(cx, tiles_x, mesh_keys);
     else if (S == 1) view_tile_body<1>(cx, tiles_x, mesh_keys);

@@ -1,7 +1,7 @@
 """Per-env cycle counts of the mesh kernel (MW_K3_PROF hook) for the PickupObjects config."""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "gpurun_out", "k3prof.bin")
 os.environ["MW_K3_PROF"] = out
 from miniworld_amd.vec_env import MiniWorldVecEnv
@@ -13,7 +13,9 @@ for t in range(80):
     vec.step(torch.randint(0, 5, (n,), generator=g, device="cuda", dtype=torch.int32))
 torch.cuda.synchronize()
 vec.close()
-d = np.fromfile(out, np.uint64).reshape(n, 4).astype(np.float64)
+raw = np.fromfile(out, np.uint64).astype(np.float64)
+d = raw[:n * 4].reshape(n, 4)
+tp = raw[n * 4:].reshape(n, 4)
 mesh, tile, nm, nt = d.T
 print("envs with meshes in view: %.3f" % (nm > 0).mean())
 for name, v in (("mesh phase", mesh), ("tile phase", tile)):
@@ -26,3 +28,7 @@ big = nt >= 5000
 print("  envs with a ball in view: %.3f, mesh phase %.0f, tile phase %.0f" % (big.mean(), mesh[big].mean(), tile[big].mean()))
 w = np.argsort(mesh + tile)[-5:]
 print("worst envs (mesh, tile, n_mesh, tris):", d[w].astype(int).tolist())
+if tp.sum() > 0:       # MW_DEBUG_FLAGS != 0 (general kernel): accumulated over the run, per env: coverage cycles, shading cycles, shading iterations, exact tiles
+    m = tp[:, 3] > 0
+    print("exact tiles per env-frame (accumulated): coverage cycles/tile %.0f, shading cycles/tile %.0f, shading iterations/tile %.2f, cycles/iteration %.0f"
+          % (tp[m, 0].sum() / tp[m, 3].sum(), tp[m, 1].sum() / tp[m, 3].sum(), tp[m, 2].sum() / tp[m, 3].sum(), tp[m, 1].sum() / tp[m, 2].sum()))
