@@ -3,8 +3,8 @@
 The reference holds no golden images and no GL context can be created in the build container, so every
 RGB assertion elsewhere is HIP engine vs oracle/mwo_render.c ("parity unpinned").  The only pixels under
 /root/reference that a real OpenGL driver produced are the JPEG screenshots of the manual_control window
-(images/hallway_0.jpg, oneroom_0.jpg, pickupobjs_0.jpg, sidewalk_0.jpg): the 800x600x16spp vis_fb view, the 80x60 observation
-as an inset, and the printed pose (miniworld.py:1340-1443).  tools/gen_screenshot_fixtures.py box-filtered them
+(images/hallway_0.jpg, oneroom_0.jpg, pickupobjs_0.jpg, sidewalk_0.jpg, tmaze_0.jpg, and ymaze_0.jpg with the top view in
+its main pane): the 800x600x16spp vis_fb view, the 80x60 observation as an inset, and the printed pose (miniworld.py:1340-1443).  tools/gen_screenshot_fixtures.py box-filtered them
 into tests/golden/screenshots.npz; here the oracle renders the same room from the printed pose and must agree
 region by region — the reference's own L3-style check (tests/test_miniworld.py:26-31, |d mean| < 5) made
 much tighter and per surface.  A systematic error shared by oracle and engine (handedness, the directional-light
@@ -18,6 +18,8 @@ import pyoracle
 
 SHOTS = np.load(__import__("os").path.join(__import__("conftest").GOLDEN, "screenshots.npz"))
 NAMES = sorted({k.split("/")[0] for k in SHOTS.files})
+TOP = [n for n in NAMES if n + "/patch" in SHOTS.files]          # main pane = render_top_view
+NAMES = [n for n in NAMES if n not in TOP]
 
 
 def _down(a, f):
@@ -88,7 +90,7 @@ def test_oracle_matches_reference_screenshot_surfaces(name):
     ents = _entity_mask(main)
     err = _register(sc, name, main)
     # whole frame outside the objects: mean |difference| of the 4x4-filtered 800x600 views (JPEG noise included)
-    assert err < 4.0, (name, err)
+    assert err < 2.0, (name, err)       # measured 0.8 - 1.3: the JPEG's own noise
     r = _render(sc, 800, 600, 16, want_prim=True)
     full = _down(r["rgb"], 4)
     pb = r["prim"][:, :, 0].reshape(150, 4, 200, 4).transpose(0, 2, 1, 3).reshape(150, 200, 16)
@@ -200,3 +202,42 @@ def test_oracle_box_matches_reference_screenshot(name):
     assert abs(main[core][:, 0].mean() - got[core][:, 0].mean()) < 6
     # no face is darker than the ambient-only shade 0.2 + 0.45 (hallway_0's visible face is exactly that: 166 = 0.65 * 255)
     assert main[core][:, 0].min() > 0.65 * 255 - 8 and np.abs(main[core][:, 0] - got[core][:, 0]).mean() < 6
+
+
+@pytest.mark.parametrize("name", TOP)
+def test_oracle_top_view_matches_reference_screenshot(name):
+    """render_top_view (miniworld.py:1237-1338): the orthographic framing of the floorplan, the floor texture seen from
+    above (scale, phase and orientation: the 4-pixel checker of the screenshot must line up pixel for pixel), the sky
+    colour as background, and the agent's triangle (Agent.render, entity.py:468-497)."""
+    from miniworld_amd import envs
+    from miniworld_amd.scene import scene_from_env
+    env = getattr(envs, str(SHOTS[name + "/env"]))(host_only=True)
+    env.reset(seed=0)
+    env.entities = [e for e in env.entities if e is env.agent]
+    sc = scene_from_env(env)
+    sc["agent_pos"] = SHOTS[name + "/pos"].astype(np.float64)
+    sc["agent_dir"] = np.deg2rad(float(SHOTS[name + "/angle_deg"]) + 0.5)
+    main = SHOTS[name + "/main"].astype(np.float32)
+    full = pyoracle.render(sc, 800, 600, 16, view="top", render_agent=True)["rgb"].astype(np.float32)
+    got = _down(full.astype(np.uint8), 4)
+    red = lambda a: (a[..., 0] > 100) & (a[..., 1] < 80) & (a[..., 2] < 80)
+    ents = _dilate(red(main) | red(got), 2)           # the agent's triangle (both) and the randomly placed box (screenshot)
+    sky = lambda a: (a[..., 2] > 200) & (a[..., 0] < 120)
+    # background = the sky colour; floorplan outline
+    assert np.abs(main[sky(main)].mean(0) - got[sky(got)].mean(0)).max() < 2.5
+    inter, union = (~sky(main) & ~sky(got) & ~ents).sum(), ((~sky(main) | ~sky(got)) & ~ents).sum()
+    assert inter / union > 0.97, inter / union
+    floor = ~sky(main) & ~sky(got) & ~ents
+    assert np.abs(main[floor].mean(0) - got[floor].mean(0)).max() < 2.5
+    # the floor texture, pixel for pixel at full resolution
+    x0, y0, x1, y1 = (int(v) for v in SHOTS[name + "/patch_box"])
+    a, b = SHOTS[name + "/patch"].astype(np.float32).mean(-1), full[y0:y1, x0:x1].mean(-1)
+    a, b = a - a.mean(), b - b.mean()
+    corr = (a * b).sum() / np.sqrt((a * a).sum() * (b * b).sum())
+    assert corr > 0.98, corr
+    assert abs(a.std() - b.std()) < 5.0
+    # the agent's triangle: same place (within a pixel of the 200x150 view), same size, same colour
+    ys, xs = np.nonzero(red(main) & (np.arange(200)[None, :] < 100))          # the box lies in the right half
+    yo, xo = np.nonzero(red(got))
+    assert len(yo) >= 6 and abs(len(ys) - len(yo)) <= 0.35 * len(yo) + 2, (len(ys), len(yo))
+    assert abs(ys.mean() - yo.mean()) < 1.0 and abs(xs.mean() - xo.mean()) < 1.0, (ys.mean(), yo.mean(), xs.mean(), xo.mean())
