@@ -93,7 +93,7 @@ struct MwArgs {
     int32_t task, goal_ent, num_objs, max_steps;
     int32_t domain_rand, generator, autoreset, tiles_x;
     int32_t tiles_y, n_tiles, goal_ent2, env_base;    // env_base: first env of this launch (0 for the batched step)
-    int32_t rng_mode, pad0;
+    int32_t rng_mode, occlusion;    // occlusion: K1 of big scenes drops room polygons hidden behind full-height walls (mw_setup.hip; MW_OCCLUSION=0 turns it off)
     double agent_radius, max_forward_step, agent_height;
     mw_range fwd, drift, turn;
     mw_range sky[3], light_pos[3], light_color[3], light_ambient[3], color_bias[3];

@@ -667,6 +667,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     a.shared_geom = cfg->shared_geometry ? 1 : 0;
     a.task = cfg->task; a.goal_ent = cfg->goal_ent; a.goal_ent2 = cfg->goal_ent2; a.num_objs = cfg->num_objs; a.max_steps = cfg->max_episode_steps;
     a.rng_mode = cfg->rng_mode;
+    a.occlusion = 1;
+    if (const char *s = getenv("MW_OCCLUSION")) a.occlusion = atoi(s) != 0;
     a.domain_rand = cfg->domain_rand; a.generator = cfg->generator; a.autoreset = cfg->autoreset;
     a.tiles_x = a.W / MW_TILE_W; a.tiles_y = a.H / MW_TILE_H; a.n_tiles = a.tiles_x * a.tiles_y;
     a.agent_radius = cfg->agent_radius; a.max_forward_step = cfg->max_forward_step;

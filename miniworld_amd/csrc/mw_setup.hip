@@ -28,10 +28,66 @@
 // wave 0, and all 256 threads sort.
 #if MW_SORT_VIS
 #define MW_K1_WAVES 4
+#define MW_K1_OCC 4
 #else
 #define MW_K1_WAVES 1
+#define MW_K1_OCC 3      // waves per SIMD the register allocation aims at (168 VGPRs: the wave-per-env batch sizes leave 2-4 resident)
 #endif
-extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_waves_per_eu(4, 4))) void MW_SETUP_KERNEL_NAME(
+#if MW_SORT_VIS
+// ---------------------------------------------------------------- occlusion culling (big scenes)
+// A Maze view holds ~95 front-facing polygons inside the frustum and ~13 that own a sample: everything else lies behind
+// walls.  With an unpitched camera a wall that spans the whole height of the world (the slab [lo, hi] of all room
+// polygons, the eye inside it) hides every room polygon behind it in the screen columns it covers: a ray to a point
+// of the slab farther away crosses the wall's plane inside the slab.  So: every such wall in front of the eye marks the
+// column bins it covers completely with its farthest depth there (the nearest wall wins the bin), and a polygon
+// whose columns are all marked with depths in front of its nearest vertex is dropped before it costs a record, a
+// sort slot and the raster kernel's visits.  Frames do not change: a dropped polygon owns no sample —
+//   * its fragments are no nearer than its nearest vertex: R6p (mw_setup_common.h::write_poly) computes the depth plane
+//     from window coordinates in binary64, so a fragment's depth stays inside its polygon's vertex range (with the 2DH
+//     sums of R6 a wall stub 0.1 px wide came out dozens of D16 steps in front of the wall hiding it);
+//   * not even through the 16-bit depth quantisation (GL_LESS ties go to the polygon drawn first): "in front" demands
+//     more than three depth-buffer steps, 1/z_wall - 1/z_poly > 1.2e-3, one step of D16 over [0.04, 100] being 3.8e-4 in 1/z;
+//   * all margins are on the keeping side: walls shrink by 0.05 px and are cut at z = 0.1 (the near plane is at 0.04),
+//     polygons grow by 0.1 px (an edge function's rounding moves an edge by < 1e-3 px), polygons with a vertex nearer than
+//     0.1 are kept untested.
+// tests/test_gpu_env_api.py::test_occlusion_culling_never_changes_a_frame compares MW_OCCLUSION=0 / 1 bit for bit.
+#define MW_OCC_BINS 256
+#define MW_OCC_CAP 192
+
+// occ_z[0 .. BINS): the bins; occ_z[BINS .. BINS + BINS / 16): the largest value of every group of 16 bins
+__device__ inline bool occluded(const float *occ_z, const HV h[4], int nv, float bins_per_px)
+{
+    float zq = 1e30f, xmn = 1e30f, xmx = -1e30f;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (k < nv) {
+            ok &= h[k].hw >= 0.1f;
+            const float X = h[k].hx * __builtin_amdgcn_rcpf(h[k].hw);
+            xmn = fminf(xmn, X); xmx = fmaxf(xmx, X); zq = fminf(zq, h[k].hw);
+        }
+    if (!ok) return false;
+    const float fb0 = floorf(fmaxf(xmn - 0.1f, 0.0f) * bins_per_px), fb1 = floorf(fmaxf(xmx + 0.1f, 0.0f) * bins_per_px);
+    const int b0 = (int)fminf(fb0, (float)(MW_OCC_BINS - 1)), b1 = (int)fminf(fb1, (float)(MW_OCC_BINS - 1));
+    const float thr = zq * __builtin_amdgcn_rcpf(fmaf(1.2e-3f, zq, 1.0f)) * 0.9999f;
+    // every bin of b0 .. b1 in front of thr: whole groups through their maxima
+    const int g0 = (b0 + 15) >> 4, g1 = (b1 + 1) >> 4;
+    if (g0 >= g1) {
+        for (int b = b0; b <= b1; ++b)
+            if (!(occ_z[b] < thr)) return false;
+        return true;
+    }
+    for (int b = b0; b < (g0 << 4); ++b)
+        if (!(occ_z[b] < thr)) return false;
+    for (int g = g0; g < g1; ++g)
+        if (!(occ_z[MW_OCC_BINS + g] < thr)) return false;
+    for (int b = g1 << 4; b <= b1; ++b)
+        if (!(occ_z[b] < thr)) return false;
+    return true;
+}
+#endif
+
+extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_waves_per_eu(MW_K1_OCC, 4))) void MW_SETUP_KERNEL_NAME(
     MwArgs a, int do_step, int view_flags, const int32_t *__restrict__ actions, float *__restrict__ reward,
     uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
 {
@@ -47,6 +103,11 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
 #if MW_SORT_VIS
     __shared__ unsigned long long s_zmin_buf[MW_SORT_CAP];
     unsigned long long *s_zmin = s_zmin_buf;
+    __shared__ float s_occ_z[MW_OCC_BINS + MW_OCC_BINS / 16];      // occlusion culling (below): farthest depth of the nearest wall per column bin, group maxima
+    __shared__ float s_occ_wall[MW_OCC_CAP * 5];
+    __shared__ float s_slab[2 * KW];
+    __shared__ int s_occ_n;
+    __shared__ uint16_t s_list[MW_SORT_CAP];        // the visible room polygons, in draw order
 #else
     unsigned long long *s_zmin = nullptr;
 #endif
@@ -240,8 +301,209 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
     int count = 0;
     const mw_poly *polys = a.polys + (size_t)c.set * a.max_polys;
     const int np = a.npolys[c.set];
-    for (int base = 0, round = 0; base < np; base += 64 * KW, ++round) {         // display list 1: rooms
-        const int i = base + wave * 64 + lane;
+#if MW_SORT_VIS
+    // ---- display list 1 (rooms), big scenes: vertices read once into registers -> slab, occluder walls, column bins ->
+    // visibility of every polygon (back face, frustum, occlusion) -> ordered list -> records of the listed ones
+    constexpr int PR = 2;                               // polygon rounds held in registers (2 * 256 = 512 polygons)
+    const bool cached = np <= PR * 64 * KW;
+    float pv[PR][12];
+    int pnv[PR];
+#pragma unroll
+    for (int r = 0; r < PR; ++r) {
+        const int i = r * 64 * KW + wave * 64 + lane;
+        pnv[r] = 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) pv[r][k] = 0.0f;
+        if (cached && i < np) {
+            const float4 *src = reinterpret_cast<const float4 *>(polys[i].v);      // 12 floats at the head of the 112-byte struct
+            const float4 v0 = src[0], v1 = src[1], v2 = src[2];
+            pv[r][0] = v0.x; pv[r][1] = v0.y; pv[r][2] = v0.z; pv[r][3] = v0.w; pv[r][4] = v1.x; pv[r][5] = v1.y;
+            pv[r][6] = v1.z; pv[r][7] = v1.w; pv[r][8] = v2.x; pv[r][9] = v2.y; pv[r][10] = v2.z; pv[r][11] = v2.w;
+            pnv[r] = polys[i].nv;
+        }
+    }
+    unsigned long long pq[4] = {0ull, 0ull, 0ull, 0ull};
+    if (a.k1_prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pq[0] = __builtin_readcyclecounter(); }
+    bool occ_on = cached && a.occlusion && !cam.ortho && cam.m[0][1] == 0.0f && cam.m[2][1] == 0.0f;
+    const float bins_per_px = (float)MW_OCC_BINS / (float)a.W;
+    if (occ_on) {
+        // the slab: lowest and highest point of the room polygons
+        float lo = 1e30f, hi = -1e30f;
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (k < (pnv[r] & 0xFF)) { lo = fminf(lo, pv[r][3 * k + 1]); hi = fmaxf(hi, pv[r][3 * k + 1]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) { s_slab[wave] = lo; s_slab[KW + wave] = hi; }
+        if (threadIdx.x == 0) s_occ_n = 0;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < KW; ++w) { lo = fminf(lo, s_slab[w]); hi = fmaxf(hi, s_slab[KW + w]); }
+        if (a.k1_prof) pq[1] = __builtin_readcyclecounter();
+        const float eye_y = -cam.m[1][3];           // the unpitched camera's up row is (0, 1, 0)
+        occ_on = eye_y > lo + 1e-3f && eye_y < hi - 1e-3f;
+        if (occ_on) {
+            const float wc = 0.1f;
+            // the eye in world space (the rotation part of the modelview is orthonormal)
+            const float eye_x = -(cam.m[0][0] * cam.m[0][3] + cam.m[1][0] * cam.m[1][3] + cam.m[2][0] * cam.m[2][3]);
+            const float eye_z = -(cam.m[0][2] * cam.m[0][3] + cam.m[1][2] * cam.m[1][3] + cam.m[2][2] * cam.m[2][3]);
+            const float inv_p00 = 1.0f / cam.p00, inv_hp = 1.0f / (cam.halfw * cam.p00), px_per_bin = 1.0f / bins_per_px;
+#pragma unroll
+            for (int r = 0; r < PR; ++r) {
+                if (pnv[r] != 4) continue;          // triangles, and the quads of static entities (flag bit), are no walls
+                float vx[4], vy[4], vz[4];
+                bool ys = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    vx[k] = pv[r][3 * k]; vy[k] = pv[r][3 * k + 1]; vz[k] = pv[r][3 * k + 2];
+                    ys &= vy[k] == lo || vy[k] == hi;
+                }
+                // a vertical rectangle from lo to hi: two vertical edges
+                const bool pa = vx[0] == vx[1] && vz[0] == vz[1] && vx[2] == vx[3] && vz[2] == vz[3] && vy[0] != vy[1] && vy[2] != vy[3];
+                const bool pb = vx[1] == vx[2] && vz[1] == vz[2] && vx[3] == vx[0] && vz[3] == vz[0] && vy[1] != vy[2] && vy[3] != vy[0];
+                if (!ys || !(pa || pb)) continue;
+                const float bx = pa ? vx[2] : vx[1], bz = pa ? vz[2] : vz[1];
+                if (bx == vx[0] && bz == vz[0]) continue;
+                // drawn at all?  GL_CCW front faces (miniworld.py:512): the winding normal, s * (tz, 0, -tx) for a vertical
+                // rectangle over the foot line B0 -> B1 = (tx, tz), points at the eye — by a centimetre at least
+                const float tx = bx - vx[0], tz = bz - vz[0];
+                const float sgn = pa ? vy[1] - vy[0] : vy[1] - vy[2];
+                const float side = tz * (eye_x - vx[0]) - tx * (eye_z - vz[0]);
+                const float facing = sgn > 0.0f ? side : -side;
+                if (!(facing > 0.0f && facing * facing > 1e-4f * (tx * tx + tz * tz))) continue;
+                // its foot line in eye space: (x, depth) of the two vertical edges, cut at depth wc
+                float ea = fmaf(cam.m[0][0], vx[0], fmaf(cam.m[0][2], vz[0], cam.m[0][3]));
+                float wa = -fmaf(cam.m[2][0], vx[0], fmaf(cam.m[2][2], vz[0], cam.m[2][3]));
+                float eb = fmaf(cam.m[0][0], bx, fmaf(cam.m[0][2], bz, cam.m[0][3]));
+                float wb = -fmaf(cam.m[2][0], bx, fmaf(cam.m[2][2], bz, cam.m[2][3]));
+                if (!(wa >= wc) && !(wb >= wc)) continue;
+                // (hardware reciprocals: their last-bit error moves a column by 1e-5 px, the margins are 0.05)
+                if (!(wa >= wc)) { const float t = (wc - wa) * __builtin_amdgcn_rcpf(wb - wa); ea = fmaf(t, eb - ea, ea); wa = wc; }
+                else if (!(wb >= wc)) { const float t = (wc - wb) * __builtin_amdgcn_rcpf(wa - wb); eb = fmaf(t, ea - eb, eb); wb = wc; }
+                if (!(fmaxf(wa, wb) < 95.0f)) continue;         // the far plane is at 100
+                const float xa = cam.halfw * fmaf(cam.p00, ea * __builtin_amdgcn_rcpf(wa), 1.0f);
+                const float xb = cam.halfw * fmaf(cam.p00, eb * __builtin_amdgcn_rcpf(wb), 1.0f);
+                const float xl = fminf(xa, xb) + 0.05f, xr = fmaxf(xa, xb) - 0.05f;
+                if (!(xr > 0.0f && xl < (float)a.W && xr - xl >= px_per_bin)) continue;
+                // depth along the wall as a function of the pixel column: A ex + B w = D with ex / w = (x / halfw - 1) / p00
+                float A = wb - wa, B = -(eb - ea), D = A * ea + B * wa;
+                if (D < 0.0f) { A = -A; B = -B; D = -D; }
+                if (!(D > 1e-4f)) continue;
+                const float A2 = A * inv_hp, B2 = B - A * inv_p00;
+                const float dl = fmaf(A2, xl, B2), dr = fmaf(A2, xr, B2);
+                if (!(dl * 100.0f > D && dr * 100.0f > D)) continue;       // depths below 100 at both ends (and positive denominators)
+                const int j = atomicAdd(&s_occ_n, 1);
+                if (j < MW_OCC_CAP) {
+                    float *ow = s_occ_wall + 5 * j;
+                    ow[0] = xl; ow[1] = xr; ow[2] = A2; ow[3] = B2; ow[4] = D;
+                }
+            }
+        }
+        __syncthreads();
+        if (a.k1_prof) pq[2] = __builtin_readcyclecounter();
+        if (occ_on) {
+            const int n_occ = s_occ_n < MW_OCC_CAP ? s_occ_n : MW_OCC_CAP;
+            for (int b = (int)threadIdx.x; b < MW_OCC_BINS; b += 64 * KW) {
+                const float xa = (float)b / bins_per_px, xb = (float)(b + 1) / bins_per_px;
+                float z = 1e30f;
+                for (int j = 0; j < n_occ; ++j) {
+                    const float *ow = s_occ_wall + 5 * j;
+                    if (xa >= ow[0] && xb <= ow[1]) {
+                        const float far = ow[4] * fmaxf(__builtin_amdgcn_rcpf(fmaf(ow[2], xa, ow[3])), __builtin_amdgcn_rcpf(fmaf(ow[2], xb, ow[3])));
+                        z = fminf(z, far);
+                    }
+                }
+                s_occ_z[b] = z * 1.0001f;
+            }
+            __syncthreads();
+            if (threadIdx.x < MW_OCC_BINS / 16) {
+                float z = 0.0f;
+                for (int b = 0; b < 16; ++b) z = fmaxf(z, s_occ_z[threadIdx.x * 16 + b]);
+                s_occ_z[MW_OCC_BINS + threadIdx.x] = z;
+            }
+        }
+        __syncthreads();
+    }
+    const unsigned long long ptocc = a.k1_prof ? __builtin_readcyclecounter() : 0ull;
+    const bool dense_write = a.max_vis <= MW_SORT_CAP;      // visible polygons are listed first and set up with every lane busy
+    // one round of 64 * KW polygons: visibility, ordered compaction across the waves, list entry (or the record at once)
+    auto list_round = [&](const float (&v)[12], int nvflags, int i, int round) {
+        bool vis = false;
+        HV h[4];
+        PolyGeom g;
+        const int nv = nvflags & 0xFF;
+        if (i < np) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = xform(cam, v[3 * k], v[3 * k + 1], v[3 * k + 2]);
+            vis = cull_poly(a, h, nv, g) && !((nvflags & MW_POLY_ENTITY) && (view_flags & 4));     // the queries draw rooms only
+            if (vis && occ_on) vis = !occluded(s_occ_z, h, nv, bins_per_px);
+        }
+        // ordered compaction across the waves of the env: wave w's batch comes after those of waves < w
+        const uint64_t m = ballot(vis);
+        if (lane == 0) s_cnt[round & 1][wave] = __popcll((unsigned long long)m);
+        __syncthreads();
+        int before = 0, total = 0;
+#pragma unroll
+        for (int w = 0; w < KW; ++w) {
+            const int cw = s_cnt[round & 1][w];
+            before += w < wave ? cw : 0;
+            total += cw;
+        }
+        const int idx = count + before + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
+        count += total;
+        if (vis) {
+            if (idx >= a.max_vis) {
+                atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+            } else if (dense_write) {
+                s_list[idx] = (uint16_t)i;
+            } else {
+                const mw_poly &q = polys[i];
+                float col[3];
+                light(cam, q.n, q.rgb, col);
+                const float uv[3][2] = {{q.uv[0][0], q.uv[0][1]}, {q.uv[1][0], q.uv[1][1]}, {q.uv[2][0], q.uv[2][1]}};
+                write_poly(a, env, idx, (uint32_t)idx, h, nv, g, uv, col, q.tex, s_zmin);
+            }
+        }
+    };
+    if (cached) {
+#pragma unroll
+        for (int r = 0; r < PR; ++r)
+            if (r * 64 * KW < np) list_round(pv[r], pnv[r], r * 64 * KW + wave * 64 + lane, r);
+    } else {
+        for (int base = 0, round = 0; base < np; base += 64 * KW, ++round) {
+            const int i = base + wave * 64 + lane;
+            float v[12];
+            int nvflags = 0;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) v[k] = i < np ? polys[i].v[k / 3][k % 3] : 0.0f;
+            if (i < np) nvflags = polys[i].nv;
+            list_round(v, nvflags, i, round);
+        }
+    }
+    if (dense_write) {
+        // the records of the listed polygons: a few dozen of the hundreds looked at, one per thread
+        __syncthreads();
+        const int n_room = count < a.max_vis ? count : a.max_vis;
+        // (wave 1 takes the first 64: wave 0 goes on to the entities meanwhile)
+        for (int t = ((int)threadIdx.x + 64 * (KW - 1)) % (64 * KW); t < n_room; t += 64 * KW) {
+            mw_poly q = polys[s_list[t]];
+            q.nv &= 0xFF;
+            HV h[4];
+            PolyGeom g;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) h[k] = xform(cam, q.v[k][0], q.v[k][1], q.v[k][2]);
+            (void)cull_poly(a, h, q.nv, g);
+            float col[3];
+            light(cam, q.n, q.rgb, col);
+            const float uv[3][2] = {{q.uv[0][0], q.uv[0][1]}, {q.uv[1][0], q.uv[1][1]}, {q.uv[2][0], q.uv[2][1]}};
+            write_poly(a, env, t, (uint32_t)t, h, q.nv, g, uv, col, q.tex, s_zmin);
+        }
+    }
+#else
+    for (int base = 0; base < np; base += 64) {         // display list 1: rooms
+        const int i = base + lane;
         bool vis = false;
         HV h[4];
         PolyGeom g;
@@ -254,24 +516,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
             for (int k = 0; k < 4; ++k) h[k] = xform(cam, q.v[k][0], q.v[k][1], q.v[k][2]);
             vis = cull_poly(a, h, q.nv, g) && !(ent_poly && (view_flags & 4));     // the queries draw rooms only
         }
-        int idx;
-        if (KW == 1) {
-            idx = compact(lane, vis, count);
-        } else {
-            // ordered compaction across the waves of the env: wave w's batch comes after those of waves < w
-            const uint64_t m = ballot(vis);
-            if (lane == 0) s_cnt[round & 1][wave] = __popcll((unsigned long long)m);
-            __syncthreads();
-            int before = 0, total = 0;
-#pragma unroll
-            for (int w = 0; w < KW; ++w) {
-                const int cw = s_cnt[round & 1][w];
-                before += w < wave ? cw : 0;
-                total += cw;
-            }
-            idx = count + before + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)));
-            count += total;
-        }
+        const int idx = compact(lane, vis, count);
         if (vis) {
             if (idx < a.max_vis) {
                 float col[3];
@@ -283,6 +528,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
             }
         }
     }
+#endif
     if (np > 0) {
         const mw_poly &lastq = polys[np - 1];
         stale_n[0] = lastq.n[0]; stale_n[1] = lastq.n[1]; stale_n[2] = lastq.n[2];
@@ -478,7 +724,15 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         const int n = count < a.max_vis ? count : a.max_vis;
         uint16_t *ord = a.rec_order + (size_t)env * (a.max_vis + 1);
         __syncthreads();
-        if (n <= MW_SORT_CAP) {
+        if (n <= 64 * KW) {
+            // a short list (the usual case once the hidden polygons are gone): every thread ranks its own key —
+            // the keys are distinct, their low bits being the list index
+            const unsigned long long key = (int)threadIdx.x < n ? s_zmin[threadIdx.x] : ~0ull;
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += s_zmin[j] < key ? 1 : 0;
+            if ((int)threadIdx.x < n) ord[1 + rank] = (uint16_t)(key & 0xFFFFull);
+            if (writer) ord[0] = 1;
+        } else if (n <= MW_SORT_CAP) {
             // bitonic sort of the packed (bound, index) keys in LDS by the 64 lanes of the wave
             int P = 64;
             while (P < n) P <<= 1;
@@ -507,6 +761,10 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         const unsigned long long pt4 = __builtin_readcyclecounter();
         unsigned long long *pp = a.k1_prof + (size_t)env * 8;
         pp[0] = pt1 - pt0; pp[1] = pt2 - pt1; pp[2] = pt3 - pt2; pp[3] = pt4 - pt3; pp[4] = (unsigned long long)regenerated;
+        pp[5] = (unsigned long long)count;
+#if MW_SORT_VIS
+        pp[6] = (unsigned long long)s_occ_n | ((pq[0] - pt2) << 8); pp[7] = (ptocc - pt2) | ((pq[1] - pt2) << 20) | ((pq[2] - pt2) << 40);
+#endif
     }
     if (writer) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;

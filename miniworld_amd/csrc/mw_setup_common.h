@@ -449,7 +449,27 @@ __device__ __forceinline__ void write_poly(const MwArgs &a, int env, int idx, ui
     const float ta = fmaf(h[2].cz, g.ga[2], fmaf(h[1].cz, g.ga[1], h[0].cz * g.ga[0]));
     const float tb = fmaf(h[2].cz, g.gb[2], fmaf(h[1].cz, g.gb[1], h[0].cz * g.gb[0]));
     const float tc = fmaf(h[2].cz, g.gc[2], fmaf(h[1].cz, g.gc[1], h[0].cz * g.gc[0]));
-    const float zx = (ta * invD) * 0.5f, zy = (tb * invD) * 0.5f, zc = fmaf(tc * invD, 0.5f, 0.5f);
+    float zx = (ta * invD) * 0.5f, zy = (tb * invD) * 0.5f, zc = fmaf(tc * invD, 0.5f, 0.5f);
+    if (h[0].hw > 0.0f && h[1].hw > 0.0f && h[2].hw > 0.0f) {
+        // R6p: first three vertices in front of the eye — the plane through their window coordinates (X, Y, z_w), solved
+        // in binary64 and rounded to binary32 (the sums above cancel catastrophically for a polygon seen edge-on: a far
+        // floor two pixels high, a wall stub a tenth of a pixel wide).  Differences of the window coordinates over common
+        // denominators, X1 - X0 = (hx1 w0 - hx0 w1) / (w0 w1): the products are exact in binary64 and the denominators
+        // cancel between the numerators and the determinant.
+        const double w0 = h[0].hw, w1 = h[1].hw, w2 = h[2].hw;
+        const double nax = (double)h[1].hx * w0 - (double)h[0].hx * w1, nay = (double)h[1].hy * w0 - (double)h[0].hy * w1;
+        const double naz = (double)h[1].cz * w0 - (double)h[0].cz * w1;
+        const double nbx = (double)h[2].hx * w0 - (double)h[0].hx * w2, nby = (double)h[2].hy * w0 - (double)h[0].hy * w2;
+        const double nbz = (double)h[2].cz * w0 - (double)h[0].cz * w2;
+        const double det = nax * nby - nbx * nay;
+        if (det != 0.0) {
+            const double r = 1.0 / det, i0 = 1.0 / w0;
+            const double zxd = 0.5 * ((naz * nby - nbz * nay) * r), zyd = 0.5 * ((nax * nbz - nbx * naz) * r);
+            zx = (float)zxd;
+            zy = (float)zyd;
+            zc = (float)(0.5 + ((0.5 * (double)h[0].cz - zxd * (double)h[0].hx) - zyd * (double)h[0].hy) * i0);
+        }
+    }
     float zo[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) zo[s] = fmaf(zx, kSampleDx[s], zy * kSampleDy[s]);

@@ -230,6 +230,28 @@ static int setup_prim(const mwo_scene *sc, const hvert *h, int nv, const float (
     p->zx = (ta * invD) * 0.5f;
     p->zy = (tb * invD) * 0.5f;
     p->zc = fmaf(tc * invD, 0.5f, 0.5f);
+    if (!gouraud && h[0].hw > 0.0f && h[1].hw > 0.0f && h[2].hw > 0.0f) {
+        /* R6p: a polygon whose first three vertices lie in front of the eye takes the plane through their window
+         * coordinates (X, Y, z_w), solved in binary64 and rounded to binary32.  Same plane, different arithmetic: the
+         * sums above cancel catastrophically for a polygon seen edge-on (a far floor two pixels high, a wall stub a
+         * tenth of a pixel wide) — depths dozens of D16 steps outside the range of the polygon's own vertices, which a
+         * rasteriser working on snapped window coordinates never produces. */
+        /* differences of the window coordinates over common denominators: X1 - X0 = (hx1 w0 - hx0 w1) / (w0 w1), the
+         * products exact in binary64; the denominators cancel between the plane's numerators and its determinant */
+        double w0 = h[0].hw, w1 = h[1].hw, w2 = h[2].hw;
+        double nax = (double)h[1].hx * w0 - (double)h[0].hx * w1, nay = (double)h[1].hy * w0 - (double)h[0].hy * w1;
+        double naz = (double)h[1].cz * w0 - (double)h[0].cz * w1;
+        double nbx = (double)h[2].hx * w0 - (double)h[0].hx * w2, nby = (double)h[2].hy * w0 - (double)h[0].hy * w2;
+        double nbz = (double)h[2].cz * w0 - (double)h[0].cz * w2;
+        double det = nax * nby - nbx * nay;
+        if (det != 0.0) {
+            double r = 1.0 / det, i0 = 1.0 / w0;
+            double zx = 0.5 * ((naz * nby - nbz * nay) * r), zy = 0.5 * ((nax * nbz - nbx * naz) * r);
+            p->zx = (float)zx;
+            p->zy = (float)zy;
+            p->zc = (float)(0.5 + ((0.5 * (double)h[0].cz - zx * (double)h[0].hx) - zy * (double)h[0].hy) * i0);
+        }
+    }
     p->Wa = (ga[0] + ga[1]) + ga[2];
     p->Wb = (gb[0] + gb[1]) + gb[2];
     p->Wc = (gc[0] + gc[1]) + gc[2];

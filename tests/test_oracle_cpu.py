@@ -70,7 +70,7 @@ def test_render_reproduces_committed_golden(case):
 def _empty_scene():
     s0, *_ = helpers.load_case("hallway_s0")
     sc = dict(s0)
-    for k in ("polys_v", "polys_uv", "polys_n", "polys_nv", "polys_tex"):
+    for k in ("polys_v", "polys_uv", "polys_n", "polys_nv", "polys_tex", "polys_rgb"):
         sc[k] = s0[k][:0]
     for k in [k for k in s0 if k.startswith("ents_")]:
         sc[k] = s0[k][:0]
@@ -94,6 +94,7 @@ def test_fronto_parallel_white_quad_is_lit_factor_times_255():
     sc["polys_v"], sc["polys_uv"] = v, np.zeros((1, 4, 2), np.float32)
     sc["polys_n"] = np.array([[-1, 0, 0]], np.float32)
     sc["polys_nv"], sc["polys_tex"] = np.array([4], np.int32), np.array([-1], np.int32)
+    sc["polys_rgb"] = np.ones((1, 3), np.float32)
     out = pyoracle.render(sc)
     if (out["z16"] == 65535).all():       # winding the other way round -> culled; flip it
         sc["polys_v"] = v[:, ::-1].copy()
