@@ -108,6 +108,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
     __shared__ float s_slab[2 * KW];
     __shared__ int s_occ_n;
     __shared__ uint16_t s_list[MW_SORT_CAP];        // the visible room polygons, in draw order
+    __shared__ float4 s_pv[2 * 3 * 64 * KW];        // the vertices of up to 512 room polygons (24 KB)
 #else
     unsigned long long *s_zmin = nullptr;
 #endif
@@ -304,24 +305,30 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
 #if MW_SORT_VIS
     // ---- display list 1 (rooms), big scenes: vertices read once into registers -> slab, occluder walls, column bins ->
     // visibility of every polygon (back face, frustum, occlusion) -> ordered list -> records of the listed ones
-    constexpr int PR = 2;                               // polygon rounds held in registers (2 * 256 = 512 polygons)
+    constexpr int PR = 2;                               // polygon rounds held in LDS (2 * 256 = 512 polygons)
     const bool cached = np <= PR * 64 * KW;
-    float pv[PR][12];
+    // the twelve vertex floats of thread t's polygon of round r: s_pv[(r * 3 + c) * 256 + t], c = 0 .. 2 (consecutive
+    // threads, consecutive 16 bytes).  In LDS, not in registers: 24 more live VGPRs through the occluder passes were
+    // 50 scratch reloads in their inner loops.
     int pnv[PR];
 #pragma unroll
     for (int r = 0; r < PR; ++r) {
         const int i = r * 64 * KW + wave * 64 + lane;
         pnv[r] = 0;
-#pragma unroll
-        for (int k = 0; k < 12; ++k) pv[r][k] = 0.0f;
         if (cached && i < np) {
             const float4 *src = reinterpret_cast<const float4 *>(polys[i].v);      // 12 floats at the head of the 112-byte struct
-            const float4 v0 = src[0], v1 = src[1], v2 = src[2];
-            pv[r][0] = v0.x; pv[r][1] = v0.y; pv[r][2] = v0.z; pv[r][3] = v0.w; pv[r][4] = v1.x; pv[r][5] = v1.y;
-            pv[r][6] = v1.z; pv[r][7] = v1.w; pv[r][8] = v2.x; pv[r][9] = v2.y; pv[r][10] = v2.z; pv[r][11] = v2.w;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_pv[(r * 3 + c) * 64 * KW + (int)threadIdx.x] = src[c];
             pnv[r] = polys[i].nv;
         }
     }
+    auto load_pv = [&](int r, float (&v)[12]) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float4 q = s_pv[(r * 3 + c) * 64 * KW + (int)threadIdx.x];
+            v[4 * c] = q.x; v[4 * c + 1] = q.y; v[4 * c + 2] = q.z; v[4 * c + 3] = q.w;
+        }
+    };
     unsigned long long pq[4] = {0ull, 0ull, 0ull, 0ull};
     if (a.k1_prof) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pq[0] = __builtin_readcyclecounter(); }
     bool occ_on = cached && a.occlusion && !cam.ortho && cam.m[0][1] == 0.0f && cam.m[2][1] == 0.0f;
@@ -330,10 +337,14 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         // the slab: lowest and highest point of the room polygons
         float lo = 1e30f, hi = -1e30f;
 #pragma unroll
-        for (int r = 0; r < PR; ++r)
+        for (int r = 0; r < PR; ++r) {
+            if (pnv[r] == 0) continue;
+            float v[12];
+            load_pv(r, v);
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                if (k < (pnv[r] & 0xFF)) { lo = fminf(lo, pv[r][3 * k + 1]); hi = fmaxf(hi, pv[r][3 * k + 1]); }
+                if (k < (pnv[r] & 0xFF)) { lo = fminf(lo, v[3 * k + 1]); hi = fmaxf(hi, v[3 * k + 1]); }
+        }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
         if (lane == 0) { s_slab[wave] = lo; s_slab[KW + wave] = hi; }
@@ -353,11 +364,12 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
 #pragma unroll
             for (int r = 0; r < PR; ++r) {
                 if (pnv[r] != 4) continue;          // triangles, and the quads of static entities (flag bit), are no walls
-                float vx[4], vy[4], vz[4];
+                float vx[4], vy[4], vz[4], v[12];
+                load_pv(r, v);
                 bool ys = true;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    vx[k] = pv[r][3 * k]; vy[k] = pv[r][3 * k + 1]; vz[k] = pv[r][3 * k + 2];
+                    vx[k] = v[3 * k]; vy[k] = v[3 * k + 1]; vz[k] = v[3 * k + 2];
                     ys &= vy[k] == lo || vy[k] == hi;
                 }
                 // a vertical rectangle from lo to hi: two vertical edges
@@ -405,24 +417,23 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         if (a.k1_prof) pq[2] = __builtin_readcyclecounter();
         if (occ_on) {
             const int n_occ = s_occ_n < MW_OCC_CAP ? s_occ_n : MW_OCC_CAP;
-            for (int b = (int)threadIdx.x; b < MW_OCC_BINS; b += 64 * KW) {
-                const float xa = (float)b / bins_per_px, xb = (float)(b + 1) / bins_per_px;
-                float z = 1e30f;
-                for (int j = 0; j < n_occ; ++j) {
-                    const float *ow = s_occ_wall + 5 * j;
-                    if (xa >= ow[0] && xb <= ow[1]) {
-                        const float far = ow[4] * fmaxf(__builtin_amdgcn_rcpf(fmaf(ow[2], xa, ow[3])), __builtin_amdgcn_rcpf(fmaf(ow[2], xb, ow[3])));
-                        z = fminf(z, far);
-                    }
-                }
-                s_occ_z[b] = z * 1.0001f;
+            static_assert(MW_OCC_BINS == 64 * KW, "one column bin per thread");
+            const int b = (int)threadIdx.x;
+            const float xa = (float)b / bins_per_px, xb = (float)(b + 1) / bins_per_px;
+            float z = 1e30f;
+#pragma unroll 4
+            for (int j = 0; j < n_occ; ++j) {
+                const float *ow = s_occ_wall + 5 * j;
+                const float far = ow[4] * fmaxf(__builtin_amdgcn_rcpf(fmaf(ow[2], xa, ow[3])), __builtin_amdgcn_rcpf(fmaf(ow[2], xb, ow[3])));
+                z = (xa >= ow[0] && xb <= ow[1]) ? fminf(z, far) : z;
             }
-            __syncthreads();
-            if (threadIdx.x < MW_OCC_BINS / 16) {
-                float z = 0.0f;
-                for (int b = 0; b < 16; ++b) z = fmaxf(z, s_occ_z[threadIdx.x * 16 + b]);
-                s_occ_z[MW_OCC_BINS + threadIdx.x] = z;
-            }
+            z *= 1.0001f;
+            s_occ_z[b] = z;
+            // the largest value of every group of 16 bins (= 16 consecutive lanes)
+            float gz = z;
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) gz = fmaxf(gz, __shfl_xor(gz, o));
+            if ((lane & 15) == 0) s_occ_z[MW_OCC_BINS + (b >> 4)] = gz;
         }
         __syncthreads();
     }
@@ -467,10 +478,53 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
             }
         }
     };
-    if (cached) {
+    if (cached && dense_write) {
+        // the usual case: both rounds decided first, one ordered compaction (one barrier) for the two
+        bool vis[PR];
+        uint64_t vm[PR];
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            const int i = r * 64 * KW + wave * 64 + lane;
+            vis[r] = false;
+            if (i < np) {
+                float v[12];
+                HV h[4];
+                PolyGeom g;
+                load_pv(r, v);
+                const int nv = pnv[r] & 0xFF;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) h[k] = xform(cam, v[3 * k], v[3 * k + 1], v[3 * k + 2]);
+                vis[r] = cull_poly(a, h, nv, g) && !((pnv[r] & MW_POLY_ENTITY) && (view_flags & 4));     // the queries draw rooms only
+                if (vis[r] && occ_on) vis[r] = !occluded(s_occ_z, h, nv, bins_per_px);
+            }
+            vm[r] = ballot(vis[r]);
+            if (lane == 0) s_cnt[r][wave] = __popcll((unsigned long long)vm[r]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < PR; ++r) {
+            int before = 0, total = 0;
+#pragma unroll
+            for (int w = 0; w < KW; ++w) {
+                const int cw = s_cnt[r][w];
+                before += w < wave ? cw : 0;
+                total += cw;
+            }
+            const int idx = count + before + __popcll((unsigned long long)(vm[r] & ((1ull << lane) - 1ull)));
+            count += total;
+            if (vis[r]) {
+                if (idx < a.max_vis) s_list[idx] = (uint16_t)(r * 64 * KW + wave * 64 + lane);
+                else atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+            }
+        }
+    } else if (cached) {
 #pragma unroll
         for (int r = 0; r < PR; ++r)
-            if (r * 64 * KW < np) list_round(pv[r], pnv[r], r * 64 * KW + wave * 64 + lane, r);
+            if (r * 64 * KW < np) {
+                float v[12];
+                load_pv(r, v);
+                list_round(v, pnv[r], r * 64 * KW + wave * 64 + lane, r);
+            }
     } else {
         for (int base = 0, round = 0; base < np; base += 64 * KW, ++round) {
             const int i = base + wave * 64 + lane;

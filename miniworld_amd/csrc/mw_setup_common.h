@@ -11,7 +11,7 @@
 #ifndef MW_SORT_VIS
 #define MW_SORT_VIS 0       // 1: also emit the depth-sorted visiting order of big scenes (mw_setup_sort*.hip)
 #endif
-#define MW_SORT_CAP 1024    // polygons sorted per env (their packed sort keys sit in 8 KiB of LDS)
+#define MW_SORT_CAP 768     // polygons sorted per env (their packed sort keys sit in 6 KiB of LDS)
 
 namespace {
 
