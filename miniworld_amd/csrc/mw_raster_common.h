@@ -192,23 +192,19 @@ struct TexEnv {
 };
 
 // Textured fragment colour for the lanes with tex >= 0: attribute planes q0 / q1 / q2.x, base colour in
-// q2.yzw (GL_MODULATE); a waterfall over the distinct texture ids among the active lanes.
+// q2.yzw (GL_MODULATE).  The texture id is per lane: in the deferred shading of the exact pass the lanes of a tile hold
+// floor, ceiling and wall winners at once, and a waterfall over the distinct ids (scalar descriptors) ran the whole
+// fetch up to three times per round.  One pass instead: each lane reads the two descriptor words it needs (level count,
+// level-0 size) itself and wraps with the general rule, which gives what the power-of-two mask gives (i0 >= -1).
 __device__ inline RGB apply_texture(const float4 q0, const float4 q1, const float4 q2, int tex, const TexEnv &te,
                                     float Xc, float Yc)
 {
     RGB c = {q2.y, q2.z, q2.w};                                 // untextured: the base colour
-    uint64_t pending = __ballot(tex >= 0);
-    while (pending) {
-        const int t0 = __builtin_amdgcn_readlane(tex, __ffsll((unsigned long long)pending) - 1);
-        const MwTexDesc *__restrict__ d = te.texd + t0;
-        const bool mine = tex == t0;
-        if (mine) {
-            const int tw = (int)d->w, th = (int)d->h, q = (int)d->nlevels - 1;
-            const float ftw = d->lvl[0].fw, fth = d->lvl[0].fh;
-            if (((tw & (tw - 1)) | (th & (th - 1))) == 0) c = shade_tex<true>(q0, q1, q2, te.td, te.tx, t0, ftw, fth, q, Xc, Yc);
-            else c = shade_tex<false>(q0, q1, q2, te.td, te.tx, t0, ftw, fth, q, Xc, Yc);
-        }
-        pending &= ~__ballot(mine);
+    if (tex >= 0) {
+        const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4);
+        const uint32_t nlevels = ldw(te.td, desc + 2u);
+        const u32x4 l0 = __builtin_amdgcn_raw_buffer_load_b128(te.td, (desc + 8u) << 2, 0, 0);       // lvl[0]: fw, fh, h, -
+        c = shade_tex<false>(q0, q1, q2, te.td, te.tx, tex, __uint_as_float(l0.x), __uint_as_float(l0.y), (int)nlevels - 1, Xc, Yc);
     }
     return c;
 }
