@@ -107,6 +107,7 @@ struct mw_engine {
     MwArgs args{};
     MwArgs *d_gen_live = nullptr, *d_gen_spare = nullptr;   // device copies of the argument block for the generators
     bool spare_mode = false;
+    bool side_refill_pending = false;   // Maze: spare worlds are regenerated by a kernel of their own on the side stream, across steps
     MwSpare spare_host{};
     int32_t *d_spare_dummy = nullptr;   // carry / step / picked written by the generator in spare mode go nowhere
     int n_sets = 1;
@@ -449,6 +450,10 @@ int state_xfer(mw_engine *e, int first, int count, const mw_state_view *h, bool 
 #define ON_DEVICE(e) do { hipError_t sd_ = hipSetDevice((e)->cfg.device_id); \
         if (sd_ != hipSuccess) return fail((e), MW_E_HIP, "hipSetDevice(%d): %s", (e)->cfg.device_id, hipGetErrorString(sd_)); } while (0)
 
+// ... and, for every entry point but the step / render ones, after the spare-world refills still running on the side stream
+#define ON_DEVICE_SYNC(e) do { ON_DEVICE(e); if ((e)->side_refill_pending) { (void)hipStreamSynchronize((e)->side_stream); \
+        (e)->side_refill_pending = false; } } while (0)
+
 mw_engine::Ev get_events(mw_engine *e)
 {
     if (!e->ev_free.empty()) {
@@ -522,7 +527,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         (void)hipEventRecord(ev.a, st);
     }
     // spare mode: blocks appended to the grid regenerate the spare worlds consumed in earlier steps, beside the step itself
-    const int refill_blocks = (e->spare_mode && do_step) ? (e->cfg.generator == MW_GEN_MAZE ? N : (N + 63) / 64) : 0;
+    // ... except for the Maze: regenerating one takes ~300 us on a single wave, four times a whole step of the batch, and
+    // any launch that carries such a block lasts that long.  Its refills go to a kernel of their own on the low-priority
+    // side stream (below), running beside this and the next steps; nothing waits for it but the entry points that touch
+    // the worlds from the host (ON_DEVICE_SYNC) — an env that needs its spare earlier follows the refill_mask protocol.
+    const bool async_refill = e->spare_mode && do_step && e->cfg.generator == MW_GEN_MAZE;
+    const int refill_blocks = (e->spare_mode && do_step && !async_refill) ? (N + 63) / 64 : 0;
     if (const int lanes = k1_dense_lanes(e, view_flags)) {
         const int epw = 64 / lanes;
         const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
@@ -539,6 +549,13 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                            d_trunc ? d_trunc : e->d_flag_scratch + N);
     }
     if (timed) (void)hipEventRecord(ev.b, st);
+    if (async_refill) {
+        if (ensure_side_stream(e) != MW_OK) return MW_E_HIP;
+        HIP_TRY(e, hipEventRecord(e->ev_fork, st));
+        HIP_TRY(e, hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
+        hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_refill_pcg_kernel : mw_refill_kernel, dim3(N), dim3(64), 0, e->side_stream, e->args);
+        e->side_refill_pending = true;
+    }
     bool forked = false;
     if (e->cfg.msaa != 8) {
         // FrameBuffer's fallback sample counts (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES gets 4 or 1
@@ -706,12 +723,13 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     // spare mode: a pre-generated next world per env (mw_device.h::MwSpare)
     MwSpare sp{};
     // Spare worlds pay where the inline generator is the launch's tail: in the dense K1 of small scenes (a wave with a
-    // finished env takes 26 us instead of 12, profiles/r02a) they are on by default; in the wave-per-env K1 they bought
-    // 2 us of 51 (Hallway) and nothing on Maze, where they stay off.  MW_SPARE=1 / 0 forces either.  Not with domain
-    // randomisation: the per-step draws interleave with the worlds in the env's stream.
+    // finished env takes 26 us instead of 12, profiles/r02a) and in the Maze (a block regenerating its maze takes 300 us,
+    // the launch with it; its refills run on the side stream, launch_frame); in the other wave-per-env scenes they bought
+    // 2 us of 51 (Hallway) and stay off.  MW_SPARE=1 / 0 forces either.  Not with domain randomisation: the per-step draws
+    // interleave with the worlds in the env's stream.
     {
         const bool small_scene = cfg->max_visible <= 64 && cfg->max_polys + 6 * std::max(cfg->max_ents, 1) <= 32;      // = the dense K1 (k1_dense_lanes)
-        bool want = small_scene && cfg->generator != MW_GEN_MAZE;
+        bool want = small_scene || cfg->generator == MW_GEN_MAZE;
         if (const char *s = getenv("MW_SPARE")) want = atoi(s) != 0;
         e->spare_mode = cfg->generator != MW_GEN_NONE && !cfg->domain_rand && want;
     }
@@ -801,7 +819,7 @@ void mw_destroy(mw_engine *e)
 int mw_upload_texture(mw_engine *e, int32_t tex_id, const uint8_t *rgb, int32_t w, int32_t h)
 {
     if (!e || !rgb) return fail(e, MW_E_INVALID, "null argument");
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     if (tex_id < 0 || tex_id >= MW_MAX_TEX) return fail(e, MW_E_CAPACITY, "texture id %d out of range (max %d)", tex_id, MW_MAX_TEX);
     if (w <= 0 || h <= 0 || w > 16384 || h > 16384) return fail(e, MW_E_INVALID, "bad texture size %dx%d", w, h);
     build_pyramid(rgb, w, h, e->tex_data[tex_id], e->tex_desc[tex_id]);
@@ -812,7 +830,7 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
                    const float *rgb, int32_t ntris, int32_t tex_id)
 {
     if (!e || !pos || !nrm || !rgb) return fail(e, MW_E_INVALID, "null argument");
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     if (tex_id >= MW_MAX_TEX || (tex_id >= 0 && !uv)) return fail(e, MW_E_INVALID, "textured mesh needs texcoords and a valid texture id");
     if (mesh_id < 0 || mesh_id >= MW_MAX_MESH) return fail(e, MW_E_CAPACITY, "mesh id %d out of range (max %d)", mesh_id, MW_MAX_MESH);
     if (ntris <= 0 || ntris > 60000) return fail(e, MW_E_CAPACITY, "mesh with %d triangles (1..60000 supported: 16-bit draw ids)", ntris);
@@ -882,7 +900,7 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
 int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_polys, const double *segs, int32_t n_segs)
 {
     if (!e || (n_polys > 0 && !polys) || (n_segs > 0 && !segs)) return fail(e, MW_E_INVALID, "null argument");
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     if (n_polys < 0 || n_polys > e->cfg.max_polys) return fail(e, MW_E_CAPACITY, "%d polygons > max_polys %d", n_polys, e->cfg.max_polys);
     if (n_segs < 0 || n_segs > e->cfg.max_segs) return fail(e, MW_E_CAPACITY, "%d segments > max_segs %d", n_segs, e->cfg.max_segs);
     int set = 0;
@@ -908,7 +926,7 @@ int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_p
 int mw_get_geometry(mw_engine *e, int32_t env, mw_poly *polys, int32_t *n_polys, double *segs, int32_t *n_segs)
 {
     if (!e || !polys || !n_polys || !segs || !n_segs) return fail(e, MW_E_INVALID, "null argument");
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     const int set = e->cfg.shared_geometry ? 0 : env;
     if (set < 0 || set >= e->n_sets) return fail(e, MW_E_INVALID, "env out of range");
     HIP_TRY(e, hipDeviceSynchronize());
@@ -922,14 +940,14 @@ int mw_get_geometry(mw_engine *e, int32_t env, mw_poly *polys, int32_t *n_polys,
 int mw_set_state(mw_engine *e, int32_t first_env, int32_t count, const mw_state_view *host)
 {
     if (!e) return MW_E_INVALID;
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     return state_xfer(e, first_env, count, host, true);
 }
 
 int mw_get_state(mw_engine *e, int32_t first_env, int32_t count, mw_state_view *host)
 {
     if (!e) return MW_E_INVALID;
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     (void)hipDeviceSynchronize();
     return state_xfer(e, first_env, count, host, false);
 }
@@ -938,7 +956,7 @@ int mw_set_gen_program(mw_engine *e, const mw_gen_program *prog, const mw_poly *
                        const int32_t *poly_surf, const double *poly_m, int32_t n_polys, const double *segs, int32_t n_segs)
 {
     if (!e || !prog) return fail(e, MW_E_INVALID, "null argument");
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     if (prog->n_rooms < 1 || prog->n_rooms > MW_PROG_MAX_ROOMS || prog->n_tex < 0 || prog->n_tex > MW_PROG_MAX_TEX ||
         prog->n_ops < 0 || prog->n_ops > MW_PROG_MAX_OPS || prog->n_ents < 0 || prog->n_ents > MW_PROG_MAX_ENTS ||
         prog->n_ents > e->cfg.max_ents || prog->sign_n < 0 || prog->sign_n > 8)
@@ -987,7 +1005,7 @@ int mw_set_step_params(mw_engine *e, const double *host_params)
 {
     if (!e) return MW_E_INVALID;
     if (!host_params) { e->use_step_override = false; return MW_OK; }
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     HIP_TRY(e, hipMemcpy(e->d_step_override, host_params, 24 * (size_t)e->cfg.num_envs, hipMemcpyHostToDevice));
     e->use_step_override = true;
     return MW_OK;
@@ -996,7 +1014,7 @@ int mw_set_step_params(mw_engine *e, const double *host_params)
 int mw_reset(mw_engine *e, const uint8_t *mask, const uint64_t *seeds, void *stream)
 {
     if (!e) return MW_E_INVALID;
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     if (e->cfg.generator == MW_GEN_NONE && !seeds) return fail(e, MW_E_INVALID, "engine was created without a device-side generator");
     if (e->cfg.generator == MW_GEN_PROGRAM && !e->args.prog) return fail(e, MW_E_INVALID, "MW_GEN_PROGRAM: no placement program installed (mw_set_gen_program)");
     const int N = e->cfg.num_envs;
@@ -1146,7 +1164,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
 int mw_check(mw_engine *e, void *stream)
 {
     if (!e) return MW_E_INVALID;
-    ON_DEVICE(e);
+    ON_DEVICE_SYNC(e);
     HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
     uint32_t st = 0;
     HIP_TRY(e, hipMemcpy(&st, e->args.status, 4, hipMemcpyDeviceToHost));
