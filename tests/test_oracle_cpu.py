@@ -154,3 +154,54 @@ def test_oracle_visible_ents_geometry():
     assert pyoracle.visible_ents(two).tolist() == [True, False]
     two["ents_pos"] = two["ents_pos"][::-1].copy()                              # far one drawn first: both pass
     assert pyoracle.visible_ents(two).tolist() == [True, True]
+
+
+def test_polygon_fragments_stay_inside_their_vertex_depth_range():
+    """R6p: the depth plane of a polygon comes from its vertices' window coordinates in binary64, so
+    the 16-bit depth of every fragment lies between the depths of the polygon's nearest and farthest vertex — also for
+    polygons seen edge-on (wall stubs a fraction of a pixel wide, far floors a pixel high), where the 2DH sums of R6 were
+    off by dozens to hundreds of steps.  K1's occlusion culling relies on it (mw_setup.hip)."""
+    sc, _ = _empty_scene()
+    rng = np.random.default_rng(7)
+    W, H, ch, fov = 160, 120, 1.5, 60.0
+    t = math.tan(math.radians(fov) / 2)
+
+    def z16_of(w):
+        zn, zf = 0.04, 100.0
+        return math.floor((0.5 * ((zf + zn) / (zf - zn) - 2 * zf * zn / ((zf - zn) * w)) + 0.5) * 65535 + 0.5)
+    checked = thin = 0
+    for trial in range(160):
+        d = rng.uniform(-math.pi, math.pi)
+        F2, S2 = np.array([math.cos(d), -math.sin(d)]), np.array([math.sin(d), math.cos(d)])
+        dist = rng.uniform(2, 25)
+        c = np.array([10.0, 10.0]) + F2 * dist + S2 * rng.uniform(-0.5, 0.5) * dist
+        if trial % 2:
+            width, ang = rng.choice([0.25, 0.5, 3.0]), math.radians(10 ** rng.uniform(-2, 1.5))
+            view = (c - 10.0) / np.linalg.norm(c - 10.0)
+            wd = np.array([view[0] * math.cos(ang) - view[1] * math.sin(ang), view[0] * math.sin(ang) + view[1] * math.cos(ang)])
+            A, B = c - wd * width / 2, c + wd * width / 2
+            quad = np.array([[A[0], 0, A[1]], [A[0], 2.74, A[1]], [B[0], 2.74, B[1]], [B[0], 0, B[1]]], np.float32)
+        else:
+            s1, s2, y = rng.choice([0.25, 3.0]), rng.choice([0.25, 3.0]), rng.choice([0.0, 2.74])
+            x0, z0 = np.round(c[0]), np.round(c[1])
+            quad = np.array([[x0, y, z0], [x0 + s1, y, z0], [x0 + s1, y, z0 + s2], [x0, y, z0 + s2]], np.float32)
+        eye, F = np.array([10.0, ch, 10.0]), np.array([F2[0], 0, F2[1]])
+        for order in (quad, quad[::-1].copy()):
+            w = (order.astype(np.float64) - eye) @ F
+            if np.cross(order[1] - order[0], order[2] - order[0]).astype(np.float64) @ (eye - order[0]) <= 0 or (w < 0.2).any():
+                continue
+            sc["polys_v"], sc["polys_uv"] = order[None], np.zeros((1, 4, 2), np.float32)
+            sc["polys_n"], sc["polys_rgb"] = np.array([[0, 1, 0]], np.float32), np.ones((1, 3), np.float32)
+            sc["polys_nv"], sc["polys_tex"] = np.array([4], np.int32), np.array([-1], np.int32)
+            sc["agent_pos"], sc["agent_dir"] = np.array([10.0, 0.0, 10.0]), np.float64(d)
+            sc["cam_height"], sc["cam_fov_y"], sc["cam_pitch"], sc["cam_fwd_disp"] = ch, fov, 0.0, 0.0
+            out = pyoracle.render(sc, W, H, 8, want_prim=True)
+            own = out["prim"][:, :, 0] == 0
+            if not own.any():
+                continue
+            z = out["z16"][own].astype(int)
+            assert z16_of(w.min()) - 1 <= z.min() and z.max() <= z16_of(w.max()) + 1, (trial, z.min(), z.max(), z16_of(w.min()), z16_of(w.max()))
+            checked += 1
+            ys, xs = np.nonzero(own)
+            thin += min(xs.max() - xs.min(), ys.max() - ys.min()) <= 1
+    assert checked >= 40 and thin >= 10, (checked, thin)
