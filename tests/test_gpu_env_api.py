@@ -791,19 +791,23 @@ def test_vec_env_host_rule_families_follow_reference_trajectory(case):
     vec.close()
 
 
-@pytest.mark.parametrize("env_id,cls_name", [("MiniWorld-Hallway-v0", "Hallway"), ("MiniWorld-MazeS3-v0", "MazeS3")])
-def test_spare_world_mode_keeps_the_reference_stream(env_id, cls_name, monkeypatch):
-    """MW_SPARE=1 (off by default): episodes end by copying a pre-generated world into place,
-    a side-stream kernel regenerates it beside the raster pass.  The random stream is consumed in the same order,
+@pytest.mark.parametrize("env_id,cls_name,mes", [("MiniWorld-Hallway-v0", "Hallway", None), ("MiniWorld-MazeS3-v0", "MazeS3", None),
+                                                 ("MiniWorld-MazeS3-v0", "MazeS3", 2), ("MiniWorld-Maze-v0", "Maze", 3)])
+def test_spare_world_mode_keeps_the_reference_stream(env_id, cls_name, mes, monkeypatch):
+    """MW_SPARE=1 (the default of small scenes and of the Maze): episodes end by copying a pre-generated
+    world into place; blocks appended to K1's grid — for the Maze a kernel on the side stream — regenerate it.  The random stream is consumed in the same order,
     so explicit resets and auto-resets still produce the reference's worlds."""
     import torch
     from miniworld_amd import envs
     from miniworld_amd.vec_env import MiniWorldVecEnv
     monkeypatch.setenv("MW_SPARE", "1")
-    n, s = 48, 300
-    vec = MiniWorldVecEnv(env_id, n, seed=s)
+    n, s = (48 if mes is None else 16), 300
+    # mes: episodes of 2 - 3 steps — a Maze env then needs its next spare while the side stream's refill kernel is still
+    # on the last one (or has not started): the wait / regenerate-inline branches of the refill_mask protocol
+    kw = {} if mes is None else {"max_episode_steps": mes}
+    vec = MiniWorldVecEnv(env_id, n, seed=s, **kw)
     vec.reset()
-    hosts = [getattr(envs, cls_name)(host_only=True) for _ in range(n)]
+    hosts = [getattr(envs, cls_name)(host_only=True, **kw) for _ in range(n)]
     for i, h in enumerate(hosts):
         h.reset(seed=s + i)
     st = vec.engine.get_state()
@@ -828,7 +832,7 @@ def test_spare_world_mode_keeps_the_reference_stream(env_id, cls_name, monkeypat
                 hosts[i].reset()
                 episodes[i] += 1
                 _assert_same_world(vec, st, i, hosts[i], f"auto-reset at step {t} (episode {episodes[i]})")
-        if episodes.max() >= 5 and (episodes > 2).sum() > n // 4:
+        if episodes.max() >= (5 if mes is None else 16) and (episodes > 2).sum() > n // 4:
             break
     assert (episodes > 2).any()
     vec.engine.check()
