@@ -786,8 +786,9 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
             for (int j = 0; j < n; ++j) rank += s_zmin[j] < key ? 1 : 0;
             if ((int)threadIdx.x < n) ord[1 + rank] = (uint16_t)(key & 0xFFFFull);
             if (writer) ord[0] = 1;
-        } else if (n <= MW_SORT_CAP) {
-            // bitonic sort of the packed (bound, index) keys in LDS by the 64 lanes of the wave
+        } else if (n <= MW_SORT_POW2) {
+            // bitonic sort of the packed (bound, index) keys in LDS (more polygons than that in view: no visiting order,
+            // the raster kernel then walks the list as it is)
             int P = 64;
             while (P < n) P <<= 1;
             for (int i = n + (int)threadIdx.x; i < P; i += 64 * KW) s_zmin[i] = ~0ull;

@@ -11,7 +11,9 @@
 #ifndef MW_SORT_VIS
 #define MW_SORT_VIS 0       // 1: also emit the depth-sorted visiting order of big scenes (mw_setup_sort*.hip)
 #endif
-#define MW_SORT_CAP 768     // polygons sorted per env (their packed sort keys sit in 6 KiB of LDS)
+#define MW_SORT_CAP 768     // visible polygons listed per env in LDS (their packed sort keys sit in 6 KiB)
+#define MW_SORT_POW2 512    // ... and sorted: the bitonic network pads to a power of two, the largest one inside the key buffer
+static_assert(MW_SORT_POW2 <= MW_SORT_CAP && 2 * MW_SORT_POW2 > MW_SORT_CAP && (MW_SORT_POW2 & (MW_SORT_POW2 - 1)) == 0, "MW_SORT_POW2");
 
 namespace {
 

@@ -958,15 +958,21 @@ def test_occlusion_culling_never_changes_a_frame(env_id, kw, monkeypatch):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("rows,cols", [(6, 6), (8, 8), (11, 11)])
-def test_big_host_built_worlds_match_the_oracle(rows, cols):
-    """Every branch of the big-scene K1 (mw_setup.hip): polygons cached in LDS or not (more than 512), records written
-    from the visible list or in place (max_visible above MW_SORT_CAP), rank sort / bitonic sort / no visiting order —
-    a grid of rooms joined by door-height and full-height openings, built through the host API, seen from several poses."""
+@pytest.mark.parametrize("rows,open_plan,occlusion", [(6, False, "1"), (6, False, "0"), (8, False, "1"), (11, False, "1"),
+                                                      (6, True, "1"), (9, True, "1"), (11, True, "1")])
+def test_big_host_built_worlds_match_the_oracle(rows, open_plan, occlusion, monkeypatch):
+    """Every branch of the big-scene K1 (mw_setup.hip): polygons cached in LDS or not (more than 512), occlusion culling
+    or none, records written from the visible list or in place (max_visible above MW_SORT_CAP), rank sort (up to 256
+    listed primitives), bitonic sort (up to 512), no visiting order (more) — grids of rooms built through the host API:
+    joined by doors (lists of 32 - 255 primitives, tools/debug/grid_nvis.py) or open-plan and seen along the diagonal from a
+    corner (6 x 6: 250 - 380; 9 x 9: 400 - 840; 11 x 11: up to 1250)."""
+    import math
     import pyoracle
     from miniworld_amd.entity import Box
     from miniworld_amd.miniworld import MiniWorldEnv
     from miniworld_amd.scene import scene_from_env
+    monkeypatch.setenv("MW_OCCLUSION", occlusion)
+    cols = rows
 
     class Grid(MiniWorldEnv):
         def __init__(self, **kwargs):
@@ -977,6 +983,12 @@ def test_big_host_built_worlds_match_the_oracle(rows, cols):
                      for j in range(rows)]
             for j in range(rows):
                 for i in range(cols):
+                    if open_plan:
+                        if i + 1 < cols:
+                            self.connect_rooms(rooms[j][i], rooms[j][i + 1], min_z=3.25 * j + 0.1, max_z=3.25 * j + 2.9)
+                        if j + 1 < rows:
+                            self.connect_rooms(rooms[j][i], rooms[j + 1][i], min_x=3.25 * i + 0.1, max_x=3.25 * i + 2.9)
+                        continue
                     if i + 1 < cols and (i + j) % 3 != 0:
                         self.connect_rooms(rooms[j][i], rooms[j][i + 1], min_z=3.25 * j + 0.5, max_z=3.25 * j + 2.5,
                                            **({"max_y": 2.2} if (i + j) % 2 else {}))
@@ -984,14 +996,17 @@ def test_big_host_built_worlds_match_the_oracle(rows, cols):
                         self.connect_rooms(rooms[j][i], rooms[j + 1][i], min_x=3.25 * i + 0.75, max_x=3.25 * i + 2.25,
                                            **({"max_y": 2.2} if (i + j) % 2 == 0 else {}))
             self.box = self.place_entity(Box(color="red"))
-            self.place_agent()
+            if open_plan:
+                self.place_agent(pos=np.array([0.6, 0.0, 0.6]), dir=-math.pi / 4)
+            else:
+                self.place_agent()
 
     env = Grid()
     env.reset(seed=3)
     n_polys = len(scene_from_env(env)["polys_nv"])
-    assert n_polys > {6: 250, 8: 512, 11: 768}[rows], n_polys
+    assert n_polys > {6: 250, 8: 512, 9: 768, 11: 768}[rows], n_polys
     g = np.random.default_rng(rows)
-    for t in range(24):
+    for t in range(16 if open_plan else 24):
         o, *_ = env.step(int(g.choice([0, 1, 2, 2, 2])))
         want = pyoracle.render(scene_from_env(env))["rgb"]
         assert np.array_equal(o, want), (rows, t, int((o != want).any(-1).sum()))
