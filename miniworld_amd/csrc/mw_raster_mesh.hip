@@ -88,10 +88,17 @@ __device__ inline int tri_sorted(const TileCtx &cx, const MeshEnt &e, int i)
     return (int)__float_as_uint(cx.mesh_pos[(size_t)(e.first + i) * MW_MESH_POS_STRIDE + 9]);
 }
 
-// world-space vertices of triangle `tri` (drawing order) of mesh entity e (R11: pos + scale * R_y(dir) * v)
-__device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, int tri, float halfw, float halfh, HV h[3])
+// object-space vertices of triangle `tri` (drawing order) of mesh entity e
+__device__ inline void tri_load(const TileCtx &cx, const MeshEnt &e, int tri, float (&p)[9])
 {
-    const float *p = cx.mesh_pos + (size_t)(e.first + tri) * MW_MESH_POS_STRIDE;
+    const float *src = cx.mesh_pos + (size_t)(e.first + tri) * MW_MESH_POS_STRIDE;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) p[k] = src[k];
+}
+
+// homogeneous image-space vertices from the object-space ones (R11: pos + scale * R_y(dir) * v)
+__device__ inline void tri_verts(const TileCtx &cx, const MeshEnt &e, const float (&p)[9], float halfw, float halfh, HV h[3])
+{
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const float lx = p[k * 3 + 0], ly = p[k * 3 + 1], lz = p[k * 3 + 2];
@@ -108,7 +115,9 @@ __device__ inline void mesh_tri_fragment(const TileCtx &cx, const MeshEnt &e, in
 {
     const float halfw = (float)cx.W * 0.5f, halfh = (float)cx.H * 0.5f;
     HV h[3];
-    tri_verts(cx, e, tri, halfw, halfh, h);
+    float pos[9];
+    tri_load(cx, e, tri, pos);
+    tri_verts(cx, e, pos, halfw, halfh, h);
     float ga[3], gb[3], gc[3];
     edge_coef(h[1], h[2], ga[0], gb[0], gc[0]);
     edge_coef(h[2], h[0], ga[1], gb[1], gc[1]);
@@ -200,12 +209,12 @@ __device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc,
 
 // rasterise one mesh triangle into the LDS key buffer (one lane per triangle)
 template <int S>
-__device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, uint32_t *keys)
+__device__ inline void raster_tri(const TileCtx &cx, const MeshEnt &e, int tri, const float (&pos)[9], uint32_t *keys)
 {
     const int W = cx.W, H = cx.H;
     const float halfw = (float)W * 0.5f, halfh = (float)H * 0.5f;
     HV h[3];
-    tri_verts(cx, e, tri, halfw, halfh, h);
+    tri_verts(cx, e, pos, halfw, halfh, h);
     float ga[3], gb[3], gc[3];
     edge_coef(h[1], h[2], ga[0], gb[0], gc[0]);
     edge_coef(h[2], h[0], ga[1], gb[1], gc[1]);
@@ -360,7 +369,22 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
     const int n_mesh = (!HOT && (dbg & 8)) ? 0 : __float_as_int(hdr[3]);       // MW_DEBUG_FLAGS bit 3: perf experiments only
     for (int j = 0; j < n_mesh; ++j) {
         const MeshEnt e = load_ment(cx.ment, j);
-        for (int t = tid; t < e.ntris; t += 1024) raster_tri<8>(cx, e, tri_sorted(cx, e, t), keys);
+        // two loads deep: the index of the triangle after next and the vertices of the next one are in flight while this
+        // one is rasterised (the kernel waits more than it computes: 4 waves per SIMD, two dependent gathers per triangle)
+        int t = tid;
+        int tri = t < e.ntris ? tri_sorted(cx, e, t) : 0;
+        int tri_n = t + 1024 < e.ntris ? tri_sorted(cx, e, t + 1024) : 0;
+        float pos[9];
+        tri_load(cx, e, tri, pos);
+        while (t < e.ntris) {
+            const int tri_nn = t + 2048 < e.ntris ? tri_sorted(cx, e, t + 2048) : 0;
+            float pos_n[9];
+            tri_load(cx, e, tri_n, pos_n);
+            raster_tri<8>(cx, e, tri, pos, keys);
+            t += 1024; tri = tri_n; tri_n = tri_nn;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) pos[k] = pos_n[k];
+        }
     }
     __syncthreads();
     const unsigned long long t_mesh = prof ? __builtin_readcyclecounter() : 0ull;
@@ -415,7 +439,12 @@ __device__ inline void view_mesh_body(int W, int H, const float *hdr, const floa
     const int stride = gridDim.x * blockDim.x;
     for (int j = 0; j < n_mesh; ++j) {
         const MeshEnt e = load_ment(cx.ment, j);
-        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e.ntris; t += stride) raster_tri<S>(cx, e, tri_sorted(cx, e, t), keys);
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e.ntris; t += stride) {
+            const int tri = tri_sorted(cx, e, t);
+            float pos[9];
+            tri_load(cx, e, tri, pos);
+            raster_tri<S>(cx, e, tri, pos, keys);
+        }
     }
 }
 
