@@ -91,9 +91,12 @@ __device__ inline int tri_sorted(const TileCtx &cx, const MeshEnt &e, int i)
 // object-space vertices of triangle `tri` (drawing order) of mesh entity e
 __device__ inline void tri_load(const TileCtx &cx, const MeshEnt &e, int tri, float (&p)[9])
 {
-    const float *src = cx.mesh_pos + (size_t)(e.first + tri) * MW_MESH_POS_STRIDE;
+    // (a triangle's 10 words are 8-byte aligned: four 8-byte loads and one 4-byte load instead of nine)
+    static_assert(MW_MESH_POS_STRIDE % 2 == 0, "8-byte aligned triangles");
+    const float2 *src = reinterpret_cast<const float2 *>(cx.mesh_pos + (size_t)(e.first + tri) * MW_MESH_POS_STRIDE);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) p[k] = src[k];
+    for (int k = 0; k < 4; ++k) { const float2 v = src[k]; p[2 * k] = v.x; p[2 * k + 1] = v.y; }
+    p[8] = reinterpret_cast<const float *>(src)[8];
 }
 
 // homogeneous image-space vertices from the object-space ones (R11: pos + scale * R_y(dir) * v)
