@@ -38,9 +38,13 @@ typedef struct {            /* one polygon of display list 1: a room polygon (mi
     int32_t nv;             /* 3 or 4 vertices; | MWO_POLY_ENTITY for a quad of a static entity */
     int32_t tex;            /* index into scene.tex, or -1 (untextured) */
     float rgb[3];           /* glColor3f: 1,1,1 for rooms and frame fronts, 0,0,0 for frame borders */
+    float xf[4];            /* MWO_POLY_XF: glTranslatef(x, y, z), glRotatef(angle, 0, 1, 0) in front of the quad
+                             * (entity.py:205-207, 318-320); v, n are then the object-space glVertex3f / glNormal3f */
 } mwo_poly;
 
-#define MWO_POLY_ENTITY 0x100
+#define MWO_POLY_ENTITY 0x100   /* a quad of a static ImageFrame / TextFrame                           */
+#define MWO_POLY_XF     0x200   /* drawn under its own model transform (xf)                             */
+#define MWO_POLY_QUAD   0x400   /* issued inside glBegin(GL_QUADS) (walls, frames); otherwise GL_POLYGON */
 
 /* FRAME: an ImageFrame / TextFrame; its quads are in the polygon list, it is an entity only for
  * collisions (radius 0) and for get_visible_ents */

@@ -42,7 +42,7 @@ def build(force: bool = False) -> str:
 
 class _Poly(C.Structure):
     _fields_ = [("v", C.c_float * 12), ("uv", C.c_float * 8), ("n", C.c_float * 3),
-                ("nv", C.c_int32), ("tex", C.c_int32), ("rgb", C.c_float * 3)]
+                ("nv", C.c_int32), ("tex", C.c_int32), ("rgb", C.c_float * 3), ("xf", C.c_float * 4)]
 
 
 class _Ent(C.Structure):
@@ -189,6 +189,8 @@ def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None
         polys[i].nv = int(scene["polys_nv"][i])
         polys[i].tex = int(scene["polys_tex"][i])
         polys[i].rgb[:] = prgb[i].tolist()
+        if "polys_xf" in scene:
+            polys[i].xf[:] = np.asarray(scene["polys_xf"][i], np.float32).tolist()
     tex_names = [str(t) for t in scene["tex_names"]]
     texs = (_Tex * max(len(tex_names), 1))()
     keep = []

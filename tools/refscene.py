@@ -27,7 +27,7 @@ def _tex_variant(tex):
 
 def scene_from_ref_env(env):
     import math
-    polys_v, polys_uv, polys_n, polys_nv, polys_tex, polys_rgb = [], [], [], [], [], []
+    polys_v, polys_uv, polys_n, polys_nv, polys_tex, polys_rgb, polys_xf = [], [], [], [], [], [], []
     tex_names = []
 
     def tex_id(tex):
@@ -36,7 +36,7 @@ def scene_from_ref_env(env):
             tex_names.append(name)
         return tex_names.index(name)
 
-    def add_poly(verts, texcs, normal, tex, rgb=(1, 1, 1), flags=0):
+    def add_poly(verts, texcs, normal, tex, rgb=(1, 1, 1), flags=0, xf=(0, 0, 0, 0)):
         n = len(verts)
         assert n in (3, 4), "n-gon rooms are not part of the BASELINE configs"
         v = np.zeros((4, 3), np.float32)
@@ -49,6 +49,7 @@ def scene_from_ref_env(env):
         polys_nv.append(n | flags)
         polys_tex.append(tex_id(tex) if tex is not None else -1)
         polys_rgb.append(np.asarray(rgb, np.float64).astype(np.float32))
+        polys_xf.append(np.asarray(xf, np.float64).astype(np.float32))   # glTranslatef / glRotatef arguments
 
     for room in env.rooms:                       # Room._render, miniworld.py:401-434
         add_poly(room.floor_verts, room.floor_texcs, (0, 1, 0), room.floor_tex)
@@ -56,13 +57,13 @@ def scene_from_ref_env(env):
             add_poly(room.ceil_verts, room.ceil_texcs, (0, -1, 0), room.ceil_tex)
         for q in range(room.wall_verts.shape[0] // 4):
             sl = slice(4 * q, 4 * q + 4)
-            add_poly(room.wall_verts[sl], room.wall_texcs[sl], room.wall_norms[4 * q], room.wall_tex)
+            add_poly(room.wall_verts[sl], room.wall_texcs[sl], room.wall_norms[4 * q], room.wall_tex, flags=0x400)
 
     kinds, meshes, pos, dirs, sizes, colors, scales, radii, heights, statics = ([] for _ in range(10))
     mesh_names, mesh_tex = [], []
     ents = [e for e in env.entities if e is not env.agent]
     # static ImageFrame / TextFrame quads (entity.py:193-259, 303-383; drawn into display list 1,
-    # miniworld.py:1058-1060): T(pos) R_y(dir) applied in double, rounded once for glVertex3f / glNormal3f
+    # miniworld.py:1058-1060) in object space, with the arguments of the glTranslatef / glRotatef in front of them
     for e in ents:
         cname = type(e).__name__
         if cname not in ("ImageFrame", "TextFrame"):
@@ -79,12 +80,9 @@ def scene_from_ref_env(env):
         quads.append(([(+sx, +hy, +hz), (0, +hy, +hz), (0, -hy, +hz), (+sx, -hy, +hz)], uv0, (0, 0, 1), black, None))
         quads.append(([(+sx, +hy, +hz), (+sx, +hy, -hz), (0, +hy, -hz), (0, +hy, +hz)], uv0, (0, 1, 0), black, None))
         quads.append(([(+sx, -hy, -hz), (+sx, -hy, +hz), (0, -hy, +hz), (0, -hy, -hz)], uv0, (0, -1, 0), black, None))
-        c, s_ = math.cos(e.dir), math.sin(e.dir)
-        px, py, pz = (float(x) for x in e.pos)
+        xf = (float(e.pos[0]), float(e.pos[1]), float(e.pos[2]), e.dir * (180 / math.pi))
         for verts, texcs, normal, rgb, tex in quads:
-            world = [(px + c * lx + s_ * lz, py + ly, pz + c * lz - s_ * lx) for lx, ly, lz in verts]
-            nx, ny, nz = normal
-            add_poly(world, texcs, (c * nx + s_ * nz, ny, c * nz - s_ * nx), tex, rgb, 0x100)
+            add_poly(verts, texcs, normal, tex, rgb, 0x100 | 0x200 | 0x400, xf)
     for e in ents:
         cname = type(e).__name__
         pos.append(np.array(e.pos, np.float64))
@@ -124,6 +122,7 @@ def scene_from_ref_env(env):
         "polys_nv": np.array(polys_nv, np.int32),
         "polys_tex": np.array(polys_tex, np.int32),
         "polys_rgb": np.array(polys_rgb, np.float32).reshape(-1, 3),
+        "polys_xf": np.array(polys_xf, np.float32).reshape(-1, 4),
         "tex_names": np.array(tex_names),
         "ents_kind": np.array(kinds, np.int32),
         "ents_mesh": np.array(meshes, np.int32),
