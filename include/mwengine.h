@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define MW_ABI_VERSION 3
+#define MW_ABI_VERSION 4
 
 enum {
     MW_OK = 0,
@@ -132,19 +132,23 @@ typedef struct {
     int32_t rng_mode;           /* MW_RNG_* stream of the device generators */
 } mw_config;
 
-#define MW_POLY_ENTITY 0x100
+#define MW_POLY_ENTITY 0x100     /* a quad of a static ImageFrame / TextFrame: not drawn by mw_visible_ents            */
+#define MW_POLY_XF     0x200     /* drawn under its own model transform: glTranslatef(xf[0..2]), glRotatef(xf[3], 0, 1, 0) */
+#define MW_POLY_QUAD   0x400     /* issued inside glBegin(GL_QUADS) (walls, frames); otherwise GL_POLYGON (floor, ceiling) */
 
 /* One static polygon exactly as it is fed to GL inside display list 1: a room polygon of Room._render
- * (miniworld.py:401-434, colour 1,1,1) or a quad of a static ImageFrame / TextFrame (entity.py:193-259,
- * 303-383: textured front in 1,1,1, border in 0,0,0), already in world coordinates. */
+ * (miniworld.py:401-434, colour 1,1,1; floor and ceiling are GL_POLYGONs, walls GL_QUADS — the driver splits the two
+ * kinds into different triangle pairs) or a quad of a static ImageFrame / TextFrame (entity.py:193-259, 303-383:
+ * textured front in 1,1,1, border in 0,0,0) in the frame's OBJECT space with the arguments of the glTranslatef /
+ * glRotatef in front of it: the engine composes the modelview like the GL matrix stack does. */
 typedef struct {
     float v[4][3];              /* glVertex3f   */
     float uv[4][2];             /* glTexCoord2f */
     float n[3];                 /* glNormal3f   */
-    int32_t nv;                 /* 3 or 4; | MW_POLY_ENTITY for a quad of a static entity (not drawn by mw_visible_ents,
-                                 * which renders rooms only: miniworld.py:1291-1293) */
+    int32_t nv;                 /* 3 or 4, | MW_POLY_* flags */
     int32_t tex;                /* texture id from mw_upload_texture, -1 = untextured */
     float rgb[3];               /* glColor3f    */
+    float xf[4];                /* MW_POLY_XF: translation x, y, z and rotation angle in degrees about +y (entity.py:205-207) */
 } mw_poly;
 
 /* Host view of the world state of `count` consecutive envs; any pointer may be NULL

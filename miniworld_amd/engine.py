@@ -19,6 +19,8 @@ LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
 ABI_VERSION = 3
 ENT_NONE, ENT_BOX, ENT_MESH, ENT_FRAME = 0, 1, 2, 3
 POLY_ENTITY = 0x100          # mw_poly.nv flag: quad of a static entity, not a room
+POLY_XF = 0x200              # ... drawn under its own glTranslatef / glRotatef (mw_poly.xf)
+POLY_QUAD = 0x400            # ... issued inside glBegin(GL_QUADS) (walls, frames); otherwise GL_POLYGON
 TASK_NONE, TASK_GOTO, TASK_PICKUP, TASK_PUTNEXT, TASK_SIDEWALK, TASK_SIGN, TASK_COLLECT = 0, 1, 2, 3, 4, 5, 6
 GEN_NONE, GEN_HALLWAY, GEN_ONEROOM, GEN_PICKUP, GEN_MAZE, GEN_PROGRAM = 0, 1, 2, 3, 4, 5
 OP_COIN, OP_DRAW_DIR, OP_PLACE, OP_FIXED, OP_BOX_SIZE, OP_COLOR, OP_APPEND = 1, 2, 3, 4, 5, 6, 7
@@ -67,12 +69,12 @@ class MwConfig(C.Structure):
 
 class MwPoly(C.Structure):
     _fields_ = [("v", C.c_float * 12), ("uv", C.c_float * 8), ("n", C.c_float * 3),
-                ("nv", C.c_int32), ("tex", C.c_int32), ("rgb", C.c_float * 3)]
+                ("nv", C.c_int32), ("tex", C.c_int32), ("rgb", C.c_float * 3), ("xf", C.c_float * 4)]
 
 
 POLY_DTYPE = np.dtype([("v", np.float32, (4, 3)), ("uv", np.float32, (4, 2)), ("n", np.float32, (3,)),
-                       ("nv", np.int32), ("tex", np.int32), ("rgb", np.float32, (3,))])
-assert POLY_DTYPE.itemsize == C.sizeof(MwPoly) == 112
+                       ("nv", np.int32), ("tex", np.int32), ("rgb", np.float32, (3,)), ("xf", np.float32, (4,))])
+assert POLY_DTYPE.itemsize == C.sizeof(MwPoly) == 128
 
 
 class MwProgRoom(C.Structure):

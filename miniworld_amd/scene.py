@@ -28,9 +28,9 @@ def scene_from_env(env) -> dict:
             tex_names.append(tex.variant)
         return tex_names.index(tex.variant)
 
-    pv, puv, pn, pnv, ptex, prgb = [], [], [], [], [], []
+    pv, puv, pn, pnv, ptex, prgb, pxf = [], [], [], [], [], [], []
 
-    def add_poly(verts, texcs, normal, tex, rgb=(1, 1, 1), flags=0):
+    def add_poly(verts, texcs, normal, tex, rgb=(1, 1, 1), flags=0, xf=(0, 0, 0, 0)):
         n = len(verts)
         if n not in (3, 4):
             raise NotImplementedError("room outlines with more than 4 corners are not supported yet")
@@ -38,7 +38,7 @@ def scene_from_env(env) -> dict:
         uv = np.zeros((4, 2), np.float32)
         v[:n], uv[:n] = _f32(verts), _f32(texcs)
         pv.append(v); puv.append(uv); pn.append(_f32(normal)); pnv.append(n | flags)
-        ptex.append(tex_id(tex) if tex is not None else -1); prgb.append(_f32(rgb))
+        ptex.append(tex_id(tex) if tex is not None else -1); prgb.append(_f32(rgb)); pxf.append(_f32(xf))
 
     for room in env.rooms:       # draw order of Room._render: floor, ceiling, walls
         add_poly(room.floor_verts, room.floor_texcs, (0, 1, 0), room.floor_tex)
@@ -46,21 +46,18 @@ def scene_from_env(env) -> dict:
             add_poly(room.ceil_verts, room.ceil_texcs, (0, -1, 0), room.ceil_tex)
         for q in range(room.wall_verts.shape[0] // 4):
             sl = slice(4 * q, 4 * q + 4)
-            add_poly(room.wall_verts[sl], room.wall_texcs[sl], room.wall_norms[4 * q], room.wall_tex)
+            add_poly(room.wall_verts[sl], room.wall_texcs[sl], room.wall_norms[4 * q], room.wall_tex, flags=eng.POLY_QUAD)
 
     ents = [e for e in env.entities if e is not env.agent]
     E = len(ents)
-    # static ImageFrame / TextFrame quads are part of display list 1 (miniworld.py:1058-1060): appended
-    # to the polygon list in world coordinates, T(pos) R_y(dir) applied in double and rounded once
-    # to what glVertex3f / glNormal3f would receive
+    # static ImageFrame / TextFrame quads are part of display list 1 (miniworld.py:1058-1060): appended to the polygon
+    # list in OBJECT space together with the arguments of the glTranslatef / glRotatef in front of them
+    # (entity.py:205-207, 318-320): the engine composes the modelview the way the GL matrix stack does
     for e in ents:
         if isinstance(e, _Frame):
-            c, s_ = math.cos(e.dir), math.sin(e.dir)
-            px, py, pz = (float(x) for x in e.pos)
+            xf = (float(e.pos[0]), float(e.pos[1]), float(e.pos[2]), e.dir * (180 / math.pi))
             for verts, texcs, normal, rgb, tex in e.quads():
-                world = [(px + c * lx + s_ * lz, py + ly, pz + c * lz - s_ * lx) for lx, ly, lz in verts]
-                nx, ny, nz = normal
-                add_poly(world, texcs, (c * nx + s_ * nz, ny, c * nz - s_ * nx), tex, rgb, eng.POLY_ENTITY)
+                add_poly(verts, texcs, normal, tex, rgb, eng.POLY_ENTITY | eng.POLY_XF | eng.POLY_QUAD, xf)
     mesh_names: list = []
     mesh_tex: list = []
     kind = np.zeros(E, np.int32)
@@ -92,6 +89,7 @@ def scene_from_env(env) -> dict:
         "polys_nv": np.array(pnv, np.int32),
         "polys_tex": np.array(ptex, np.int32),
         "polys_rgb": np.array(prgb, np.float32).reshape(-1, 3),
+        "polys_xf": np.array(pxf, np.float32).reshape(-1, 4),
         "tex_names": np.array(tex_names),
         "ents_kind": kind,
         "ents_mesh": mesh,
@@ -155,6 +153,8 @@ def polys_array(scene: dict, tex_map=None) -> np.ndarray:
     polys["v"], polys["uv"], polys["n"] = scene["polys_v"], scene["polys_uv"], scene["polys_n"]
     polys["nv"] = scene["polys_nv"]
     polys["rgb"] = scene["polys_rgb"] if "polys_rgb" in scene else 1.0
+    if "polys_xf" in scene:
+        polys["xf"] = scene["polys_xf"]
     polys["tex"] = scene["polys_tex"] if tex_map is None else [(tex_map[int(t)] if t >= 0 else -1) for t in scene["polys_tex"]]
     return polys
 

@@ -58,6 +58,8 @@ typedef struct {            /* entity.py:409-432 (Box.render), :150-161 (MeshEnt
     double size[3];         /* Box: sx, sy, sz */
     double color[3];        /* Box: color_vec (already clipped to [0,1]) */
     double scale;           /* MeshEnt.scale */
+    int32_t is_static;      /* drawn inside display list 1 (miniworld.py:1058-1060) rather than in immediate mode */
+    int32_t pad;
 } mwo_ent;
 
 typedef struct {            /* opengl.py:148-184 (Texture.load): RGB8, rows bottom-up   */

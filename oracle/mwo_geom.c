@@ -264,6 +264,7 @@ typedef struct {
     mwo_mat4 mv, mvp;
     unsigned flags;
     float light[3];             /* STATE_LIGHT_POSITION_NORMALIZED in OBJECT space (see make_xform) */
+    float nscale;               /* STATE_NORMAL_SCALE: _ModelViewInvScale                            */
 } xform;
 
 #define SQf(x) ((x) * (x))
@@ -356,6 +357,15 @@ static void make_xform(const glstate *st, const mwo_mat4 *mv, unsigned flags, xf
         q[0] *= len; q[1] *= len; q[2] *= len;
     }
     memcpy(x->light, q, sizeof q);
+    /* update_modelview_scale (light.c): a modelview that is not length preserving rescales the normals in the vertex
+     * program (ffvertex_prog.c get_transformed_normal: MUL normal, STATE_NORMAL_SCALE) by the length of the
+     * inverse's third row — 1 / scale for MeshEnt's glScalef, what the inverse transpose does to a normal */
+    x->nscale = 1.0f;
+    if (flags & (MF_UNIFORM_SCALE | MF_GENERAL)) {
+        float f = (inv[2] * inv[2] + inv[6] * inv[6]) + inv[10] * inv[10];
+        if (f < 1e-12f) f = 1.0f;
+        x->nscale = sqrtf(f);
+    }
 }
 
 /* one vertex through the fixed-function vertex program and the shader's viewport code */
@@ -366,7 +376,8 @@ static void shade_vertex(const glstate *st, const xform *x, const float p[3], co
     /* position: MUL, MAD, MAD, MAD by the columns of the MVP matrix, unfused */
     for (int i = 0; i < 4; ++i) v->clip[i] = ((p[0] * m[i] + p[1] * m[4 + i]) + p[2] * m[8 + i]) + m[12 + i];
     if (st->lighting) {
-        float dot = (n[0] * x->light[0] + n[1] * x->light[1]) + n[2] * x->light[2];
+        float ns[3] = {n[0] * x->nscale, n[1] * x->nscale, n[2] * x->nscale};
+        float dot = (ns[0] * x->light[0] + ns[1] * x->light[1]) + ns[2] * x->light[2];
         float d = dot > 0.0f ? dot : 0.0f;
         for (int i = 0; i < 3; ++i) {
             float scene = 0.2f * c[i];                       /* GL_LIGHT_MODEL_AMBIENT * material ambient */
@@ -501,8 +512,15 @@ static int clip_and_emit(const glstate *st, mwo_trilist *l, const mwo_vert *v0, 
     return 0;
 }
 
-/* GL primitive -> triangles in the order the draw module produces them */
-enum { PRIM_TRIANGLES, PRIM_QUADS, PRIM_POLYGON };
+/* GL primitive -> triangles.  A polygon is always the fan (1,2,0) (2,3,0).  A quad is split in one of two ways:
+ *   (0,1,3) (1,2,3)   inside display list 1 (vbo_save converts the list to indexed triangles: rooms, frames, static
+ *                     entities), and for an immediate-mode draw call (one glBegin / glEnd: a drawBox) of which ANY vertex
+ *                     lies outside the view frustum — the whole call then runs through the draw module's pipeline
+ *                     (draw_pipe.c decomposes, clips);
+ *   (0,1,2) (0,2,3)   for an immediate-mode draw call without a clipped vertex (llvmpipe's own vertex-buffer path,
+ *                     lp_setup_vbuf.c).
+ * The union is the same quad; the halves differ, and each half has its own plane coefficients. */
+enum { PRIM_TRIANGLES, PRIM_QUADS, PRIM_POLYGON, PRIM_IMMEDIATE = 8 };
 
 static int draw_prim(const glstate *st, const xform *x, mwo_trilist *l, int mode, int nv, const float (*pos)[3],
                      const float (*nrm)[3], const float (*col)[3], const float (*uv)[2], int tex, int draw)
@@ -510,8 +528,12 @@ static int draw_prim(const glstate *st, const xform *x, mwo_trilist *l, int mode
     mwo_vert v[4];
     if (nv > 4) return -3;
     for (int k = 0; k < nv; ++k) shade_vertex(st, x, pos[k], nrm[k], col[k], uv ? uv[k] : NULL, &v[k]);
-    if (mode == PRIM_TRIANGLES) return clip_and_emit(st, l, &v[0], &v[1], &v[2], tex, draw);
+    if ((mode & 7) == PRIM_TRIANGLES) return clip_and_emit(st, l, &v[0], &v[1], &v[2], tex, draw);
     if (nv == 3) return clip_and_emit(st, l, &v[1], &v[2], &v[0], tex, draw);       /* GL_POLYGON of three vertices */
+    if ((mode & 7) == PRIM_QUADS && (mode & PRIM_IMMEDIATE)) {
+        if (clip_and_emit(st, l, &v[0], &v[1], &v[2], tex, draw)) return -1;
+        return clip_and_emit(st, l, &v[0], &v[2], &v[3], tex, draw);
+    }
     if (mode == PRIM_QUADS) {
         if (clip_and_emit(st, l, &v[0], &v[1], &v[3], tex, draw)) return -1;
         return clip_and_emit(st, l, &v[1], &v[2], &v[3], tex, draw);
@@ -533,8 +555,18 @@ static const int BOXV[6][4][3] = {
 static const float BOXN[6][3] = {{0, 0, 1}, {0, 0, -1}, {-1, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, -1, 0}};
 
 static int draw_box(const glstate *st, const xform *x, mwo_trilist *l, const float lo[3], const float hi[3],
-                    const float col[3], int *draw)
+                    const float col[3], int *draw, int immediate)
 {
+    if (immediate) {
+        /* one glBegin / glEnd = one draw call: a clipped vertex anywhere sends all six faces through the pipeline */
+        for (int f = 0; f < 6 && immediate; ++f)
+            for (int k = 0; k < 4; ++k) {
+                float p[3] = {BOXV[f][k][0] ? hi[0] : lo[0], BOXV[f][k][1] ? hi[1] : lo[1], BOXV[f][k][2] ? hi[2] : lo[2]};
+                mwo_vert tmp;
+                shade_vertex(st, x, p, BOXN[f], col, NULL, &tmp);
+                if (tmp.clipmask) immediate = 0;
+            }
+    }
     for (int f = 0; f < 6; ++f, ++*draw) {
         float v[4][3], n[4][3], c[4][3];
         for (int k = 0; k < 4; ++k) {
@@ -544,8 +576,8 @@ static int draw_box(const glstate *st, const xform *x, mwo_trilist *l, const flo
             memcpy(n[k], BOXN[f], sizeof n[k]);
             memcpy(c[k], col, sizeof c[k]);
         }
-        int rc = draw_prim(st, x, l, PRIM_QUADS, 4, (const float (*)[3])v, (const float (*)[3])n, (const float (*)[3])c,
-                           NULL, -1, *draw);
+        int rc = draw_prim(st, x, l, PRIM_QUADS | (immediate ? PRIM_IMMEDIATE : 0), 4, (const float (*)[3])v,
+                           (const float (*)[3])n, (const float (*)[3])c, NULL, -1, *draw);
         if (rc) return rc;
     }
     return 0;
@@ -560,7 +592,8 @@ int mwo_geometry(const mwo_scene *sc, int proxies, mwo_trilist *out, int *ent_fi
     unsigned cam_flags = analyse_from_scratch(&st.view);
     make_xform(&st, &st.view, cam_flags, &cam);
     int draw = 0;
-    float stale_n[3] = {0.0f, 1.0f, 0.0f};      /* the GL "current normal" left behind by the last draw */
+    /* the GL "current normal": what the last glNormal3f — immediate mode, or the end of the display list — left */
+    float stale_n[3] = {0.0f, 1.0f, 0.0f};
     static const float white[3] = {1.0f, 1.0f, 1.0f};
     /* display list 1: rooms (miniworld.py:1053-1055), then static entities' quads */
     for (int i = 0; i < sc->n_polys; ++i, ++draw) {
@@ -594,7 +627,7 @@ int mwo_geometry(const mwo_scene *sc, int proxies, mwo_trilist *out, int *ent_fi
             /* drawBox arguments are python doubles and reach GL through glVertex3f (miniworld.py:1303-1311) */
             float lo[3] = {(float)(en->pos[0] - 0.1), (float)en->pos[1], (float)(en->pos[2] - 0.1)};
             float hi[3] = {(float)(en->pos[0] + 0.1), (float)(en->pos[1] + 0.2), (float)(en->pos[2] + 0.1)};
-            int rc = draw_box(&st, &cam, out, lo, hi, white, &draw);
+            int rc = draw_box(&st, &cam, out, lo, hi, white, &draw, 1);
             if (rc) return rc;
             continue;
         }
@@ -608,7 +641,7 @@ int mwo_geometry(const mwo_scene *sc, int proxies, mwo_trilist *out, int *ent_fi
             float lo[3] = {(float)(-en->size[0] / 2), 0.0f, (float)(-en->size[2] / 2)};
             float hi[3] = {(float)(en->size[0] / 2), (float)en->size[1], (float)(en->size[2] / 2)};
             float col[3] = {(float)en->color[0], (float)en->color[1], (float)en->color[2]};
-            int rc = draw_box(&st, &ex, out, lo, hi, col, &draw);
+            int rc = draw_box(&st, &ex, out, lo, hi, col, &draw, !en->is_static);
             if (rc) return rc;
             stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f;
         } else if (en->kind == MWO_ENT_MESH) {
@@ -629,7 +662,7 @@ int mwo_geometry(const mwo_scene *sc, int proxies, mwo_trilist *out, int *ent_fi
                 int rc = draw_prim(&st, &ex, out, PRIM_TRIANGLES, 3, p, n, c, m->tex >= 0 ? uv : NULL, m->tex, draw);
                 if (rc) return rc;
             }
-            if (m->ntris > 0) memcpy(stale_n, &m->nrm[((size_t)(m->ntris - 1) * 3 + 2) * 3], sizeof stale_n);
+            /* glDrawArrays with a normal array leaves the current normal alone */
         }
     }
     if (ent_first) ent_first[sc->n_ents] = out->n;

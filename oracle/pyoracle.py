@@ -48,7 +48,7 @@ class _Poly(C.Structure):
 class _Ent(C.Structure):
     _fields_ = [("kind", C.c_int32), ("mesh", C.c_int32), ("pos", C.c_double * 3),
                 ("dir", C.c_double), ("size", C.c_double * 3), ("color", C.c_double * 3),
-                ("scale", C.c_double)]
+                ("scale", C.c_double), ("is_static", C.c_int32), ("pad", C.c_int32)]
 
 
 class _Tex(C.Structure):
@@ -214,6 +214,7 @@ def pack_scene(scene: dict, width=80, height=60, nsamples=8, meshes: dict | None
         ents[j].size[:] = [float(x) for x in scene["ents_size"][i]]
         ents[j].color[:] = [float(x) for x in scene["ents_color"][i]]
         ents[j].scale = float(scene["ents_scale"][i])
+        ents[j].is_static = stat[i]
     mesh_names = [str(m) for m in scene.get("mesh_names", [])]
     mstructs = (_Mesh * max(len(mesh_names), 1))()
     for i, name in enumerate(mesh_names):

@@ -99,6 +99,8 @@ def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_ran
     polys["v"], polys["uv"], polys["n"] = s0["polys_v"], s0["polys_uv"], s0["polys_n"]
     polys["nv"], polys["tex"] = s0["polys_nv"], s0["polys_tex"]
     polys["rgb"] = s0["polys_rgb"] if "polys_rgb" in s0 else 1.0
+    if "polys_xf" in s0:
+        polys["xf"] = s0["polys_xf"]
     e.set_geometry(-1, polys, s0["wall_segs"])
     from miniworld_amd.scene import upload_scene_meshes
     tex_ids = {str(t): i for i, t in enumerate(s0["tex_names"])}
@@ -187,6 +189,7 @@ def scene_of_vec_env(vec, st, i, row=None):
         polys, segs = vec.engine.get_geometry(i)
         sc["polys_v"], sc["polys_uv"], sc["polys_n"] = polys["v"], polys["uv"], polys["n"]
         sc["polys_nv"], sc["polys_tex"], sc["polys_rgb"] = polys["nv"], polys["tex"], polys["rgb"]
+        sc["polys_xf"] = polys["xf"]
         sc["wall_segs"] = segs
         ids = vec.tex_ids
         sc["tex_names"] = np.array(sorted(ids, key=ids.get))
