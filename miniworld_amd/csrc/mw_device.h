@@ -10,13 +10,15 @@
 #define MW_RASTER_REC 64     // dwords per raster record
 #define MW_SHADE_REC 32      // dwords per shade record (attribute planes, colour, tex, depth plane)
 #define MW_CULL_REC 24       // a[4] b[4] c[4] tmin[4] tmax[4] flags pad[3]
+#define MW_LDS_RECS 48       // triangle records a small-scene raster wave stages in LDS (10.5 KB)
 #define MW_TILE_W 16
 #define MW_TILE_H 4
 #define MW_SKY_PID 0xFFFFu
-#define MW_ENVHDR 288         // floats per env: sky, camera, light, mesh-entity table (K1 -> K2/K3)
+#define MW_ENVHDR 640         // floats per env: sky, light colours, mesh-entity table (geometry kernel -> raster kernels)
 #define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
 #define MW_K3_WAVE_LDS 192     // LDS bytes per wave of the mesh kernel beside the key buffer: its pack buffer
-#define MW_HDR_MESH 32        // first float of the mesh-entity table; 12 floats per entry
+#define MW_HDR_MESH 32        // first float of the mesh-entity table
+#define MW_HDR_MESH_STRIDE 28 // floats per entry: slot, first draw id, triangles, first triangle, texture, normal scale, light[3], mvp[16]
 
 // status bits written by kernels, read by mw_check()
 #define MW_ST_VIS_OVERFLOW 1u
@@ -143,5 +145,6 @@ struct MwArgs {
     // mw_mesh_order_kernel turns them into the order in which the mesh kernel's blocks take the envs
     int32_t *k3_cost;       // [N]
     int32_t *k3_order;      // [N] env ids, heaviest first
+    int32_t *pending_remove; // [N] entity slot that leaves the list after this step's frame (-1 none): written by K1, applied by the geometry kernel
     unsigned long long *k1_prof;   // MW_K1_PROF: [N][8] cycle counters of K1's phases (perf experiments only), else null
 };

@@ -33,6 +33,7 @@ extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int 
                                                      float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                          float *reward, uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_geom_kernel(MwArgs a, int view_flags, int S);
 extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                             int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                             const float *rec_shade, const float *rec_cull, const int32_t *nvis,
@@ -261,21 +262,24 @@ void seed_env(const mw_engine *e, uint64_t *rng, int i, uint64_t seed)
     }
 }
 
-// R8: mip pyramid.  level k+1 dims max(1, floor(n/2)); even axis = 2-tap box, odd
-// axis n = 2d+1 = 3-tap polyphase box with weights (d-i, d, i+1); exact integers, round half up.
-struct Taps { int n; int idx[3]; int w[3]; int total; };
-Taps axis_taps(int n, int i)
+// Mip pyramid as glGenerateMipmap builds it on the reference's driver (llvmpipe: a GL_LINEAR blit of the previous level):
+// destination texel i of dn reads source texels i0, i1 with an 8-bit weight — 24.8 fixed-point coordinate
+// iround((i + 0.5) n / dn * 256) - 128, CLAMP_TO_EDGE; 2i, 2i + 1 with weight 128 on an even axis — and
+// lerp a + ((w (b - a) + 128) >> 8), x first, then y.  tests/golden/gl_meta.npz holds the driver's own levels (checksums).
+struct Taps { int i0, i1, w; };
+Taps axis_taps(int n, int dn, int i)
 {
-    Taps t{};
-    if (n == 1) { t.n = 1; t.idx[0] = 0; t.w[0] = 1; t.total = 1; return t; }
-    if ((n & 1) == 0) { t.n = 2; t.idx[0] = 2 * i; t.idx[1] = 2 * i + 1; t.w[0] = t.w[1] = 1; t.total = 2; return t; }
-    const int d = n / 2;
-    t.n = 3;
-    for (int k = 0; k < 3; ++k) t.idx[k] = 2 * i + k;
-    t.w[0] = d - i; t.w[1] = d; t.w[2] = i + 1;
-    t.total = n;
+    Taps t{0, 0, 0};
+    if (n == 1) return t;
+    const double sc = ((double)i + 0.5) * (double)n / (double)dn * 256.0;
+    const long fixed = lrint(sc) - 128;         // round half to even
+    const long ip = fixed >> 8;
+    t.w = (int)(fixed & 255);
+    t.i0 = ip < 0 ? 0 : (ip > n - 1 ? n - 1 : (int)ip);
+    t.i1 = ip + 1 < 0 ? 0 : (ip + 1 > n - 1 ? n - 1 : (int)(ip + 1));
     return t;
 }
+inline int lerp8(int a, int b, int w) { return a + ((w * (b - a) + 128) >> 8); }
 
 void build_pyramid(const uint8_t *rgb, int w, int h, std::vector<uint32_t> &out, MwTexDesc &desc)
 {
@@ -301,16 +305,13 @@ void build_pyramid(const uint8_t *rgb, int w, int h, std::vector<uint32_t> &out,
         const int nw = std::max(1, w / 2), nh = std::max(1, h / 2);
         nxt.assign((size_t)nw * nh * 3, 0);
         for (int j = 0; j < nh; ++j) {
-            const Taps ty = axis_taps(h, j);
+            const Taps ty = axis_taps(h, nh, j);
             for (int i = 0; i < nw; ++i) {
-                const Taps tx = axis_taps(w, i);
-                const long long tot = (long long)tx.total * ty.total;
+                const Taps tx = axis_taps(w, nw, i);
                 for (int c = 0; c < 3; ++c) {
-                    long long acc = 0;
-                    for (int b = 0; b < ty.n; ++b)
-                        for (int a = 0; a < tx.n; ++a)
-                            acc += (long long)tx.w[a] * ty.w[b] * cur[((size_t)ty.idx[b] * w + tx.idx[a]) * 3 + c];
-                    nxt[((size_t)j * nw + i) * 3 + c] = (uint8_t)((2 * acc + tot) / (2 * tot));
+                    const int t0 = lerp8(cur[((size_t)ty.i0 * w + tx.i0) * 3 + c], cur[((size_t)ty.i0 * w + tx.i1) * 3 + c], tx.w);
+                    const int t1 = lerp8(cur[((size_t)ty.i1 * w + tx.i0) * 3 + c], cur[((size_t)ty.i1 * w + tx.i1) * 3 + c], tx.w);
+                    nxt[((size_t)j * nw + i) * 3 + c] = (uint8_t)lerp8(t0, t1, ty.w);
                 }
             }
         }
@@ -533,7 +534,9 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // the worlds from the host (ON_DEVICE_SYNC) — an env that needs its spare earlier follows the refill_mask protocol.
     const bool async_refill = e->spare_mode && do_step && e->cfg.generator == MW_GEN_MAZE;
     const int refill_blocks = (e->spare_mode && do_step && !async_refill) ? (N + 63) / 64 : 0;
-    if (const int lanes = k1_dense_lanes(e, view_flags)) {
+    if (!do_step) {
+        // render only: nothing to step
+    } else if (const int lanes = k1_dense_lanes(e, 0)) {
         const int epw = 64 / lanes;
         const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
         auto k1d = e->have_meshes ? (pcg ? mw_step_setup_dense_mesh_pcg_kernel : mw_step_setup_dense_mesh_kernel)
@@ -548,6 +551,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                            d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch,
                            d_trunc ? d_trunc : e->d_flag_scratch + N);
     }
+    // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
+    hipLaunchKernelGGL(mw_geom_kernel, dim3(N), dim3(64), 0, st, a, view_flags, e->cfg.msaa);
     if (timed) (void)hipEventRecord(ev.b, st);
     if (async_refill) {
         if (ensure_side_stream(e) != MW_OK) return MW_E_HIP;
@@ -624,7 +629,9 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
         const int groups = (N + 7) / 8;
         const bool big = e->cfg.max_visible > 64;      // records stay in global memory
-        const size_t lds = big ? 192 : (size_t)e->cfg.max_visible * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
+        // small scenes stage up to MW_LDS_RECS records in LDS (a wave whose env holds more reads them in place)
+        const int lds_recs = a.max_vis < MW_LDS_RECS ? a.max_vis : MW_LDS_RECS;
+        const size_t lds = big ? 192 : (size_t)lds_recs * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
         // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
         // anything else goes to the general kernel
         auto k2 = big ? (d_depth ? mw_raster_big_depth_kernel : mw_raster_big_kernel) : (d_depth ? mw_raster_depth_kernel : mw_raster_kernel);
@@ -680,7 +687,9 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     e->n_sets = cfg->shared_geometry ? 1 : N;
     MwArgs &a = e->args;
     a.N = N; a.W = cfg->obs_width; a.H = cfg->obs_height; a.E = E;
-    a.max_polys = cfg->max_polys; a.max_segs = cfg->max_segs; a.max_vis = cfg->max_visible;
+    a.max_polys = cfg->max_polys; a.max_segs = cfg->max_segs;
+    // triangle records per env: a polygon or box face is two triangles, clipping adds a few
+    a.max_vis = cfg->max_visible * 6 < 60000 ? cfg->max_visible * 6 : 60000;
     a.shared_geom = cfg->shared_geometry ? 1 : 0;
     a.task = cfg->task; a.goal_ent = cfg->goal_ent; a.goal_ent2 = cfg->goal_ent2; a.num_objs = cfg->num_objs; a.max_steps = cfg->max_episode_steps;
     a.rng_mode = cfg->rng_mode;
@@ -755,11 +764,12 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     }
     ALLOC(e->d_meshdesc, MW_MAX_MESH);
     a.mesh = e->d_meshdesc;      // a.tex / a.texels: upload_textures
-    ALLOC(a.rec_raster, (size_t)N * cfg->max_visible * MW_RASTER_REC);
-    ALLOC(a.rec_shade, (size_t)N * cfg->max_visible * MW_SHADE_REC);
-    ALLOC(a.rec_cull, (size_t)N * cfg->max_visible * MW_CULL_REC);
+    ALLOC(a.rec_raster, (size_t)N * a.max_vis * MW_RASTER_REC);
+    ALLOC(a.rec_shade, (size_t)N * a.max_vis * MW_SHADE_REC);
+    ALLOC(a.rec_cull, (size_t)N * a.max_vis * MW_CULL_REC);
     ALLOC(a.k3_cost, (size_t)N); ALLOC(a.k3_order, (size_t)N);
-    if (cfg->max_visible > 64) ALLOC(a.rec_order, (size_t)N * (cfg->max_visible + 1));     // big scenes: visiting order (mw_raster_big_kernel)
+    ALLOC(a.pending_remove, (size_t)N);
+    if (rc == MW_OK) (void)hipMemset(a.pending_remove, 0xFF, 4 * (size_t)N);
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
@@ -911,7 +921,7 @@ int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_p
         set = env;
     }
     for (int i = 0; i < n_polys; ++i) {
-        const int nv = polys[i].nv & ~MW_POLY_ENTITY;
+        const int nv = polys[i].nv & 0xFF;
         if (nv != 3 && nv != 4) return fail(e, MW_E_INVALID, "polygon %d has %d vertices (3 or 4 supported)", i, nv);
         if (polys[i].tex >= MW_MAX_TEX) return fail(e, MW_E_INVALID, "polygon %d: bad texture id", i);
         if (polys[i].tex >= 0 && e->tex_desc[polys[i].tex].nlevels == 0) return fail(e, MW_E_INVALID, "polygon %d uses texture %d which was never uploaded", i, polys[i].tex);
@@ -1095,8 +1105,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     b.W = width; b.H = height;
     b.tiles_x = width / MW_TILE_W; b.tiles_y = height / MW_TILE_H; b.n_tiles = b.tiles_x * b.tiles_y;
     b.env_base = env;
-    hipLaunchKernelGGL(k1_of(e), dim3(1), dim3(k1_threads(e)), 0, st, b, 0, view_flags, e->d_action_scratch,
-                       e->d_reward_scratch, e->d_flag_scratch, e->d_flag_scratch + e->cfg.num_envs);
+    hipLaunchKernelGGL(mw_geom_kernel, dim3(1), dim3(64), 0, st, b, view_flags, msaa);
     uint32_t *keys = nullptr;
     if (e->have_meshes) {
         const size_t need = (size_t)width * height * msaa * 4;
@@ -1149,8 +1158,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     b.step_override = nullptr;
     b.env_base = first_env;
     // K1 in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
-    hipLaunchKernelGGL(k1_of(e), dim3(count), dim3(k1_threads(e)), 0, st, b, 0, 4, e->d_action_scratch,
-                       e->d_reward_scratch, e->d_flag_scratch, e->d_flag_scratch + e->cfg.num_envs);
+    hipLaunchKernelGGL(mw_geom_kernel, dim3(count), dim3(64), 0, st, b, 4, e->cfg.msaa);
     if (!e->visible_attr_set) {
         HIP_TRY(e, hipFuncSetAttribute((const void *)mw_visible_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         e->visible_attr_set = true;

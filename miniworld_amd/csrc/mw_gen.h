@@ -158,7 +158,7 @@ __device__ inline void emit_room(const MwArgs &a, int set, const RoomTex &rt, co
         // normal = -cross(b - a, Y) / |.|   (miniworld.py:335-336)
         const double ex = bx - ax, ez = bz - az, len = sqrt(ez * ez + ex * ex);
         q.n[0] = (float)(-(-ez) / len); q.n[1] = 0.0f; q.n[2] = (float)(-(ex) / len);
-        q.nv = 4; q.tex = tex_w; q.rgb[0] = q.rgb[1] = q.rgb[2] = 1.0f;
+        q.nv = 4 | MW_POLY_QUAD; q.tex = tex_w; q.rgb[0] = q.rgb[1] = q.rgb[2] = 1.0f;
         segs[ns * 4 + 0] = bx; segs[ns * 4 + 1] = bz; segs[ns * 4 + 2] = ax; segs[ns * 4 + 3] = az;   // [s_p1, s_p0]
         ++ns;
     }

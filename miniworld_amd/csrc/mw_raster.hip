@@ -21,9 +21,9 @@
 
 namespace {
 // the quad kernel never sees mesh draw ids
-__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, float Xc, float Yc)
+__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, int px, int gy)
 {
-    return shade_prim(cx.s_shade + id * (MW_SHADE_REC / 4), cx.te, Xc, Yc);
+    return shade_frag(cx.s_shade + id * (MW_SHADE_REC / 4), cx.te, px, gy, 0.5f);
 }
 }  // namespace
 
@@ -39,7 +39,7 @@ __device__ inline void raster_kernel_body(
     const uint16_t *__restrict__ rec_order)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lds_recs = LDS_RECS ? max_vis : 0;
+    const int lds_recs = LDS_RECS ? (max_vis < MW_LDS_RECS ? max_vis : MW_LDS_RECS) : 0;
     float4 *s_shade = reinterpret_cast<float4 *>(smem);                                       // [max_vis][8]
     float4 *s_cull = reinterpret_cast<float4 *>(smem + (size_t)lds_recs * MW_SHADE_REC * 4);  // [max_vis][6]
     uint8_t *s_pack = smem + (size_t)lds_recs * (MW_SHADE_REC + MW_CULL_REC) * 4;             // 192 B
@@ -58,7 +58,8 @@ __device__ inline void raster_kernel_body(
     const float *__restrict__ rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     const float4 *g_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
     const float4 *g_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
-    if (LDS_RECS) {
+    const bool in_lds = LDS_RECS && nvis <= lds_recs;
+    if (in_lds) {
         for (int i = lane; i < nvis * (MW_SHADE_REC / 4); i += 64) s_shade[i] = g_shade[i];
         for (int i = lane; i < nvis * (MW_CULL_REC / 4); i += 64) s_cull[i] = g_cull[i];
         __syncthreads();
@@ -72,7 +73,7 @@ __device__ inline void raster_kernel_body(
     te.flat = HOT ? 0 : (dbg & 1);
 
     TileCtx cx;
-    cx.s_shade = LDS_RECS ? s_shade : g_shade; cx.s_cull = LDS_RECS ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = nullptr; cx.ment = nullptr; cx.tprof = nullptr;
+    cx.s_shade = in_lds ? s_shade : g_shade; cx.s_cull = in_lds ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = nullptr; cx.ment = nullptr; cx.tprof = nullptr;
     cx.mesh_pos = cx.mesh_nrm = cx.mesh_rgb = cx.mesh_uv = nullptr;
     cx.obs = obs; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3); cx.te = te;
@@ -82,7 +83,7 @@ __device__ inline void raster_kernel_body(
     const int t_end = min(t_begin + tiles_per_wave, n_tiles);
     int tx = t_begin % tiles_x, ty = t_begin / tiles_x;
     // small scenes: classify (tile, primitive) pairs for as many tiles as fit in the 64 lanes at once
-    const bool pairs = LDS_RECS && nvis > 0 && nvis <= 32 && (HOT || !(dbg & 2));
+    const bool pairs = in_lds && nvis > 0 && nvis <= 32 && (HOT || !(dbg & 2));
     const int per_group = pairs ? 64 / nvis : 0;
     const uint64_t prim_mask = pairs ? ((1ull << nvis) - 1ull) : 0ull;
     cx.order = (!LDS_RECS && rec_order) ? rec_order + (size_t)env * (max_vis + 1) : nullptr;
@@ -92,7 +93,7 @@ __device__ inline void raster_kernel_body(
         // the masks of the g-th tile of the current group live in lane g of three VGPRs (<= 32 primitives: 32 bits
         // each); a tile fetches its three with v_readlane instead of carrying 64-bit group masks through the tile
         // loop in SGPRs
-        uint32_t vT = 0u, vF = 0u, vCl = 0u;
+        uint32_t vT = 0u, vF = 0u;
         uint32_t vE01 = ~0u, vE23 = ~0u;    // per-edge "needs a test" masks, 16 bits each (more than 16 primitives: test all)
         int gi = 0, G = 0;
         cx.have_pre = 1;
@@ -100,20 +101,19 @@ __device__ inline void raster_kernel_body(
             if (gi == G) {
                 G = min(per_group, t_end - tile);
                 gi = 0;
-                uint64_t T, F, Cl, Eo[4];
-                classify_group(s_cull, lane, nvis, tile, G, tiles_x, T, F, Cl, Eo);
+                uint64_t T, F, Eo[3];
+                classify_group(s_cull, lane, nvis, tile, G, tiles_x, H, T, F, Eo);
                 const int sh = lane < G ? lane * nvis : 0;
-                vT = (uint32_t)((T >> sh) & prim_mask); vF = (uint32_t)((F >> sh) & prim_mask); vCl = (uint32_t)((Cl >> sh) & prim_mask);
+                vT = (uint32_t)((T >> sh) & prim_mask); vF = (uint32_t)((F >> sh) & prim_mask);
                 if (nvis <= 16) {
                     vE01 = (uint32_t)((Eo[0] >> sh) & prim_mask) | ((uint32_t)((Eo[1] >> sh) & prim_mask) << 16);
-                    vE23 = (uint32_t)((Eo[2] >> sh) & prim_mask) | ((uint32_t)((Eo[3] >> sh) & prim_mask) << 16);
+                    vE23 = (uint32_t)((Eo[2] >> sh) & prim_mask) | 0xFFFF0000u;
                 }
             }
             cx.pre_edges = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)vE01, gi) |
                            ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)vE23, gi) << 32);
             cx.pre_touch = (uint32_t)__builtin_amdgcn_readlane((int)vT, gi);
             cx.pre_full = (uint32_t)__builtin_amdgcn_readlane((int)vF, gi);
-            cx.pre_clip = (uint32_t)__builtin_amdgcn_readlane((int)vCl, gi);
             ++gi;
             raster_tile_fmt<false, FMT, false, HOT, 1>(cx, tx, ty, nullptr);
         }

@@ -11,7 +11,7 @@
 //
 // Per-triangle arithmetic (transform, unnormalised-normal lighting, edge / depth / colour
 // planes) follows DESIGN.md R3, R4, R6, R10, R11 exactly like the oracle's mesh path.
-#include "mw_raster_common.h"
+#include "mw_raster_common_old.h"
 
 namespace {
 

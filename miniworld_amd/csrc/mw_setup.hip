@@ -281,8 +281,15 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         }
     }
 
+    {
+        // The frame's vertex half — camera, lighting, transform, clipping, triangle setup under the pinned GL rules — is
+        // mw_geom_kernel's (mw_geom.hip); what this step leaves for after its frame (a picked-up object is drawn one last
+        // time, pickupobjects.py:86-88) goes with it.
+        if (writer && do_step) a.pending_remove[env] = remove_slot;
+        return;
+    }
     const unsigned long long pt1 = a.k1_prof ? __builtin_readcyclecounter() : 0ull;
-    // ---- camera + primitive setup -----------------------------------------------
+    // ---- camera + primitive setup (superseded: kept until the occlusion culling moves to the geometry kernel) -----
     Cam cam;
     float sky[3];
     build_camera(a, env, c.px, c.py, c.pz, c.dir, cam, sky, (view_flags & 1) != 0);

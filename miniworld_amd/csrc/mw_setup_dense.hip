@@ -215,8 +215,13 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1
         }
     }
 
+    {
+        // the frame's vertex half is mw_geom_kernel's (mw_geom.hip); see mw_setup.hip
+        if (leader && do_step) a.pending_remove[env] = remove_slot;
+        return;
+    }
     if (prof) pt[2] = __builtin_readcyclecounter();
-    // ---- camera (per env, evaluated by each of its lanes) --------------------------------------
+    // ---- camera (superseded) ---------------------------------------------------------------------
     Cam cam;
     float sky[3];
     build_camera(a, env, c.px, c.py, c.pz, c.dir, cam, sky, false);

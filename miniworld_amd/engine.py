@@ -16,7 +16,7 @@ import numpy as np
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ENT_NONE, ENT_BOX, ENT_MESH, ENT_FRAME = 0, 1, 2, 3
 POLY_ENTITY = 0x100          # mw_poly.nv flag: quad of a static entity, not a room
 POLY_XF = 0x200              # ... drawn under its own glTranslatef / glRotatef (mw_poly.xf)

@@ -77,7 +77,7 @@ def test_c_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(engine.LIB_PATH)
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"{sym} declared in mwengine.h but not exported"
-    assert ctypes.sizeof(engine.MwPoly) == 112
+    assert ctypes.sizeof(engine.MwPoly) == 128
 
 
 def test_engine_fails_loudly_without_gpu():
