@@ -71,11 +71,11 @@ extern "C" __global__ void mw_refill_pcg_kernel(MwArgs a);
 extern "C" __global__ void mw_take_spare_kernel(MwArgs a, const uint8_t *mask, int force_all);
 extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, int first_env, const float *envhdr, const float *mesh_pos, uint32_t *keys);
 extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
-                                                 const float *rec_shade, const int32_t *nvis, const float *envhdr,
+                                                 const float *rec_shade, const float *rec_cull, const int32_t *nvis, const float *envhdr,
                                                  const MwTexDesc *texd, const uint32_t *texels, const float *mesh_pos,
                                                  const float *mesh_nrm, const float *mesh_rgb, const float *mesh_uv, const uint32_t *mesh_keys,
                                                  uint8_t *out, float *depth, int texel_bytes);
-extern "C" __global__ void mw_visible_kernel(int env_base, int W, int H, int max_vis, int E, const float *rec_raster,
+extern "C" __global__ void mw_visible_kernel(int env_base, int W, int H, int S, int max_vis, int E, const float *rec_raster, const float *rec_cull,
                                              const int32_t *nvis, uint8_t *vis);
 extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                                  const float *rec_raster, const float *rec_shade, const float *rec_cull,
@@ -583,11 +583,11 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             hipLaunchKernelGGL(mw_view_mesh_kernel, dim3(32, N), dim3(256), 0, st, a.W, a.H, S, 0, (const float *)a.envhdr, a.mesh_pos, keys);
         }
         hipLaunchKernelGGL(mw_view_raster_kernel, dim3(a.n_tiles, N), dim3(64), 0, st, 0, a.W, a.H, S, a.max_vis, a.tiles_x,
-                           (const float *)a.rec_raster, (const float *)a.rec_shade, (const int32_t *)a.nvis, (const float *)a.envhdr,
+                           (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull, (const int32_t *)a.nvis, (const float *)a.envhdr,
                            a.tex, a.texels, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, (const uint32_t *)keys, d_obs, d_depth, e->texel_bytes);
     } else if (e->have_meshes) {
         // envs may contain mesh entities: one 1024-thread workgroup per env, sample keys in LDS
-        const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * MW_K3_WAVE_LDS + 16 + MW_MAX_MESH_ENTS * 48;   // keys, 16 pack buffers, the tile counter, the mesh table
+        const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * MW_K3_WAVE_LDS + 16 + MW_MAX_MESH_ENTS * MW_HDR_MESH_STRIDE * 4;   // keys, 16 pack buffers, the tile counter, the mesh table
         if (lds > 160 * 1024) return fail(e, MW_E_CAPACITY, "mesh entities need the env's sample keys in LDS: %dx%d is too large", a.W, a.H);
         if (!e->mesh_lds_ready) {
             for (auto k : {mw_raster_mesh_kernel, mw_raster_mesh_depth_kernel, mw_raster_mesh_wrap_kernel})
@@ -1121,7 +1121,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
         hipLaunchKernelGGL(mw_view_mesh_kernel, dim3(128), dim3(256), 0, st, width, height, msaa, env, (const float *)b.envhdr, b.mesh_pos, keys);
     }
     hipLaunchKernelGGL(mw_view_raster_kernel, dim3(b.n_tiles), dim3(64), 0, st, env, width, height, msaa, b.max_vis, b.tiles_x,
-                       (const float *)b.rec_raster, (const float *)b.rec_shade, (const int32_t *)b.nvis, (const float *)b.envhdr,
+                       (const float *)b.rec_raster, (const float *)b.rec_shade, (const float *)b.rec_cull, (const int32_t *)b.nvis, (const float *)b.envhdr,
                        b.tex, b.texels, b.mesh_pos, b.mesh_nrm, b.mesh_rgb, b.mesh_uv, (const uint32_t *)keys, d_out, d_depth, e->texel_bytes);
     HIP_TRY(e, hipGetLastError());
     return MW_OK;
@@ -1151,7 +1151,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     if (!e || !d_vis) return fail(e, MW_E_INVALID, "null argument");
     ON_DEVICE(e);
     if (first_env < 0 || count <= 0 || first_env + count > e->cfg.num_envs) return fail(e, MW_E_INVALID, "env range out of bounds");
-    const size_t lds = (size_t)e->cfg.obs_width * e->cfg.obs_height * 8 * 4;
+    const size_t lds = (size_t)e->cfg.obs_width * e->cfg.obs_height * e->cfg.msaa * 4;
     if (lds + 1024 > 160 * 1024) return fail(e, MW_E_CAPACITY, "obs frame too large for the in-LDS depth buffer of mw_visible_ents");
     hipStream_t st = (hipStream_t)stream;
     MwArgs b = e->args;
@@ -1164,7 +1164,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
         e->visible_attr_set = true;
     }
     hipLaunchKernelGGL(mw_visible_kernel, dim3(count), dim3(256), lds, st, first_env, e->cfg.obs_width, e->cfg.obs_height,
-                       b.max_vis, e->cfg.max_ents, (const float *)b.rec_raster, (const int32_t *)b.nvis, d_vis);
+                       e->cfg.msaa, b.max_vis, e->cfg.max_ents, (const float *)b.rec_raster, (const float *)b.rec_cull, (const int32_t *)b.nvis, d_vis);
     HIP_TRY(e, hipGetLastError());
     return MW_OK;
 }

@@ -37,14 +37,17 @@ __device__ inline int wave_excl_scan(int v, int lane, int &total)
     return x - v;
 }
 
+// Draw ids order the frame's triangles for the depth test's ties (GL_LESS: the first drawn wins) and name them in the
+// sample keys: a record's id is its list position plus the mesh triangles drawn before it (a mesh entity takes one id
+// per triangle); the proxy boxes of get_visible_ents carry their entity's tag instead.
 struct Emit {
     const MwArgs &a;
     int env, S, tex;
-    uint32_t draw_id;
+    uint32_t id_base, tag;
     int idx, end;            // next list position / one past this triangle's range
     __device__ void operator()(const mwgl::TriSetup &t)
     {
-        if (idx < end && idx < a.max_vis) mwrec::write_tri(a, env, idx, draw_id, t, tex, S);
+        if (idx < end && idx < a.max_vis) mwrec::write_tri(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t, tex, S);
         ++idx;
     }
 };
@@ -61,7 +64,7 @@ __device__ inline int tri_bound(const mwgl::Vert &a, const mwgl::Vert &b, const 
 // list positions [base, base + bound) in order and fills what stays unused with NULL records.
 template <bool GOURAUD>
 __device__ inline void emit_round(const MwArgs &a, const mwgl::Frame &f, int env, int lane, int S, const mwgl::Vert v[4], int nt,
-                                  const int tri[2][3], int tex, uint32_t draw_id, int &count, mwgl::Vert (*s_clip)[2][MWGL_MAX_CLIP_VERTS])
+                                  const int tri[2][3], int tex, uint32_t id_base, uint32_t tag, int &count, mwgl::Vert (*s_clip)[2][MWGL_MAX_CLIP_VERTS])
 {
     int bound[2] = {0, 0};
 #pragma unroll
@@ -75,7 +78,7 @@ __device__ inline void emit_round(const MwArgs &a, const mwgl::Frame &f, int env
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         const int b0 = base + (t ? bound[0] : 0);
-        Emit em{a, env, S, tex, draw_id, b0, b0 + bound[t]};
+        Emit em{a, env, S, tex, id_base, tag, b0, b0 + bound[t]};
         const mwgl::Vert &va = v[tri[t][0]], &vb = v[tri[t][1]], &vc = v[tri[t][2]];
         const bool clipped = bound[t] > 1;
         if (bound[t] == 1) {
@@ -159,7 +162,6 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
     mwgl::make_xform(f, f.view, f.view_flags, cam);
 
     int count = 0;
-    uint32_t draw = 0;          // GL primitives drawn so far (a mesh entity takes one id per triangle)
     float stale_n[3] = {0.0f, 1.0f, 0.0f};
     const mw_poly *polys = a.polys + (size_t)set * a.max_polys;
     const int np = a.npolys[set];
@@ -194,8 +196,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
                 else { nt = 2; tri[0][0] = 1; tri[0][1] = 2; tri[0][2] = 0; tri[1][0] = 2; tri[1][1] = 3; tri[1][2] = 0; }
             }
         }
-        emit_round<false>(a, f, env, lane, S, v, nt, tri, tex, draw + (uint32_t)lane, count, s_clip);
-        draw += (uint32_t)((np - base) < 64 ? (np - base) : 64);
+        emit_round<false>(a, f, env, lane, S, v, nt, tri, tex, 0u, 0u, count, s_clip);
     }
     if (np > 0) { stale_n[0] = polys[np - 1].n[0]; stale_n[1] = polys[np - 1].n[1]; stale_n[2] = polys[np - 1].n[2]; }
 
@@ -243,11 +244,11 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
                     in_view = !(w + brad < 0.04f) && !(w - fabsf(o.clip[0]) < -(brad * lx)) && !(w - fabsf(o.clip[1]) < -(brad * ly));
                 }
                 if (in_view) {
-                    if (n_mesh < MW_MAX_MESH_ENTS && draw + (uint32_t)md_ntris < 0xFFF0u) {
+                    if (n_mesh < MW_MAX_MESH_ENTS && count + mesh_tris + md_ntris < 0xFFF0) {
                         if (lane == 0) {
                             float *m = hdr + MW_HDR_MESH + MW_HDR_MESH_STRIDE * n_mesh;
                             m[0] = __int_as_float(s0);
-                            m[1] = __uint_as_float(draw);
+                            m[1] = __int_as_float(count + mesh_tris);
                             m[2] = __int_as_float(md_ntris);
                             m[3] = __int_as_float((int)mdp->first);
                             m[4] = __int_as_float((int)mdp->tex);
@@ -256,9 +257,8 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
 #pragma unroll
                             for (int k = 0; k < 16; ++k) m[9 + k] = ex.mvp.m[k];
                         }
-                        mesh_tris += md_ntris;
+                        mesh_tris += md_ntris;      // one draw id per triangle (a mesh out of view takes none)
                         ++n_mesh;
-                        draw += (uint32_t)md_ntris;     // one draw id per triangle (a mesh out of view takes none)
                     } else {
                         atomicOr(a.status, MW_ST_VIS_OVERFLOW);
                     }
@@ -326,9 +326,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
                 const bool box_clipped = ((cm >> (bi * 6)) & 0x3Full) != 0ull;
                 const bool in_list = !proxy && mine && a.estatic[(size_t)slot * a.N + env] != 0;
                 if (mine && !box_clipped && !in_list) { tri[0][0] = 0; tri[0][1] = 1; tri[0][2] = 2; tri[1][0] = 0; tri[1][1] = 2; tri[1][2] = 3; }
-                const uint32_t id = proxy ? (0x10000u | (uint32_t)slot) : draw + (uint32_t)lane;
-                emit_round<false>(a, f, env, lane, S, v, nt, tri, -1, id, count, s_clip);
-                draw += (uint32_t)((s1 - s0) * 6);
+                emit_round<false>(a, f, env, lane, S, v, nt, tri, -1, (uint32_t)mesh_tris, proxy ? (0x10000u | (uint32_t)slot) : 0u, count, s_clip);
                 stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f;     // drawBox ends with glNormal3f(0, -1, 0)
             }
             s0 = s1;
@@ -361,8 +359,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
             }
             nt = 1;
         }
-        emit_round<false>(a, f, env, lane, S, v, nt, tri, -1, draw, count, s_clip);
-        draw += 1;
+        emit_round<false>(a, f, env, lane, S, v, nt, tri, -1, (uint32_t)mesh_tris, 0u, count, s_clip);
     }
     if (lane == 0) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;

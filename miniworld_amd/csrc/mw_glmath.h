@@ -430,6 +430,47 @@ MW_HD void plane_coef(Plane &p, float a0, float a1, float a2, float dy20_ooa, fl
     p.a0 = a0 - (p.dadx * x0c + p.dady * y0c);
 }
 
+// The position-only part of the setup (edges + depth plane): what a kernel that only needs coverage and depth keys pays.
+struct TriEdges {
+    int32_t dcdx[3], dcdy[3];
+    int64_t c[3];
+    int32_t minx, maxx, miny, maxy;
+    Plane z;
+};
+
+MW_HD bool setup_triangle_pos(const float wa[4], const float wb[4], const float wc[4], bool multisampled, TriEdges &s)
+{
+    const float off = multisampled ? 0.0f : 0.5f;
+    const float *v[3] = {wa, wb, wc};
+    int32_t fx[3], fy[3];
+    for (int i = 0; i < 3; ++i) {
+        fx[i] = iround_even((v[i][0] - off) * 256.0f);
+        fy[i] = iround_even((v[i][1] - off) * 256.0f);
+    }
+    const int64_t dx01 = fx[0] - fx[1], dy01 = fy[0] - fy[1], dx20 = fx[2] - fx[0], dy20 = fy[2] - fy[0];
+    if (dx01 * dy20 - dx20 * dy01 >= 0) return false;
+    const float *t = v[0]; v[0] = v[1]; v[1] = t;
+    int32_t ti = fx[0]; fx[0] = fx[1]; fx[1] = ti;
+    ti = fy[0]; fy[0] = fy[1]; fy[1] = ti;
+    for (int i = 0; i < 3; ++i) {
+        const int j = i == 2 ? 0 : i + 1;
+        s.dcdy[i] = fx[i] - fx[j];
+        s.dcdx[i] = fy[i] - fy[j];
+        s.c[i] = (int64_t)s.dcdx[i] * fx[i] - (int64_t)s.dcdy[i] * fy[i];
+        if (s.dcdx[i] < 0) s.c[i]++;
+        else if (s.dcdx[i] == 0 && s.dcdy[i] > 0) s.c[i]++;
+    }
+    s.minx = fx[0] < fx[1] ? fx[0] : fx[1]; if (fx[2] < s.minx) s.minx = fx[2];
+    s.maxx = fx[0] > fx[1] ? fx[0] : fx[1]; if (fx[2] > s.maxx) s.maxx = fx[2];
+    s.miny = fy[0] < fy[1] ? fy[0] : fy[1]; if (fy[2] < s.miny) s.miny = fy[2];
+    s.maxy = fy[0] > fy[1] ? fy[0] : fy[1]; if (fy[2] > s.maxy) s.maxy = fy[2];
+    const float fdx01 = v[0][0] - v[1][0], fdy01 = v[0][1] - v[1][1];
+    const float fdx20 = v[2][0] - v[0][0], fdy20 = v[2][1] - v[0][1];
+    const float ooa = 1.0f / (fdx01 * fdy20 - fdx20 * fdy01);
+    plane_coef(s.z, v[0][2], v[1][2], v[2][2], fdy20 * ooa, fdy01 * ooa, fdx20 * ooa, fdx01 * ooa, v[0][0] - off, v[0][1] - off);
+    return true;
+}
+
 // multisampled != 0: pixel_offset 0 (integer coordinates are pixel corners); else 0.5 (integer coordinates are centres).
 // Returns false for a back-facing or zero-area triangle (culled on the snapped area).
 MW_HD bool setup_triangle(const Vert &a, const Vert &b, const Vert &c, bool multisampled, bool textured, TriSetup &s)

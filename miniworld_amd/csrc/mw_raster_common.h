@@ -64,43 +64,38 @@ __device__ inline void fetch_level(const TexEnv &te, uint32_t desc, int l, float
     mwgl::bilerp_rgb(q.x, q.y, q.z, q.w, wx, wy, out);
 }
 
-// fragment colour of the triangle with shade record sr (per lane) at GL pixel (px, gy) of an S-sample target
-__device__ inline RGB shade_frag(const float4 *sr, const TexEnv &te, int px, int gy, float eo)
+// fragment colour from a triangle's attribute planes at GL pixel (px, gy); eo: where the pixel centre sits in the planes'
+// coordinates (0.5 for a multisampled target, 0 for a single-sampled one)
+__device__ inline RGB shade_planes(const mwgl::Plane &wp, const mwgl::Plane &sp, const mwgl::Plane &tp, const mwgl::Plane &pr,
+                                   const mwgl::Plane &pg, const mwgl::Plane &pb, int tex, const TexEnv &te, int px, int gy, float eo)
 {
-    const float4 q0 = sr[0];
-    const mwgl::Plane wp = {q0.x, q0.y, q0.z};
-    const int tex = te.flat ? -1 : __float_as_int(q0.w);
     const float x = (float)px + eo, y = (float)gy + eo;
-    const float4 qr = sr[3], qg = sr[4], qb = sr[5];
-    const mwgl::Plane pr = {qr.x, qr.y, qr.z}, pg = {qg.x, qg.y, qg.z}, pb = {qb.x, qb.y, qb.z};
     const float wv = mwgl::plane_at(wp, x, y);
     const float oow = rcp_safe(wv);
     RGB c = {mwgl::plane_at(pr, x, y) * oow, mwgl::plane_at(pg, x, y) * oow, mwgl::plane_at(pb, x, y) * oow};
-    if (tex >= 0) {
-        const float4 q1 = sr[1], q2 = sr[2];
-        const mwgl::Plane sp = {q1.x, q1.y, q1.z}, tp = {q2.x, q2.y, q2.z};
-        const float invq = rcp_safe(wv * oow);
-        const float s = (mwgl::plane_at(sp, x, y) * oow) * invq, t = (mwgl::plane_at(tp, x, y) * oow) * invq;
-        // the quad's three corner coordinates
-        const float qx = (float)(px & ~1) + eo, qy = (float)(gy & ~1) + eo;
-        float sc[3], tc[3];
+    if (__any(tex >= 0)) {
+        if (tex >= 0) {
+            const float invq = rcp_safe(wv * oow);
+            const float s = (mwgl::plane_at(sp, x, y) * oow) * invq, t = (mwgl::plane_at(tp, x, y) * oow) * invq;
+            // the quad's three corner coordinates
+            const float qx = (float)(px & ~1) + eo, qy = (float)(gy & ~1) + eo;
+            float sc[3], tc[3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const float cx = qx + (k == 1 ? 1.0f : 0.0f), cy = qy + (k == 2 ? 1.0f : 0.0f);
-            const float w2 = mwgl::plane_at(wp, cx, cy);
-            const float o2 = rcp_safe(w2);
-            const float i2 = rcp_safe(w2 * o2);
-            sc[k] = (mwgl::plane_at(sp, cx, cy) * o2) * i2;
-            tc[k] = (mwgl::plane_at(tp, cx, cy) * o2) * i2;
-        }
-        const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4);
-        const uint32_t nlevels = ldw(te.td, desc + 2u);
-        const u32x4 l0r = __builtin_amdgcn_raw_buffer_load_b128(te.td, (desc + 8u) << 2, 0, 0);       // lvl[0]: fw, fh, h, -
-        int l0, w8;
-        mwgl::lod_select(sc[0], tc[0], sc[1], tc[1], sc[2], tc[2], __uint_as_float(l0r.x), __uint_as_float(l0r.y), (int)nlevels, l0, w8);
-        int c0[3];
-        fetch_level(te, desc, l0, s, t, c0);
-        if (__any(w8 > 0)) {
+            for (int k = 0; k < 3; ++k) {
+                const float cx = qx + (k == 1 ? 1.0f : 0.0f), cy = qy + (k == 2 ? 1.0f : 0.0f);
+                const float w2 = mwgl::plane_at(wp, cx, cy);
+                const float o2 = rcp_safe(w2);
+                const float i2 = rcp_safe(w2 * o2);
+                sc[k] = (mwgl::plane_at(sp, cx, cy) * o2) * i2;
+                tc[k] = (mwgl::plane_at(tp, cx, cy) * o2) * i2;
+            }
+            const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4);
+            const uint32_t nlevels = ldw(te.td, desc + 2u);
+            const u32x4 l0r = __builtin_amdgcn_raw_buffer_load_b128(te.td, (desc + 8u) << 2, 0, 0);       // lvl[0]: fw, fh, h, -
+            int l0, w8;
+            mwgl::lod_select(sc[0], tc[0], sc[1], tc[1], sc[2], tc[2], __uint_as_float(l0r.x), __uint_as_float(l0r.y), (int)nlevels, l0, w8);
+            int c0[3];
+            fetch_level(te, desc, l0, s, t, c0);
             if (w8 > 0) {
                 int c1[3];
                 const int l1 = l0 + 1 > (int)nlevels - 1 ? (int)nlevels - 1 : l0 + 1;
@@ -108,12 +103,22 @@ __device__ inline RGB shade_frag(const float4 *sr, const TexEnv &te, int px, int
 #pragma unroll
                 for (int k = 0; k < 3; ++k) c0[k] = mwgl::lerp8(c0[k], c1[k], w8);
             }
+            c.r = ((float)c0[0] * (1.0f / 255.0f)) * c.r;
+            c.g = ((float)c0[1] * (1.0f / 255.0f)) * c.g;
+            c.b = ((float)c0[2] * (1.0f / 255.0f)) * c.b;
         }
-        c.r = ((float)c0[0] * (1.0f / 255.0f)) * c.r;
-        c.g = ((float)c0[1] * (1.0f / 255.0f)) * c.g;
-        c.b = ((float)c0[2] * (1.0f / 255.0f)) * c.b;
     }
     return c;
+}
+
+// ... of the triangle with shade record sr (per lane)
+__device__ inline RGB shade_frag(const float4 *sr, const TexEnv &te, int px, int gy, float eo)
+{
+    const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], qr = sr[3], qg = sr[4], qb = sr[5];
+    const mwgl::Plane wp = {q0.x, q0.y, q0.z}, sp = {q1.x, q1.y, q1.z}, tp = {q2.x, q2.y, q2.z};
+    const mwgl::Plane pr = {qr.x, qr.y, qr.z}, pg = {qg.x, qg.y, qg.z}, pb = {qb.x, qb.y, qb.z};
+    const int tex = te.flat ? -1 : __float_as_int(q0.w);
+    return shade_planes(wp, sp, tp, pr, pg, pb, tex, te, px, gy, eo);
 }
 
 struct TileCtx;
