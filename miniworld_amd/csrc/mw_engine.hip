@@ -68,6 +68,8 @@ extern "C" __global__ void mw_raster_big_wrap_kernel(int N, int W, int H, int ma
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all, int mark_refill);
 extern "C" __global__ void mw_refill_kernel(MwArgs a);
 extern "C" __global__ void mw_refill_pcg_kernel(MwArgs a);
+extern "C" __global__ void mw_collect_respawn_kernel(MwArgs a);
+extern "C" __global__ void mw_collect_respawn_pcg_kernel(MwArgs a);
 extern "C" __global__ void mw_take_spare_kernel(MwArgs a, const uint8_t *mask, int force_all);
 extern "C" __global__ void mw_view_mesh_kernel(int W, int H, int S, int first_env, const float *envhdr, const float *mesh_pos, uint32_t *keys);
 extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, int max_vis, int tiles_x, const float *rec_raster,
@@ -553,6 +555,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     }
     // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
     hipLaunchKernelGGL(mw_geom_kernel, dim3(N), dim3(64), 0, st, a, view_flags, e->cfg.msaa);
+    if (do_step && e->cfg.task == MW_TASK_COLLECT)
+        hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_collect_respawn_pcg_kernel : mw_collect_respawn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, a);
     if (timed) (void)hipEventRecord(ev.b, st);
     if (async_refill) {
         if (ensure_side_stream(e) != MW_OK) return MW_E_HIP;
@@ -740,7 +744,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
         const bool small_scene = cfg->max_visible <= 64 && cfg->max_polys + 6 * std::max(cfg->max_ents, 1) <= 32;      // = the dense K1 (k1_dense_lanes)
         bool want = small_scene || cfg->generator == MW_GEN_MAZE;
         if (const char *s = getenv("MW_SPARE")) want = atoi(s) != 0;
-        e->spare_mode = cfg->generator != MW_GEN_NONE && !cfg->domain_rand && want;
+        e->spare_mode = cfg->generator != MW_GEN_NONE && !cfg->domain_rand && want && cfg->task != MW_TASK_COLLECT;     // CollectHealth's respawns draw from the stream mid-episode
     }
     if (e->spare_mode) {
         ALLOC(sp.ax, N); ALLOC(sp.ay, N); ALLOC(sp.az, N); ALLOC(sp.adir, N);

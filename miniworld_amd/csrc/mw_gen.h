@@ -803,6 +803,7 @@ __device__ inline void refill_spares(const MwArgs &a, int r, int tid, unsigned c
     if (env < a.N && lane == 0) got = atomicCAS(a.refill_mask + env, 1u, 2u) == 1u;
     if (wpe) got = __shfl(got, 0);
     if (!got) return;
+    __threadfence();        // acquire: the live state this world is generated from / over is read behind the claim
     generate_world(*a.gen_spare, env, ws, lane);       // the workspace is the Maze generator's (one env per block there)
     __threadfence();
     if (lane == 0) atomicExch(a.refill_mask + env, 0u);

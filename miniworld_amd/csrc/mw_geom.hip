@@ -369,11 +369,11 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
 #pragma unroll
         for (int i = 0; i < 3; ++i) { hdr[4 + i] = f.l_amb[i]; hdr[8 + i] = f.l_dif[i]; }
         // the step's pending removal: the picked-up object leaves the entity list after its last frame
-        // (pickupobjects.py:86-88), the consumed kit respawns (collecthealth.py:86-90)
+        // (pickupobjects.py:86-88); CollectHealth's consumed kit respawns instead, with draws from the env's stream:
+        // mw_collect_respawn_kernel, launched behind this one
         const int rs = a.pending_remove[env];
-        if (rs >= 0 && !proxy) {
-            if (a.task == MW_TASK_COLLECT) mw::collect_respawn(a, env, set, rs, px, pz);
-            else a.ekind[(size_t)rs * a.N + env] = MW_ENT_NONE;
+        if (rs >= 0 && !proxy && a.task != MW_TASK_COLLECT) {
+            a.ekind[(size_t)rs * a.N + env] = MW_ENT_NONE;
             a.pending_remove[env] = -1;
         }
     }

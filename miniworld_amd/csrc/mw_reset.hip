@@ -26,6 +26,21 @@ extern "C" __global__ __launch_bounds__(64) void MW_REFILL_KERNEL_NAME(MwArgs a)
     mw::refill_spares(a, (int)blockIdx.x, (int)threadIdx.x, refill_ws);
 }
 
+#ifndef MW_RESPAWN_KERNEL_NAME
+#define MW_RESPAWN_KERNEL_NAME mw_collect_respawn_kernel
+#endif
+// CollectHealth: the kit consumed by this step respawns after its frame was set up (collecthealth.py:86-90), with
+// place_entity's draws from the env's stream; one thread per env, launched behind the geometry kernel
+extern "C" __global__ __launch_bounds__(64) void MW_RESPAWN_KERNEL_NAME(MwArgs a)
+{
+    const int env = (int)(blockIdx.x * 64 + threadIdx.x);
+    if (env >= a.N) return;
+    const int rs = a.pending_remove[env];
+    if (rs < 0) return;
+    mw::collect_respawn(a, env, a.shared_geom ? 0 : env, rs, a.ax[env], a.az[env]);
+    a.pending_remove[env] = -1;
+}
+
 #if MW_RNG_KIND == 0
 // mw_reset without seeds in spare mode: the masked envs take their pre-generated world (one wavefront per env)
 extern "C" __global__ __launch_bounds__(64) void mw_take_spare_kernel(MwArgs a, const uint8_t *__restrict__ mask, int force_all)

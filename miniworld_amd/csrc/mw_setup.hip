@@ -257,6 +257,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
                 // the next world was generated ahead (by a refill block of an earlier launch): claim it
                 if (writer) s_cnt[0][0] = (int)atomicCAS(a.refill_mask + env, 1u, 3u);
                 __syncthreads();
+                __threadfence();        // acquire: the spare's contents (written by another block, released with its state) are read behind the claim
                 const int old = s_cnt[0][0];
                 if (old == 1) {
                     // the previous episode lasted one step and the refill has not run yet: generate in place

@@ -193,6 +193,7 @@ extern "C" __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1
                     // spare mode: the next world was generated ahead by a refill block of an earlier launch (the
                     // blocks behind the env blocks of this grid): claim it.  States of refill_mask: mw_device.h.
                     const unsigned old = atomicCAS(a.refill_mask + env, 1u, 3u);
+                    __threadfence();        // acquire: the spare's contents are read behind the claim
                     if (old == 1u) {
                         // the previous episode lasted one step and the refill has not run yet: generate in place
                         mw::generate_world(*a.gen_live, env, gen_ws, 0);
