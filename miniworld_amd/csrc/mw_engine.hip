@@ -33,7 +33,7 @@ extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int 
                                                      float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                          float *reward, uint8_t *term, uint8_t *trunc);
-extern "C" __global__ void mw_geom_kernel(MwArgs a, int view_flags, int S);
+extern "C" __global__ void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
 extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
                                             int waves_per_env, int tiles_per_wave, const float *rec_raster,
                                             const float *rec_shade, const float *rec_cull, const int32_t *nvis,
@@ -205,6 +205,16 @@ int k1_threads(const mw_engine *e) { return e->args.rec_order ? 256 : 64; }     
 // Lanes per env of the dense K1 (mw_setup_dense.hip: one lane per room polygon + six per entity slot), or 0 when the
 // frame has to go through the wave-per-env kernel: big scenes, mesh entities, spare-world mode, other views,
 // or too many primitive slots to pack two envs into a wavefront.  MW_K1_DENSE=0 switches it off (A/B runs).
+// lanes per env of the geometry kernel: the power of two that holds an env's primitives (polygons, six faces per box,
+// the agent marker), 8 .. 64
+int geom_lanes(const mw_engine *e)
+{
+    const int items = e->cfg.max_polys + 6 * e->cfg.max_ents + 1;
+    int L = 8;
+    while (L < items && L < 64) L <<= 1;
+    return L;
+}
+
 int k1_dense_lanes(const mw_engine *e, int view_flags)
 {
     if (e->args.rec_order || view_flags != 0 || !e->k1_dense || e->cfg.task == MW_TASK_COLLECT) return 0;
@@ -554,7 +564,10 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                            d_trunc ? d_trunc : e->d_flag_scratch + N);
     }
     // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
-    hipLaunchKernelGGL(mw_geom_kernel, dim3(N), dim3(64), 0, st, a, view_flags, e->cfg.msaa);
+    {
+        const int L = geom_lanes(e), epw = 64 / L;
+        hipLaunchKernelGGL(mw_geom_kernel, dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
+    }
     if (do_step && e->cfg.task == MW_TASK_COLLECT)
         hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_collect_respawn_pcg_kernel : mw_collect_respawn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, a);
     if (timed) (void)hipEventRecord(ev.b, st);
@@ -1109,7 +1122,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     b.W = width; b.H = height;
     b.tiles_x = width / MW_TILE_W; b.tiles_y = height / MW_TILE_H; b.n_tiles = b.tiles_x * b.tiles_y;
     b.env_base = env;
-    hipLaunchKernelGGL(mw_geom_kernel, dim3(1), dim3(64), 0, st, b, view_flags, msaa);
+    hipLaunchKernelGGL(mw_geom_kernel, dim3(1), dim3(64), 0, st, b, view_flags, msaa, 64, 1);
     uint32_t *keys = nullptr;
     if (e->have_meshes) {
         const size_t need = (size_t)width * height * msaa * 4;
@@ -1162,7 +1175,10 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     b.step_override = nullptr;
     b.env_base = first_env;
     // K1 in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
-    hipLaunchKernelGGL(mw_geom_kernel, dim3(count), dim3(64), 0, st, b, 4, e->cfg.msaa);
+    {
+        const int L = geom_lanes(e), epw = 64 / L;
+        hipLaunchKernelGGL(mw_geom_kernel, dim3((count + epw - 1) / epw), dim3(64), 0, st, b, 4, e->cfg.msaa, L, count);
+    }
     if (!e->visible_attr_set) {
         HIP_TRY(e, hipFuncSetAttribute((const void *)mw_visible_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         e->visible_attr_set = true;

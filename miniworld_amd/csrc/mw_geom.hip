@@ -1,4 +1,4 @@
-// KG — the vertex half of a frame: camera, lighting, transform, clipping, triangle setup.  One wavefront per environment.
+// KG — the vertex half of a frame: camera, lighting, transform, clipping, triangle setup.
 //
 // Replaces, per env and per frame (reference file:line), what the reference hands to OpenGL and what the driver does with
 // it before a single sample is touched:
@@ -10,219 +10,126 @@
 //   MeshEnt.render                        entity.py:150-161   (described to the mesh kernel: transform, light, draw-id range)
 //   Agent.render                          entity.py:518-539   (top view's marker, lit by the stale current normal)
 //   get_visible_ents' proxy boxes         miniworld.py:1291-1313
-// with the arithmetic of mw_glmath.h (Mesa 23.2.1 / llvmpipe, measured).  Output: per env a list of triangle records in
-// drawing order (mw_records.h), the env header (sky colour, mesh-entity table), and the entity removals the step left pending
-// (a picked-up object is still drawn in the frame of the step that picked it up: pickupobjects.py:86-88 runs after :717).
+// with the arithmetic of mw_glmath.h (Mesa 23.2.1 / llvmpipe, measured).  Output: per env the list of the triangles that
+// leave llvmpipe's setup, in drawing order and without gaps (mw_records.h), the env header (sky colour, mesh-entity
+// table), and the entity removals the step left pending (a picked-up object is still drawn in the frame of the step that
+// picked it up: pickupobjects.py:86-88 runs after :717).
 //
-// Lanes: one GL primitive (polygon / box face) per lane and round.  A primitive yields up to two triangles; a triangle that
-// needs clipping takes one of 8 work slots in LDS (two vertex lists), the lanes with such a triangle go through the slots in
-// batches.  List positions come from an exclusive scan of per-lane UPPER BOUNDS (a triangle cut by k planes becomes at most
-// k + 1): drawing order is kept, what clipping or culling removes is left as a NULL record that touches no tile.
+// Lanes: a wavefront serves 64 / L envs, L lanes each (L: the power of two that holds an env's primitives — polygons, six
+// faces per box, the agent marker — or 64, with several rounds).  One GL primitive per lane and round, up to two triangles.
+// A round runs twice over its triangles: pass 1 counts what survives clipping and culling, a segmented scan turns the
+// counts into list positions, pass 2 writes the records.  Unclipped triangles keep their setup in registers between the
+// passes; a triangle that crosses a frustum plane goes through one of kClipSlots work lists in LDS, in both passes.
 #include "mw_setup_common.h"
 #include "mw_records.h"
 
 namespace {
 
-constexpr int kClipSlots = 8;
+constexpr int kClipSlots = 32;
 
-__device__ inline int wave_excl_scan(int v, int lane, int &total)
+// exclusive scan inside the env's L-lane group; total: the group's sum
+__device__ inline int group_excl_scan(int v, int sub, int L, int &total)
 {
     int x = v;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int y = __shfl_up(x, off);
-        if (lane >= off) x += y;
+    for (int off = 1; off < L; off <<= 1) {
+        const int y = __shfl_up(x, off, L);
+        if (sub >= off) x += y;
     }
-    total = __shfl(x, 63);
+    total = __shfl(x, L - 1, L);
     return x - v;
 }
 
-// Draw ids order the frame's triangles for the depth test's ties (GL_LESS: the first drawn wins) and name them in the
-// sample keys: a record's id is its list position plus the mesh triangles drawn before it (a mesh entity takes one id
-// per triangle); the proxy boxes of get_visible_ents carry their entity's tag instead.
-struct Emit {
-    const MwArgs &a;
-    int env, S, tex;
-    uint32_t id_base, tag;
-    int idx, end;            // next list position / one past this triangle's range
-    __device__ void operator()(const mwgl::TriSetup &t)
-    {
-        if (idx < end && idx < a.max_vis) mwrec::write_tri(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t, tex, S);
-        ++idx;
-    }
-};
-
-// upper bound of the triangles (a, b, c) turns into
-__device__ inline int tri_bound(const mwgl::Vert &a, const mwgl::Vert &b, const mwgl::Vert &c)
+// does the triangle (window coordinates) leave setup?  (the snapped-area cull of setup_triangle alone)
+__device__ inline bool tri_front(const float wa[4], const float wb[4], const float wc[4], bool multisampled)
 {
-    const uint32_t m = a.clipmask | b.clipmask | c.clipmask;
-    if (a.clipmask & b.clipmask & c.clipmask) return 0;
-    return 1 + __popc(m);
-}
-
-// One round: every lane holds a primitive of `nt` triangles (0: none) given as vertex indices into v[4]; emits them at
-// list positions [base, base + bound) in order and fills what stays unused with NULL records.
-template <bool GOURAUD>
-__device__ inline void emit_round(const MwArgs &a, const mwgl::Frame &f, int env, int lane, int S, const mwgl::Vert v[4], int nt,
-                                  const int tri[2][3], int tex, uint32_t id_base, uint32_t tag, int &count, mwgl::Vert (*s_clip)[2][MWGL_MAX_CLIP_VERTS])
-{
-    int bound[2] = {0, 0};
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-        if (t < nt) bound[t] = tri_bound(v[tri[t][0]], v[tri[t][1]], v[tri[t][2]]);
-    int total;
-    const int base = count + wave_excl_scan(bound[0] + bound[1], lane, total);
-    count += total;
-    if (base + bound[0] + bound[1] > a.max_vis && (bound[0] | bound[1])) atomicOr(a.status, MW_ST_VIS_OVERFLOW);
-    const bool ms = S > 1;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int b0 = base + (t ? bound[0] : 0);
-        Emit em{a, env, S, tex, id_base, tag, b0, b0 + bound[t]};
-        const mwgl::Vert &va = v[tri[t][0]], &vb = v[tri[t][1]], &vc = v[tri[t][2]];
-        const bool clipped = bound[t] > 1;
-        if (bound[t] == 1) {
-            mwgl::TriSetup ts;
-            if (mwgl::setup_triangle(va, vb, vc, ms, tex >= 0, ts)) em(ts);
-        }
-        // triangles that cross a frustum plane: kClipSlots lanes at a time through the LDS work lists
-        uint64_t pend = __ballot(clipped);
-        while (pend) {
-            // the batch: the lowest kClipSlots set bits
-            uint64_t batch = 0ull, rest = pend;
-            for (int k = 0; k < kClipSlots && rest; ++k) { batch |= rest & (0ull - rest); rest &= rest - 1ull; }
-            if (clipped && ((batch >> lane) & 1ull)) {
-                const int slot = __popcll((unsigned long long)(batch & ((1ull << lane) - 1ull)));
-                mwgl::Vert *r;
-                const int n = mwgl::clip_triangle<GOURAUD>(f, va, vb, vc, s_clip[slot][0], s_clip[slot][1], &r);
-                for (int i = 2; i < n; ++i) {
-                    mwgl::TriSetup ts;
-                    if (mwgl::setup_triangle(r[i - 1], r[i], r[0], ms, tex >= 0, ts)) em(ts);
-                }
-            }
-            pend = rest;
-        }
-        for (int i = em.idx; i < em.end && i < a.max_vis; ++i) mwrec::write_null(a, env, i);
-    }
+    const float off = multisampled ? 0.0f : 0.5f;
+    const int32_t x0 = mwgl::iround_even((wa[0] - off) * 256.0f), y0 = mwgl::iround_even((wa[1] - off) * 256.0f);
+    const int32_t x1 = mwgl::iround_even((wb[0] - off) * 256.0f), y1 = mwgl::iround_even((wb[1] - off) * 256.0f);
+    const int32_t x2 = mwgl::iround_even((wc[0] - off) * 256.0f), y2 = mwgl::iround_even((wc[1] - off) * 256.0f);
+    const int64_t dx01 = x0 - x1, dy01 = y0 - y1, dx20 = x2 - x0, dy20 = y2 - y0;
+    return dx01 * dy20 - dx20 * dy01 < 0;
 }
 
 }  // namespace
 
 // view_flags: bit 0 top view, bit 1 draw the agent marker, bit 2 get_visible_ents' proxy pass (rooms untextured + one
-// 0.2 m box per entity, tagged 0x10000 | slot).  S: samples per pixel of the target (1, 4, 8, 16).
-extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int view_flags, int S)
+// 0.2 m box per entity, tagged 0x10000 | slot).  S: samples per pixel of the target (1, 4, 8, 16).  L: lanes per env
+// (8, 16, 32 or 64); n_env: envs a.env_base .. a.env_base + n_env - 1.
+extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env)
 {
     __shared__ mwgl::Vert s_clip[kClipSlots][2][MWGL_MAX_CLIP_VERTS];
-    const int env = a.env_base + blockIdx.x;
+    __shared__ int s_pos[8][66];
     const int lane = threadIdx.x;
+    const int epw = 64 / L, sub = lane & (L - 1), grp = lane / L;
+    const int rel = (int)blockIdx.x * epw + grp;
+    const bool live = rel < n_env;
+    const int env = a.env_base + (live ? rel : n_env - 1);      // a padding group recomputes the last env and writes nothing
     const int set = a.shared_geom ? 0 : env;
-    const bool top = (view_flags & 1) != 0, proxy = (view_flags & 4) != 0;
-    // ---- the frame's GL state (every lane evaluates it: same instruction stream)
+    const bool top = (view_flags & 1) != 0, proxy = (view_flags & 4) != 0, ms = S > 1;
+    // ---- the frame's GL state (every lane of the group evaluates it: same instruction stream)
     mwgl::Frame f;
     const double px = a.ax[env], py = a.ay[env], pz = a.az[env], dir = a.adir[env];
-    double lpos[3], lcol[3], lamb[3];
+    {
+        double lpos[3], lcol[3], lamb[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        lpos[i] = a.light[(size_t)(3 + i) * a.N + env];
-        lcol[i] = a.light[(size_t)(6 + i) * a.N + env];
-        lamb[i] = a.light[(size_t)(9 + i) * a.N + env];
-    }
-    if (top) {
-        double min_x = a.extent[(size_t)0 * a.N + env] - 1, max_x = a.extent[(size_t)1 * a.N + env] + 1;
-        double min_z = a.extent[(size_t)2 * a.N + env] - 1, max_z = a.extent[(size_t)3 * a.N + env] + 1;
-        const double width = max_x - min_x, height = max_z - min_z;
-        const double aspect = width / height, fb_aspect = (double)a.W / (double)a.H;
-        if (aspect > fb_aspect) {
-            const double new_h = width / fb_aspect, h_diff = new_h - height;
-            min_z -= h_diff / 2; max_z += h_diff / 2;
-        } else if (aspect < fb_aspect) {
-            const double new_w = height * fb_aspect, w_diff = new_w - width;
-            min_x -= w_diff / 2; max_x += w_diff / 2;
+        for (int i = 0; i < 3; ++i) {
+            lpos[i] = a.light[(size_t)(3 + i) * a.N + env];
+            lcol[i] = a.light[(size_t)(6 + i) * a.N + env];
+            lamb[i] = a.light[(size_t)(9 + i) * a.N + env];
         }
-        mwgl::frame_top(f, min_x, max_x, min_z, max_z);
-    } else {
-        // Agent.cam_pos / cam_dir via gen_rot_matrix (math.py:11-27, entity.py:476-503) as numpy evaluates them
-        const double cam_height = a.cam[(size_t)0 * a.N + env], fwd_disp = a.cam[(size_t)1 * a.N + env];
-        const double pitch_deg = a.cam[(size_t)2 * a.N + env], fov_y = a.cam[(size_t)3 * a.N + env];
-        const mw::SinCos hd = mw::sincos_det(dir / 2.0);
-        const double ya = hd.c, yc = -1.0 * hd.s;
-        const double ry00 = ya * ya - yc * yc, ry02 = 2.0 * (ya * yc), ry11 = ya * ya + yc * yc;
-        const double pitch = pitch_deg * kPi / 180.0;
-        const mw::SinCos hp = mw::sincos_det(pitch / 2.0);
-        const double za = hp.c, zd = -1.0 * hp.s;
-        const double rz00 = za * za - zd * zd, rz01 = 2.0 * (0.0 - za * zd);
-        const double eye[3] = {px + fwd_disp * ry00, py + cam_height * ry11, pz + fwd_disp * ry02};
-        const double cd[3] = {rz00 * ry00, rz01 * ry11, rz00 * ry02};
-        const double at[3] = {eye[0] + cd[0], eye[1] + cd[1], eye[2] + cd[2]};
-        const mw::SinCos hf = mw::sincos_det(fov_y / 2 * kPi / 180);
-        mwgl::frame_perspective(f, eye, at, hf.c / hf.s, a.W, a.H);
+        if (top) {
+            double min_x = a.extent[(size_t)0 * a.N + env] - 1, max_x = a.extent[(size_t)1 * a.N + env] + 1;
+            double min_z = a.extent[(size_t)2 * a.N + env] - 1, max_z = a.extent[(size_t)3 * a.N + env] + 1;
+            const double width = max_x - min_x, height = max_z - min_z;
+            const double aspect = width / height, fb_aspect = (double)a.W / (double)a.H;
+            if (aspect > fb_aspect) {
+                const double new_h = width / fb_aspect, h_diff = new_h - height;
+                min_z -= h_diff / 2; max_z += h_diff / 2;
+            } else if (aspect < fb_aspect) {
+                const double new_w = height * fb_aspect, w_diff = new_w - width;
+                min_x -= w_diff / 2; max_x += w_diff / 2;
+            }
+            mwgl::frame_top(f, min_x, max_x, min_z, max_z);
+        } else {
+            // Agent.cam_pos / cam_dir via gen_rot_matrix (math.py:11-27, entity.py:476-503) as numpy evaluates them
+            const double cam_height = a.cam[(size_t)0 * a.N + env], fwd_disp = a.cam[(size_t)1 * a.N + env];
+            const double pitch_deg = a.cam[(size_t)2 * a.N + env], fov_y = a.cam[(size_t)3 * a.N + env];
+            const mw::SinCos hd = mw::sincos_det(dir / 2.0);
+            const double ya = hd.c, yc = -1.0 * hd.s;
+            const double ry00 = ya * ya - yc * yc, ry02 = 2.0 * (ya * yc), ry11 = ya * ya + yc * yc;
+            const double pitch = pitch_deg * kPi / 180.0;
+            const mw::SinCos hp = mw::sincos_det(pitch / 2.0);
+            const double za = hp.c, zd = -1.0 * hp.s;
+            const double rz00 = za * za - zd * zd, rz01 = 2.0 * (0.0 - za * zd);
+            const double eye[3] = {px + fwd_disp * ry00, py + cam_height * ry11, pz + fwd_disp * ry02};
+            const double cd[3] = {rz00 * ry00, rz01 * ry11, rz00 * ry02};
+            const double at[3] = {eye[0] + cd[0], eye[1] + cd[1], eye[2] + cd[2]};
+            const mw::SinCos hf = mw::sincos_det(fov_y / 2 * kPi / 180);
+            mwgl::frame_perspective(f, eye, at, hf.c / hf.s, a.W, a.H);
+        }
+        mwgl::frame_finish(f, a.W, a.H, lpos, lcol, lamb);
     }
-    mwgl::frame_finish(f, a.W, a.H, lpos, lcol, lamb);
     mwgl::Xform cam;
     mwgl::make_xform(f, f.view, f.view_flags, cam);
 
-    int count = 0;
-    float stale_n[3] = {0.0f, 1.0f, 0.0f};
     const mw_poly *polys = a.polys + (size_t)set * a.max_polys;
     const int np = a.npolys[set];
-    const float white[3] = {1.0f, 1.0f, 1.0f};
-    // ---- display list 1: rooms, frames
-    for (int base = 0; base < np; base += 64) {
-        const int i = base + lane;
-        mwgl::Vert v[4];
-        int nt = 0, tex = -1;
-        int tri[2][3] = {{0, 1, 2}, {0, 2, 3}};
-        if (i < np) {
-            const mw_poly q = polys[i];
-            const int nv = q.nv & 0xFF;
-            if (!(proxy && (q.nv & MW_POLY_ENTITY))) {       // the queries draw rooms only
-                mwgl::Xform ex;
-                const bool own = (q.nv & MW_POLY_XF) != 0;
-                if (own) mwgl::entity_xform(f, q.xf, q.xf[3], 1.0f, false, ex);
-                const mwgl::Xform &x = own ? ex : cam;
-                float col[3];
-                mwgl::light_vertex(f, x, q.n, proxy ? white : q.rgb, col);
-                tex = proxy ? -1 : q.tex;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (k < nv) {
-                        mwgl::transform_vertex(f, x, q.v[k], v[k]);
-                        v[k].st[0] = tex >= 0 ? q.uv[k][0] : 0.0f; v[k].st[1] = tex >= 0 ? q.uv[k][1] : 0.0f;
-                        v[k].col[0] = col[0]; v[k].col[1] = col[1]; v[k].col[2] = col[2];
-                    }
-                }
-                if (nv == 3) { nt = 1; tri[0][0] = 1; tri[0][1] = 2; tri[0][2] = 0; }
-                else if (q.nv & MW_POLY_QUAD) { nt = 2; tri[0][0] = 0; tri[0][1] = 1; tri[0][2] = 3; tri[1][0] = 1; tri[1][1] = 2; tri[1][2] = 3; }
-                else { nt = 2; tri[0][0] = 1; tri[0][1] = 2; tri[0][2] = 0; tri[1][0] = 2; tri[1][1] = 3; tri[1][2] = 0; }
-            }
-        }
-        emit_round<false>(a, f, env, lane, S, v, nt, tri, tex, 0u, 0u, count, s_clip);
-    }
-    if (np > 0) { stale_n[0] = polys[np - 1].n[0]; stale_n[1] = polys[np - 1].n[1]; stale_n[2] = polys[np - 1].n[2]; }
-
-    // ---- entities: static ones first (inside display list 1), then dynamic ones, each in slot order
     float *hdr = a.envhdr + (size_t)env * MW_ENVHDR;
-    int n_mesh = 0, mesh_tris = 0;
-    uint64_t box_m, mesh_m, frame_m, static_m;
-    {
-        int kind_l = MW_ENT_NONE, static_l = 0;
-        if (lane < a.E) {
-            kind_l = a.ekind[(size_t)lane * a.N + env];
-            static_l = a.estatic[(size_t)lane * a.N + env];
-        }
-        box_m = ballot(kind_l == MW_ENT_BOX);
-        mesh_m = ballot(kind_l == MW_ENT_MESH);
-        frame_m = ballot(kind_l == MW_ENT_FRAME);
-        static_m = ballot(static_l != 0);
-    }
-    if (proxy) { box_m |= mesh_m | frame_m; mesh_m = 0ull; static_m = ~0ull; }
+
+    // ---- the env's draw list behind the polygons: boxes in drawing order (static entities first, inside display list 1,
+    // then the dynamic ones, each in slot order).  A mesh entity's triangles belong to the mesh kernel; here it gets its
+    // place in the drawing order (one draw id per triangle) and its transform (env header, written by the group's lane 0).
+    // This lane's primitive of round r is item r * L + sub: a polygon, else face (item - np) % 6 of box (item - np) / 6,
+    // else the agent marker.
+    int total_meshes = 0, total_mesh_tris = 0, total_boxes = 0;
+    uint64_t mesh_in_view = 0ull;       // per entity slot: a mesh entity that is drawn
     for (int pass = 0; pass < 2; ++pass) {
-        const uint64_t mine_m = pass == 0 ? static_m : ~static_m;
-        const uint64_t mesh_mine = mesh_m & mine_m, box_mine = box_m & mine_m;
-        int s0 = 0;
-        while (s0 < a.E) {
-            if ((mesh_mine >> s0) & 1ull) {
-                // a mesh entity: its triangles belong to the mesh kernel; here its place in the drawing order and its transform
+        for (int s0 = 0; s0 < a.E; ++s0) {
+            const int kind = a.ekind[(size_t)s0 * a.N + env];
+            if (kind == MW_ENT_NONE) continue;
+            const bool stat = proxy ? true : a.estatic[(size_t)s0 * a.N + env] != 0;
+            if (stat != (pass == 0)) continue;
+            if (kind == MW_ENT_MESH && !proxy) {
                 const int mid = a.emesh[(size_t)s0 * a.N + env];
                 const MwMeshDesc *mdp = a.mesh + mid;
                 const int md_ntris = (int)mdp->ntris;
@@ -243,102 +150,143 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
                     const float lx = sqrtf(fmaf(p00, p00, 1.0f)), ly = sqrtf(fmaf(p11, p11, 1.0f));
                     in_view = !(w + brad < 0.04f) && !(w - fabsf(o.clip[0]) < -(brad * lx)) && !(w - fabsf(o.clip[1]) < -(brad * ly));
                 }
-                if (in_view) {
-                    if (n_mesh < MW_MAX_MESH_ENTS && count + mesh_tris + md_ntris < 0xFFF0) {
-                        if (lane == 0) {
-                            float *m = hdr + MW_HDR_MESH + MW_HDR_MESH_STRIDE * n_mesh;
-                            m[0] = __int_as_float(s0);
-                            m[1] = __int_as_float(count + mesh_tris);
-                            m[2] = __int_as_float(md_ntris);
-                            m[3] = __int_as_float((int)mdp->first);
-                            m[4] = __int_as_float((int)mdp->tex);
-                            m[5] = ex.nscale;
-                            m[6] = ex.light[0]; m[7] = ex.light[1]; m[8] = ex.light[2];
+                if (!in_view) continue;
+                if (total_meshes < MW_MAX_MESH_ENTS && total_mesh_tris + md_ntris < 0xC000 && s0 < 64) {
+                    if (sub == 0 && live) {
+                        float *m = hdr + MW_HDR_MESH + MW_HDR_MESH_STRIDE * total_meshes;
+                        m[0] = __int_as_float(s0);
+                        m[1] = __int_as_float(total_boxes);         // boxes drawn before: turned into the first draw id at the end
+                        m[2] = __int_as_float(md_ntris);
+                        m[3] = __int_as_float((int)mdp->first);
+                        m[4] = __int_as_float((int)mdp->tex);
+                        m[5] = ex.nscale;
+                        m[6] = ex.light[0]; m[7] = ex.light[1]; m[8] = ex.light[2];
 #pragma unroll
-                            for (int k = 0; k < 16; ++k) m[9 + k] = ex.mvp.m[k];
-                        }
-                        mesh_tris += md_ntris;      // one draw id per triangle (a mesh out of view takes none)
-                        ++n_mesh;
-                    } else {
-                        atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+                        for (int k = 0; k < 16; ++k) m[9 + k] = ex.mvp.m[k];
+                        m[25] = __int_as_float(total_mesh_tris);    // mesh triangles drawn before
                     }
+                    mesh_in_view |= 1ull << s0;
+                    total_mesh_tris += md_ntris;      // one draw id per triangle (a mesh out of view takes none)
+                    ++total_meshes;
+                } else {
+                    atomicOr(a.status, MW_ST_VIS_OVERFLOW);
                 }
-                ++s0;
-                continue;
+            } else if (kind == MW_ENT_BOX || proxy) {
+                ++total_boxes;
             }
-            // a run of up to 10 box slots (6 faces each), ending before the next mesh of this pass
-            int s1 = s0 + 10 < a.E ? s0 + 10 : a.E;
-            {
-                const uint64_t ahead = mesh_mine >> s0;
-                if (ahead) {
-                    const int nxt = s0 + __builtin_ctzll(ahead);
-                    s1 = nxt < s1 ? nxt : s1;
-                }
-            }
-            const uint64_t run_boxes = (box_mine >> s0) & ((1ull << (s1 - s0)) - 1ull);
-            if (run_boxes) {
-                const int bi = lane / 6, fc = lane - bi * 6, slot = s0 + bi;
-                const bool mine = lane < (s1 - s0) * 6 && ((run_boxes >> bi) & 1ull);
-                mwgl::Vert v[4];
-                int nt = 0;
-                int tri[2][3] = {{0, 1, 3}, {1, 2, 3}};
-                bool clipped_l = false;
-                if (mine) {
-                    const double ex_ = a.epos[((size_t)0 * a.E + slot) * a.N + env], ey_ = a.epos[((size_t)1 * a.E + slot) * a.N + env],
-                                 ez_ = a.epos[((size_t)2 * a.E + slot) * a.N + env];
-                    float lo[3], hi[3], base_col[3];
-                    mwgl::Xform ex;
-                    const mwgl::Xform *x = &cam;
-                    if (proxy) {
-                        // drawBox(pos -+ 0.1, pos.y .. pos.y + 0.2): python doubles through glVertex3f, under the camera alone
-                        lo[0] = (float)(ex_ - 0.1); lo[1] = (float)ey_; lo[2] = (float)(ez_ - 0.1);
-                        hi[0] = (float)(ex_ + 0.1); hi[1] = (float)(ey_ + 0.2); hi[2] = (float)(ez_ + 0.1);
-                        base_col[0] = base_col[1] = base_col[2] = 1.0f;
-                    } else {
-                        const float pos[3] = {(float)ex_, (float)ey_, (float)ez_};
-                        mwgl::entity_xform(f, pos, (float)(a.edir[(size_t)slot * a.N + env] * (180 / kPi)), 1.0f, false, ex);
-                        x = &ex;
-                        const double sx = a.egeom[((size_t)0 * a.E + slot) * a.N + env], sy = a.egeom[((size_t)1 * a.E + slot) * a.N + env],
-                                     sz = a.egeom[((size_t)2 * a.E + slot) * a.N + env];
-                        lo[0] = (float)(-sx / 2); lo[1] = 0.0f; lo[2] = (float)(-sz / 2);
-                        hi[0] = (float)(sx / 2); hi[1] = (float)sy; hi[2] = (float)(sz / 2);
-#pragma unroll
-                        for (int k = 0; k < 3; ++k) base_col[k] = (float)a.egeom[((size_t)(3 + k) * a.E + slot) * a.N + env];
-                    }
-                    float n[3], col[3];
-                    mwgl::box_normal(fc, n);
-                    mwgl::light_vertex(f, *x, n, base_col, col);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int sel = mwgl::box_sel(fc, k);
-                        const float p[3] = {(sel & 1) ? hi[0] : lo[0], (sel & 2) ? hi[1] : lo[1], (sel & 4) ? hi[2] : lo[2]};
-                        mwgl::transform_vertex(f, *x, p, v[k]);
-                        v[k].st[0] = v[k].st[1] = 0.0f;
-                        v[k].col[0] = col[0]; v[k].col[1] = col[1]; v[k].col[2] = col[2];
-                        clipped_l |= v[k].clipmask != 0u;
-                    }
-                    nt = 2;
-                }
-                // one glBegin / glEnd per box: a clipped vertex anywhere in the call sends all six faces through the draw
-                // module's pipeline, whose quads split (0,1,3) (1,2,3); an immediate-mode call without one splits (0,1,2)
-                // (0,2,3); a static box sits in display list 1 (always the first split)
-                const uint64_t cm = __ballot(clipped_l);
-                const bool box_clipped = ((cm >> (bi * 6)) & 0x3Full) != 0ull;
-                const bool in_list = !proxy && mine && a.estatic[(size_t)slot * a.N + env] != 0;
-                if (mine && !box_clipped && !in_list) { tri[0][0] = 0; tri[0][1] = 1; tri[0][2] = 2; tri[1][0] = 0; tri[1][1] = 2; tri[1][2] = 3; }
-                emit_round<false>(a, f, env, lane, S, v, nt, tri, -1, (uint32_t)mesh_tris, proxy ? (0x10000u | (uint32_t)slot) : 0u, count, s_clip);
-                stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f;     // drawBox ends with glNormal3f(0, -1, 0)
-            }
-            s0 = s1;
         }
     }
-    if (view_flags & 2) {
-        // Agent.render (entity.py:518-539): no glNormal3f => lit with the normal the last immediate-mode glNormal3f or the
-        // end of the display list left current (glDrawArrays with a normal array leaves it alone)
+    // the want-th box of the drawing order: its slot and the mesh triangles drawn before it
+    auto find_box = [&](int want, int &slot_out, int &idbase_out) {
+        int nb = 0, mt = 0;
+        slot_out = -1; idbase_out = 0;
+        for (int pass = 0; pass < 2; ++pass) {
+            for (int s0 = 0; s0 < a.E; ++s0) {
+                const int kind = a.ekind[(size_t)s0 * a.N + env];
+                if (kind == MW_ENT_NONE) continue;
+                const bool stat = proxy ? true : a.estatic[(size_t)s0 * a.N + env] != 0;
+                if (stat != (pass == 0)) continue;
+                if (kind == MW_ENT_MESH && !proxy) {
+                    if (s0 < 64 && ((mesh_in_view >> s0) & 1ull)) mt += (int)a.mesh[a.emesh[(size_t)s0 * a.N + env]].ntris;
+                } else if (kind == MW_ENT_BOX || proxy) {
+                    if (nb == want) { slot_out = s0; idbase_out = mt; }
+                    ++nb;
+                }
+            }
+        }
+    };
+
+    int count = 0;          // the env's list length so far (uniform in the group)
+    float stale_n[3] = {0.0f, 1.0f, 0.0f};
+    if (np > 0) { stale_n[0] = polys[np - 1].n[0]; stale_n[1] = polys[np - 1].n[1]; stale_n[2] = polys[np - 1].n[2]; }
+    if (total_boxes > 0) { stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f; }     // drawBox ends with glNormal3f(0, -1, 0)
+    const float white[3] = {1.0f, 1.0f, 1.0f};
+    const int marker = (view_flags & 2) ? 1 : 0;
+    const int n_items = np + 6 * total_boxes + marker;
+    // list position of each box's first record and of the end of the boxes: a mesh's first draw id is the number of
+    // records drawn before it plus the mesh triangles drawn before it
+    int *pos = s_pos[grp];
+    if (sub == 0) for (int i = 0; i <= (total_boxes < 64 ? total_boxes : 64); ++i) pos[i] = -1;
+
+    for (int r0 = 0; r0 < n_items; r0 += L) {
+        const int item = r0 + sub;
+        int box_slot = -1, box_idbase = 0;
+        if (__any(item >= np && item < np + 6 * total_boxes)) find_box(item >= np ? (item - np) / 6 : -1, box_slot, box_idbase);
+        if (!(item >= np && item < np + 6 * total_boxes)) box_slot = -1;
         mwgl::Vert v[4];
-        int nt = 0;
-        const int tri[2][3] = {{0, 1, 2}, {0, 1, 2}};
-        if (lane == 0) {
+        int nt = 0, tex = -1;
+        bool direct = false;        // the triangles of v[]: (0,1,3) (1,2,3), or (0,1,2) (0,2,3) for a direct quad
+        uint32_t id_base = 0u, tag = 0u;
+        bool is_box = false, clipped_l = false, in_list = false;
+        if (item < np) {
+            const mw_poly *qp = polys + item;
+            const int nvf = qp->nv, nv = nvf & 0xFF;
+            if (!(proxy && (nvf & MW_POLY_ENTITY))) {       // the queries draw rooms only
+                mwgl::Xform ex;
+                const bool own = (nvf & MW_POLY_XF) != 0;
+                if (own) mwgl::entity_xform(f, qp->xf, qp->xf[3], 1.0f, false, ex);
+                const mwgl::Xform &x = own ? ex : cam;
+                float col[3];
+                const float qn[3] = {qp->n[0], qp->n[1], qp->n[2]}, qc[3] = {qp->rgb[0], qp->rgb[1], qp->rgb[2]};
+                mwgl::light_vertex(f, x, qn, proxy ? white : qc, col);
+                tex = proxy ? -1 : qp->tex;
+                // a polygon is the fan (1,2,0) (2,3,0), a quad of the list (0,1,3) (1,2,3): the same triangles of v[] once
+                // the polygon's vertices are taken one further round
+                const bool fan = nv == 3 || !(nvf & MW_POLY_QUAD);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int sk = fan ? ((k + 1) & 3) : k;
+                    if (nv == 3) sk = k == 0 ? 1 : (k == 1 ? 2 : 0);
+                    const float pk[3] = {qp->v[sk][0], qp->v[sk][1], qp->v[sk][2]};
+                    mwgl::transform_vertex(f, x, pk, v[k]);
+                    v[k].st[0] = tex >= 0 ? qp->uv[sk][0] : 0.0f; v[k].st[1] = tex >= 0 ? qp->uv[sk][1] : 0.0f;
+                    v[k].col[0] = col[0]; v[k].col[1] = col[1]; v[k].col[2] = col[2];
+                }
+                nt = nv == 3 ? 1 : 2;
+            }
+        } else if (box_slot >= 0) {
+            const int slot = box_slot, fc = (item - np) % 6;
+            is_box = true;
+            id_base = (uint32_t)box_idbase;
+            tag = proxy ? (0x10000u | (uint32_t)slot) : 0u;
+            const double ex_ = a.epos[((size_t)0 * a.E + slot) * a.N + env], ey_ = a.epos[((size_t)1 * a.E + slot) * a.N + env],
+                         ez_ = a.epos[((size_t)2 * a.E + slot) * a.N + env];
+            float lo[3], hi[3], base_col[3];
+            mwgl::Xform ex;
+            const mwgl::Xform *x = &cam;
+            if (proxy) {
+                // drawBox(pos -+ 0.1, pos.y .. pos.y + 0.2): python doubles through glVertex3f, under the camera alone
+                lo[0] = (float)(ex_ - 0.1); lo[1] = (float)ey_; lo[2] = (float)(ez_ - 0.1);
+                hi[0] = (float)(ex_ + 0.1); hi[1] = (float)(ey_ + 0.2); hi[2] = (float)(ez_ + 0.1);
+                base_col[0] = base_col[1] = base_col[2] = 1.0f;
+            } else {
+                const float pos[3] = {(float)ex_, (float)ey_, (float)ez_};
+                mwgl::entity_xform(f, pos, (float)(a.edir[(size_t)slot * a.N + env] * (180 / kPi)), 1.0f, false, ex);
+                x = &ex;
+                const double sx = a.egeom[((size_t)0 * a.E + slot) * a.N + env], sy = a.egeom[((size_t)1 * a.E + slot) * a.N + env],
+                             sz = a.egeom[((size_t)2 * a.E + slot) * a.N + env];
+                lo[0] = (float)(-sx / 2); lo[1] = 0.0f; lo[2] = (float)(-sz / 2);
+                hi[0] = (float)(sx / 2); hi[1] = (float)sy; hi[2] = (float)(sz / 2);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) base_col[k] = (float)a.egeom[((size_t)(3 + k) * a.E + slot) * a.N + env];
+                in_list = a.estatic[(size_t)slot * a.N + env] != 0;
+            }
+            float n[3], col[3];
+            mwgl::box_normal(fc, n);
+            mwgl::light_vertex(f, *x, n, base_col, col);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int sel = mwgl::box_sel(fc, k);
+                const float p[3] = {(sel & 1) ? hi[0] : lo[0], (sel & 2) ? hi[1] : lo[1], (sel & 4) ? hi[2] : lo[2]};
+                mwgl::transform_vertex(f, *x, p, v[k]);
+                v[k].st[0] = v[k].st[1] = 0.0f;
+                v[k].col[0] = col[0]; v[k].col[1] = col[1]; v[k].col[2] = col[2];
+                clipped_l |= v[k].clipmask != 0u;
+            }
+            nt = 2;
+        } else if (marker && item == n_items - 1) {
+            // Agent.render (entity.py:518-539): no glNormal3f => lit with the normal the last immediate-mode glNormal3f or the
+            // end of the display list left current (glDrawArrays with a normal array leaves it alone)
             const mw::SinCos sc = mw::sincos_det(dir);
             const double rad = a.agent_radius, hgt = a.agent_height;
             const double p[3] = {px + 0 * hgt, py + 1 * hgt, pz + 0 * hgt};
@@ -352,22 +300,149 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
             const float red[3] = {1.0f, 0.0f, 0.0f};
             float col[3];
             mwgl::light_vertex(f, cam, stale_n, red, col);
+#pragma unroll
             for (int k = 0; k < 3; ++k) {
-                mwgl::transform_vertex(f, cam, pv[k], v[k]);
-                v[k].st[0] = v[k].st[1] = 0.0f;
-                v[k].col[0] = col[0]; v[k].col[1] = col[1]; v[k].col[2] = col[2];
+                mwgl::Vert &d = k == 2 ? v[3] : v[k];          // the triangle (0, 1, 3) of v[]
+                mwgl::transform_vertex(f, cam, pv[k], d);
+                d.st[0] = d.st[1] = 0.0f;
+                d.col[0] = col[0]; d.col[1] = col[1]; d.col[2] = col[2];
             }
             nt = 1;
+            id_base = (uint32_t)total_mesh_tris;
         }
-        emit_round<false>(a, f, env, lane, S, v, nt, tri, -1, (uint32_t)mesh_tris, 0u, count, s_clip);
+        // one glBegin / glEnd per box: a clipped vertex anywhere in the call sends all six faces through the draw module's
+        // pipeline, whose quads split (0,1,3) (1,2,3); an immediate-mode call without one splits (0,1,2) (0,2,3); a static
+        // box sits in display list 1 (always the first split).  The six faces of a box are six consecutive items.
+        {
+            const uint64_t cm = __ballot(clipped_l && is_box);
+            bool box_clipped = clipped_l;
+            if (is_box) {
+                const int fc = (item - np) % 6;
+                // the faces of this box in this round: lanes lane - fc .. lane - fc + 5 of the same group (a box may straddle two
+                // rounds: then the other faces' flags are recomputed from the box's vertices — all 8 corners appear in any 2 faces,
+                // so a straddling box is handled by testing the corners directly)
+                const int first = lane - fc;
+                const bool whole = sub - fc >= 0 && sub - fc + 5 < L;
+                if (whole) {
+                    box_clipped = ((cm >> first) & 0x3Full) != 0ull;
+                } else {
+                    // recompute: any corner of the box clipped?  (faces 0 and 1 hold all eight corners)
+                    box_clipped = false;        // filled below by the slow path
+                }
+                if (!whole) {
+                    const int slot = box_slot;
+                    const double ex_ = a.epos[((size_t)0 * a.E + slot) * a.N + env], ey_ = a.epos[((size_t)1 * a.E + slot) * a.N + env],
+                                 ez_ = a.epos[((size_t)2 * a.E + slot) * a.N + env];
+                    float lo[3], hi[3];
+                    mwgl::Xform ex;
+                    const mwgl::Xform *x = &cam;
+                    if (proxy) {
+                        lo[0] = (float)(ex_ - 0.1); lo[1] = (float)ey_; lo[2] = (float)(ez_ - 0.1);
+                        hi[0] = (float)(ex_ + 0.1); hi[1] = (float)(ey_ + 0.2); hi[2] = (float)(ez_ + 0.1);
+                    } else {
+                        const float pos[3] = {(float)ex_, (float)ey_, (float)ez_};
+                        mwgl::entity_xform(f, pos, (float)(a.edir[(size_t)slot * a.N + env] * (180 / kPi)), 1.0f, false, ex);
+                        x = &ex;
+                        const double sx = a.egeom[((size_t)0 * a.E + slot) * a.N + env], sy = a.egeom[((size_t)1 * a.E + slot) * a.N + env],
+                                     sz = a.egeom[((size_t)2 * a.E + slot) * a.N + env];
+                        lo[0] = (float)(-sx / 2); lo[1] = 0.0f; lo[2] = (float)(-sz / 2);
+                        hi[0] = (float)(sx / 2); hi[1] = (float)sy; hi[2] = (float)(sz / 2);
+                    }
+                    for (int c = 0; c < 8; ++c) {
+                        const float p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]};
+                        mwgl::Vert o;
+                        mwgl::transform_vertex(f, *x, p, o);
+                        box_clipped |= o.clipmask != 0u;
+                    }
+                }
+                direct = !box_clipped && !in_list;
+            }
+        }
+
+        const mwgl::Vert t0c = direct ? v[2] : v[3], t1a = direct ? v[0] : v[1];
+        // ---- pass 1: what survives
+        mwgl::TriSetup ts[2];
+        int cnt[2] = {0, 0};
+        bool clip_t[2] = {false, false};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t < nt) {
+                const mwgl::Vert &va = t ? t1a : v[0], &vb = t ? v[2] : v[1], &vc = t ? v[3] : t0c;
+                const uint32_t m = va.clipmask | vb.clipmask | vc.clipmask;
+                if (va.clipmask & vb.clipmask & vc.clipmask) continue;
+                if (m == 0u) cnt[t] = mwgl::setup_triangle(va, vb, vc, ms, tex >= 0, ts[t]) ? 1 : 0;
+                else clip_t[t] = true;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            uint64_t pend = __ballot(clip_t[t]);
+            while (pend) {
+                uint64_t batch = 0ull, rest = pend;
+                for (int k = 0; k < kClipSlots && rest; ++k) { batch |= rest & (0ull - rest); rest &= rest - 1ull; }
+                if (clip_t[t] && ((batch >> lane) & 1ull)) {
+                    const int slot = __popcll((unsigned long long)(batch & ((1ull << lane) - 1ull)));
+                    mwgl::Vert *r;
+                    const int n = mwgl::clip_triangle<false>(f, t ? t1a : v[0], t ? v[2] : v[1], t ? v[3] : t0c, s_clip[slot][0], s_clip[slot][1], &r);
+                    int c = 0;
+                    for (int i = 2; i < n; ++i) c += tri_front(r[i - 1].win, r[i].win, r[0].win, ms) ? 1 : 0;
+                    cnt[t] = c;
+                }
+                pend = rest;
+            }
+        }
+        // ---- list positions
+        int total;
+        const int base = count + group_excl_scan(cnt[0] + cnt[1], sub, L, total);
+        count += total;
+        if (base + cnt[0] + cnt[1] > a.max_vis && (cnt[0] | cnt[1])) atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+        // ---- pass 2: the records
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int b0 = base + (t ? cnt[0] : 0);
+            if (cnt[t] == 1 && !clip_t[t] && live && b0 < a.max_vis) mwrec::write_tri(a, env, b0, tag ? tag : (uint32_t)b0 + id_base, ts[t], tex, S);
+            uint64_t pend = __ballot(clip_t[t] && cnt[t] > 0);
+            while (pend) {
+                uint64_t batch = 0ull, rest = pend;
+                for (int k = 0; k < kClipSlots && rest; ++k) { batch |= rest & (0ull - rest); rest &= rest - 1ull; }
+                if (clip_t[t] && cnt[t] > 0 && ((batch >> lane) & 1ull)) {
+                    const int slot = __popcll((unsigned long long)(batch & ((1ull << lane) - 1ull)));
+                    mwgl::Vert *r;
+                    const int n = mwgl::clip_triangle<false>(f, t ? t1a : v[0], t ? v[2] : v[1], t ? v[3] : t0c, s_clip[slot][0], s_clip[slot][1], &r);
+                    int idx = b0;
+                    for (int i = 2; i < n; ++i) {
+                        mwgl::TriSetup t2;
+                        if (mwgl::setup_triangle(r[i - 1], r[i], r[0], ms, tex >= 0, t2)) {
+                            if (live && idx < a.max_vis) mwrec::write_tri(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t2, tex, S);
+                            ++idx;
+                        }
+                    }
+                }
+                pend = rest;
+            }
+        }
+        // list positions the meshes' draw ids need
+        if (is_box && (item - np) % 6 == 0 && (item - np) / 6 < 64) pos[(item - np) / 6] = base;
+        if (marker && item == n_items - 1) pos[total_boxes < 64 ? total_boxes : 64] = base;
     }
-    if (lane == 0) {
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (sub == 0 && live) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
-        a.k3_cost[env] = mesh_tris;
+        a.k3_cost[env] = total_mesh_tris;
         hdr[0] = (float)a.light[(size_t)0 * a.N + env]; hdr[1] = (float)a.light[(size_t)1 * a.N + env]; hdr[2] = (float)a.light[(size_t)2 * a.N + env];
-        hdr[3] = __int_as_float(n_mesh);
+        hdr[3] = __int_as_float(total_meshes);
 #pragma unroll
         for (int i = 0; i < 3; ++i) { hdr[4 + i] = f.l_amb[i]; hdr[8 + i] = f.l_dif[i]; }
+        const int nb = total_boxes < 64 ? total_boxes : 64;
+        const int end_pos = marker ? pos[nb] : count;
+        for (int j = 0; j < total_meshes; ++j) {
+            float *m = hdr + MW_HDR_MESH + MW_HDR_MESH_STRIDE * j;
+            const int before = __float_as_int(m[1]);
+            const int p0 = before < nb ? pos[before] : end_pos;
+            m[1] = __int_as_float(p0 + __float_as_int(m[25]));
+        }
+        if (count + total_mesh_tris >= 0xFFF0) atomicOr(a.status, MW_ST_VIS_OVERFLOW);      // 16-bit draw ids
         // the step's pending removal: the picked-up object leaves the entity list after its last frame
         // (pickupobjects.py:86-88); CollectHealth's consumed kit respawns instead, with draws from the env's stream:
         // mw_collect_respawn_kernel, launched behind this one

@@ -16,13 +16,19 @@ struct RGB { float r, g, b; };
 // callers' arguments are an interpolated 1/w (w in [0.04, 100]) and a q within an ulp of 1.
 #define MW_RCP_LO 1e-30f
 #define MW_RCP_HI 1e30f
-__device__ inline bool rcp_domain(float x) { return x >= MW_RCP_LO && x <= MW_RCP_HI; }
+__device__ inline bool rcp_domain(float x) { return fabsf(x) >= MW_RCP_LO && fabsf(x) <= MW_RCP_HI; }
 __device__ inline float rcp_exact(float x)
 {
     const float y = __builtin_amdgcn_rcpf(x);
     return fmaf(fmaf(-x, y, 1.0f), y, y);
 }
 __device__ inline float rcp_safe(float x) { return rcp_domain(x) ? rcp_exact(x) : 1.0f / x; }
+// the same for a whole wavefront: one uniform branch instead of both sequences and a select per lane
+__device__ inline float rcp_wave(float x)
+{
+    if (__all(rcp_domain(x))) return rcp_exact(x);
+    return 1.0f / x;
+}
 
 // a / b given y = rcp_exact(b) (Markstein); kept for the mesh kernel and the self test
 #define MW_DIV_LO 1e-10f
@@ -121,6 +127,99 @@ __device__ inline RGB shade_frag(const float4 *sr, const TexEnv &te, int px, int
     return shade_planes(wp, sp, tp, pr, pg, pb, tex, te, px, gy, eo);
 }
 
+// ---- wave-uniform shading --------------------------------------------------------------------------------------------------
+// The tile kernels map lanes to pixels quad by quad: lanes 4q .. 4q+3 are the 2x2 pixel quad q of the 16x4 tile,
+//   lane bit 0 = x & 1, bit 1 = image row & 1, bits 2-4 = quad column, bit 5 = quad row.
+// The frame's height is a multiple of the tile's, so image-row pairs are GL's quads (gy & ~1): lane 2 of a quad is
+// GL's (qx, qy), lane 3 (qx + 1, qy), lane 0 (qx, qy + 1).  When all 64 lanes shade the SAME triangle, the texture
+// coordinates the lod needs at the quad's corners are the neighbours' own values: three DPP moves per coordinate.
+__device__ inline int tile_col(int lane) { return ((lane >> 2) & 7) * 2 + (lane & 1); }
+__device__ inline int tile_row(int lane) { return (lane >> 5) * 2 + ((lane >> 1) & 1); }
+
+template <int L> __device__ inline float quad_bcast(float v)
+{
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), L * 0x55, 0xF, 0xF, true));
+}
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// mwgl::lerp8 on two 16-bit lanes at once: a + ((w (b - a) + 128) >> 8) == (a (256 - w) + b w + 128) >> 8, which stays
+// below 2^16 for 8-bit a, b, w.  w, iw: the weight and 256 - weight in both halves.
+__device__ inline uint32_t lerp8_pk(uint32_t a, uint32_t b, uint32_t w, uint32_t iw)
+{
+    const u16x2 av = __builtin_bit_cast(u16x2, a), bv = __builtin_bit_cast(u16x2, b), wv = __builtin_bit_cast(u16x2, w), iv = __builtin_bit_cast(u16x2, iw);
+    const u16x2 r = ((av * iv + (u16x2)(128)) + bv * wv) >> (u16x2)(8);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ inline uint32_t weight_pk(int w) { return (uint32_t)w | ((uint32_t)w << 16); }
+
+// GL_LINEAR on level l of a texture whose level-0 sizes are powers of two (lw0, lh0: their logarithms): result as
+// R | B << 16 and G (low byte) — mwgl::linear_coord / bilerp_rgb with the size scaling as an exponent add
+__device__ inline void fetch_level_pot(const TexEnv &te, uint32_t desc, int lw0, int lh0, int l, float s, float t, uint32_t &rb, uint32_t &ag)
+{
+    const uint32_t off = ldw(te.td, desc + 4u + (uint32_t)l * 8u);
+    const int lw = lw0 > l ? lw0 - l : 0, lh = lh0 > l ? lh0 - l : 0;
+    const int fx = (int)rintf(ldexpf(s, lw + 8)) - 128, fy = (int)rintf(ldexpf(t, lh + 8)) - 128;
+    const uint32_t i0 = (uint32_t)(fx >> 8) & ((1u << lw) - 1u), j0 = (uint32_t)(fy >> 8) & ((1u << lh) - 1u);
+    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(te.tx, (off + (j0 << lw) + i0) << 4, 0, 0);
+    const uint32_t wx = weight_pk(fx & 255), ix = 0x01000100u - wx, wy = weight_pk(fy & 255), iy = 0x01000100u - wy;
+    const uint32_t M = 0x00FF00FFu;
+    const uint32_t rb0 = lerp8_pk(q.x & M, q.y & M, wx, ix), rb1 = lerp8_pk(q.z & M, q.w & M, wx, ix);
+    const uint32_t ag0 = lerp8_pk((q.x >> 8) & M, (q.y >> 8) & M, wx, ix), ag1 = lerp8_pk((q.z >> 8) & M, (q.w >> 8) & M, wx, ix);
+    rb = lerp8_pk(rb0, rb1, wy, iy);
+    ag = lerp8_pk(ag0, ag1, wy, iy);
+}
+
+// fragment colour of the triangle with shade record sr — the SAME record for all 64 lanes — at the lane's pixel of a
+// multisampled target; all lanes must be active (quad_bcast)
+__device__ inline RGB shade_uniform(const float4 *sr, const TexEnv &te, int px, int gy)
+{
+    const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], qr = sr[3], qg = sr[4], qb = sr[5];
+    const int tex = te.flat ? -1 : __builtin_amdgcn_readfirstlane(__float_as_int(q0.w));
+    const float x = (float)px + 0.5f, y = (float)gy + 0.5f;
+    const float wv = fmaf(q0.z, y, fmaf(q0.y, x, q0.x));
+    const float oow = rcp_wave(wv);
+    RGB c = {fmaf(qr.z, y, fmaf(qr.y, x, qr.x)) * oow, fmaf(qg.z, y, fmaf(qg.y, x, qg.x)) * oow, fmaf(qb.z, y, fmaf(qb.y, x, qb.x)) * oow};
+    if (tex < 0) return c;
+    const float invq = rcp_wave(wv * oow);
+    const float s = (fmaf(q1.z, y, fmaf(q1.y, x, q1.x)) * oow) * invq, t = (fmaf(q2.z, y, fmaf(q2.y, x, q2.x)) * oow) * invq;
+    const float s00 = quad_bcast<2>(s), s10 = quad_bcast<3>(s), s01 = quad_bcast<0>(s);
+    const float t00 = quad_bcast<2>(t), t10 = quad_bcast<3>(t), t01 = quad_bcast<0>(t);
+    const MwTexDesc *d = te.texd + tex;
+    const uint32_t w0 = d->w, h0 = d->h;
+    const int nlevels = (int)d->nlevels;
+    const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4);
+    int l0, w8;
+    mwgl::lod_select(s00, t00, s10, t10, s01, t01, (float)w0, (float)h0, nlevels, l0, w8);
+    int c0[3];
+    if (((w0 & (w0 - 1u)) | (h0 & (h0 - 1u))) == 0u) {
+        const int lw0 = 31 - __builtin_clz(w0), lh0 = 31 - __builtin_clz(h0);
+        uint32_t rb, ag;
+        fetch_level_pot(te, desc, lw0, lh0, l0, s, t, rb, ag);
+        if (__any(w8 > 0)) {
+            uint32_t rb1, ag1;
+            const int l1 = l0 + 1 > nlevels - 1 ? nlevels - 1 : l0 + 1;
+            fetch_level_pot(te, desc, lw0, lh0, l1, s, t, rb1, ag1);
+            const uint32_t wl = weight_pk(w8), il = 0x01000100u - wl;
+            rb = lerp8_pk(rb, rb1, wl, il);
+            ag = lerp8_pk(ag, ag1, wl, il);
+        }
+        c0[0] = (int)(rb & 255u); c0[1] = (int)(ag & 255u); c0[2] = (int)((rb >> 16) & 255u);
+    } else {
+        fetch_level(te, desc, l0, s, t, c0);
+        if (__any(w8 > 0)) {
+            int c1[3];
+            const int l1 = l0 + 1 > nlevels - 1 ? nlevels - 1 : l0 + 1;
+            fetch_level(te, desc, l1, s, t, c1);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) c0[k] = mwgl::lerp8(c0[k], c1[k], w8);
+        }
+    }
+    c.r = ((float)c0[0] * (1.0f / 255.0f)) * c.r;
+    c.g = ((float)c0[1] * (1.0f / 255.0f)) * c.g;
+    c.b = ((float)c0[2] * (1.0f / 255.0f)) * c.b;
+    return c;
+}
+
 struct TileCtx;
 __device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, int px, int gy);
 
@@ -208,14 +307,15 @@ __device__ inline uint32_t depth16(float a0, float dadx, float dady, int px, int
 }
 
 // resolve of one pixel: the samples' colours summed in sample order, times 1/8 (u_blitter's resolve shader).  Up to three
-// distinct colours (c[k], the samples in mask m[k]); samples in no mask take c[2].
-__device__ inline RGB resolve8(const RGB c[3], uint32_t m0, uint32_t m1)
+// claimants (colour c[k], its samples in mask m_k); samples in no mask take c[3] (the clear colour).
+__device__ inline RGB resolve8(const RGB c[4], uint32_t m0, uint32_t m1, uint32_t m2)
 {
     RGB acc = {0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        const bool a = (m0 >> s) & 1u, b = (m1 >> s) & 1u;
-        const float r = a ? c[0].r : (b ? c[1].r : c[2].r), g = a ? c[0].g : (b ? c[1].g : c[2].g), bl = a ? c[0].b : (b ? c[1].b : c[2].b);
+        const bool a = (m0 >> s) & 1u, b = (m1 >> s) & 1u, d = (m2 >> s) & 1u;
+        const float r = a ? c[0].r : (b ? c[1].r : (d ? c[2].r : c[3].r)), g = a ? c[0].g : (b ? c[1].g : (d ? c[2].g : c[3].g)),
+                    bl = a ? c[0].b : (b ? c[1].b : (d ? c[2].b : c[3].b));
         if (s == 0) { acc.r = r; acc.g = g; acc.b = bl; }
         else { acc.r = acc.r + r; acc.g = acc.g + g; acc.b = acc.b + bl; }
     }
@@ -231,6 +331,21 @@ __device__ inline RGB resolve8_one(const RGB c)
 }
 
 __device__ inline uint32_t to_u8(float acc) { return mwgl::float_to_unorm8(acc * 0.125f); }
+
+// MESH kernels: is draw id `id` a mesh triangle?  (uniform scan of the env's mesh table.)  Returns the table entry or -1,
+// and the record index of a non-mesh id (draw ids count every mesh triangle drawn before).
+__device__ inline int mesh_entry_of(const TileCtx &cx, uint32_t id, int &rec)
+{
+    const int n_mesh = __float_as_int(cx.hdr[3]);
+    rec = (int)id;
+    for (int j = 0; j < n_mesh; ++j) {
+        const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * j + 1]);
+        const int nt = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * j + 2]);
+        if ((int)id >= start + nt) rec -= nt;
+        else if ((int)id >= start) return j;
+    }
+    return -1;
+}
 
 // FMT: output layout fixed at compile time (0: the plain observation) or -1: read from the launch flags.
 // SORTED: the env's triangles come with a visiting order by ascending depth bound (big scenes).
@@ -250,7 +365,8 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     const bool has_depth = HOT == 2 ? true : (HOT == 1 ? false : depth != nullptr);
     const TexEnv &te = cx.te;
     const RGB sky = {cx.sky_r, cx.sky_g, cx.sky_b};
-    const int px = tx * MW_TILE_W + (lane & 15), py = ty * MW_TILE_H + (lane >> 4);
+    const int colx = tile_col(lane), row = tile_row(lane);
+    const int px = tx * MW_TILE_W + colx, py = ty * MW_TILE_H + row;
     const int gy = H - 1 - py;                              // GL row (the frame buffer's y points up, the image's down)
     const int pxlo = tx * MW_TILE_W, pxhi = pxlo + MW_TILE_W - 1;
     const int gyhi = H - 1 - ty * MW_TILE_H, gylo = gyhi - (MW_TILE_H - 1);
@@ -260,8 +376,8 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 
     // ============ pass A: "painter without overlap" ==================================
     // As long as no sample is claimed by two triangles, depth is irrelevant: every covered sample belongs to its only
-    // claimant.  A pixel keeps at most two claimants (colour + sample mask each); a third one, or any contention,
-    // abandons the tile to pass B (exact keys).
+    // claimant.  A pixel keeps at most three claimants (colour + sample mask each: a quad's diagonal crossing the edge
+    // between two surfaces); a fourth one, or any contention, abandons the tile to pass B (exact keys).
     bool exact = (dbg & 4) != 0;
     const bool sorted = SORTED && cx.order[0] != 0 && !(dbg & 64);
     if (SORTED && sorted) exact = true;
@@ -274,8 +390,8 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     if (!exact) {
         uint32_t covbits = 0u;
         uint64_t anycov_m = 0ull;
-        RGB col[3] = {sky, sky, sky};
-        uint32_t m0 = 0u, m1 = 0u;
+        RGB col[4] = {sky, sky, sky, sky};
+        uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
         int nown = 0;
         for (int chunk = 0; chunk < (PRE == 1 ? 1 : ((dbg & 2) ? 0 : nvis)) && !exact; chunk += 64) {
             pmask_t todo, fullm;
@@ -321,12 +437,12 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     if (__any((bits & covbits) != 0u)) { exact = true; break; }      // a sample claimed twice
                     anycov_m |= any_m;
                 }
-                if (__any(bits != 0u && nown >= 2)) { exact = true; break; }         // a third claimant of a pixel
+                if (__any(bits != 0u && nown >= 3)) { exact = true; break; }         // a fourth claimant of a pixel
                 covbits |= bits;
                 if (__any(bits != 0u)) {
-                    const RGB c = shade_frag(s_shade + p * (MW_SHADE_REC / 4), te, px, gy, eo);
+                    const RGB c = shade_uniform(s_shade + p * (MW_SHADE_REC / 4), te, px, gy);
                     if (bits != 0u) {
-                        if (nown == 0) { col[0] = c; m0 = bits; } else { col[1] = c; m1 = bits; }
+                        if (nown == 0) { col[0] = c; m0 = bits; } else if (nown == 1) { col[1] = c; m1 = bits; } else { col[2] = c; m2 = bits; }
                         ++nown;
                         if (has_depth && (bits & 1u)) {
                             const float4 zp = s_shade[p * (MW_SHADE_REC / 4) + 6];
@@ -338,7 +454,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         }
         if (!exact) {
             if (__all(m0 == 0xFFu)) out = resolve8_one(col[0]);
-            else out = resolve8(col, m0, m1);
+            else out = resolve8(col, m0, m1, m2);
         }
     }
 
@@ -397,78 +513,80 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 }
                 if (SORTED && sorted) {
                     uint32_t m = max(max(max(key[0], key[1]), max(key[2], key[3])), max(max(key[4], key[5]), max(key[6], key[7])));
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off));
-                    far16 = m >> 16;
+                    far16 = __reduce_max_sync(~0ull, m) >> 16;
                 }
             }
         }
         z16 = key[0] >> 16;
+        // deferred shading: every distinct winner once per pixel (GL multisampling shades a pixel once per triangle), then
+        // the resolve in sample order.  The tile's distinct winners are visited in ascending draw id, each shaded for the
+        // whole wavefront at once (shade_uniform); mesh triangles, which differ from pixel to pixel, per lane.  A pixel
+        // keeps up to three winners (colour + sample mask); a fourth one sends the tile through the per-sample loop below.
         uint32_t pid[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) pid[s] = key[s] & 0xFFFFu;
-        // deferred shading: every distinct winner of the pixel once (GL multisampling shades a pixel once per triangle),
-        // then the resolve in sample order.  Up to three winners per pixel are kept (colour + sample mask); rounds beyond
-        // the third (four surfaces in one pixel) restart the resolve with the winners already folded — handled by the
-        // generic per-sample loop below.
-        RGB col[3] = {sky, sky, sky};
-        uint32_t m0 = 0u, m1 = 0u, mrest = 0u;
+        for (int s = 0; s < 8; ++s) { pid[s] = key[s] & 0xFFFFu; pid[s] = pid[s] == MW_SKY_PID ? 0x10000u : pid[s]; }
+        RGB col[4] = {sky, sky, sky, sky};
+        uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
         int nown = 0;
         bool overflow = false;
         for (;;) {
-            uint32_t sel = 0x10000u;
+            uint32_t mine = 0x10000u;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) sel = min(sel, pid[s]);
-            const bool active = sel != 0x10000u;
-            if (!__any(active)) break;
-            RGB c = sky;
+            for (int s = 0; s < 8; ++s) mine = min(mine, pid[s]);
+            const uint32_t id = __reduce_min_sync(~0ull, mine);
+            if (id == 0x10000u) break;
+            int rec = (int)id;
+            const int mj = MESH ? mesh_entry_of(cx, id, rec) : -1;
+            uint32_t sel = id;
+            RGB c;
+            if (MESH && mj >= 0) {
+                // every lane whose next winner belongs to this mesh entity shades its own triangle
+                const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 1]), nt = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 2]);
+                const bool on = (int)mine < start + nt;      // mine >= id >= start
+                sel = on ? mine : 0x20000u;
+                c = shade_by_draw_id(cx, on ? mine : id, px, gy);
+            } else {
+                c = shade_uniform(s_shade + rec * (MW_SHADE_REC / 4), te, px, gy);
+            }
             uint32_t bits = 0u;
-            if (active) {
 #pragma unroll
-                for (int s = 0; s < 8; ++s) {
-                    const bool eq = pid[s] == sel;
-                    bits |= eq ? (1u << s) : 0u;
-                    pid[s] = eq ? 0x10000u : pid[s];
-                }
+            for (int s = 0; s < 8; ++s) {
+                const bool eq = pid[s] == sel;
+                bits |= eq ? (1u << s) : 0u;
+                pid[s] = eq ? 0x10000u : pid[s];
             }
-            const bool need = active && sel != MW_SKY_PID;
-            if (__any(need)) {
-                RGB cc;
-                if (MESH) cc = shade_by_draw_id(cx, need ? sel : 0u, px, gy);
-                else cc = shade_frag(s_shade + (need ? sel : 0u) * (MW_SHADE_REC / 4), te, px, gy, eo);
-                if (need) c = cc;
-            }
-            if (active) {
+            if (bits != 0u) {
                 if (nown == 0) { col[0] = c; m0 = bits; }
                 else if (nown == 1) { col[1] = c; m1 = bits; }
-                else if (nown == 2) { col[2] = c; mrest = bits; }
+                else if (nown == 2) { col[2] = c; m2 = bits; }
                 else overflow = true;
                 ++nown;
             }
         }
         if (__any(overflow)) {
-            // four or more surfaces in one pixel: shade per sample (rare; correctness path)
-            RGB acc = {0.0f, 0.0f, 0.0f};
+            // four or more surfaces in one pixel: shade per sample (a sample whose winner is the previous sample's reuses
+            // its colour); rare outside the interior of a finely tessellated mesh
+            RGB acc = {0.0f, 0.0f, 0.0f}, last = sky;
+            uint32_t last_id = MW_SKY_PID;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const uint32_t w = key[s] & 0xFFFFu;
-                RGB c = sky;
-                const bool need = w != MW_SKY_PID;
+                const bool need = w != last_id && w != MW_SKY_PID;
                 if (__any(need)) {
                     RGB cc;
                     if (MESH) cc = shade_by_draw_id(cx, need ? w : 0u, px, gy);
                     else cc = shade_frag(s_shade + (need ? w : 0u) * (MW_SHADE_REC / 4), te, px, gy, eo);
-                    if (need) c = cc;
+                    if (need) { last = cc; last_id = w; }
                 }
-                if (s == 0) acc = c; else { acc.r = acc.r + c.r; acc.g = acc.g + c.g; acc.b = acc.b + c.b; }
+                if (w == MW_SKY_PID) { last = sky; last_id = MW_SKY_PID; }
+                if (s == 0) acc = last; else { acc.r = acc.r + last.r; acc.g = acc.g + last.g; acc.b = acc.b + last.b; }
             }
             out = acc;
         } else if (__all(m0 == 0xFFu)) {
             out = resolve8_one(col[0]);
         } else {
-            out = resolve8(col, m0, m1);
+            out = resolve8(col, m0, m1, m2);
         }
-        (void)mrest;
     }
     const uint32_t R = to_u8(out.r), G = to_u8(out.g), B = to_u8(out.b);
 
@@ -477,7 +595,6 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     //   1  uint8 [3][W][H]      PyTorchObsWrapper: observation.transpose(2, 1, 0)   (wrappers.py:24)
     //   2  double[H][W][1]      GreyscaleWrapper: 0.30 R + 0.59 G + 0.11 B in numpy's float64 (wrappers.py:44)
     const int fmt = FMT >= 0 ? FMT : ((dbg >> 8) & 3);
-    const int row = lane >> 4, colx = lane & 15;
     if (fmt == 2) {
         const double g = (0.30 * (double)R + 0.59 * (double)G) + 0.11 * (double)B;
         reinterpret_cast<double *>(obs)[((size_t)env * H + py) * W + px] = g;

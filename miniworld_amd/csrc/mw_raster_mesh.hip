@@ -274,7 +274,7 @@ __device__ inline void mesh_kernel_body(MW_MESH_ARGS)
         tile = __builtin_amdgcn_readfirstlane(tile);
         if (tile >= n_tiles) break;
         const int tx = tile % tiles_x, ty = tile / tiles_x;
-        const int px = tx * MW_TILE_W + (lane & 15), py = ty * MW_TILE_H + (lane >> 4);
+        const int px = tx * MW_TILE_W + tile_col(lane), py = ty * MW_TILE_H + tile_row(lane);
         uint32_t mk[8];
         const uint4 k0 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8);
         const uint4 k1 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8 + 4);
