@@ -16,6 +16,7 @@
 #define MW_SKY_PID 0xFFFFu
 #define MW_ENVHDR 640         // floats per env: sky, light colours, mesh-entity table (geometry kernel -> raster kernels)
 #define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
+#define MW_K3_THREADS 512     // threads of the mesh kernel's workgroup (one per CU: the key buffer fills the LDS): 8 wavefronts, 256 VGPRs each
 #define MW_K3_WAVE_LDS 192     // LDS bytes per wave of the mesh kernel beside the key buffer: its pack buffer
 #define MW_HDR_MESH 32        // first float of the mesh-entity table
 #define MW_HDR_MESH_STRIDE 28 // floats per entry: slot, first draw id, triangles, first triangle, texture, normal scale, light[3], mvp[16]

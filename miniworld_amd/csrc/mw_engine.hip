@@ -34,37 +34,29 @@ extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int 
 extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
                                                          float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
-extern "C" __global__ void mw_raster_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                            int waves_per_env, int tiles_per_wave, const float *rec_raster,
-                                            const float *rec_shade, const float *rec_cull, const int32_t *nvis,
-                                            const float *envhdr,
-                                            const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth, int dbg,
-                                            int texel_bytes, const uint16_t *rec_order);
-extern "C" __global__ void mw_raster_depth_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                                  int waves_per_env, int tiles_per_wave, const float *rec_raster,
-                                                  const float *rec_shade, const float *rec_cull, const int32_t *nvis,
-                                                  const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
-                                                  uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
-extern "C" __global__ void mw_raster_big_depth_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                                      int waves_per_env, int tiles_per_wave, const float *rec_raster,
-                                                      const float *rec_shade, const float *rec_cull, const int32_t *nvis,
-                                                      const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
-                                                      uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
-extern "C" __global__ void mw_raster_big_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                                int waves_per_env, int tiles_per_wave, const float *rec_raster,
-                                                const float *rec_shade, const float *rec_cull, const int32_t *nvis,
-                                                const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
-                                                uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
-extern "C" __global__ void mw_raster_wrap_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                                 int waves_per_env, int tiles_per_wave, const float *rec_raster,
-                                                 const float *rec_shade, const float *rec_cull, const int32_t *nvis,
-                                                 const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
-                                                 uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
-extern "C" __global__ void mw_raster_big_wrap_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                                     int waves_per_env, int tiles_per_wave, const float *rec_raster,
-                                                     const float *rec_shade, const float *rec_cull, const int32_t *nvis,
-                                                     const float *envhdr, const MwTexDesc *texd, const uint32_t *texels,
-                                                     uint8_t *obs, float *depth, int dbg, int texel_bytes, const uint16_t *rec_order);
+#define MW_RASTER_DECL(name) \
+    extern "C" __global__ void name(int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave, \
+                                    const float *rec_raster, const float *rec_shade, const float *rec_cull, const int32_t *nvis, \
+                                    const float *envhdr, const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth, int dbg, \
+                                    int texel_bytes, const uint16_t *rec_order, const float *mesh_pos, const float *mesh_nrm, \
+                                    const float *mesh_rgb, const float *mesh_uv, uint32_t *mesh_keys, const float *plane_cache, int plane_cap, \
+                                    const float4 *slow_frags, const uint32_t *slow_head)
+MW_RASTER_DECL(mw_raster_kernel);
+MW_RASTER_DECL(mw_raster_depth_kernel);
+MW_RASTER_DECL(mw_raster_big_kernel);
+MW_RASTER_DECL(mw_raster_big_depth_kernel);
+MW_RASTER_DECL(mw_raster_wrap_kernel);
+MW_RASTER_DECL(mw_raster_big_wrap_kernel);
+MW_RASTER_DECL(mw_raster_mesh_kernel);
+MW_RASTER_DECL(mw_raster_mesh_depth_kernel);
+MW_RASTER_DECL(mw_raster_mesh_wrap_kernel);
+MW_RASTER_DECL(mw_raster_big_mesh_wrap_kernel);
+extern "C" __global__ void mw_mesh_scatter_kernel(int W, int H, const float *envhdr, const float *mesh_pos, const float *mesh_nrm, const float *mesh_rgb,
+                                                  const float *mesh_uv, uint32_t *keys, float *plane_cache, int plane_cap, int32_t *slow_count,
+                                                  uint32_t *slow_tris);
+extern "C" __global__ void mw_mesh_slow_kernel(int W, int H, const float *envhdr, const float *mesh_pos, const float *mesh_nrm, const float *mesh_rgb,
+                                               const float *mesh_uv, const uint32_t *texels, int texel_bytes, uint32_t *keys, int32_t *slow_count,
+                                               const uint32_t *slow_tris, int32_t *frag_count, float4 *frags, uint16_t *frag_pix, uint32_t *heads, uint32_t *status, int dbg);
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all, int mark_refill);
 extern "C" __global__ void mw_refill_kernel(MwArgs a);
 extern "C" __global__ void mw_refill_pcg_kernel(MwArgs a);
@@ -79,25 +71,6 @@ extern "C" __global__ void mw_view_raster_kernel(int env, int W, int H, int S, i
                                                  uint8_t *out, float *depth, int texel_bytes);
 extern "C" __global__ void mw_visible_kernel(int env_base, int W, int H, int S, int max_vis, int E, const float *rec_raster, const float *rec_cull,
                                              const int32_t *nvis, uint8_t *vis);
-extern "C" __global__ void mw_raster_mesh_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                                 const float *rec_raster, const float *rec_shade, const float *rec_cull,
-                                                 const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
-                                                 const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
-                                                 const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes,
-                                                 unsigned long long *prof, const int32_t *env_order);
-extern "C" __global__ void mw_raster_mesh_depth_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                                 const float *rec_raster, const float *rec_shade, const float *rec_cull,
-                                                 const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
-                                                 const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
-                                                 const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes,
-                                                 unsigned long long *prof, const int32_t *env_order);
-extern "C" __global__ void mw_raster_mesh_wrap_kernel(int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
-                                                 const float *rec_raster, const float *rec_shade, const float *rec_cull,
-                                                 const int32_t *nvis, const float *envhdr, const MwTexDesc *texd,
-                                                 const uint32_t *texels, const float *mesh_pos, const float *mesh_nrm,
-                                                 const float *mesh_rgb, const float *mesh_uv, uint8_t *obs, float *depth, int dbg, int texel_bytes,
-                                                 unsigned long long *prof, const int32_t *env_order);
-extern "C" __global__ void mw_mesh_order_kernel(int N, const int32_t *cost, int32_t *order);
 
 #define MW_TIMING_STRIDE 8
 
@@ -132,6 +105,15 @@ struct mw_engine {
     bool visible_attr_set = false;
     hipStream_t side_stream = nullptr;      // co-run of K2 beside the mesh kernel
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    uint32_t *d_mesh_keys = nullptr;    // [N][H][W][8] sample keys of the mesh scatter kernel (all-ones between frames)
+    bool mesh_keys_dirty = true;
+    int32_t *d_slow_count = nullptr;    // [2][N] listed triangles, fragments
+    uint32_t *d_slow_tris = nullptr;
+    float4 *d_slow_frags = nullptr;
+    uint16_t *d_slow_pix = nullptr;
+    uint32_t *d_slow_head = nullptr;
+    float *d_plane_cache = nullptr;     // [N][plane_cap][20] attribute planes of the mesh triangles that win samples (mw_raster_mesh.hip)
+    int plane_cap = 0, max_mesh_tris = 0;
     unsigned long long *d_k3prof = nullptr;   // MW_K3_PROF=<file>: per-env cycle counts of the mesh kernel
     int obs_layout = MW_OBS_HWC_U8;
     size_t view_keys_bytes = 0;
@@ -602,46 +584,43 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         hipLaunchKernelGGL(mw_view_raster_kernel, dim3(a.n_tiles, N), dim3(64), 0, st, 0, a.W, a.H, S, a.max_vis, a.tiles_x,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull, (const int32_t *)a.nvis, (const float *)a.envhdr,
                            a.tex, a.texels, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, (const uint32_t *)keys, d_obs, d_depth, e->texel_bytes);
-    } else if (e->have_meshes) {
-        // envs may contain mesh entities: one 1024-thread workgroup per env, sample keys in LDS
-        const size_t lds = (size_t)a.W * a.H * 8 * 4 + 16 * MW_K3_WAVE_LDS + 16 + MW_MAX_MESH_ENTS * MW_HDR_MESH_STRIDE * 4;   // keys, 16 pack buffers, the tile counter, the mesh table
-        if (lds > 160 * 1024) return fail(e, MW_E_CAPACITY, "mesh entities need the env's sample keys in LDS: %dx%d is too large", a.W, a.H);
-        if (!e->mesh_lds_ready) {
-            for (auto k : {mw_raster_mesh_kernel, mw_raster_mesh_depth_kernel, mw_raster_mesh_wrap_kernel})
-                HIP_TRY(e, hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            e->mesh_lds_ready = true;
-        }
-        // Co-run: the mesh kernel holds one workgroup per CU (its key buffer fills the LDS) but only 352 of a
-        // SIMD's 512 VGPRs, so the envs WITHOUT a mesh in view are drawn at the same time, in its shadow, by the
-        // records-from-global variant of K2 (192 B of LDS per wave) on a second stream; both kernels run over all
-        // envs with flag 16 and each workgroup checks its env's mesh count first.
-        const int kflags = e->dbg_flags | (e->obs_layout << 8) | 16;
-        if (!forked) {
-            if (ensure_side_stream(e) != MW_OK) return MW_E_HIP;
-            HIP_TRY(e, hipEventRecord(e->ev_fork, st));
-            HIP_TRY(e, hipStreamWaitEvent(e->side_stream, e->ev_fork, 0));
-            forked = true;
-        }
-        {
-            const int wpe = e->waves_per_env;
-            const int tpw = (a.n_tiles + wpe - 1) / wpe;
-            const int groups = (N + 7) / 8;
-            auto k2 = d_depth ? mw_raster_big_depth_kernel : mw_raster_big_kernel;
-            if (e->obs_layout != MW_OBS_HWC_U8 || e->dbg_flags != 0) k2 = mw_raster_big_wrap_kernel;
-            hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), 192, e->side_stream, a.N, a.W, a.H, a.max_vis, a.tiles_x,
-                               a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
-                               (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, kflags, e->texel_bytes,
-                               (const uint16_t *)nullptr);
-        }
-        hipLaunchKernelGGL(mw_mesh_order_kernel, dim3(1), dim3(1024), 0, st, N, (const int32_t *)a.k3_cost, a.k3_order);
-        auto k3 = d_depth ? mw_raster_mesh_depth_kernel : mw_raster_mesh_kernel;
-        if (e->obs_layout != MW_OBS_HWC_U8 || e->dbg_flags != 0) k3 = mw_raster_mesh_wrap_kernel;
-        hipLaunchKernelGGL(k3, dim3(N), dim3(1024), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x, a.n_tiles,
-                           (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
-                           (const int32_t *)a.nvis, (const float *)a.envhdr, a.tex, a.texels, a.mesh_pos, a.mesh_nrm,
-                           a.mesh_rgb, a.mesh_uv, d_obs, d_depth, kflags, e->texel_bytes, e->d_k3prof,
-                           (const int32_t *)a.k3_order);
     } else {
+        const bool mesh = e->have_meshes;
+        if (mesh) {
+            if (a.W > 255 * MW_TILE_W || a.H > 255 * MW_TILE_H) return fail(e, MW_E_CAPACITY, "frame too large for the mesh tile rectangles");
+            if (a.W > 128 || a.H > 128) return fail(e, MW_E_CAPACITY, "mesh entities: obs frames up to 128x128 (32-bit triangle setup), got %dx%d", a.W, a.H);
+            // the plane cache: one record per mesh triangle that can be in view (the geometry kernel admits 0xC000 per env);
+            // the sample keys of the tiles a mesh can touch: all-ones between frames (K2 clears what it reads)
+            const long long want = std::min<long long>(0xC000, (long long)e->cfg.max_ents * e->max_mesh_tris);
+            const size_t key_bytes = (size_t)N * a.W * a.H * 8 * 4;
+            if ((int)want > e->plane_cap || !e->d_mesh_keys) {
+                HIP_TRY(e, hipStreamSynchronize(st));
+                if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
+                e->d_plane_cache = nullptr; e->plane_cap = 0;
+                HIP_TRY(e, hipMalloc((void **)&e->d_plane_cache, (size_t)N * (size_t)want * 20 * 4));
+                e->plane_cap = (int)want;
+                if (!e->d_mesh_keys) {
+                    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_keys, key_bytes));
+                    // triangles that cross a frustum plane and their fragments (mw_mesh_slow_kernel): counts, 1024 / 2048 entries per env
+                    HIP_TRY(e, hipFuncSetAttribute((const void *)mw_mesh_slow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 2 * 10 * 56));
+                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_count, (size_t)N * 2 * 4));
+                    HIP_TRY(e, hipMemset(e->d_slow_count, 0, (size_t)N * 2 * 4));
+                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_tris, (size_t)N * 1024 * 4));
+                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_frags, (size_t)N * 8192 * 16));
+                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_pix, (size_t)N * 8192 * 2));
+                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_head, (size_t)N * a.W * a.H * 4));
+                    HIP_TRY(e, hipMemset(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4));
+                }
+                e->mesh_keys_dirty = true;
+            }
+            if (e->mesh_keys_dirty) HIP_TRY(e, hipMemsetAsync(e->d_mesh_keys, 0xFF, key_bytes, st));
+            e->mesh_keys_dirty = true;      // until the raster kernel that clears them again has been enqueued
+            hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(8, N), dim3(256), 0, st, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm,
+                               a.mesh_rgb, a.mesh_uv, e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count, e->d_slow_tris);
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(N), dim3(64), 64 * 2 * 10 * 56, st, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+                               a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, (const uint32_t *)e->d_slow_tris,
+                               e->d_slow_count + N, e->d_slow_frags, e->d_slow_pix, e->d_slow_head, a.status, getenv("MW_SLOW_DBG") ? atoi(getenv("MW_SLOW_DBG")) : 0);
+        }
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
         const int groups = (N + 7) / 8;
@@ -651,13 +630,20 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const size_t lds = big ? 192 : (size_t)lds_recs * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
         // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
         // anything else goes to the general kernel
+        const bool general = e->obs_layout != MW_OBS_HWC_U8 || e->dbg_flags != 0;
         auto k2 = big ? (d_depth ? mw_raster_big_depth_kernel : mw_raster_big_kernel) : (d_depth ? mw_raster_depth_kernel : mw_raster_kernel);
-        if (e->obs_layout != MW_OBS_HWC_U8 || e->dbg_flags != 0) k2 = big ? mw_raster_big_wrap_kernel : mw_raster_wrap_kernel;
+        if (general) k2 = big ? mw_raster_big_wrap_kernel : mw_raster_wrap_kernel;
+        if (mesh) {
+            k2 = big ? mw_raster_big_mesh_wrap_kernel : (d_depth ? mw_raster_mesh_depth_kernel : mw_raster_mesh_kernel);
+            if (general && !big) k2 = mw_raster_mesh_wrap_kernel;
+        }
         hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                            a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis,
                            (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes,
-                           (const uint16_t *)a.rec_order);
+                           (const uint16_t *)a.rec_order, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, e->d_mesh_keys,
+                           (const float *)e->d_plane_cache, e->plane_cap, (const float4 *)e->d_slow_frags, (const uint32_t *)e->d_slow_head);
+        if (mesh) e->mesh_keys_dirty = false;
     }
     if (forked) {
         HIP_TRY(e, hipEventRecord(e->ev_join, e->side_stream));
@@ -828,6 +814,14 @@ void mw_destroy(mw_engine *e)
         if (hipMemcpy(h.data(), e->args.k1_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(getenv("MW_K1_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
+    if (getenv("MW_SLOW_STATS") && e->d_slow_count) {      // perf experiments only: the last frame's slow fragments per env
+        std::vector<int32_t> h((size_t)e->cfg.num_envs * 2);
+        if (hipMemcpy(h.data(), e->d_slow_count, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
+            long long tot = 0, nz = 0, mx = 0;
+            for (int i = 0; i < e->cfg.num_envs; ++i) { const int v = h[(size_t)e->cfg.num_envs + i]; tot += v; nz += v > 0; mx = std::max<long long>(mx, v); }
+            fprintf(stderr, "slow fragments: total %lld, envs with any %lld of %d, max %lld\n", tot, nz, e->cfg.num_envs, mx);
+        }
+    }
     if (e->d_k3prof) {      // dump the last frame's per-env cycle counts: [env][mesh phase, tile phase, meshes, triangles]
         std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 8);
         if (hipMemcpy(h.data(), e->d_k3prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -837,6 +831,9 @@ void mw_destroy(mw_engine *e)
     if (e->d_texels) (void)hipFree(e->d_texels);
     for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb, e->d_mesh_uv}) if (p) (void)hipFree(p);
     if (e->d_view_keys) (void)hipFree(e->d_view_keys);
+    if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
+    if (e->d_mesh_keys) (void)hipFree(e->d_mesh_keys);
+    for (void *q : {(void *)e->d_slow_count, (void *)e->d_slow_tris, (void *)e->d_slow_frags, (void *)e->d_slow_pix, (void *)e->d_slow_head}) if (q) (void)hipFree(q);
     if (e->side_stream) { (void)hipStreamDestroy(e->side_stream); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
     for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     for (auto &ev : e->ev_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
@@ -921,6 +918,7 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
     e->args.mesh_pos = e->d_mesh_pos; e->args.mesh_nrm = e->d_mesh_nrm; e->args.mesh_rgb = e->d_mesh_rgb; e->args.mesh_uv = e->d_mesh_uv;
     if (e->d_gen_live && sync_gen_args(e) != MW_OK) return MW_E_HIP;
     e->have_meshes = true;
+    e->max_mesh_tris = std::max(e->max_mesh_tris, (int)ntris);
     return MW_OK;
 }
 

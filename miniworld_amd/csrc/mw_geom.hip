@@ -140,15 +140,35 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
                 mwgl::entity_xform(f, pos, (float)(a.edir[(size_t)s0 * a.N + env] * 180 / kPi), scale, true, ex);
                 // whole-entity frustum test on the bounding sphere (conservative): clip-space distance to the five planes
                 bool in_view = true;
-                if (!top) {
+                uint32_t rect;      // the tiles the entity's bounding sphere can touch: tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24 (image rows)
+                {
                     const float brad = __uint_as_float(mdp->bound_bits) * scale * 1.001f + 1e-3f;
                     mwgl::Vert o;
                     const float zero[3] = {0.0f, 0.0f, 0.0f};
                     mwgl::transform_vertex(f, ex, zero, o);
                     const float w = o.clip[3];
                     const float p00 = f.proj.m[0], p11 = f.proj.m[5];
-                    const float lx = sqrtf(fmaf(p00, p00, 1.0f)), ly = sqrtf(fmaf(p11, p11, 1.0f));
-                    in_view = !(w + brad < 0.04f) && !(w - fabsf(o.clip[0]) < -(brad * lx)) && !(w - fabsf(o.clip[1]) < -(brad * ly));
+                    float xlo = -1.0f, xhi = 1.0f, ylo = -1.0f, yhi = 1.0f;
+                    if (!top) {
+                        const float lx = sqrtf(fmaf(p00, p00, 1.0f)), ly = sqrtf(fmaf(p11, p11, 1.0f));
+                        in_view = !(w + brad < 0.04f) && !(w - fabsf(o.clip[0]) < -(brad * lx)) && !(w - fabsf(o.clip[1]) < -(brad * ly));
+                        if (w - brad > 0.04f) {
+                            // eye-space box around the sphere, projected: x / d with d in [w - r, w + r]
+                            const float dn = 1.0f / (w - brad), df = 1.0f / (w + brad);
+                            const float nxl = o.clip[0] - brad * p00, nxh = o.clip[0] + brad * p00, nyl = o.clip[1] - brad * p11, nyh = o.clip[1] + brad * p11;
+                            xlo = fminf(nxl * dn, nxl * df); xhi = fmaxf(nxh * dn, nxh * df);
+                            ylo = fminf(nyl * dn, nyl * df); yhi = fmaxf(nyh * dn, nyh * df);
+                        }
+                    } else {
+                        xlo = o.clip[0] - brad * fabsf(p00); xhi = o.clip[0] + brad * fabsf(p00);
+                        ylo = o.clip[1] - brad * fabsf(p11); yhi = o.clip[1] + brad * fabsf(p11);
+                    }
+                    const float Wf = (float)a.W, Hf = (float)a.H;
+                    int x0 = (int)floorf(fmaxf((xlo * 0.5f + 0.5f) * Wf - 1.5f, 0.0f)), x1 = (int)fminf((xhi * 0.5f + 0.5f) * Wf + 1.5f, Wf - 1.0f);
+                    int g0 = (int)floorf(fmaxf((ylo * 0.5f + 0.5f) * Hf - 1.5f, 0.0f)), g1 = (int)fminf((yhi * 0.5f + 0.5f) * Hf + 1.5f, Hf - 1.0f);
+                    if (x1 < x0 || g1 < g0) in_view = false;
+                    const int y0 = a.H - 1 - g1, y1 = a.H - 1 - g0;
+                    rect = (uint32_t)(x0 / MW_TILE_W) | ((uint32_t)(x1 / MW_TILE_W) << 8) | ((uint32_t)(y0 / MW_TILE_H) << 16) | ((uint32_t)(y1 / MW_TILE_H) << 24);
                 }
                 if (!in_view) continue;
                 if (total_meshes < MW_MAX_MESH_ENTS && total_mesh_tris + md_ntris < 0xC000 && s0 < 64) {
@@ -164,6 +184,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
 #pragma unroll
                         for (int k = 0; k < 16; ++k) m[9 + k] = ex.mvp.m[k];
                         m[25] = __int_as_float(total_mesh_tris);    // mesh triangles drawn before
+                        m[26] = __uint_as_float(rect);
                     }
                     mesh_in_view |= 1ull << s0;
                     total_mesh_tris += md_ntris;      // one draw id per triangle (a mesh out of view takes none)

@@ -1,0 +1,353 @@
+// Mesh entities (Ball / Key / Building / ...: entity.py:124-165, 435-452; ObjMesh.render objmesh.py:280-292) on the device:
+// the per-triangle vertex stage, triangle setup and key scatter of the mesh scatter kernel (mw_raster_mesh.hip), and the
+// shading of a mesh triangle that won a sample (K2's mesh tiles, the view kernels).
+//
+// A ball is 5 192 sub-pixel triangles, so the pixel-per-lane scheme of K2 would waste 60+ lanes per triangle.  Mesh
+// triangles are rasterised one per LANE instead, scattering packed keys (depth16 << 16 | draw id) with atomic unsigned
+// minima — GL_LESS / first-drawn-wins is an unsigned min, hence order independent — into the env's sample-key buffer;
+// K2 then starts the tiles a mesh can touch from those keys.  Per-triangle arithmetic is mw_glmath.h's (the driver's
+// vertex stage and triangle setup): the entity's MVP matrix, its object-space light and normal scale come from the
+// geometry kernel's mesh table.
+#pragma once
+#include "mw_raster_common.h"
+
+namespace {
+
+struct MeshEnt {            // one entry of the env header's mesh table (mw_geom.hip)
+    int slot, start, ntris, first, tex;
+    mwgl::Xform x;
+};
+
+__device__ inline MeshEnt load_ment(const float *table, int j)
+{
+    const float *m = table + MW_HDR_MESH_STRIDE * j;
+    MeshEnt e;
+    e.slot = __float_as_int(m[0]); e.start = __float_as_int(m[1]); e.ntris = __float_as_int(m[2]);
+    e.first = __float_as_int(m[3]); e.tex = __float_as_int(m[4]);
+    e.x.nscale = m[5];
+    e.x.light[0] = m[6]; e.x.light[1] = m[7]; e.x.light[2] = m[8];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) e.x.mvp.m[k] = m[9 + k];
+    return e;
+}
+
+// what the per-vertex functions need of the frame: viewport and light colours (env header)
+__device__ inline void frame_lite(const float *hdr, int W, int H, mwgl::Frame &f)
+{
+    f.vp_scale[0] = (float)W * 0.5f; f.vp_trans[0] = (float)W * 0.5f;
+    f.vp_scale[1] = (float)H * 0.5f; f.vp_trans[1] = (float)H * 0.5f;
+    f.vp_scale[2] = 0.5f; f.vp_trans[2] = 0.5f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { f.l_amb[i] = hdr[4 + i]; f.l_dif[i] = hdr[8 + i]; }
+}
+
+// the i-th triangle of the rasterisation order (sorted by face-normal direction; mw_device.h: MW_MESH_POS_STRIDE)
+__device__ inline int tri_sorted(const float *mesh_pos, const MeshEnt &e, int i)
+{
+    return (int)__float_as_uint(mesh_pos[(size_t)(e.first + i) * MW_MESH_POS_STRIDE + 9]);
+}
+
+__device__ inline void tri_load(const float *mesh_pos, const MeshEnt &e, int tri, float (&p)[9])
+{
+    static_assert(MW_MESH_POS_STRIDE % 2 == 0, "8-byte aligned triangles");
+    const float2 *src = reinterpret_cast<const float2 *>(mesh_pos + (size_t)(e.first + tri) * MW_MESH_POS_STRIDE);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const float2 v = src[k]; p[2 * k] = v.x; p[2 * k + 1] = v.y; }
+    p[8] = reinterpret_cast<const float *>(src)[8];
+}
+
+// sample s of an S-sample pixel: offset inside the pixel in pixels (the planes' coordinates)
+template <int S> __device__ inline float samp_fx(int s) { return S == 1 ? 0.0f : (float)mwrec::kPat[mwrec::pat_index(S)][s][0] * 0.0625f; }
+template <int S> __device__ inline float samp_fy(int s) { return S == 1 ? 0.0f : (float)mwrec::kPat[mwrec::pat_index(S)][s][1] * 0.0625f; }
+
+// scatter one set-up triangle's keys: every sample inside gets min(key, depth16 << 16 | id)
+template <int S>
+__device__ inline void scatter_tri(const mwgl::TriEdges &t, int W, int H, uint32_t id, uint32_t *keys)
+{
+    const int off = S == 1 ? 128 : 0;
+    int x0 = (t.minx + off) >> 8, x1 = (t.maxx + off) >> 8, y0 = (t.miny + off) >> 8, y1 = (t.maxy + off) >> 8;
+    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
+    x1 = x1 > W - 1 ? W - 1 : x1; y1 = y1 > H - 1 ? H - 1 : y1;
+    for (int gy = y0; gy <= y1; ++gy)
+        for (int px = x0; px <= x1; ++px) {
+            uint32_t *kp = keys + ((size_t)(H - 1 - gy) * W + px) * S;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                int sx, sy;
+                mwrec::sample_offset(S, s, sx, sy);
+                const int64_t fx = (int64_t)px * 256 + sx, fy = (int64_t)gy * 256 + sy;
+                bool in = true;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) in &= (t.c[k] + (int64_t)t.dcdy[k] * fy - (int64_t)t.dcdx[k] * fx) > 0;
+                if (in) {
+                    const float xs = (float)px + samp_fx<S>(s), ys = (float)gy + samp_fy<S>(s);
+                    atomicMin(kp + s, (mwgl::z_to_unorm16(mwgl::plane_at(t.z, xs, ys)) << 16) | id);
+                }
+            }
+        }
+}
+
+// rasterise one mesh triangle into the key buffer (one lane per triangle)
+template <int S>
+__device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys)
+{
+    mwgl::Vert v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
+        mwgl::transform_vertex(f, e.x, p, v[k]);
+    }
+    const uint32_t id = (uint32_t)(e.start + tri);
+    const uint32_t m = v[0].clipmask | v[1].clipmask | v[2].clipmask;
+    if (v[0].clipmask & v[1].clipmask & v[2].clipmask) return;
+    mwgl::TriEdges te;
+    if (m == 0u) {
+        if (mwgl::setup_triangle_pos(v[0].win, v[1].win, v[2].win, S > 1, te)) scatter_tri<S>(te, W, H, id, keys);
+        return;
+    }
+    // a triangle that crosses a frustum plane (rare: a mesh at the screen's edge or the near plane): clipped in private memory
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { v[k].st[0] = v[k].st[1] = 0.0f; v[k].col[0] = v[k].col[1] = v[k].col[2] = 0.0f; }
+    mwgl::Vert buf0[MWGL_MAX_CLIP_VERTS], buf1[MWGL_MAX_CLIP_VERTS], *r;
+    const int n = mwgl::clip_triangle<false>(f, v[0], v[1], v[2], buf0, buf1, &r);
+    for (int i = 2; i < n; ++i)
+        if (mwgl::setup_triangle_pos(r[i - 1].win, r[i].win, r[0].win, S > 1, te)) scatter_tri<S>(te, W, H, id, keys);
+}
+
+// ---- the obs-sized frame's fast path ----------------------------------------------------------------------------------------
+// For frames up to 128 x 128 the 24.8 coordinates stay below 2^15 and every product of the triangle setup fits 32 bits.
+// A triangle inside the frustum is set up and scattered with 32-bit integers; what crosses a frustum plane takes
+// raster_tri above.  A triangle that wins a sample at the time of writing leaves its attribute planes in the env's plane
+// cache (MW_PLANE_REC floats per mesh triangle in view, indexed like the draw ids), so that the tile phase shades a mesh
+// winner with a 80-byte lookup instead of re-deriving its three vertices.
+#define MW_PLANE_REC 20         // (w plane, tex) (r plane, state) (g plane, s.a0) (b plane, s.dadx) (s.dady, t plane)
+#define MW_PLANE_SLOW 2         // state: the triangle crosses a frustum plane — its fragments come from the env's slow-fragment list
+#define MW_SLOW_TRIS 1024       // per env: mesh triangles that cross a frustum plane (a mesh at the frame's edge)
+#define MW_SLOW_FRAGS 8192      // per env: their fragments, (draw id << 16 | next fragment of the pixel + 1, r, g, b), chained per pixel
+
+__device__ inline bool scatter_tri_narrow(const int dcdx[3], const int dcdy[3], const int c[3], const mwgl::Plane &zp, int minx, int maxx,
+                                          int miny, int maxy, int W, int H, uint32_t id, uint32_t *keys)
+{
+    int x0 = minx >> 8, x1 = maxx >> 8, y0 = miny >> 8, y1 = maxy >> 8;
+    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
+    x1 = x1 > W - 1 ? W - 1 : x1; y1 = y1 > H - 1 ? H - 1 : y1;
+    if (x0 > x1 || y0 > y1) return false;
+    // sample thresholds: inside <=> E_k(pixel corner) > thr_k[s]
+    int thr[3][8];
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            thr[k][s] = __mul24(dcdx[k], (int)mwrec::kPat[2][s][0] * 16) - __mul24(dcdy[k], (int)mwrec::kPat[2][s][1] * 16);
+    bool won = false;
+    for (int gy = y0; gy <= y1; ++gy) {
+        const int e0 = c[0] + __mul24(dcdy[0], gy * 256), e1 = c[1] + __mul24(dcdy[1], gy * 256), e2 = c[2] + __mul24(dcdy[2], gy * 256);
+        for (int px = x0; px <= x1; ++px) {
+            const int E0 = e0 - __mul24(dcdx[0], px * 256), E1 = e1 - __mul24(dcdx[1], px * 256), E2 = e2 - __mul24(dcdx[2], px * 256);
+            uint32_t in = 0u;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) in |= (E0 > thr[0][s] && E1 > thr[1][s] && E2 > thr[2][s]) ? (1u << s) : 0u;
+            if (in == 0u) continue;
+            uint32_t *kp = keys + ((size_t)(H - 1 - gy) * W + px) * 8;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if ((in >> s) & 1u) {
+                    const float xs = (float)px + samp_fx<8>(s), ys = (float)gy + samp_fy<8>(s);
+                    const uint32_t key = (mwgl::z_to_unorm16(mwgl::plane_at(zp, xs, ys)) << 16) | id;
+                    won |= atomicMin(kp + s, key) > key;
+                }
+            }
+        }
+    }
+    return won;
+}
+
+__device__ inline void store_planes(float *rec, const mwgl::TriSetup &ts, int tex, int state)
+{
+    float4 *q = reinterpret_cast<float4 *>(rec);
+    q[0] = make_float4(ts.w.a0, ts.w.dadx, ts.w.dady, __int_as_float(tex));
+    q[1] = make_float4(ts.col[0].a0, ts.col[0].dadx, ts.col[0].dady, __int_as_float(state));
+    q[2] = make_float4(ts.col[1].a0, ts.col[1].dadx, ts.col[1].dady, ts.s.a0);
+    q[3] = make_float4(ts.col[2].a0, ts.col[2].dadx, ts.col[2].dady, ts.s.dadx);
+    if (tex >= 0) q[4] = make_float4(ts.s.dady, ts.t.a0, ts.t.dadx, ts.t.dady);
+}
+
+// one mesh triangle of an obs-sized 8-sample frame: keys into LDS, planes of a winner into the cache
+__device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys,
+                                      const float *mesh_nrm, const float *mesh_rgb, const float *mesh_uv, float *cache, int j, int32_t *slow_count,
+                                      uint32_t *slow_tris)
+{
+    mwgl::Vert v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
+        mwgl::transform_vertex(f, e.x, p, v[k]);
+    }
+    if (v[0].clipmask & v[1].clipmask & v[2].clipmask) return;
+    const uint32_t id = (uint32_t)(e.start + tri);
+    float *rec = cache + (size_t)tri * MW_PLANE_REC;
+    if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) != 0u) {
+        // crosses a frustum plane (rare): left to mw_mesh_slow_kernel, which clips it, scatters its keys and shades its fragments
+        const int k = atomicAdd(slow_count, 1);
+        if (k < MW_SLOW_TRIS) slow_tris[k] = ((uint32_t)j << 16) | (uint32_t)tri;
+        reinterpret_cast<float4 *>(rec)[1] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(MW_PLANE_SLOW));
+        return;
+    }
+    // setup_triangle_pos in 32 bits
+    int fx[3], fy[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        fx[i] = mwgl::iround_even(v[i].win[0] * 256.0f);
+        fy[i] = mwgl::iround_even(v[i].win[1] * 256.0f);
+    }
+    {
+        const int dx01 = fx[0] - fx[1], dy01 = fy[0] - fy[1], dx20 = fx[2] - fx[0], dy20 = fy[2] - fy[0];
+        if (dx01 * dy20 - dx20 * dy01 >= 0) return;        // back-facing or empty
+    }
+    // front faces are set up in the order (v1, v0, v2)
+    const int X[3] = {fx[1], fx[0], fx[2]}, Y[3] = {fy[1], fy[0], fy[2]};
+    int dcdx[3], dcdy[3], c[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int j = i == 2 ? 0 : i + 1;
+        dcdy[i] = X[i] - X[j];
+        dcdx[i] = Y[i] - Y[j];
+        c[i] = dcdx[i] * X[i] - dcdy[i] * Y[i];
+        c[i] += (dcdx[i] < 0 || (dcdx[i] == 0 && dcdy[i] > 0)) ? 1 : 0;
+    }
+    const int minx = min(min(X[0], X[1]), X[2]), maxx = max(max(X[0], X[1]), X[2]);
+    const int miny = min(min(Y[0], Y[1]), Y[2]), maxy = max(max(Y[0], Y[1]), Y[2]);
+    const float *w0 = v[1].win, *w1 = v[0].win, *w2 = v[2].win;
+    const float fdx01 = w0[0] - w1[0], fdy01 = w0[1] - w1[1], fdx20 = w2[0] - w0[0], fdy20 = w2[1] - w0[1];
+    const float ooa = 1.0f / (fdx01 * fdy20 - fdx20 * fdy01);
+    mwgl::Plane zp;
+    mwgl::plane_coef(zp, w0[2], w1[2], w2[2], fdy20 * ooa, fdy01 * ooa, fdx20 * ooa, fdx01 * ooa, w0[0], w0[1]);
+    if (!scatter_tri_narrow(dcdx, dcdy, c, zp, minx, maxx, miny, maxy, W, H, id, keys)) return;
+    // a winner (so far): light its vertices, set up its attribute planes
+    const float *nrm = mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = mesh_rgb + (size_t)(e.first + tri) * 9;
+    const float *uv = mesh_uv + (size_t)(e.first + tri) * 6;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float n[3] = {nrm[k * 3], nrm[k * 3 + 1], nrm[k * 3 + 2]}, cl[3] = {rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2]};
+        mwgl::light_vertex(f, e.x, n, cl, v[k].col);
+        v[k].st[0] = e.tex >= 0 ? uv[k * 2] : 0.0f;
+        v[k].st[1] = e.tex >= 0 ? uv[k * 2 + 1] : 0.0f;
+    }
+    mwgl::TriSetup ts;
+    if (mwgl::setup_triangle(v[0], v[1], v[2], true, e.tex >= 0, ts)) store_planes(rec, ts, e.tex, 1);
+}
+
+// Attribute planes of mesh triangle (e, tri) for the pixel (px, gy): the triangle is taken through the vertex stage again
+// (lighting per vertex: Gouraud), clipped if it has to be — then the part of the fan that covers the pixel — and set up.
+template <int S>
+__device__ __attribute__((noinline)) RGB shade_mesh_tri(const TileCtx &cx, const MeshEnt &e, int tri, int px, int gy)
+{
+    mwgl::Frame f;
+    frame_lite(cx.hdr, cx.W, cx.H, f);
+    float pos[9];
+    tri_load(cx.mesh_pos, e, tri, pos);
+    const float *nrm = cx.mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = cx.mesh_rgb + (size_t)(e.first + tri) * 9;
+    const float *uv = cx.mesh_uv + (size_t)(e.first + tri) * 6;
+    mwgl::Vert v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
+        mwgl::transform_vertex(f, e.x, p, v[k]);
+        const float n[3] = {nrm[k * 3], nrm[k * 3 + 1], nrm[k * 3 + 2]}, c[3] = {rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2]};
+        mwgl::light_vertex(f, e.x, n, c, v[k].col);
+        v[k].st[0] = e.tex >= 0 ? uv[k * 2] : 0.0f;
+        v[k].st[1] = e.tex >= 0 ? uv[k * 2 + 1] : 0.0f;
+    }
+    const float eo = S > 1 ? 0.5f : 0.0f;
+    mwgl::TriSetup ts;
+    bool have = false;
+    if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) == 0u) {
+        have = mwgl::setup_triangle(v[0], v[1], v[2], S > 1, e.tex >= 0, ts);
+    } else {
+        mwgl::Vert buf0[MWGL_MAX_CLIP_VERTS], buf1[MWGL_MAX_CLIP_VERTS], *r;
+        const int n = mwgl::clip_triangle<true>(f, v[0], v[1], v[2], buf0, buf1, &r);
+        // the first triangle of the fan with a sample of this pixel inside
+        for (int i = 2; i < n && !have; ++i) {
+            mwgl::TriSetup t2;
+            if (!mwgl::setup_triangle(r[i - 1], r[i], r[0], S > 1, e.tex >= 0, t2)) continue;
+            bool any = false;
+            for (int s = 0; s < S; ++s) {
+                int sx, sy;
+                mwrec::sample_offset(S, s, sx, sy);
+                const int64_t fx = (int64_t)px * 256 + sx, fy = (int64_t)gy * 256 + sy;
+                bool in = true;
+                for (int k = 0; k < 3; ++k) in &= (t2.c[k] + (int64_t)t2.dcdy[k] * fy - (int64_t)t2.dcdx[k] * fx) > 0;
+                any |= in;
+            }
+            if (any) { ts = t2; have = true; }
+        }
+    }
+    if (!have) return RGB{0.0f, 0.0f, 0.0f};
+    return shade_planes(ts.w, ts.s, ts.t, ts.col[0], ts.col[1], ts.col[2], cx.te.flat ? -1 : e.tex, cx.te, px, gy, eo);
+}
+
+// draw id -> fragment colour: ids inside a mesh entity's range are triangles, the others index the record list once the
+// mesh triangles drawn before them are subtracted
+template <int S, bool CACHED>
+__device__ inline RGB shade_by_draw_id_s(const TileCtx &cx, uint32_t id, int px, int gy)
+{
+    const int n_mesh = __float_as_int(cx.hdr[3]);
+    int vis = (int)id;
+    for (int j = 0; j < n_mesh; ++j) {
+        const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * j + 1]);
+        const int nt = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * j + 2]);
+        if ((int)id >= start + nt) {
+            vis -= nt;
+        } else if ((int)id >= start) {
+            if (CACHED) {
+                // the plane cache of the obs path (raster_tri_obs)
+                const float4 *q = reinterpret_cast<const float4 *>(cx.planes + ((size_t)__float_as_int(cx.ment[MW_HDR_MESH_STRIDE * j + 25]) + ((int)id - start)) * MW_PLANE_REC);
+                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                const int tex = cx.te.flat ? -1 : __float_as_int(q0.w);
+                if (__float_as_int(q1.w) == MW_PLANE_SLOW) {
+                    // a triangle that crosses a frustum plane: its fragments were shaded by mw_mesh_slow_kernel
+                    // (the pixel's chain, newest first: the first one appended for this id — the first piece of the fan — counts)
+                    RGB c = {0.0f, 0.0f, 0.0f};
+                    uint32_t k = cx.slow_head[(cx.H - 1 - gy) * cx.W + px];
+                    for (int guard = 0; k != 0u && k <= MW_SLOW_FRAGS && guard < MW_SLOW_FRAGS; ++guard) {
+                        const float4 fr = cx.slow_frags[k - 1u];
+                        const uint32_t w = __float_as_uint(fr.x);
+                        if ((w >> 16) == id) c = RGB{fr.y, fr.z, fr.w};
+                        k = w & 0xFFFFu;
+                    }
+                    return c;
+                }
+                const mwgl::Plane wp = {q0.x, q0.y, q0.z}, pr = {q1.x, q1.y, q1.z}, pg = {q2.x, q2.y, q2.z}, pb = {q3.x, q3.y, q3.z};
+                if (tex < 0) {      // an untextured mesh (the common case): three planes over 1 / w
+                    const float x = (float)px + 0.5f, y = (float)gy + 0.5f;
+                    const float oow = rcp_safe(mwgl::plane_at(wp, x, y));
+                    return RGB{mwgl::plane_at(pr, x, y) * oow, mwgl::plane_at(pg, x, y) * oow, mwgl::plane_at(pb, x, y) * oow};
+                }
+                const float4 q4 = q[4];
+                const mwgl::Plane sp = {q2.w, q3.w, q4.x}, tp = {q4.y, q4.z, q4.w};
+                return shade_planes(wp, sp, tp, pr, pg, pb, tex, cx.te, px, gy, 0.5f);
+            } else {
+                const MeshEnt e = load_ment(cx.ment, j);
+                return shade_mesh_tri<S>(cx, e, (int)id - start, px, gy);
+            }
+        }
+    }
+    return shade_frag(cx.s_shade + vis * (MW_SHADE_REC / 4), cx.te, px, gy, S > 1 ? 0.5f : 0.0f);
+}
+
+// the tile kernels (obs path)
+__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, int px, int gy) { return shade_by_draw_id_s<8, true>(cx, id, px, gy); }
+
+// a mesh tile's sample keys: read, and left cleared for the next frame's scatter
+__device__ inline void take_mesh_keys(uint32_t *env_keys, int W, int tx, int ty, int lane, uint32_t (&mk)[8])
+{
+    const int px = tx * MW_TILE_W + tile_col(lane), py = ty * MW_TILE_H + tile_row(lane);
+    uint4 *kp = reinterpret_cast<uint4 *>(env_keys + ((size_t)py * W + px) * 8);
+    const uint4 k0 = kp[0], k1 = kp[1];
+    mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
+    const uint4 ones = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    if ((k0.x & k0.y & k0.z & k0.w) != 0xFFFFFFFFu) kp[0] = ones;
+    if ((k1.x & k1.y & k1.z & k1.w) != 0xFFFFFFFFu) kp[1] = ones;
+}
+
+}  // namespace

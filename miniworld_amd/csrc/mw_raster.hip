@@ -17,26 +17,22 @@
 //   output   : RGB bytes staged through 192 B of LDS so the tile leaves as dword stores.
 // HBM traffic per env-step is the observation (14 400 B, + 19 200 B with depth) plus the
 // K1 records; textures and records are L2-resident.
-#include "mw_raster_common.h"
-
-namespace {
-// the quad kernel never sees mesh draw ids
-__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, int px, int gy)
-{
-    return shade_frag(cx.s_shade + id * (MW_SHADE_REC / 4), cx.te, px, gy, 0.5f);
-}
-}  // namespace
+#include "mw_mesh.h"
 
 // LDS_RECS = true : the env's shade / classification records are staged in LDS (small scenes);
 // LDS_RECS = false: they are read in place from global memory (L1/L2) — scenes with hundreds of
 //                   visible primitives (Maze) would not leave room for enough resident waves.
-template <bool LDS_RECS, int FMT, int HOT = 0>
+// MESHAWARE   : envs may hold mesh entities — the tiles inside a mesh entity's tile rectangle (env header) start from the
+//               sample keys the scatter kernel left (mw_raster_mesh.hip) and give them back cleared.
+template <bool LDS_RECS, int FMT, int HOT = 0, bool MESHAWARE = false>
 __device__ inline void raster_kernel_body(
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave,
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
     const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes,
-    const uint16_t *__restrict__ rec_order)
+    const uint16_t *__restrict__ rec_order, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
+    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint32_t *__restrict__ mesh_keys,
+    const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lds_recs = LDS_RECS ? (max_vis < MW_LDS_RECS ? max_vis : MW_LDS_RECS) : 0;
@@ -52,8 +48,9 @@ __device__ inline void raster_kernel_body(
     const int part = slot % waves_per_env;
     if (env >= N) return;
     const int lane = threadIdx.x;
-    // co-run mode (flag 16): envs with a mesh in view belong to mw_raster_mesh_kernel
-    if ((dbg & 16) && __float_as_int(envhdr[(size_t)env * MW_ENVHDR + 3]) != 0) return;
+    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
+    const bool mesh_env = MESHAWARE && __float_as_int(hdr[3]) != 0;
+    uint32_t *env_keys = MESHAWARE ? mesh_keys + (size_t)env * W * H * 8 : nullptr;
     const int nvis = nvis_arr[env];
     const float *__restrict__ rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     const float4 *g_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
@@ -73,8 +70,11 @@ __device__ inline void raster_kernel_body(
     te.flat = HOT ? 0 : (dbg & 1);
 
     TileCtx cx;
-    cx.s_shade = in_lds ? s_shade : g_shade; cx.s_cull = in_lds ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = nullptr; cx.ment = nullptr; cx.tprof = nullptr;
-    cx.mesh_pos = cx.mesh_nrm = cx.mesh_rgb = cx.mesh_uv = nullptr;
+    cx.s_shade = in_lds ? s_shade : g_shade; cx.s_cull = in_lds ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH; cx.tprof = nullptr;
+    cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
+    cx.planes = MESHAWARE ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
+    cx.slow_frags = MESHAWARE ? slow_frags + (size_t)env * MW_SLOW_FRAGS : nullptr;
+    cx.slow_head = MESHAWARE ? slow_head + (size_t)env * W * H : nullptr;
     cx.obs = obs; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3); cx.te = te;
     cx.sky_r = sky_r; cx.sky_g = sky_g; cx.sky_b = sky_b;
@@ -115,11 +115,23 @@ __device__ inline void raster_kernel_body(
             cx.pre_touch = (uint32_t)__builtin_amdgcn_readlane((int)vT, gi);
             cx.pre_full = (uint32_t)__builtin_amdgcn_readlane((int)vF, gi);
             ++gi;
+            if (MESHAWARE && mesh_env && tile_in_mesh_rect(hdr, tx, ty)) {
+                uint32_t mk[8];
+                take_mesh_keys(env_keys, W, tx, ty, lane, mk);
+                raster_tile_fmt<true, FMT, false, HOT, 1>(cx, tx, ty, mk);
+                continue;
+            }
             raster_tile_fmt<false, FMT, false, HOT, 1>(cx, tx, ty, nullptr);
         }
         return;
     }
     for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
+        if (MESHAWARE && mesh_env && tile_in_mesh_rect(hdr, tx, ty)) {
+            uint32_t mk[8];
+            take_mesh_keys(env_keys, W, tx, ty, lane, mk);
+            raster_tile_fmt<true, FMT, false, HOT, 0>(cx, tx, ty, mk);
+            continue;
+        }
         if (!LDS_RECS && rec_order) raster_tile_fmt<false, FMT, true, HOT, 0>(cx, tx, ty, nullptr);
         else raster_tile_fmt<false, FMT, false, HOT, 0>(cx, tx, ty, nullptr);
     }
@@ -132,9 +144,11 @@ __device__ inline void raster_kernel_body(
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull, \
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd, \
     const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, \
-    const uint16_t *__restrict__ rec_order
+    const uint16_t *__restrict__ rec_order, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm, \
+    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint32_t *__restrict__ mesh_keys, \
+    const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head
 #define MW_RASTER_FWD N, W, H, max_vis, tiles_x, n_tiles, waves_per_env, tiles_per_wave, rec_raster, rec_shade, rec_cull, \
-    nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order
+    nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order, mesh_pos, mesh_nrm, mesh_rgb, mesh_uv, mesh_keys, plane_cache, plane_cap, slow_frags, slow_head
 
 // the production kernels of small scenes: no debug flags (mw_engine.hip launches the general kernel below when
 // MW_DEBUG_FLAGS asks for any), RGB only / RGB + depth
@@ -168,3 +182,9 @@ extern "C" __global__ __launch_bounds__(64) void mw_raster_big_wrap_kernel(MW_RA
 {
     raster_kernel_body<false, -1>(MW_RASTER_FWD);
 }
+
+// the same for envs that may hold mesh entities (PickupObjects, Sign, CollectHealth, ...)
+extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 1, true>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_depth_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 2, true>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, -1, 0, true>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64) void mw_raster_big_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<false, -1, 0, true>(MW_RASTER_FWD); }

@@ -72,7 +72,7 @@ __device__ inline void fetch_level(const TexEnv &te, uint32_t desc, int l, float
 
 // fragment colour from a triangle's attribute planes at GL pixel (px, gy); eo: where the pixel centre sits in the planes'
 // coordinates (0.5 for a multisampled target, 0 for a single-sampled one)
-__device__ inline RGB shade_planes(const mwgl::Plane &wp, const mwgl::Plane &sp, const mwgl::Plane &tp, const mwgl::Plane &pr,
+__device__ __attribute__((noinline)) RGB shade_planes(const mwgl::Plane &wp, const mwgl::Plane &sp, const mwgl::Plane &tp, const mwgl::Plane &pr,
                                    const mwgl::Plane &pg, const mwgl::Plane &pb, int tex, const TexEnv &te, int px, int gy, float eo)
 {
     const float x = (float)px + eo, y = (float)gy + eo;
@@ -232,6 +232,9 @@ struct TileCtx {
     const float *hdr;               // env header (mesh kernel only)
     const float *ment;              // the env's mesh-entity table
     const float *mesh_pos, *mesh_nrm, *mesh_rgb, *mesh_uv;
+    const float *planes;            // the env's plane cache (mesh-aware K2; null elsewhere)
+    const float4 *slow_frags;       // the env's slow-fragment list and its length (mw_mesh_slow_kernel)
+    const uint32_t *slow_head;      // [H][W] newest fragment of the pixel + 1, 0 = none
     uint8_t *__restrict__ obs;
     float *__restrict__ depth;
     rsrc_t obs_rsrc;                // this env's uint8[H][W][3] frame as a raw buffer (HWC layout only)
@@ -331,6 +334,19 @@ __device__ inline RGB resolve8_one(const RGB c)
 }
 
 __device__ inline uint32_t to_u8(float acc) { return mwgl::float_to_unorm8(acc * 0.125f); }
+
+// Is tile (tx, ty) inside the tile rectangle of one of the env's mesh entities (env header, mw_geom.hip)?  Those tiles
+// belong to the mesh kernel, all others to K2.
+__device__ inline bool tile_in_mesh_rect(const float *hdr, int tx, int ty)
+{
+    const int n_mesh = __float_as_int(hdr[3]);
+    bool in = false;
+    for (int j = 0; j < n_mesh; ++j) {
+        const uint32_t r = __float_as_uint(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 26]);
+        in |= tx >= (int)(r & 255u) && tx <= (int)((r >> 8) & 255u) && ty >= (int)((r >> 16) & 255u) && ty <= (int)(r >> 24);
+    }
+    return in;
+}
 
 // MESH kernels: is draw id `id` a mesh triangle?  (uniform scan of the env's mesh table.)  Returns the table entry or -1,
 // and the record index of a non-mesh id (draw ids count every mesh triangle drawn before).
@@ -568,9 +584,11 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             // its colour); rare outside the interior of a finely tessellated mesh
             RGB acc = {0.0f, 0.0f, 0.0f}, last = sky;
             uint32_t last_id = MW_SKY_PID;
-#pragma unroll
+#pragma unroll 1
             for (int s = 0; s < 8; ++s) {
-                const uint32_t w = key[s] & 0xFFFFu;
+                const uint32_t w = key[0] & 0xFFFFu;
+#pragma unroll
+                for (int i = 0; i < 7; ++i) key[i] = key[i + 1];        // the loop stays rolled: one copy of the shading code
                 const bool need = w != last_id && w != MW_SKY_PID;
                 if (__any(need)) {
                     RGB cc;

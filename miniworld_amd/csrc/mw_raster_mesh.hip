@@ -1,303 +1,213 @@
-// K3 — raster kernel for envs that contain mesh entities (Ball / Key / Building / ...: entity.py:124-165, 435-452;
-// ObjMesh.render objmesh.py:280-292), and the generic-resolution view kernels.  One 1024-thread workgroup per env.
-//
-// A ball is 5 192 sub-pixel triangles, so the pixel-per-lane scheme of K2 would waste 60+ lanes per triangle.  Here the
-// whole env's sample-key buffer (80*60*8 dwords = 153 600 B) lives in the CU's 160 KiB LDS and the mesh triangles are
-// rasterised one per lane, scattering packed keys (depth16 << 16 | draw id) with ds_min_u32 — GL_LESS / first-drawn-wins
-// is an unsigned min, hence order independent.  After a barrier the 16 wavefronts walk the tiles exactly like K2, starting
-// from the mesh keys; winners whose draw id falls into a mesh entity's range are shaded by re-deriving that triangle.
-//
-// Per-triangle arithmetic is mw_glmath.h's (the driver's vertex stage and triangle setup): the entity's MVP matrix, its
-// object-space light and normal scale come from the geometry kernel's mesh table.
-#include "mw_raster_common.h"
+// The mesh scatter kernel (mesh triangles -> sample keys + attribute planes of the winners) and the generic-resolution
+// view kernels.  See mw_mesh.h.
+#include "mw_mesh.h"
 
+// Grid (MW_SCATTER_BLOCKS_X, N): the blocks of row y walk the mesh entities in view of env y, 256 triangles per block and
+// step, one triangle per lane, in the order sorted by face normal (mw_upload_mesh: the 64 triangles of a wavefront face
+// the same way, so back-face culling retires whole waves).  keys: [N][H][W][8] dwords, all 0xFFFFFFFF on entry inside the
+// entities' tile rectangles (K2 resets what it reads); planes: [N][plane_cap][MW_PLANE_REC].
+extern "C" __global__ __launch_bounds__(256) void mw_mesh_scatter_kernel(int W, int H, const float *__restrict__ envhdr,
+                                                                        const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
+                                                                        const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv,
+                                                                        uint32_t *__restrict__ keys_all, float *__restrict__ plane_cache, int plane_cap,
+                                                                        int32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_tris)
+{
+    const int env = blockIdx.y;
+    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
+    const int n_mesh = __float_as_int(hdr[3]);
+    if (n_mesh == 0) return;
+    uint32_t *keys = keys_all + (size_t)env * W * H * 8;
+    mwgl::Frame f;
+    frame_lite(hdr, W, H, f);
+    for (int j = 0; j < n_mesh; ++j) {
+        const MeshEnt e = load_ment(hdr + MW_HDR_MESH, j);
+        float *cache_e = plane_cache + ((size_t)env * plane_cap + (size_t)__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 25])) * MW_PLANE_REC;
+        for (int t = (int)blockIdx.x * 256 + (int)threadIdx.x; t < e.ntris; t += (int)gridDim.x * 256) {
+            const int tri = tri_sorted(mesh_pos, e, t);
+            float pos[9];
+            tri_load(mesh_pos, e, tri, pos);
+            raster_tri_obs(f, e, tri, pos, W, H, keys, mesh_nrm, mesh_rgb, mesh_uv, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS);
+        }
+    }
+}
+
+// The mesh triangles that cross a frustum plane (a mesh at the frame's edge; the scatter kernel lists them): clipped, every
+// piece set up on its own (llvmpipe's clipper output), its keys scattered and its fragments shaded right here — one entry
+// (draw id, colour) per pixel with a covered sample, chained per pixel, in fan order — so that neither the scatter kernel
+// nor K2 carries the clipper.  One wavefront per env, a triangle per lane (work lists in LDS); a piece that spans more than
+// 32 pixels is spread over the lanes, a pixel each.  Exits at once for an env without such triangles.
 namespace {
 
-struct MeshEnt {            // one entry of the env header's mesh table (mw_geom.hip)
-    int slot, start, ntris, first, tex;
-    mwgl::Xform x;
+struct SlowPiece {       // what the pixel loop needs of one set-up piece
+    int dcdx[3], dcdy[3], c[3];
+    mwgl::Plane z, w, s, t, r, g, b;
+    int x0, x1, y0, y1;
+    uint32_t id;
+    int tex;
 };
 
-__device__ inline MeshEnt load_ment(const float *table, int j)
+// the piece's samples in pixel (px, gy): keys scattered; true if any
+__device__ inline bool slow_cover(const SlowPiece &p, int px, int gy, int W, int H, uint32_t *keys)
 {
-    const float *m = table + MW_HDR_MESH_STRIDE * j;
-    MeshEnt e;
-    e.slot = __float_as_int(m[0]); e.start = __float_as_int(m[1]); e.ntris = __float_as_int(m[2]);
-    e.first = __float_as_int(m[3]); e.tex = __float_as_int(m[4]);
-    e.x.nscale = m[5];
-    e.x.light[0] = m[6]; e.x.light[1] = m[7]; e.x.light[2] = m[8];
+    uint32_t *kp = keys + ((size_t)(H - 1 - gy) * W + px) * 8;
+    bool any = false;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) e.x.mvp.m[k] = m[9 + k];
-    return e;
-}
-
-// what the per-vertex functions need of the frame: viewport and light colours (env header)
-__device__ inline void frame_lite(const float *hdr, int W, int H, mwgl::Frame &f)
-{
-    f.vp_scale[0] = (float)W * 0.5f; f.vp_trans[0] = (float)W * 0.5f;
-    f.vp_scale[1] = (float)H * 0.5f; f.vp_trans[1] = (float)H * 0.5f;
-    f.vp_scale[2] = 0.5f; f.vp_trans[2] = 0.5f;
+    for (int s = 0; s < 8; ++s) {
+        const int fx = px * 256 + (int)mwrec::kPat[2][s][0] * 16, fy = gy * 256 + (int)mwrec::kPat[2][s][1] * 16;
+        bool in = true;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) { f.l_amb[i] = hdr[4 + i]; f.l_dif[i] = hdr[8 + i]; }
-}
-
-// the i-th triangle of the rasterisation order (sorted by face-normal direction; mw_device.h: MW_MESH_POS_STRIDE)
-__device__ inline int tri_sorted(const float *mesh_pos, const MeshEnt &e, int i)
-{
-    return (int)__float_as_uint(mesh_pos[(size_t)(e.first + i) * MW_MESH_POS_STRIDE + 9]);
-}
-
-__device__ inline void tri_load(const float *mesh_pos, const MeshEnt &e, int tri, float (&p)[9])
-{
-    static_assert(MW_MESH_POS_STRIDE % 2 == 0, "8-byte aligned triangles");
-    const float2 *src = reinterpret_cast<const float2 *>(mesh_pos + (size_t)(e.first + tri) * MW_MESH_POS_STRIDE);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { const float2 v = src[k]; p[2 * k] = v.x; p[2 * k + 1] = v.y; }
-    p[8] = reinterpret_cast<const float *>(src)[8];
-}
-
-// sample s of an S-sample pixel: offset inside the pixel in pixels (the planes' coordinates)
-template <int S> __device__ inline float samp_fx(int s) { return S == 1 ? 0.0f : (float)mwrec::kPat[mwrec::pat_index(S)][s][0] * 0.0625f; }
-template <int S> __device__ inline float samp_fy(int s) { return S == 1 ? 0.0f : (float)mwrec::kPat[mwrec::pat_index(S)][s][1] * 0.0625f; }
-
-// scatter one set-up triangle's keys: every sample inside gets min(key, depth16 << 16 | id)
-template <int S>
-__device__ inline void scatter_tri(const mwgl::TriEdges &t, int W, int H, uint32_t id, uint32_t *keys)
-{
-    const int off = S == 1 ? 128 : 0;
-    int x0 = (t.minx + off) >> 8, x1 = (t.maxx + off) >> 8, y0 = (t.miny + off) >> 8, y1 = (t.maxy + off) >> 8;
-    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
-    x1 = x1 > W - 1 ? W - 1 : x1; y1 = y1 > H - 1 ? H - 1 : y1;
-    for (int gy = y0; gy <= y1; ++gy)
-        for (int px = x0; px <= x1; ++px) {
-            uint32_t *kp = keys + ((size_t)(H - 1 - gy) * W + px) * S;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                int sx, sy;
-                mwrec::sample_offset(S, s, sx, sy);
-                const int64_t fx = (int64_t)px * 256 + sx, fy = (int64_t)gy * 256 + sy;
-                bool in = true;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) in &= (t.c[k] + (int64_t)t.dcdy[k] * fy - (int64_t)t.dcdx[k] * fx) > 0;
-                if (in) {
-                    const float xs = (float)px + samp_fx<S>(s), ys = (float)gy + samp_fy<S>(s);
-                    atomicMin(kp + s, (mwgl::z_to_unorm16(mwgl::plane_at(t.z, xs, ys)) << 16) | id);
-                }
-            }
-        }
-}
-
-// rasterise one mesh triangle into the key buffer (one lane per triangle)
-template <int S>
-__device__ inline void raster_tri(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys)
-{
-    mwgl::Vert v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
-        mwgl::transform_vertex(f, e.x, p, v[k]);
-    }
-    const uint32_t id = (uint32_t)(e.start + tri);
-    const uint32_t m = v[0].clipmask | v[1].clipmask | v[2].clipmask;
-    if (v[0].clipmask & v[1].clipmask & v[2].clipmask) return;
-    mwgl::TriEdges te;
-    if (m == 0u) {
-        if (mwgl::setup_triangle_pos(v[0].win, v[1].win, v[2].win, S > 1, te)) scatter_tri<S>(te, W, H, id, keys);
-        return;
-    }
-    // a triangle that crosses a frustum plane (rare: a mesh at the screen's edge or the near plane): clipped in private memory
-#pragma unroll
-    for (int k = 0; k < 3; ++k) { v[k].st[0] = v[k].st[1] = 0.0f; v[k].col[0] = v[k].col[1] = v[k].col[2] = 0.0f; }
-    mwgl::Vert buf0[MWGL_MAX_CLIP_VERTS], buf1[MWGL_MAX_CLIP_VERTS], *r;
-    const int n = mwgl::clip_triangle<false>(f, v[0], v[1], v[2], buf0, buf1, &r);
-    for (int i = 2; i < n; ++i)
-        if (mwgl::setup_triangle_pos(r[i - 1].win, r[i].win, r[0].win, S > 1, te)) scatter_tri<S>(te, W, H, id, keys);
-}
-
-// Attribute planes of mesh triangle (e, tri) for the pixel (px, gy): the triangle is taken through the vertex stage again
-// (lighting per vertex: Gouraud), clipped if it has to be — then the part of the fan that covers the pixel — and set up.
-template <int S>
-__device__ inline RGB shade_mesh_tri(const TileCtx &cx, const MeshEnt &e, int tri, int px, int gy)
-{
-    mwgl::Frame f;
-    frame_lite(cx.hdr, cx.W, cx.H, f);
-    float pos[9];
-    tri_load(cx.mesh_pos, e, tri, pos);
-    const float *nrm = cx.mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = cx.mesh_rgb + (size_t)(e.first + tri) * 9;
-    const float *uv = cx.mesh_uv + (size_t)(e.first + tri) * 6;
-    mwgl::Vert v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
-        mwgl::transform_vertex(f, e.x, p, v[k]);
-        const float n[3] = {nrm[k * 3], nrm[k * 3 + 1], nrm[k * 3 + 2]}, c[3] = {rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2]};
-        mwgl::light_vertex(f, e.x, n, c, v[k].col);
-        v[k].st[0] = e.tex >= 0 ? uv[k * 2] : 0.0f;
-        v[k].st[1] = e.tex >= 0 ? uv[k * 2 + 1] : 0.0f;
-    }
-    const float eo = S > 1 ? 0.5f : 0.0f;
-    mwgl::TriSetup ts;
-    bool have = false;
-    if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) == 0u) {
-        have = mwgl::setup_triangle(v[0], v[1], v[2], S > 1, e.tex >= 0, ts);
-    } else {
-        mwgl::Vert buf0[MWGL_MAX_CLIP_VERTS], buf1[MWGL_MAX_CLIP_VERTS], *r;
-        const int n = mwgl::clip_triangle<true>(f, v[0], v[1], v[2], buf0, buf1, &r);
-        // the first triangle of the fan with a sample of this pixel inside
-        for (int i = 2; i < n && !have; ++i) {
-            mwgl::TriSetup t2;
-            if (!mwgl::setup_triangle(r[i - 1], r[i], r[0], S > 1, e.tex >= 0, t2)) continue;
-            bool any = false;
-            for (int s = 0; s < S; ++s) {
-                int sx, sy;
-                mwrec::sample_offset(S, s, sx, sy);
-                const int64_t fx = (int64_t)px * 256 + sx, fy = (int64_t)gy * 256 + sy;
-                bool in = true;
-                for (int k = 0; k < 3; ++k) in &= (t2.c[k] + (int64_t)t2.dcdy[k] * fy - (int64_t)t2.dcdx[k] * fx) > 0;
-                any |= in;
-            }
-            if (any) { ts = t2; have = true; }
+        for (int k = 0; k < 3; ++k) in &= p.c[k] + __mul24(p.dcdy[k], fy) - __mul24(p.dcdx[k], fx) > 0;
+        if (in) {
+            const float xs = (float)px + samp_fx<8>(s), ys = (float)gy + samp_fy<8>(s);
+            atomicMin(kp + s, (mwgl::z_to_unorm16(mwgl::plane_at(p.z, xs, ys)) << 16) | p.id);
+            any = true;
         }
     }
-    if (!have) return RGB{0.0f, 0.0f, 0.0f};
-    return shade_planes(ts.w, ts.s, ts.t, ts.col[0], ts.col[1], ts.col[2], cx.te.flat ? -1 : e.tex, cx.te, px, gy, eo);
+    return any;
 }
 
-// draw id -> fragment colour: ids inside a mesh entity's range are triangles, the others index the record list once the
-// mesh triangles drawn before them are subtracted
-template <int S>
-__device__ inline RGB shade_by_draw_id_s(const TileCtx &cx, uint32_t id, int px, int gy)
+// the piece's fragment of pixel (px, gy) as entry k of the env's list
+__device__ inline void slow_frag(const SlowPiece &p, int px, int gy, int W, int H, const TexEnv &te, int k, float4 *frags, uint16_t *frag_pix,
+                                 uint32_t *head, uint32_t *status)
 {
-    const int n_mesh = __float_as_int(cx.hdr[3]);
-    int vis = (int)id;
-    for (int j = 0; j < n_mesh; ++j) {
-        const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * j + 1]);
-        const int nt = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * j + 2]);
-        if ((int)id >= start + nt) {
-            vis -= nt;
-        } else if ((int)id >= start) {
-            const MeshEnt e = load_ment(cx.ment, j);
-            return shade_mesh_tri<S>(cx, e, (int)id - start, px, gy);
-        }
-    }
-    return shade_frag(cx.s_shade + vis * (MW_SHADE_REC / 4), cx.te, px, gy, S > 1 ? 0.5f : 0.0f);
+    if (k >= MW_SLOW_FRAGS) { atomicOr(status, MW_ST_VIS_OVERFLOW); return; }
+    const RGB c = shade_planes(p.w, p.s, p.t, p.r, p.g, p.b, p.tex, te, px, gy, 0.5f);
+    const uint32_t pix = (uint32_t)((H - 1 - gy) * W + px);
+    const uint32_t next = atomicExch(head + pix, (uint32_t)k + 1u);
+    frags[k] = make_float4(__uint_as_float((p.id << 16) | (next & 0xFFFFu)), c.r, c.g, c.b);
+    frag_pix[k] = (uint16_t)pix;
 }
 
-__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, int px, int gy) { return shade_by_draw_id_s<8>(cx, id, px, gy); }
+__device__ inline void slow_pixel(const SlowPiece &p, int px, int gy, int W, int H, uint32_t *keys, const TexEnv &te, int32_t *frag_count,
+                                  float4 *frags, uint16_t *frag_pix, uint32_t *head, uint32_t *status)
+{
+    if (slow_cover(p, px, gy, W, H, keys)) slow_frag(p, px, gy, W, H, te, atomicAdd(frag_count, 1), frags, frag_pix, head, status);
+}
+
+__device__ inline int bcast_i(int v, int src) { return __shfl(v, src); }
+__device__ inline float bcast_f(float v, int src) { return __shfl(v, src); }
+__device__ inline mwgl::Plane bcast_p(const mwgl::Plane &q, int src) { return mwgl::Plane{bcast_f(q.a0, src), bcast_f(q.dadx, src), bcast_f(q.dady, src)}; }
 
 }  // namespace
 
-#define MW_MESH_ARGS \
-    int N, int W, int H, int max_vis, int tiles_x, int n_tiles, \
-    const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull, \
-    const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd, \
-    const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm, \
-    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, \
-    unsigned long long *__restrict__ prof, const int32_t *__restrict__ env_order
-#define MW_MESH_FWD N, W, H, max_vis, tiles_x, n_tiles, rec_raster, rec_shade, rec_cull, nvis_arr, envhdr, texd, texels, mesh_pos, \
-    mesh_nrm, mesh_rgb, mesh_uv, obs, depth, dbg, texel_bytes, prof, env_order
-
-#define MW_K3_TAIL (16 * MW_K3_WAVE_LDS + 16 + MW_MAX_MESH_ENTS * MW_HDR_MESH_STRIDE * 4)    // LDS beside the keys: pack buffers, tile counter, mesh table
-
-// FMT / HOT as in mw_raster.hip
-template <int FMT, int HOT>
-__device__ inline void mesh_kernel_body(MW_MESH_ARGS)
+extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int H, const float *__restrict__ envhdr, const float *__restrict__ mesh_pos,
+                                                                     const float *__restrict__ mesh_nrm, const float *__restrict__ mesh_rgb,
+                                                                     const float *__restrict__ mesh_uv, const uint32_t *__restrict__ texels, int texel_bytes,
+                                                                     uint32_t *__restrict__ keys_all, int32_t *__restrict__ slow_count,
+                                                                     const uint32_t *__restrict__ slow_tris, int32_t *__restrict__ frag_count,
+                                                                     float4 *__restrict__ frags_all, uint16_t *__restrict__ pix_all,
+                                                                     uint32_t *__restrict__ heads_all, uint32_t *__restrict__ status, int dbg)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);                     // [H][W][8], image rows
-    const unsigned long long t_start = prof ? __builtin_readcyclecounter() : 0ull;
-    const int nkeys = W * H * 8;
-    // block b draws the b-th env in order of decreasing mesh work (mw_mesh_order_kernel)
-    const int env = env_order ? env_order[blockIdx.x] : (int)blockIdx.x;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint8_t *s_pack = smem + (size_t)nkeys * 4 + wave * MW_K3_WAVE_LDS;
-    // co-run mode (flag 16): the envs without a mesh in view are drawn at the same time by mw_raster_big_kernel
-    if ((dbg & 16) && __float_as_int(envhdr[(size_t)env * MW_ENVHDR + 3]) == 0) return;
-    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
-    float *s_ment = reinterpret_cast<float *>(smem + (size_t)nkeys * 4 + 16 * MW_K3_WAVE_LDS + 16);
+    extern __shared__ __attribute__((aligned(16))) unsigned char slow_smem[];     // the clipper's work lists: [64][2][MWGL_MAX_CLIP_VERTS] vertices
+    const int env = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = slow_count[env];
+    uint32_t *head = heads_all + (size_t)env * W * H;
+    float4 *frags = frags_all + (size_t)env * MW_SLOW_FRAGS;
+    uint16_t *frag_pix = pix_all + (size_t)env * MW_SLOW_FRAGS;      // the fragments' pixels, for the next frame's clean-up
     {
-        uint4 *k4 = reinterpret_cast<uint4 *>(keys);
-        for (int i = tid; i < nkeys / 4; i += 1024) k4[i] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
-        if (tid == 0) *reinterpret_cast<int *>(smem + (size_t)nkeys * 4 + 16 * MW_K3_WAVE_LDS) = 0;       // the tile counter of phase 2
-        if (tid < MW_MAX_MESH_ENTS * MW_HDR_MESH_STRIDE) s_ment[tid] = hdr[MW_HDR_MESH + tid];
+        // the previous frame's chains: every pixel that got a fragment then is emptied now
+        const int prev = min(frag_count[env], MW_SLOW_FRAGS);
+        for (int k = tid; k < prev; k += 64) head[frag_pix[k]] = 0u;
+        __syncthreads();
+        if (tid == 0) frag_count[env] = 0;
+        __threadfence();
+        __syncthreads();
     }
-    __syncthreads();
-
-    TileCtx cx;
-    cx.s_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
-    cx.s_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
-    cx.rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
-    cx.s_pack = s_pack;
-    cx.hdr = hdr;
-    cx.ment = s_ment;
-    cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
-    cx.obs = obs; cx.depth = depth;
-    cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3);
-    cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
-    cx.te.td = cx.te.tx;
-    cx.te.texd = texd;
-    cx.te.flat = HOT ? 0 : (dbg & 1);
-    cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
-    cx.env = env; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane; cx.have_pre = 0; cx.order = nullptr;
-    cx.pre_touch = cx.pre_full = cx.pre_clip = cx.pre_edges = 0ull;
-    cx.tprof = nullptr;
-
-    // ---- phase 1: every mesh triangle -> LDS keys, one triangle per lane -------------------
+    if (n == 0) return;
+    if (dbg & 1) { if (tid == 0) slow_count[env] = 0; return; }
+    if (n > MW_SLOW_TRIS && tid == 0) atomicOr(status, MW_ST_VIS_OVERFLOW);
+    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
+    uint32_t *keys = keys_all + (size_t)env * W * H * 8;
+    TexEnv te;
+    te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
+    te.td = te.tx;
+    te.texd = reinterpret_cast<const MwTexDesc *>(texels);
+    te.flat = 0;
     mwgl::Frame f;
     frame_lite(hdr, W, H, f);
-    const int n_mesh = (!HOT && (dbg & 8)) ? 0 : __float_as_int(hdr[3]);
-    for (int j = 0; j < n_mesh; ++j) {
-        const MeshEnt e = load_ment(cx.ment, j);
-        int t = tid;
-        int tri = t < e.ntris ? tri_sorted(mesh_pos, e, t) : 0;
-        int tri_n = t + 1024 < e.ntris ? tri_sorted(mesh_pos, e, t + 1024) : 0;
-        float pos[9];
-        tri_load(mesh_pos, e, tri, pos);
-        while (t < e.ntris) {
-            const int tri_nn = t + 2048 < e.ntris ? tri_sorted(mesh_pos, e, t + 2048) : 0;
-            float pos_n[9];
-            tri_load(mesh_pos, e, tri_n, pos_n);
-            raster_tri<8>(f, e, tri, pos, W, H, keys);
-            t += 1024; tri = tri_n; tri_n = tri_nn;
+    const int nn = min(n, MW_SLOW_TRIS);
+    mwgl::Vert *buf0 = reinterpret_cast<mwgl::Vert *>(slow_smem) + (size_t)tid * 2 * MWGL_MAX_CLIP_VERTS, *buf1 = buf0 + MWGL_MAX_CLIP_VERTS;
+    for (int base = 0; base < nn; base += 64) {
+        const int i = base + tid;
+        const bool valid = i < nn;
+        mwgl::Vert *r = buf0;
+        int nv = 0, tex = -1;
+        uint32_t id = 0u;
+        if (valid) {
+            const uint32_t it = slow_tris[(size_t)env * MW_SLOW_TRIS + i];
+            const MeshEnt e = load_ment(hdr + MW_HDR_MESH, (int)(it >> 16));
+            const int tri = (int)(it & 0xFFFFu);
+            id = (uint32_t)(e.start + tri);
+            tex = e.tex;
+            float pos[9];
+            tri_load(mesh_pos, e, tri, pos);
+            const float *nrm = mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = mesh_rgb + (size_t)(e.first + tri) * 9;
+            const float *uv = mesh_uv + (size_t)(e.first + tri) * 6;
+            mwgl::Vert v[3];
+            for (int k = 0; k < 3; ++k) {
+                const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
+                mwgl::transform_vertex(f, e.x, p, v[k]);
+                const float nv3[3] = {nrm[k * 3], nrm[k * 3 + 1], nrm[k * 3 + 2]}, c[3] = {rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2]};
+                mwgl::light_vertex(f, e.x, nv3, c, v[k].col);
+                v[k].st[0] = e.tex >= 0 ? uv[k * 2] : 0.0f;
+                v[k].st[1] = e.tex >= 0 ? uv[k * 2 + 1] : 0.0f;
+            }
+            nv = mwgl::clip_triangle<true>(f, v[0], v[1], v[2], buf0, buf1, &r);
+            if (dbg & 2) nv = 0;
+        }
+        // the pieces (r[q-1], r[q], r[0]), q = 2 .. nv - 1, in fan order
+        for (int q = 2; __any(q < nv); ++q) {
+            SlowPiece p;
+            bool have = false;
+            if (q < nv) {
+                mwgl::TriSetup ts;
+                if (mwgl::setup_triangle(r[q - 1], r[q], r[0], true, tex >= 0, ts)) {
+                    have = true;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) pos[k] = pos_n[k];
+                    for (int k = 0; k < 3; ++k) { p.dcdx[k] = ts.dcdx[k]; p.dcdy[k] = ts.dcdy[k]; p.c[k] = (int)ts.c[k]; }
+                    p.z = ts.z; p.w = ts.w; p.s = ts.s; p.t = ts.t; p.r = ts.col[0]; p.g = ts.col[1]; p.b = ts.col[2];
+                    p.x0 = max(ts.minx >> 8, 0); p.x1 = min(ts.maxx >> 8, W - 1);
+                    p.y0 = max(ts.miny >> 8, 0); p.y1 = min(ts.maxy >> 8, H - 1);
+                    p.id = id; p.tex = tex;
+                    have = p.x0 <= p.x1 && p.y0 <= p.y1;
+                }
+            }
+            if (dbg & 4) have = false;
+            const int npx = have ? (p.x1 - p.x0 + 1) * (p.y1 - p.y0 + 1) : 0;
+            const bool big = npx > 32;
+            if (have && !big) {
+                // coverage of its (at most 32) pixels first, then one list allocation for the piece
+                const int bw = p.x1 - p.x0 + 1;
+                uint32_t cov = 0u;
+                for (int k = 0; k < npx; ++k) cov |= slow_cover(p, p.x0 + k % bw, p.y0 + k / bw, W, H, keys) ? (1u << k) : 0u;
+                if (cov) {
+                    int k0 = atomicAdd(frag_count + env, __popc(cov));
+                    for (uint32_t mm = cov; mm; mm &= mm - 1u, ++k0) {
+                        const int k = __ffs((int)mm) - 1;
+                        slow_frag(p, p.x0 + k % bw, p.y0 + k / bw, W, H, te, k0, frags, frag_pix, head, status);
+                    }
+                }
+            }
+            // a piece that spans many pixels: all 64 lanes of the wavefront, a pixel each
+            uint64_t m = __ballot(big);
+            while (m) {
+                const int src = __ffsll((unsigned long long)m) - 1;
+                m &= m - 1;
+                SlowPiece u;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { u.dcdx[k] = bcast_i(p.dcdx[k], src); u.dcdy[k] = bcast_i(p.dcdy[k], src); u.c[k] = bcast_i(p.c[k], src); }
+                u.z = bcast_p(p.z, src); u.w = bcast_p(p.w, src); u.s = bcast_p(p.s, src); u.t = bcast_p(p.t, src);
+                u.r = bcast_p(p.r, src); u.g = bcast_p(p.g, src); u.b = bcast_p(p.b, src);
+                u.x0 = bcast_i(p.x0, src); u.x1 = bcast_i(p.x1, src); u.y0 = bcast_i(p.y0, src); u.y1 = bcast_i(p.y1, src);
+                u.id = (uint32_t)bcast_i((int)p.id, src); u.tex = bcast_i(p.tex, src);
+                const int bw = u.x1 - u.x0 + 1, tot = bw * (u.y1 - u.y0 + 1);
+                for (int k = lane; k < tot; k += 64) slow_pixel(u, u.x0 + k % bw, u.y0 + k / bw, W, H, keys, te, frag_count + env, frags, frag_pix, head, status);
+            }
         }
     }
     __syncthreads();
-    const unsigned long long t_mesh = prof ? __builtin_readcyclecounter() : 0ull;
-
-    // ---- phase 2: tiles, taken by the 16 wavefronts from a shared counter --------------------------------------
-    int *s_next = reinterpret_cast<int *>(smem + (size_t)nkeys * 4 + 16 * MW_K3_WAVE_LDS);
-    for (;;) {
-        int tile = 0;
-        if (lane == 0) tile = atomicAdd(s_next, 1);
-        tile = __builtin_amdgcn_readfirstlane(tile);
-        if (tile >= n_tiles) break;
-        const int tx = tile % tiles_x, ty = tile / tiles_x;
-        const int px = tx * MW_TILE_W + tile_col(lane), py = ty * MW_TILE_H + tile_row(lane);
-        uint32_t mk[8];
-        const uint4 k0 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8);
-        const uint4 k1 = *reinterpret_cast<const uint4 *>(keys + ((size_t)py * W + px) * 8 + 4);
-        mk[0] = k0.x; mk[1] = k0.y; mk[2] = k0.z; mk[3] = k0.w; mk[4] = k1.x; mk[5] = k1.y; mk[6] = k1.z; mk[7] = k1.w;
-        raster_tile_fmt<true, FMT, false, HOT, 0>(cx, tx, ty, mk);
-    }
-    if (prof) {     // MW_K3_PROF: per-env cycle counts (perf experiments only)
-        __syncthreads();
-        if (tid == 0) {
-            const unsigned long long t_end = __builtin_readcyclecounter();
-            prof[(size_t)env * 4 + 0] = t_mesh - t_start;
-            prof[(size_t)env * 4 + 1] = t_end - t_mesh;
-            prof[(size_t)env * 4 + 2] = (unsigned long long)n_mesh;
-            unsigned long long nt = 0;
-            for (int j = 0; j < n_mesh; ++j) nt += (unsigned long long)__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 2]);
-            prof[(size_t)env * 4 + 3] = nt;
-        }
-    }
+    if (tid == 0) slow_count[env] = 0;         // the next frame's scatter starts a new list
 }
-
-extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_kernel(MW_MESH_ARGS) { mesh_kernel_body<0, 1>(MW_MESH_FWD); }
-extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_depth_kernel(MW_MESH_ARGS) { mesh_kernel_body<0, 2>(MW_MESH_FWD); }
-extern "C" __global__ __launch_bounds__(1024) void mw_raster_mesh_wrap_kernel(MW_MESH_ARGS) { mesh_kernel_body<-1, 0>(MW_MESH_FWD); }
 
 // ======================================================================================
 // Generic-resolution path: render()/vis_fb 800x600 (miniworld.py:518, 1340-1362), the fallback sample counts of
@@ -379,7 +289,7 @@ __device__ inline void view_tile_body(TileCtx &cx, int tiles_x, const uint32_t *
         const uint32_t w = key[s] & 0xFFFFu;
         const bool need = w != last_id && w != MW_SKY_PID;
         if (__any(need)) {
-            const RGB c = shade_by_draw_id_s<S>(cx, need ? w : 0u, px, gy);
+            const RGB c = shade_by_draw_id_s<S, false>(cx, need ? w : 0u, px, gy);
             if (need) { last = c; last_id = w; }
         }
         if (w == MW_SKY_PID) { last = sky; last_id = MW_SKY_PID; }
@@ -429,6 +339,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.te.flat = 0;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
     cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr; cx.tprof = nullptr;
+    cx.planes = nullptr; cx.slow_frags = nullptr; cx.slow_head = nullptr;
     cx.pre_touch = cx.pre_full = cx.pre_clip = cx.pre_edges = 0ull;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
     else if (S == 4) view_tile_body<4>(cx, tiles_x, mesh_keys);
@@ -436,21 +347,3 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     else view_tile_body<8>(cx, tiles_x, mesh_keys);
 }
 
-// Order in which mw_raster_mesh_kernel's blocks take the envs: a counting sort of the envs by mesh triangles in
-// view (the geometry kernel's k3_cost), most first; one workgroup, bins of 2048 triangles.
-extern "C" __global__ __launch_bounds__(1024) void mw_mesh_order_kernel(int N, const int32_t *__restrict__ cost, int32_t *__restrict__ order)
-{
-    constexpr int BINS = 16;
-    __shared__ int hist[BINS], start[BINS];
-    const int tid = threadIdx.x;
-    if (tid < BINS) hist[tid] = 0;
-    __syncthreads();
-    for (int e = tid; e < N; e += 1024) atomicAdd(&hist[(BINS - 1) - min(cost[e] >> 11, BINS - 1)], 1);
-    __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int b = 0; b < BINS; ++b) { start[b] = acc; acc += hist[b]; }
-    }
-    __syncthreads();
-    for (int e = tid; e < N; e += 1024) order[atomicAdd(&start[(BINS - 1) - min(cost[e] >> 11, BINS - 1)], 1)] = e;
-}
