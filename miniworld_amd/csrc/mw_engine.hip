@@ -25,15 +25,8 @@ extern "C" __global__ void mw_step_setup_dense_kernel(MwArgs a, int do_step, int
                                                        float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_step_setup_dense_pcg_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
                                                            float *reward, uint8_t *term, uint8_t *trunc);
-extern "C" __global__ void mw_step_setup_dense_mesh_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
-                                                            float *reward, uint8_t *term, uint8_t *trunc);
-extern "C" __global__ void mw_step_setup_dense_mesh_pcg_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
-                                                                float *reward, uint8_t *term, uint8_t *trunc);
-extern "C" __global__ void mw_step_setup_sort_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
-                                                     float *reward, uint8_t *term, uint8_t *trunc);
-extern "C" __global__ void mw_step_setup_sort_pcg_kernel(MwArgs a, int do_step, int view_flags, const int32_t *actions,
-                                                         float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
+extern "C" __global__ void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
 #define MW_RASTER_DECL(name) \
     extern "C" __global__ void name(int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave, \
                                     const float *rec_raster, const float *rec_shade, const float *rec_cull, const int32_t *nvis, \
@@ -100,7 +93,6 @@ struct mw_engine {
     std::vector<std::vector<float>> mesh_pos, mesh_nrm, mesh_rgb, mesh_uv;   // per mesh id, [ntris][9] ([6] for uv)
     float *d_mesh_pos = nullptr, *d_mesh_nrm = nullptr, *d_mesh_rgb = nullptr, *d_mesh_uv = nullptr;
     bool have_meshes = false;
-    bool mesh_lds_ready = false;
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
     bool visible_attr_set = false;
     hipStream_t side_stream = nullptr;      // co-run of K2 beside the mesh kernel
@@ -114,7 +106,6 @@ struct mw_engine {
     uint32_t *d_slow_head = nullptr;
     float *d_plane_cache = nullptr;     // [N][plane_cap][20] attribute planes of the mesh triangles that win samples (mw_raster_mesh.hip)
     int plane_cap = 0, max_mesh_tris = 0;
-    unsigned long long *d_k3prof = nullptr;   // MW_K3_PROF=<file>: per-env cycle counts of the mesh kernel
     int obs_layout = MW_OBS_HWC_U8;
     size_t view_keys_bytes = 0;
     // scratch for the step outputs when the caller passes none
@@ -173,16 +164,13 @@ int dev_alloc(mw_engine *e, T **out, size_t count, bool zero = true)
     return MW_OK;
 }
 
-// K1 for the engine's random stream (the device code is compiled once per stream, mw_rng.h) and scene size
-// (big scenes also get the depth-sorted visiting order, mw_setup_sort.hip)
+// K1 for the engine's random stream (the device code is compiled once per stream, mw_rng.h)
 auto k1_of(const mw_engine *e) -> decltype(&mw_step_setup_kernel)
 {
-    const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
-    if (e->args.rec_order) return pcg ? mw_step_setup_sort_pcg_kernel : mw_step_setup_sort_kernel;   // big scenes
-    return pcg ? mw_step_setup_pcg_kernel : mw_step_setup_kernel;
+    return e->cfg.rng_mode == MW_RNG_PCG64 ? mw_step_setup_pcg_kernel : mw_step_setup_kernel;
 }
 
-int k1_threads(const mw_engine *e) { return e->args.rec_order ? 256 : 64; }     // MW_K1_WAVES of the variant (mw_setup.hip)
+int k1_threads(const mw_engine *) { return 64; }
 
 // Lanes per env of the dense K1 (mw_setup_dense.hip: one lane per room polygon + six per entity slot), or 0 when the
 // frame has to go through the wave-per-env kernel: big scenes, mesh entities, spare-world mode, other views,
@@ -533,8 +521,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     } else if (const int lanes = k1_dense_lanes(e, 0)) {
         const int epw = 64 / lanes;
         const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
-        auto k1d = e->have_meshes ? (pcg ? mw_step_setup_dense_mesh_pcg_kernel : mw_step_setup_dense_mesh_kernel)
-                                  : (pcg ? mw_step_setup_dense_pcg_kernel : mw_step_setup_dense_kernel);
+        auto k1d = pcg ? mw_step_setup_dense_pcg_kernel : mw_step_setup_dense_kernel;
         // spare mode: blocks appended to the grid regenerate the spare worlds consumed in earlier steps (64 envs each)
         const int refill = (e->spare_mode && do_step) ? (N + 63) / 64 : 0;
         hipLaunchKernelGGL(k1d, dim3((N + epw - 1) / epw + refill), dim3(64), 0, st, a, do_step ? 1 : 0, lanes, d_actions,
@@ -548,7 +535,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
     {
         const int L = geom_lanes(e), epw = 64 / L;
-        hipLaunchKernelGGL(mw_geom_kernel, dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
+        hipLaunchKernelGGL(L == 64 ? mw_geom_big_kernel : mw_geom_kernel, dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
     }
     if (do_step && e->cfg.task == MW_TASK_COLLECT)
         hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_collect_respawn_pcg_kernel : mw_collect_respawn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, a);
@@ -561,11 +548,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         e->side_refill_pending = true;
     }
     bool forked = false;
-    if (e->cfg.msaa != 8) {
+    if (e->cfg.msaa != 8 || a.W > 128 || a.H > 128) {
         // FrameBuffer's fallback sample counts (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES gets 4 or 1
-        // samples): not the hot path — the generic-resolution kernels, exact packed-key resolution, the whole batch
-        // in one grid (blockIdx.y = env)
-        if (e->obs_layout != MW_OBS_HWC_U8) return fail(e, MW_E_INVALID, "wrapper layouts need msaa = 8");
+        // samples) and observations beyond 128 x 128 (the tile kernels' 24-bit edge arithmetic): not the hot path — the
+        // generic-resolution kernels, 64-bit edge values, exact packed-key resolution, the whole batch in one grid
+        // (blockIdx.y = env)
+        if (e->obs_layout != MW_OBS_HWC_U8) return fail(e, MW_E_INVALID, "wrapper layouts need msaa = 8 and observations up to 128 x 128");
         const int S = e->cfg.msaa;
         uint32_t *keys = nullptr;
         if (e->have_meshes) {
@@ -588,7 +576,6 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const bool mesh = e->have_meshes;
         if (mesh) {
             if (a.W > 255 * MW_TILE_W || a.H > 255 * MW_TILE_H) return fail(e, MW_E_CAPACITY, "frame too large for the mesh tile rectangles");
-            if (a.W > 128 || a.H > 128) return fail(e, MW_E_CAPACITY, "mesh entities: obs frames up to 128x128 (32-bit triangle setup), got %dx%d", a.W, a.H);
             // the plane cache: one record per mesh triangle that can be in view (the geometry kernel admits 0xC000 per env);
             // the sample keys of the tiles a mesh can touch: all-ones between frames (K2 clears what it reads)
             const long long want = std::min<long long>(0xC000, (long long)e->cfg.max_ents * e->max_mesh_tris);
@@ -624,8 +611,9 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
         const int groups = (N + 7) / 8;
-        const bool big = e->cfg.max_visible > 64;      // records stay in global memory
-        // small scenes stage up to MW_LDS_RECS records in LDS (a wave whose env holds more reads them in place)
+        // (MW_RASTER_BIG=1: the variant that never stages records in LDS)
+        const bool big = getenv("MW_RASTER_BIG") && atoi(getenv("MW_RASTER_BIG")) != 0;
+        // the env's records are staged in LDS when there are at most MW_LDS_RECS of them (a wave whose env holds more reads them in place): stage up to MW_LDS_RECS records in LDS (a wave whose env holds more reads them in place)
         const int lds_recs = a.max_vis < MW_LDS_RECS ? a.max_vis : MW_LDS_RECS;
         const size_t lds = big ? 192 : (size_t)lds_recs * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
         // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
@@ -776,7 +764,6 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
-    if (getenv("MW_K3_PROF")) ALLOC(e->d_k3prof, 8 * (size_t)N);      // perf experiments only: dumped by mw_destroy
     if (getenv("MW_K1_PROF")) {     // perf experiments only: per-env cycle stamps of K1's phases, dumped by mw_destroy
         ALLOC(a.k1_prof, 8 * (size_t)N);
         if (rc == MW_OK) (void)hipMemset(a.k1_prof, 0, 64 * (size_t)N);
@@ -821,11 +808,6 @@ void mw_destroy(mw_engine *e)
             for (int i = 0; i < e->cfg.num_envs; ++i) { const int v = h[(size_t)e->cfg.num_envs + i]; tot += v; nz += v > 0; mx = std::max<long long>(mx, v); }
             fprintf(stderr, "slow fragments: total %lld, envs with any %lld of %d, max %lld\n", tot, nz, e->cfg.num_envs, mx);
         }
-    }
-    if (e->d_k3prof) {      // dump the last frame's per-env cycle counts: [env][mesh phase, tile phase, meshes, triangles]
-        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 8);
-        if (hipMemcpy(h.data(), e->d_k3prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
-            if (FILE *f = fopen(getenv("MW_K3_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_texels) (void)hipFree(e->d_texels);
@@ -1120,7 +1102,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     b.W = width; b.H = height;
     b.tiles_x = width / MW_TILE_W; b.tiles_y = height / MW_TILE_H; b.n_tiles = b.tiles_x * b.tiles_y;
     b.env_base = env;
-    hipLaunchKernelGGL(mw_geom_kernel, dim3(1), dim3(64), 0, st, b, view_flags, msaa, 64, 1);
+    hipLaunchKernelGGL(mw_geom_big_kernel, dim3(1), dim3(64), 0, st, b, view_flags, msaa, 64, 1);
     uint32_t *keys = nullptr;
     if (e->have_meshes) {
         const size_t need = (size_t)width * height * msaa * 4;
@@ -1175,7 +1157,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     // K1 in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
     {
         const int L = geom_lanes(e), epw = 64 / L;
-        hipLaunchKernelGGL(mw_geom_kernel, dim3((count + epw - 1) / epw), dim3(64), 0, st, b, 4, e->cfg.msaa, L, count);
+        hipLaunchKernelGGL(L == 64 ? mw_geom_big_kernel : mw_geom_kernel, dim3((count + epw - 1) / epw), dim3(64), 0, st, b, 4, e->cfg.msaa, L, count);
     }
     if (!e->visible_attr_set) {
         HIP_TRY(e, hipFuncSetAttribute((const void *)mw_visible_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -50,15 +50,69 @@ __device__ inline bool tri_front(const float wa[4], const float wb[4], const flo
     return dx01 * dy20 - dx20 * dy01 < 0;
 }
 
+// ---------------------------------------------------------------- occlusion culling (big scenes)
+// A Maze view holds ~95 front-facing polygons inside the frustum and ~13 that own a sample: everything else lies behind
+// walls.  With an unpitched camera a wall that spans the whole height of the world (the slab [lo, hi] of all room
+// polygons, the eye inside it) hides every room polygon behind it in the screen columns it covers: a ray to a point
+// of the slab farther away crosses the wall's plane inside the slab.  So: every such wall in front of the eye marks the
+// column bins it covers completely with its farthest depth there (the nearest wall wins the bin), and a polygon
+// whose columns are all marked with depths in front of its nearest vertex is dropped before it costs a record and the
+// raster kernel's visits.  Frames do not change: a dropped polygon owns no sample —
+//   * its fragments are no nearer than its nearest vertex up to the rounding of the float32 depth plane (1e-6 of the depth
+//     range), and "in front" demands more than three steps of the 16-bit depth buffer: 1/z_wall - 1/z_poly > 1.2e-3, one
+//     step of D16 over [0.04, 100] being 3.8e-4 in 1/z (GL_LESS ties go to the polygon drawn first);
+//   * all margins are on the keeping side: walls shrink by 0.05 px and are cut at z = 0.1 (the near plane is at 0.04),
+//     polygons grow by 0.1 px, polygons with a vertex nearer than 0.1 are kept untested.
+// tests/test_gpu_env_api.py::test_occlusion_culling_never_changes_a_frame compares MW_OCCLUSION=0 / 1 bit for bit.
+#define MW_OCC_BINS 256
+#define MW_OCC_CAP 192
+
+// occ_z[0 .. BINS): the bins; occ_z[BINS .. BINS + BINS / 16): the largest value of every group of 16 bins
+__device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float bins_per_px)
+{
+    float zq = 1e30f, xmn = 1e30f, xmx = -1e30f;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ok &= v[k].clip[3] >= 0.1f;
+        xmn = fminf(xmn, v[k].win[0]); xmx = fmaxf(xmx, v[k].win[0]); zq = fminf(zq, v[k].clip[3]);
+    }
+    if (!ok) return false;
+    const float fb0 = floorf(fmaxf(xmn - 0.1f, 0.0f) * bins_per_px), fb1 = floorf(fmaxf(xmx + 0.1f, 0.0f) * bins_per_px);
+    const int b0 = (int)fminf(fb0, (float)(MW_OCC_BINS - 1)), b1 = (int)fminf(fb1, (float)(MW_OCC_BINS - 1));
+    const float thr = zq * __builtin_amdgcn_rcpf(fmaf(1.2e-3f, zq, 1.0f)) * 0.9999f;
+    // every bin of b0 .. b1 in front of thr: whole groups through their maxima
+    const int g0 = (b0 + 15) >> 4, g1 = (b1 + 1) >> 4;
+    if (g0 >= g1) {
+        for (int b = b0; b <= b1; ++b)
+            if (!(occ_z[b] < thr)) return false;
+        return true;
+    }
+    for (int b = b0; b < (g0 << 4); ++b)
+        if (!(occ_z[b] < thr)) return false;
+    for (int g = g0; g < g1; ++g)
+        if (!(occ_z[MW_OCC_BINS + g] < thr)) return false;
+    for (int b = g1 << 4; b <= b1; ++b)
+        if (!(occ_z[b] < thr)) return false;
+    return true;
+}
+
 }  // namespace
 
 // view_flags: bit 0 top view, bit 1 draw the agent marker, bit 2 get_visible_ents' proxy pass (rooms untextured + one
 // 0.2 m box per entity, tagged 0x10000 | slot).  S: samples per pixel of the target (1, 4, 8, 16).  L: lanes per env
 // (8, 16, 32 or 64); n_env: envs a.env_base .. a.env_base + n_env - 1.
-extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env)
+// BIG: one env per wavefront (L = 64) with the sifting and occlusion culling of big scenes — their LDS stays out of the
+// small scenes' kernel, whose workgroups then fit four to a CU.
+template <bool BIG>
+__device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, int n_env)
 {
     __shared__ mwgl::Vert s_clip[kClipSlots][2][MWGL_MAX_CLIP_VERTS];
     __shared__ int s_pos[8][66];
+    __shared__ float s_occ_z[BIG ? MW_OCC_BINS + MW_OCC_BINS / 16 : 1];      // occlusion culling: farthest depth of the nearest wall per column bin, group maxima
+    __shared__ float s_occ_wall[BIG ? MW_OCC_CAP * 5 : 1];
+    __shared__ int s_occ_n;
+    __shared__ uint16_t s_list[BIG ? 4096 : 1];      // big scenes: the polygons that pass the cheap tests (frustum, occlusion), in drawing order
     const int lane = threadIdx.x;
     const int epw = 64 / L, sub = lane & (L - 1), grp = lane / L;
     const int rel = (int)blockIdx.x * epw + grp;
@@ -69,6 +123,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
     // ---- the frame's GL state (every lane of the group evaluates it: same instruction stream)
     mwgl::Frame f;
     const double px = a.ax[env], py = a.ay[env], pz = a.az[env], dir = a.adir[env];
+    float eye_x = 0.0f, eye_y = 0.0f, eye_z = 0.0f;
     {
         double lpos[3], lcol[3], lamb[3];
 #pragma unroll
@@ -106,6 +161,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
             const double at[3] = {eye[0] + cd[0], eye[1] + cd[1], eye[2] + cd[2]};
             const mw::SinCos hf = mw::sincos_det(fov_y / 2 * kPi / 180);
             mwgl::frame_perspective(f, eye, at, hf.c / hf.s, a.W, a.H);
+            eye_x = (float)eye[0]; eye_y = (float)eye[1]; eye_z = (float)eye[2];
         }
         mwgl::frame_finish(f, a.W, a.H, lpos, lcol, lamb);
     }
@@ -217,13 +273,144 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
         }
     };
 
+    // ---- occlusion culling of big scenes (one env per wavefront): the walls that hide what lies behind them
+    bool occ_on = BIG && L == 64 && a.occlusion && !top && f.view.m[4] == 0.0f && f.view.m[6] == 0.0f;      // an unpitched camera
+    const float bins_per_px = (float)MW_OCC_BINS / (float)a.W;
+    if (occ_on) {
+        // the slab: lowest and highest point of the room polygons
+        float lo = 1e30f, hi = -1e30f;
+        for (int i = lane; i < np; i += 64) {
+            const mw_poly *qp = polys + i;
+            const int nv = qp->nv & 0xFF;
+            for (int k = 0; k < nv; ++k) { lo = fminf(lo, qp->v[k][1]); hi = fmaxf(hi, qp->v[k][1]); }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+        if (lane == 0) s_occ_n = 0;
+        __syncthreads();
+        occ_on = eye_y > lo + 1e-3f && eye_y < hi - 1e-3f;
+        if (occ_on) {
+            const float wc = 0.1f;
+            const float *V = f.view.m;          // column major: eye x = V[0] x + V[8] z + V[12], depth = -(V[2] x + V[10] z + V[14])
+            const float p00 = f.proj.m[0], halfw = (float)a.W * 0.5f;
+            const float inv_p00 = 1.0f / p00, inv_hp = 1.0f / (halfw * p00), px_per_bin = 1.0f / bins_per_px;
+            for (int i = lane; i < np; i += 64) {
+                const mw_poly *qp = polys + i;
+                if (qp->nv != 4 && qp->nv != (4 | MW_POLY_QUAD)) continue;      // triangles, and the quads of static entities (flag bits), are no walls
+                float vx[4], vy[4], vz[4];
+                bool ys = true;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    vx[k] = qp->v[k][0]; vy[k] = qp->v[k][1]; vz[k] = qp->v[k][2];
+                    ys &= vy[k] == lo || vy[k] == hi;
+                }
+                // a vertical rectangle from lo to hi: two vertical edges
+                const bool pa = vx[0] == vx[1] && vz[0] == vz[1] && vx[2] == vx[3] && vz[2] == vz[3] && vy[0] != vy[1] && vy[2] != vy[3];
+                const bool pb = vx[1] == vx[2] && vz[1] == vz[2] && vx[3] == vx[0] && vz[3] == vz[0] && vy[1] != vy[2] && vy[3] != vy[0];
+                if (!ys || !(pa || pb)) continue;
+                const float bx = pa ? vx[2] : vx[1], bz = pa ? vz[2] : vz[1];
+                if (bx == vx[0] && bz == vz[0]) continue;
+                // drawn at all?  GL_CCW front faces (miniworld.py:512): the winding normal, s * (tz, 0, -tx) for a vertical
+                // rectangle over the foot line B0 -> B1 = (tx, tz), points at the eye — by a centimetre at least
+                const float tx = bx - vx[0], tz = bz - vz[0];
+                const float sgn = pa ? vy[1] - vy[0] : vy[1] - vy[2];
+                const float side = tz * (eye_x - vx[0]) - tx * (eye_z - vz[0]);
+                const float facing = sgn > 0.0f ? side : -side;
+                if (!(facing > 0.0f && facing * facing > 1e-4f * (tx * tx + tz * tz))) continue;
+                // its foot line in eye space: (x, depth) of the two vertical edges, cut at depth wc
+                float ea = fmaf(V[0], vx[0], fmaf(V[8], vz[0], V[12]));
+                float wa = -fmaf(V[2], vx[0], fmaf(V[10], vz[0], V[14]));
+                float eb = fmaf(V[0], bx, fmaf(V[8], bz, V[12]));
+                float wb = -fmaf(V[2], bx, fmaf(V[10], bz, V[14]));
+                if (!(wa >= wc) && !(wb >= wc)) continue;
+                // (hardware reciprocals: their last-bit error moves a column by 1e-5 px, the margins are 0.05)
+                if (!(wa >= wc)) { const float t = (wc - wa) * __builtin_amdgcn_rcpf(wb - wa); ea = fmaf(t, eb - ea, ea); wa = wc; }
+                else if (!(wb >= wc)) { const float t = (wc - wb) * __builtin_amdgcn_rcpf(wa - wb); eb = fmaf(t, ea - eb, eb); wb = wc; }
+                if (!(fmaxf(wa, wb) < 95.0f)) continue;         // the far plane is at 100
+                const float xa = halfw * fmaf(p00, ea * __builtin_amdgcn_rcpf(wa), 1.0f);
+                const float xb = halfw * fmaf(p00, eb * __builtin_amdgcn_rcpf(wb), 1.0f);
+                const float xl = fminf(xa, xb) + 0.05f, xr = fmaxf(xa, xb) - 0.05f;
+                if (!(xr > 0.0f && xl < (float)a.W && xr - xl >= px_per_bin)) continue;
+                // depth along the wall as a function of the pixel column: A ex + B w = D with ex / w = (x / halfw - 1) / p00
+                float A = wb - wa, B = -(eb - ea), D = A * ea + B * wa;
+                if (D < 0.0f) { A = -A; B = -B; D = -D; }
+                if (!(D > 1e-4f)) continue;
+                const float A2 = A * inv_hp, B2 = B - A * inv_p00;
+                const float dl = fmaf(A2, xl, B2), dr = fmaf(A2, xr, B2);
+                if (!(dl * 100.0f > D && dr * 100.0f > D)) continue;       // depths below 100 at both ends (and positive denominators)
+                const int j = atomicAdd(&s_occ_n, 1);
+                if (j < MW_OCC_CAP) {
+                    float *ow = s_occ_wall + 5 * j;
+                    ow[0] = xl; ow[1] = xr; ow[2] = A2; ow[3] = B2; ow[4] = D;
+                }
+            }
+        }
+        __syncthreads();
+        if (occ_on) {
+            const int n_occ = s_occ_n < MW_OCC_CAP ? s_occ_n : MW_OCC_CAP;
+            for (int b = lane; b < MW_OCC_BINS; b += 64) {
+                const float xa = (float)b / bins_per_px, xb = (float)(b + 1) / bins_per_px;
+                float z = 1e30f;
+                for (int j = 0; j < n_occ; ++j) {
+                    const float *ow = s_occ_wall + 5 * j;
+                    const float far = ow[4] * fmaxf(__builtin_amdgcn_rcpf(fmaf(ow[2], xa, ow[3])), __builtin_amdgcn_rcpf(fmaf(ow[2], xb, ow[3])));
+                    z = (xa >= ow[0] && xb <= ow[1]) ? fminf(z, far) : z;
+                }
+                z *= 1.0001f;
+                s_occ_z[b] = z;
+                // the largest value of every group of 16 bins (= 16 consecutive lanes)
+                float gz = z;
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) gz = fmaxf(gz, __shfl_xor(gz, o));
+                if ((lane & 15) == 0) s_occ_z[MW_OCC_BINS + (b >> 4)] = gz;
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- big scenes: most polygons lie outside the frustum or behind walls — sift them with the cheap tests first, so that
+    // the rounds below (clipping, setup) run over the survivors only
+    int n_polys_drawn = np;
+    const bool sifted = BIG && L == 64 && np > 64 && np <= 4096;
+    if (sifted) {
+        int ns = 0;
+        for (int base = 0; base < np; base += 64) {
+            const int i = base + lane;
+            bool keep = false;
+            if (i < np) {
+                const mw_poly *qp = polys + i;
+                const int nvf = qp->nv, nv = nvf & 0xFF;
+                keep = !(proxy && (nvf & MW_POLY_ENTITY));
+                if (keep && !(nvf & MW_POLY_XF)) {
+                    mwgl::Vert v[4];
+                    uint32_t all = 0x3Fu;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int sk = k < nv ? k : 0;
+                        const float pk[3] = {qp->v[sk][0], qp->v[sk][1], qp->v[sk][2]};
+                        mwgl::transform_vertex(f, cam, pk, v[k]);
+                        all &= v[k].clipmask;
+                    }
+                    keep = all == 0u;       // no frustum plane has every vertex outside
+                    if (keep && occ_on && nv == 4 && occluded(s_occ_z, v, bins_per_px)) keep = false;
+                }
+            }
+            const uint64_t m = __ballot(keep);
+            if (keep) s_list[ns + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)))] = (uint16_t)i;
+            ns += __popcll((unsigned long long)m);
+        }
+        n_polys_drawn = ns;
+        __syncthreads();
+    }
+
     int count = 0;          // the env's list length so far (uniform in the group)
     float stale_n[3] = {0.0f, 1.0f, 0.0f};
     if (np > 0) { stale_n[0] = polys[np - 1].n[0]; stale_n[1] = polys[np - 1].n[1]; stale_n[2] = polys[np - 1].n[2]; }
     if (total_boxes > 0) { stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f; }     // drawBox ends with glNormal3f(0, -1, 0)
     const float white[3] = {1.0f, 1.0f, 1.0f};
     const int marker = (view_flags & 2) ? 1 : 0;
-    const int n_items = np + 6 * total_boxes + marker;
+    const int npd = n_polys_drawn;      // polygons among the items
+    const int n_items = npd + 6 * total_boxes + marker;
     // list position of each box's first record and of the end of the boxes: a mesh's first draw id is the number of
     // records drawn before it plus the mesh triangles drawn before it
     int *pos = s_pos[grp];
@@ -232,15 +419,15 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
     for (int r0 = 0; r0 < n_items; r0 += L) {
         const int item = r0 + sub;
         int box_slot = -1, box_idbase = 0;
-        if (__any(item >= np && item < np + 6 * total_boxes)) find_box(item >= np ? (item - np) / 6 : -1, box_slot, box_idbase);
-        if (!(item >= np && item < np + 6 * total_boxes)) box_slot = -1;
+        if (__any(item >= npd && item < npd + 6 * total_boxes)) find_box(item >= npd ? (item - npd) / 6 : -1, box_slot, box_idbase);
+        if (!(item >= npd && item < npd + 6 * total_boxes)) box_slot = -1;
         mwgl::Vert v[4];
         int nt = 0, tex = -1;
         bool direct = false;        // the triangles of v[]: (0,1,3) (1,2,3), or (0,1,2) (0,2,3) for a direct quad
         uint32_t id_base = 0u, tag = 0u;
         bool is_box = false, clipped_l = false, in_list = false;
-        if (item < np) {
-            const mw_poly *qp = polys + item;
+        if (item < npd) {
+            const mw_poly *qp = polys + (sifted ? (int)s_list[item] : item);
             const int nvf = qp->nv, nv = nvf & 0xFF;
             if (!(proxy && (nvf & MW_POLY_ENTITY))) {       // the queries draw rooms only
                 mwgl::Xform ex;
@@ -264,9 +451,10 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
                     v[k].col[0] = col[0]; v[k].col[1] = col[1]; v[k].col[2] = col[2];
                 }
                 nt = nv == 3 ? 1 : 2;
+                if (occ_on && nv == 4 && !own && occluded(s_occ_z, v, bins_per_px)) nt = 0;      // hidden behind a full-height wall
             }
         } else if (box_slot >= 0) {
-            const int slot = box_slot, fc = (item - np) % 6;
+            const int slot = box_slot, fc = (item - npd) % 6;
             is_box = true;
             id_base = (uint32_t)box_idbase;
             tag = proxy ? (0x10000u | (uint32_t)slot) : 0u;
@@ -338,7 +526,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
             const uint64_t cm = __ballot(clipped_l && is_box);
             bool box_clipped = clipped_l;
             if (is_box) {
-                const int fc = (item - np) % 6;
+                const int fc = (item - npd) % 6;
                 // the faces of this box in this round: lanes lane - fc .. lane - fc + 5 of the same group (a box may straddle two
                 // rounds: then the other faces' flags are recomputed from the box's vertices — all 8 corners appear in any 2 faces,
                 // so a straddling box is handled by testing the corners directly)
@@ -443,7 +631,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
             }
         }
         // list positions the meshes' draw ids need
-        if (is_box && (item - np) % 6 == 0 && (item - np) / 6 < 64) pos[(item - np) / 6] = base;
+        if (is_box && (item - npd) % 6 == 0 && (item - npd) / 6 < 64) pos[(item - npd) / 6] = base;
         if (marker && item == n_items - 1) pos[total_boxes < 64 ? total_boxes : 64] = base;
     }
     __builtin_amdgcn_wave_barrier();
@@ -474,3 +662,6 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int vi
         }
     }
 }
+
+extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false>(a, view_flags, S, L, n_env); }
+extern "C" __global__ __launch_bounds__(64) void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true>(a, view_flags, S, L, n_env); }

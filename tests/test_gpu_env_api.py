@@ -730,12 +730,12 @@ def test_other_observation_sizes_match_oracle(w, h):
 
 
 def test_capacity_overflow_is_reported_not_silent():
-    """More visible primitives than max_visible: the kernels set a status bit, mw_check turns it into an error
-    (nothing is dropped silently); a too small entity table is refused at mw_set_state."""
+    """More triangles in the list than the records max_visible pays for (six per visible primitive): the geometry kernel
+    sets a status bit, mw_check turns it into an error (nothing is dropped silently)."""
     import torch
     from miniworld_amd import engine as eng
     s0, tr, meta, obs = helpers.load_case("maze_s0")          # dozens of polygons in view
-    e = helpers.make_engine_for_scene(s0, 1, max_visible=16)
+    e = helpers.make_engine_for_scene(s0, 1, max_visible=2)
     e.set_state(helpers.scene_state_arrays([s0]))
     rgb = torch.zeros((1, 60, 80, 3), dtype=torch.uint8, device="cuda")
     e.render(rgb, None)
