@@ -45,22 +45,41 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PREWARM_S = 0.5             # untimed steps before the W warm-up steps: clocks and caches of a cold box (reported)
 
 
-def pmc_traffic(kernel, config, n):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*/pmc_hbm_summary[_<config>].json:
-    FETCH_SIZE and WRITE_SIZE collected in separate --pmc passes of this same command, KiB per launch).
-    Only meaningful for the workload the passes were run on; None otherwise."""
+def pmc_profiled(kernel, config, n):
+    """What the committed rocprofv3 PMC passes say about `kernel` (profiles/<round>/pmc_hbm_summary[_<config>].json,
+    pmc_all_summary.json: FETCH_SIZE, WRITE_SIZE and the SQ counters, each collected in its own --pmc pass of this same
+    command, means per launch).  These are PROFILED numbers of the commit recorded in the file, not measurements of this
+    run — counters cannot be read without the profiler attached; only meaningful for the workload the passes were run on.
+    Returns (traffic dict or None, valu dict or None)."""
     if n != CONFIGS[config][2]:
         return None, None
     import glob
     name = "pmc_hbm_summary.json" if config == "hallway" else f"pmc_hbm_summary_{config}.json"
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", name)))
-    if not files:
-        return None, None
-    try:
-        d = json.load(open(files[-1])).get(kernel)
-        return (d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024.0, os.path.relpath(files[-1], ROOT)
-    except Exception:  # noqa: BLE001
-        return None, None
+    traffic = valu = None
+    if files:
+        try:
+            j = json.load(open(files[-1]))
+            d = j.get(kernel)
+            traffic = {"bytes_per_launch": (d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024.0,
+                       "fetch_bytes": d["FETCH_SIZE_KiB_mean"] * 1024.0, "write_bytes": d["WRITE_SIZE_KiB_mean"] * 1024.0,
+                       "source": os.path.relpath(files[-1], ROOT), "commit": (j.get("_meta") or {}).get("commit")}
+        except Exception:  # noqa: BLE001
+            traffic = None
+    name = "pmc_all_summary.json" if config == "hallway" else f"pmc_all_summary_{config}.json"
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", name)))
+    if files:
+        try:
+            j = json.load(open(files[-1]))
+            d = j.get(kernel)
+            tiles = n * 75
+            valu = {"valu_insts_per_tile": d["SQ_INSTS_VALU_mean"] / tiles, "salu_insts_per_tile": d["SQ_INSTS_SALU_mean"] / tiles,
+                    "valu_active_over_wave_cycles": d["SQ_ACTIVE_INST_VALU_mean"] / d["SQ_WAVE_CYCLES_mean"],
+                    "wait_over_wave_cycles": d["SQ_WAIT_ANY_mean"] / d["SQ_WAVE_CYCLES_mean"],
+                    "source": os.path.relpath(files[-1], ROOT), "commit": (j.get("_meta") or {}).get("commit")}
+        except Exception:  # noqa: BLE001
+            valu = None
+    return traffic, valu
 
 
 # ------------------------------------------------------------------ CPU baseline (oracle = checker, timed beside the GPU)
@@ -233,6 +252,9 @@ def main():
                     help="pre-warm with exactly this many steps instead of PREWARM_S seconds (A/B runs: the timed region then "
                          "covers the same episode phases in both)")
     ap.add_argument("--dry", action="store_true", help="CPU dry run of the multi-rank path (gloo, no engine)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still go through torch.distributed (RCCL, world size 1) — barrier, MAX-reduction, object "
+                         "gather and, with --gather-obs, the observation all-gather — so that the multi-rank code path runs on one GPU")
     ap.add_argument("--gather-obs", action="store_true",
                     help="also all-gather every rank's observations onto every rank each step (RCCL over xGMI, overlapped "
                          "with the next step; for a single-process trainer).  Not part of the headline workload")
@@ -261,6 +283,13 @@ def main():
         else:
             torch.cuda.set_device(local)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    elif args.force_dist:
+        import torch.distributed as dist
+        if not args.dry:
+            torch.cuda.set_device(0)
+        local = 0
+        dist.init_process_group("gloo" if args.dry else "nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                                **({} if args.dry else {"device_id": torch.device("cuda", 0)}))
     elif not args.dry:
         torch.cuda.set_device(0)
         local = 0
@@ -344,7 +373,7 @@ def main():
             sys.exit(f"bench.py: {len(per_rank)} rank(s) reported, {args.gpus} asked")
         steps_per_s = world * n * args.steps / elapsed_max
         slow = max(per_rank, key=lambda r: r["kernel_ms"])          # the roofline entry is the slowest rank's
-        traffic, traffic_src = pmc_traffic(dominant, args.config, n)
+        traffic, valu = pmc_profiled(dominant, args.config, n)
         out = {
             "metric": "env-steps/s (batched, 80x60 RGB)",
             "value": steps_per_s,
@@ -361,7 +390,7 @@ def main():
             "config": {"workload": f"{env_id}, {n} batched envs per GPU, 80x60 RGB{'-D' if want_depth else ''}, 8x MSAA, "
                                    f"random actions, {'domain_rand, ' if dr else ''}auto-reset",
                        "envs_per_gpu": n, "parallelism": f"env-shard x{world}",
-                       "obs_allgather": gath is not None},
+                       "obs_allgather": gath is not None, "torch_distributed": dist is not None},
             "samples_per_s": steps_per_s * 80 * 60 * 8,
             "prewarm_s": prewarm_s,
             "parity_checked": sum(r["parity_checked"] for r in per_rank),
@@ -372,16 +401,18 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": slow["frac"],
-                "traffic": traffic,
-                "traffic_source": traffic_src,
+                "traffic": traffic["bytes_per_launch"] if traffic else None,
+                "traffic_profiled": traffic,
+                "valu_profiled": valu,
                 "algorithmic_bytes_per_launch": algo_bytes * n,
                 "kernel_ms": slow["kernel_ms"],
                 "setup_kernel_ms": slow["setup_kernel_ms"],
                 "launches_timed": slow["launches_timed"],
                 "per_rank": [{k: r[k] for k in ("rank", "kernel_ms", "setup_kernel_ms", "achieved", "frac", "elapsed_s")}
                              for r in sorted(per_rank, key=lambda r: r["rank"])],
-                "note": "per GPU; path is raster/texture VALU bound, not HBM bound (SURVEY.md section 8d); traffic = PMC "
-                        "FETCH_SIZE + WRITE_SIZE per launch, bytes",
+                "note": "per GPU; the path is VALU bound (coverage, depth, texture filtering, resolve), not HBM bound (SURVEY.md "
+                        "section 8d): see valu_profiled.  traffic = traffic_profiled.bytes_per_launch = PMC FETCH_SIZE + WRITE_SIZE per "
+                        "launch from the committed profile of the named commit, not a counter read during this run",
             },
         }
         if world == 1 and not args.no_cpu_baseline and not args.dry:

@@ -65,11 +65,17 @@ class ObsAllGather:
         self.done = [torch.cuda.Event() for _ in range(2)] if self.cuda else None
         self.k = 0
         self._pending = None
+        self._used = [False, False]
 
     def gather(self, obs):
         torch = self.torch
         k = self.k
         self.k ^= 1
+        if self.cuda and self._used[k]:
+            # buffer k's previous collective (two gathers ago, on the private stream) must be through before its staging
+            # copy is overwritten
+            torch.cuda.current_stream(obs.device).wait_event(self.done[k])
+        self._used[k] = True
         self.stage[k].copy_(obs, non_blocking=True)
         if self.cuda:
             self.stream.wait_stream(torch.cuda.current_stream(obs.device))

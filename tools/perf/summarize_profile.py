@@ -37,11 +37,15 @@ for cfg in ("hallway", "oneroom_rgbd", "maze", "pickup_dr"):
             if c in ("FETCH_SIZE", "WRITE_SIZE"):
                 hbm[k][key + "_mean"] = sum(v) / len(v)
                 hbm[k][c + "_n"] = len(v)
-    if cfg == "hallway":
-        json.dump(allc, open(os.path.join(dst, "pmc_all_summary.json"), "w"), indent=1)
+    import subprocess
+    meta = {"commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=root, capture_output=True, text=True).stdout.strip(),
+            "command": f"rocprofv3 --pmc <one counter group per pass> --kernel-trace -- python bench.py --config {cfg} --steps 20 --warmup 5 --no-cpu-baseline --no-parity-check"}
+    allc["_meta"] = meta; hbm["_meta"] = meta
+    if any(len(v) > 2 for k, v in allc.items() if k != "_meta"):
+        json.dump(allc, open(os.path.join(dst, f"pmc_all_summary{suffix}.json"), "w"), indent=1)
     json.dump(hbm, open(os.path.join(dst, f"pmc_hbm_summary{suffix}.json"), "w"), indent=1)
     line = open(src + ".bench.json").read().strip().splitlines()[-1]
     open(os.path.join(dst, f"bench_line{suffix}.json"), "w").write(line + "\n")
     print("==", cfg)
     print(open(os.path.join(dst, f"kernel_stats{suffix}.csv")).read()[:420])
-    print(json.dumps({k: {kk: round(vv) for kk, vv in v.items() if kk.endswith("_mean")} for k, v in hbm.items()}))
+    print(json.dumps({k: {kk: round(vv) for kk, vv in v.items() if kk.endswith("_mean")} for k, v in hbm.items() if k != "_meta"}))
