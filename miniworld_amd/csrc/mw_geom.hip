@@ -167,6 +167,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     }
     mwgl::Xform cam;
     mwgl::make_xform(f, f.view, f.view_flags, cam);
+    if (view_flags & 0x100) { if (sub == 0 && live) a.nvis[env] = (int)cam.mvp.m[0]; return; }
 
     const mw_poly *polys = a.polys + (size_t)set * a.max_polys;
     const int np = a.npolys[set];
@@ -403,6 +404,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         __syncthreads();
     }
 
+    if (view_flags & 0x200) { if (sub == 0 && live) a.nvis[env] = total_boxes; return; }
     int count = 0;          // the env's list length so far (uniform in the group)
     float stale_n[3] = {0.0f, 1.0f, 0.0f};
     if (np > 0) { stale_n[0] = polys[np - 1].n[0]; stale_n[1] = polys[np - 1].n[1]; stale_n[2] = polys[np - 1].n[2]; }
@@ -600,6 +602,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
                 pend = rest;
             }
         }
+        if (view_flags & 0x400) { if (sub == 0 && live) a.nvis[env] = cnt[0] + cnt[1]; return; }
         // ---- list positions
         int total;
         const int base = count + group_excl_scan(cnt[0] + cnt[1], sub, L, total);

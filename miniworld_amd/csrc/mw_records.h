@@ -53,8 +53,18 @@ __device__ inline void write_null(const MwArgs &a, int env, int idx)
     rr[3] = make_float4(0.0f, big, big, big);
 }
 
+// the pattern as compile-time constants (the record writer's thresholds fold to multiply-adds)
+template <int S> struct Pat;
+template <> struct Pat<1> { static constexpr int x[1] = {8}, y[1] = {8}; };
+template <> struct Pat<4> { static constexpr int x[4] = {6, 14, 2, 10}, y[4] = {2, 6, 10, 14}; };
+template <> struct Pat<8> { static constexpr int x[8] = {9, 7, 13, 5, 3, 1, 11, 15}, y[8] = {5, 11, 9, 3, 13, 7, 15, 1}; };
+template <> struct Pat<16> {
+    static constexpr int x[16] = {9, 7, 5, 12, 3, 10, 13, 11, 6, 8, 4, 2, 0, 15, 14, 1}, y[16] = {9, 5, 10, 7, 6, 13, 11, 3, 14, 1, 2, 12, 8, 4, 15, 0};
+};
+
 // records of one triangle.  S: samples per pixel; draw_id: position in the frame's drawing order
-__device__ inline void write_tri(const MwArgs &a, int env, int idx, uint32_t draw_id, const mwgl::TriSetup &t, int tex, int S)
+template <int S>
+__device__ inline void write_tri_s(const MwArgs &a, int env, int idx, uint32_t draw_id, const mwgl::TriSetup &t, int tex)
 {
     float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
     float4 *sr = reinterpret_cast<float4 *>(a.rec_shade + ((size_t)env * a.max_vis + idx) * MW_SHADE_REC);
@@ -68,15 +78,16 @@ __device__ inline void write_tri(const MwArgs &a, int env, int idx, uint32_t dra
         int thr[16];
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
-            int sx = 0, sy = 0;
-            if (s < S) sample_offset(S, s, sx, sy);
+            // (a single-sampled buffer's snapped coordinates are relative to pixel centres: offset 0)
+            const int sx = S == 1 ? 0 : Pat<S>::x[s < S ? s : 0] * 16, sy = S == 1 ? 0 : Pat<S>::y[s < S ? s : 0] * 16;
             const int v = t.dcdx[k] * sx - t.dcdy[k] * sy;
             thr[s] = s < S ? v : 0x7fffffff;
             if (s < S) { mn = v < mn ? v : mn; mx = v > mx ? v : mx; }
         }
         tmin[k] = mn; tmax[k] = mx;
+        // (the readers of an S-sample frame look at the first S thresholds only)
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < (S + 3) / 4; ++q)
             rr[4 + 4 * k + q] = make_float4(__int_as_float(thr[4 * q]), __int_as_float(thr[4 * q + 1]), __int_as_float(thr[4 * q + 2]),
                                             __int_as_float(thr[4 * q + 3]));
     }
@@ -117,6 +128,14 @@ __device__ inline void write_tri(const MwArgs &a, int env, int idx, uint32_t dra
     sr[5] = make_float4(t.col[2].a0, t.col[2].dadx, t.col[2].dady, 0.0f);
     sr[6] = make_float4(t.z.a0, t.z.dadx, t.z.dady, 0.0f);
     sr[7] = make_float4(__int_as_float(chi[0]), __int_as_float(chi[1]), __int_as_float(chi[2]), 0.0f);
+}
+
+__device__ inline void write_tri(const MwArgs &a, int env, int idx, uint32_t draw_id, const mwgl::TriSetup &t, int tex, int S)
+{
+    if (S == 8) write_tri_s<8>(a, env, idx, draw_id, t, tex);
+    else if (S == 4) write_tri_s<4>(a, env, idx, draw_id, t, tex);
+    else if (S == 1) write_tri_s<1>(a, env, idx, draw_id, t, tex);
+    else write_tri_s<16>(a, env, idx, draw_id, t, tex);
 }
 
 }  // namespace mwrec

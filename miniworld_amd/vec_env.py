@@ -1,15 +1,15 @@
 """MiniWorldVecEnv — N environments stepped and rendered in lockstep on one MI355X.
 
 This is the performance path: world state lives on the device as Structure-of-Arrays, one
-``step()`` is two kernel launches (step+setup, raster) that write the ``uint8[N,60,80,3]``
-observation tensor (and optionally ``float32[N,60,80,1]`` depth) straight into torch memory.
+``step()`` is three kernel launches (step, geometry, raster; two more with mesh entities) that write the
+``uint8[N,60,80,3]`` observation tensor (and optionally ``float32[N,60,80,1]`` depth) straight into torch memory.
 Episodes auto-reset on the device (same-step semantics: the observation returned together
 with ``terminated|truncated`` is the first one of the next episode; the reference leaves the
 reset to the caller, scripts/benchmark.py:36-37).
 
-Hallway, OneRoom*, Maze* and PickupObjects (the BASELINE configs) are generated and auto-reset on the device, on
-the reference's own numpy PCG64 stream.  The other env families are generated on the host with the
-reference-compatible world generator and injected (`_host_generate`); their auto-reset is host-driven.
+All 23 env ids are generated, ruled and auto-reset on the device, on the reference's own numpy PCG64 stream: Hallway,
+OneRoom*, Maze* and PickupObjects through their own generators, the fixed-floorplan families through placement programs
+(`genprog.py`).  `host_generate()` (the host world generator + `mw_set_state`) remains as an injection API.
 """
 from __future__ import annotations
 
