@@ -44,8 +44,8 @@ MW_RASTER_DECL(mw_raster_mesh_kernel);
 MW_RASTER_DECL(mw_raster_mesh_depth_kernel);
 MW_RASTER_DECL(mw_raster_mesh_wrap_kernel);
 MW_RASTER_DECL(mw_raster_big_mesh_wrap_kernel);
-extern "C" __global__ void mw_mesh_scatter_kernel(int W, int H, const float *envhdr, const float *mesh_pos, const float *mesh_nrm, const float *mesh_rgb,
-                                                  const float *mesh_uv, uint32_t *keys, float *plane_cache, int plane_cap, int32_t *slow_count,
+extern "C" __global__ void mw_mesh_scatter_kernel(int W, int H, const float *envhdr, const float *mesh_stream, const float *mesh_attr,
+                                                  uint32_t *keys, float *plane_cache, int plane_cap, int32_t *slow_count,
                                                   uint32_t *slow_tris);
 extern "C" __global__ void mw_mesh_slow_kernel(int W, int H, const float *envhdr, const float *mesh_pos, const float *mesh_nrm, const float *mesh_rgb,
                                                const float *mesh_uv, const uint32_t *texels, int texel_bytes, uint32_t *keys, int32_t *slow_count,
@@ -92,10 +92,13 @@ struct mw_engine {
     std::vector<MwMeshDesc> mesh_desc;
     std::vector<std::vector<float>> mesh_pos, mesh_nrm, mesh_rgb, mesh_uv;   // per mesh id, [ntris][9] ([6] for uv)
     float *d_mesh_pos = nullptr, *d_mesh_nrm = nullptr, *d_mesh_rgb = nullptr, *d_mesh_uv = nullptr;
+    float *d_mesh_stream = nullptr, *d_mesh_attr = nullptr;     // the scatter kernel's triangle streams (rasterisation order): positions, vertex attributes
     bool have_meshes = false;
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
     bool visible_attr_set = false;
-    hipStream_t side_stream = nullptr;      // co-run of K2 beside the mesh kernel
+    hipStream_t side_stream = nullptr;      // low priority: the Maze's spare-world refills beside the steps
+    hipStream_t mesh_stream = nullptr;      // high priority: the mesh kernels beside the first part of K2
+    hipEvent_t ev_mesh_fork = nullptr, ev_mesh_join = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *d_mesh_keys = nullptr;    // [N][H][W][8] sample keys of the mesh scatter kernel (all-ones between frames)
     bool mesh_keys_dirty = true;
@@ -494,6 +497,19 @@ int ensure_side_stream(mw_engine *e)
     return MW_OK;
 }
 
+// the mesh kernels' stream: HIGH priority — they are latency bound and K2's first part, which runs beside them, would
+// otherwise keep their workgroups waiting for wave slots
+int ensure_mesh_stream(mw_engine *e)
+{
+    if (e->mesh_stream) return MW_OK;
+    int prio_least = 0, prio_greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    HIP_TRY(e, hipStreamCreateWithPriority(&e->mesh_stream, hipStreamNonBlocking, prio_greatest));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_mesh_fork, hipEventDisableTiming));
+    HIP_TRY(e, hipEventCreateWithFlags(&e->ev_mesh_join, hipEventDisableTiming));
+    return MW_OK;
+}
+
 int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_actions, uint8_t *d_obs, float *d_depth,
                  float *d_reward, uint8_t *d_term, uint8_t *d_trunc, hipStream_t st)
 {
@@ -602,11 +618,17 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             }
             if (e->mesh_keys_dirty) HIP_TRY(e, hipMemsetAsync(e->d_mesh_keys, 0xFF, key_bytes, st));
             e->mesh_keys_dirty = true;      // until the raster kernel that clears them again has been enqueued
-            hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(8, N), dim3(256), 0, st, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm,
-                               a.mesh_rgb, a.mesh_uv, e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count, e->d_slow_tris);
-            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(N), dim3(64), 64 * 2 * 10 * 56, st, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+            // The mesh kernels run on the side stream, beside the first part of K2 (every tile no mesh can touch); the
+            // tiles inside the meshes' rectangles follow behind both (part 2).
+            if (ensure_mesh_stream(e) != MW_OK) return MW_E_HIP;
+            HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
+            HIP_TRY(e, hipStreamWaitEvent(e->mesh_stream, e->ev_mesh_fork, 0));
+            hipStream_t sb = e->mesh_stream;
+            hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(4, N), dim3(256), 0, sb, a.W, a.H, (const float *)a.envhdr, (const float *)e->d_mesh_stream, (const float *)e->d_mesh_attr,
+                               e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count, e->d_slow_tris);
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(N), dim3(64), 64 * 2 * 10 * 56, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
                                a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, (const uint32_t *)e->d_slow_tris,
-                               e->d_slow_count + N, e->d_slow_frags, e->d_slow_pix, e->d_slow_head, a.status, getenv("MW_SLOW_DBG") ? atoi(getenv("MW_SLOW_DBG")) : 0);
+                               e->d_slow_count + N, e->d_slow_frags, e->d_slow_pix, e->d_slow_head, a.status, 0);
         }
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -625,12 +647,23 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             k2 = big ? mw_raster_big_mesh_wrap_kernel : (d_depth ? mw_raster_mesh_depth_kernel : mw_raster_mesh_kernel);
             if (general && !big) k2 = mw_raster_mesh_wrap_kernel;
         }
-        hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
-                           a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
-                           (const int32_t *)a.nvis,
-                           (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, e->dbg_flags | (e->obs_layout << 8), e->texel_bytes,
-                           (const uint16_t *)a.rec_order, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, e->d_mesh_keys,
-                           (const float *)e->d_plane_cache, e->plane_cap, (const float4 *)e->d_slow_frags, (const uint32_t *)e->d_slow_head);
+        const int flags = e->dbg_flags | (e->obs_layout << 8);
+        auto launch_k2 = [&](int part_flags) {
+            hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+                               a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
+                               (const int32_t *)a.nvis,
+                               (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, flags | part_flags, e->texel_bytes,
+                               (const uint16_t *)a.rec_order, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, e->d_mesh_keys,
+                               (const float *)e->d_plane_cache, e->plane_cap, (const float4 *)e->d_slow_frags, (const uint32_t *)e->d_slow_head);
+        };
+        if (mesh) {
+            launch_k2(1 << 4);
+            HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
+            HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
+            launch_k2(2 << 4);
+        } else {
+            launch_k2(0);
+        }
         if (mesh) e->mesh_keys_dirty = false;
     }
     if (forked) {
@@ -811,11 +844,12 @@ void mw_destroy(mw_engine *e)
     }
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_texels) (void)hipFree(e->d_texels);
-    for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb, e->d_mesh_uv}) if (p) (void)hipFree(p);
+    for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb, e->d_mesh_uv, e->d_mesh_stream, e->d_mesh_attr}) if (p) (void)hipFree(p);
     if (e->d_view_keys) (void)hipFree(e->d_view_keys);
     if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
     if (e->d_mesh_keys) (void)hipFree(e->d_mesh_keys);
     for (void *q : {(void *)e->d_slow_count, (void *)e->d_slow_tris, (void *)e->d_slow_frags, (void *)e->d_slow_pix, (void *)e->d_slow_head}) if (q) (void)hipFree(q);
+    if (e->mesh_stream) { (void)hipStreamDestroy(e->mesh_stream); (void)hipEventDestroy(e->ev_mesh_fork); (void)hipEventDestroy(e->ev_mesh_join); }
     if (e->side_stream) { (void)hipStreamDestroy(e->side_stream); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
     for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     for (auto &ev : e->ev_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
@@ -882,12 +916,14 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
     // repack all pools (uploads are rare)
     size_t total = 0;
     for (int i = 0; i < MW_MAX_MESH; ++i) { e->mesh_desc[i].first = (uint32_t)total; total += e->mesh_desc[i].ntris; }
-    for (float **p : {&e->d_mesh_pos, &e->d_mesh_nrm, &e->d_mesh_rgb, &e->d_mesh_uv})
+    for (float **p : {&e->d_mesh_pos, &e->d_mesh_nrm, &e->d_mesh_rgb, &e->d_mesh_uv, &e->d_mesh_stream, &e->d_mesh_attr})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_pos, total * 4 * MW_MESH_POS_STRIDE));
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_nrm, total * 36));
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_rgb, total * 36));
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_uv, total * 24));
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_stream, total * 48));
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_attr, total * 96));
     for (int i = 0; i < MW_MAX_MESH; ++i) {
         const size_t n = e->mesh_desc[i].ntris, off = (size_t)e->mesh_desc[i].first * 9;
         if (!n) continue;
@@ -895,6 +931,28 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
         HIP_TRY(e, hipMemcpy(e->d_mesh_nrm + off, e->mesh_nrm[i].data(), n * 36, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_rgb + off, e->mesh_rgb[i].data(), n * 36, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_uv + (size_t)e->mesh_desc[i].first * 6, e->mesh_uv[i].data(), n * 24, hipMemcpyHostToDevice));
+        {
+            // the scatter kernel's stream: the triangles in rasterisation order, 48 bytes each (9 coordinates, the triangle's index)
+            std::vector<float> st(n * 12, 0.0f);
+            const auto &P = e->mesh_pos[i];
+            for (size_t k = 0; k < n; ++k) {
+                uint32_t tri;
+                memcpy(&tri, &P[k * MW_MESH_POS_STRIDE + 9], 4);
+                memcpy(&st[k * 12], &P[(size_t)tri * MW_MESH_POS_STRIDE], 36);
+                memcpy(&st[k * 12 + 9], &tri, 4);
+            }
+            HIP_TRY(e, hipMemcpy(e->d_mesh_stream + (size_t)e->mesh_desc[i].first * 12, st.data(), n * 48, hipMemcpyHostToDevice));
+            // ... and their vertex attributes in the same order, 96 bytes each (normals, colours, texture coordinates)
+            std::vector<float> at(n * 24, 0.0f);
+            for (size_t k = 0; k < n; ++k) {
+                uint32_t tri;
+                memcpy(&tri, &P[k * MW_MESH_POS_STRIDE + 9], 4);
+                memcpy(&at[k * 24], &e->mesh_nrm[i][(size_t)tri * 9], 36);
+                memcpy(&at[k * 24 + 9], &e->mesh_rgb[i][(size_t)tri * 9], 36);
+                memcpy(&at[k * 24 + 18], &e->mesh_uv[i][(size_t)tri * 6], 24);
+            }
+            HIP_TRY(e, hipMemcpy(e->d_mesh_attr + (size_t)e->mesh_desc[i].first * 24, at.data(), n * 96, hipMemcpyHostToDevice));
+        }
     }
     HIP_TRY(e, hipMemcpy(e->d_meshdesc, e->mesh_desc.data(), sizeof(MwMeshDesc) * MW_MAX_MESH, hipMemcpyHostToDevice));
     e->args.mesh_pos = e->d_mesh_pos; e->args.mesh_nrm = e->d_mesh_nrm; e->args.mesh_rgb = e->d_mesh_rgb; e->args.mesh_uv = e->d_mesh_uv;

@@ -116,8 +116,8 @@ __device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const
 
 // ---- the obs-sized frame's fast path ----------------------------------------------------------------------------------------
 // For frames up to 128 x 128 the 24.8 coordinates stay below 2^15 and every product of the triangle setup fits 32 bits.
-// A triangle inside the frustum is set up and scattered with 32-bit integers; what crosses a frustum plane takes
-// raster_tri above.  A triangle that wins a sample at the time of writing leaves its attribute planes in the env's plane
+// A triangle inside the frustum is set up and scattered with 32-bit integers; what crosses a frustum plane is listed for
+// mw_mesh_slow_kernel.  A triangle that covers a sample leaves its attribute planes in the env's plane
 // cache (MW_PLANE_REC floats per mesh triangle in view, indexed like the draw ids), so that the tile phase shades a mesh
 // winner with a 80-byte lookup instead of re-deriving its three vertices.
 #define MW_PLANE_REC 20         // (w plane, tex) (r plane, state) (g plane, s.a0) (b plane, s.dadx) (s.dady, t plane)
@@ -154,7 +154,8 @@ __device__ inline bool scatter_tri_narrow(const int dcdx[3], const int dcdy[3], 
                 if ((in >> s) & 1u) {
                     const float xs = (float)px + samp_fx<8>(s), ys = (float)gy + samp_fy<8>(s);
                     const uint32_t key = (mwgl::z_to_unorm16(mwgl::plane_at(zp, xs, ys)) << 16) | id;
-                    won |= atomicMin(kp + s, key) > key;
+                    atomicMin(kp + s, key);
+                    won = true;
                 }
             }
         }
@@ -174,8 +175,7 @@ __device__ inline void store_planes(float *rec, const mwgl::TriSetup &ts, int te
 
 // one mesh triangle of an obs-sized 8-sample frame: keys into LDS, planes of a winner into the cache
 __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys,
-                                      const float *mesh_nrm, const float *mesh_rgb, const float *mesh_uv, float *cache, int j, int32_t *slow_count,
-                                      uint32_t *slow_tris)
+                                      const float4 *attr, float *cache, int j, int32_t *slow_count, uint32_t *slow_tris)
 {
     mwgl::Vert v[3];
 #pragma unroll
@@ -222,16 +222,18 @@ __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, in
     const float ooa = 1.0f / (fdx01 * fdy20 - fdx20 * fdy01);
     mwgl::Plane zp;
     mwgl::plane_coef(zp, w0[2], w1[2], w2[2], fdy20 * ooa, fdy01 * ooa, fdx20 * ooa, fdx01 * ooa, w0[0], w0[1]);
+    // the vertex attributes (normals, colours, texture coordinates: attr[0..5]) are requested before the scatter, whose
+    // atomics they then overlap; a triangle that covers a sample lights its vertices and sets up its attribute planes
+    const float4 a0 = attr[0], a1 = attr[1], a2 = attr[2], a3 = attr[3], a4 = attr[4], a5 = attr[5];
     if (!scatter_tri_narrow(dcdx, dcdy, c, zp, minx, maxx, miny, maxy, W, H, id, keys)) return;
-    // a winner (so far): light its vertices, set up its attribute planes
-    const float *nrm = mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = mesh_rgb + (size_t)(e.first + tri) * 9;
-    const float *uv = mesh_uv + (size_t)(e.first + tri) * 6;
+    const float at[24] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w,
+                          a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z, a4.w, a5.x, a5.y, a5.z, a5.w};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float n[3] = {nrm[k * 3], nrm[k * 3 + 1], nrm[k * 3 + 2]}, cl[3] = {rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2]};
+        const float n[3] = {at[k * 3], at[k * 3 + 1], at[k * 3 + 2]}, cl[3] = {at[9 + k * 3], at[9 + k * 3 + 1], at[9 + k * 3 + 2]};
         mwgl::light_vertex(f, e.x, n, cl, v[k].col);
-        v[k].st[0] = e.tex >= 0 ? uv[k * 2] : 0.0f;
-        v[k].st[1] = e.tex >= 0 ? uv[k * 2 + 1] : 0.0f;
+        v[k].st[0] = e.tex >= 0 ? at[18 + k * 2] : 0.0f;
+        v[k].st[1] = e.tex >= 0 ? at[18 + k * 2 + 1] : 0.0f;
     }
     mwgl::TriSetup ts;
     if (mwgl::setup_triangle(v[0], v[1], v[2], true, e.tex >= 0, ts)) store_planes(rec, ts, e.tex, 1);
@@ -288,7 +290,7 @@ __device__ __attribute__((noinline)) RGB shade_mesh_tri(const TileCtx &cx, const
 
 // draw id -> fragment colour: ids inside a mesh entity's range are triangles, the others index the record list once the
 // mesh triangles drawn before them are subtracted
-template <int S, bool CACHED>
+template <int S>
 __device__ inline RGB shade_by_draw_id_s(const TileCtx &cx, uint32_t id, int px, int gy)
 {
     const int n_mesh = __float_as_int(cx.hdr[3]);
@@ -299,44 +301,43 @@ __device__ inline RGB shade_by_draw_id_s(const TileCtx &cx, uint32_t id, int px,
         if ((int)id >= start + nt) {
             vis -= nt;
         } else if ((int)id >= start) {
-            if (CACHED) {
-                // the plane cache of the obs path (raster_tri_obs)
-                const float4 *q = reinterpret_cast<const float4 *>(cx.planes + ((size_t)__float_as_int(cx.ment[MW_HDR_MESH_STRIDE * j + 25]) + ((int)id - start)) * MW_PLANE_REC);
-                const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-                const int tex = cx.te.flat ? -1 : __float_as_int(q0.w);
-                if (__float_as_int(q1.w) == MW_PLANE_SLOW) {
-                    // a triangle that crosses a frustum plane: its fragments were shaded by mw_mesh_slow_kernel
-                    // (the pixel's chain, newest first: the first one appended for this id — the first piece of the fan — counts)
-                    RGB c = {0.0f, 0.0f, 0.0f};
-                    uint32_t k = cx.slow_head[(cx.H - 1 - gy) * cx.W + px];
-                    for (int guard = 0; k != 0u && k <= MW_SLOW_FRAGS && guard < MW_SLOW_FRAGS; ++guard) {
-                        const float4 fr = cx.slow_frags[k - 1u];
-                        const uint32_t w = __float_as_uint(fr.x);
-                        if ((w >> 16) == id) c = RGB{fr.y, fr.z, fr.w};
-                        k = w & 0xFFFFu;
-                    }
-                    return c;
-                }
-                const mwgl::Plane wp = {q0.x, q0.y, q0.z}, pr = {q1.x, q1.y, q1.z}, pg = {q2.x, q2.y, q2.z}, pb = {q3.x, q3.y, q3.z};
-                if (tex < 0) {      // an untextured mesh (the common case): three planes over 1 / w
-                    const float x = (float)px + 0.5f, y = (float)gy + 0.5f;
-                    const float oow = rcp_safe(mwgl::plane_at(wp, x, y));
-                    return RGB{mwgl::plane_at(pr, x, y) * oow, mwgl::plane_at(pg, x, y) * oow, mwgl::plane_at(pb, x, y) * oow};
-                }
-                const float4 q4 = q[4];
-                const mwgl::Plane sp = {q2.w, q3.w, q4.x}, tp = {q4.y, q4.z, q4.w};
-                return shade_planes(wp, sp, tp, pr, pg, pb, tex, cx.te, px, gy, 0.5f);
-            } else {
-                const MeshEnt e = load_ment(cx.ment, j);
-                return shade_mesh_tri<S>(cx, e, (int)id - start, px, gy);
-            }
+            const MeshEnt e = load_ment(cx.ment, j);
+            return shade_mesh_tri<S>(cx, e, (int)id - start, px, gy);
         }
     }
     return shade_frag(cx.s_shade + vis * (MW_SHADE_REC / 4), cx.te, px, gy, S > 1 ? 0.5f : 0.0f);
 }
 
-// the tile kernels (obs path)
-__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, int px, int gy) { return shade_by_draw_id_s<8, true>(cx, id, px, gy); }
+// the tile kernels (obs path): mesh triangle `id` of table entry mj from the plane cache (raster_tri_obs)
+__device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, int px, int gy)
+{
+    const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 1]);
+    const float4 *q = reinterpret_cast<const float4 *>(cx.planes + ((size_t)__float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 25]) + ((int)id - start)) * MW_PLANE_REC);
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const int tex = cx.te.flat ? -1 : __float_as_int(q0.w);
+    if (__float_as_int(q1.w) == MW_PLANE_SLOW) {
+        // a triangle that crosses a frustum plane: its fragments were shaded by mw_mesh_slow_kernel
+        // (the pixel's chain, newest first: the first one appended for this id — the first piece of the fan — counts)
+        RGB c = {0.0f, 0.0f, 0.0f};
+        uint32_t k = cx.slow_head[(cx.H - 1 - gy) * cx.W + px];
+        for (int guard = 0; k != 0u && k <= MW_SLOW_FRAGS && guard < MW_SLOW_FRAGS; ++guard) {
+            const float4 fr = cx.slow_frags[k - 1u];
+            const uint32_t w = __float_as_uint(fr.x);
+            if ((w >> 16) == id) c = RGB{fr.y, fr.z, fr.w};
+            k = w & 0xFFFFu;
+        }
+        return c;
+    }
+    const mwgl::Plane wp = {q0.x, q0.y, q0.z}, pr = {q1.x, q1.y, q1.z}, pg = {q2.x, q2.y, q2.z}, pb = {q3.x, q3.y, q3.z};
+    if (tex < 0) {      // an untextured mesh (the common case): three planes over 1 / w
+        const float x = (float)px + 0.5f, y = (float)gy + 0.5f;
+        const float oow = rcp_safe(mwgl::plane_at(wp, x, y));
+        return RGB{mwgl::plane_at(pr, x, y) * oow, mwgl::plane_at(pg, x, y) * oow, mwgl::plane_at(pb, x, y) * oow};
+    }
+    const float4 q4 = q[4];
+    const mwgl::Plane sp = {q2.w, q3.w, q4.x}, tp = {q4.y, q4.z, q4.w};
+    return shade_planes(wp, sp, tp, pr, pg, pb, tex, cx.te, px, gy, 0.5f);
+}
 
 // a mesh tile's sample keys: read, and left cleared for the next frame's scatter
 __device__ inline void take_mesh_keys(uint32_t *env_keys, int W, int tx, int ty, int lane, uint32_t (&mk)[8])

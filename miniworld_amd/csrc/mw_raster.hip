@@ -51,6 +51,15 @@ __device__ inline void raster_kernel_body(
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     const bool mesh_env = MESHAWARE && __float_as_int(hdr[3]) != 0;
     uint32_t *env_keys = MESHAWARE ? mesh_keys + (size_t)env * W * H * 8 : nullptr;
+    // mesh-aware launches come in two parts (launch flags bits 4-5): 1 = every tile but those a mesh can touch — they need
+    // nothing of the mesh kernels and run beside them —, 2 = those tiles only, behind the mesh kernels; 0 = all tiles
+    const int part_mode = MESHAWARE ? (dbg >> 4) & 3 : 0;
+    if (part_mode == 2) {
+        if (!mesh_env) return;
+        bool any = false;
+        for (int t = part * tiles_per_wave; t < min(part * tiles_per_wave + tiles_per_wave, n_tiles); ++t) any |= tile_in_mesh_rect(hdr, t % tiles_x, t / tiles_x);
+        if (!any) return;
+    }
     const int nvis = nvis_arr[env];
     const float *__restrict__ rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     const float4 *g_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
@@ -115,7 +124,9 @@ __device__ inline void raster_kernel_body(
             cx.pre_touch = (uint32_t)__builtin_amdgcn_readlane((int)vT, gi);
             cx.pre_full = (uint32_t)__builtin_amdgcn_readlane((int)vF, gi);
             ++gi;
-            if (MESHAWARE && mesh_env && tile_in_mesh_rect(hdr, tx, ty)) {
+            const bool mesh_tile = MESHAWARE && mesh_env && tile_in_mesh_rect(hdr, tx, ty);
+            if (MESHAWARE && part_mode != 0 && mesh_tile != (part_mode == 2)) continue;
+            if (MESHAWARE && mesh_tile) {
                 uint32_t mk[8];
                 take_mesh_keys(env_keys, W, tx, ty, lane, mk);
                 raster_tile_fmt<true, FMT, false, HOT, 1>(cx, tx, ty, mk);
@@ -126,7 +137,9 @@ __device__ inline void raster_kernel_body(
         return;
     }
     for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
-        if (MESHAWARE && mesh_env && tile_in_mesh_rect(hdr, tx, ty)) {
+        const bool mesh_tile = MESHAWARE && mesh_env && tile_in_mesh_rect(hdr, tx, ty);
+        if (MESHAWARE && part_mode != 0 && mesh_tile != (part_mode == 2)) continue;
+        if (MESHAWARE && mesh_tile) {
             uint32_t mk[8];
             take_mesh_keys(env_keys, W, tx, ty, lane, mk);
             raster_tile_fmt<true, FMT, false, HOT, 0>(cx, tx, ty, mk);

@@ -221,7 +221,8 @@ __device__ inline RGB shade_uniform(const float4 *sr, const TexEnv &te, int px, 
 }
 
 struct TileCtx;
-__device__ inline RGB shade_by_draw_id(const TileCtx &cx, uint32_t id, int px, int gy);
+// colour of mesh triangle `id` (entry mj of the env's mesh table) at the lane's pixel: defined by the kernels that see meshes
+__device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, int px, int gy);
 
 // Everything a wavefront needs to produce one 16x4 tile of one env.
 struct TileCtx {
@@ -309,31 +310,31 @@ __device__ inline uint32_t depth16(float a0, float dadx, float dady, int px, int
     return mwgl::z_to_unorm16(fmaf(dady, ys, fmaf(dadx, xs, a0)));
 }
 
-// resolve of one pixel: the samples' colours summed in sample order, times 1/8 (u_blitter's resolve shader).  Up to three
-// claimants (colour c[k], its samples in mask m_k); samples in no mask take c[3] (the clear colour).
-__device__ inline RGB resolve8(const RGB c[4], uint32_t m0, uint32_t m1, uint32_t m2)
-{
-    RGB acc = {0.0f, 0.0f, 0.0f};
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        const bool a = (m0 >> s) & 1u, b = (m1 >> s) & 1u, d = (m2 >> s) & 1u;
-        const float r = a ? c[0].r : (b ? c[1].r : (d ? c[2].r : c[3].r)), g = a ? c[0].g : (b ? c[1].g : (d ? c[2].g : c[3].g)),
-                    bl = a ? c[0].b : (b ? c[1].b : (d ? c[2].b : c[3].b));
-        if (s == 0) { acc.r = r; acc.g = g; acc.b = bl; }
-        else { acc.r = acc.r + r; acc.g = acc.g + g; acc.b = acc.b + bl; }
-    }
-    return acc;
-}
-
-__device__ inline RGB resolve8_one(const RGB c)
-{
-    RGB acc = c;
-#pragma unroll
-    for (int s = 1; s < 8; ++s) { acc.r = acc.r + c.r; acc.g = acc.g + c.g; acc.b = acc.b + c.b; }
-    return acc;
-}
-
 __device__ inline uint32_t to_u8(float acc) { return mwgl::float_to_unorm8(acc * 0.125f); }
+
+// lanes whose bit is set in the wave mask m take a, the others keep b: one v_cndmask with the mask in an SGPR pair
+__device__ inline float sel_mask(uint64_t m, float a, float b)
+{
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+__device__ inline uint32_t sel_mask(uint64_t m, uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
+// the eight samples' colours of one pixel; the resolve is their sum in sample order (u_blitter's resolve shader)
+struct Samples { float r[8], g[8], b[8]; };
+__device__ inline RGB resolve_samples(const Samples &q)
+{
+    RGB acc = {q.r[0], q.g[0], q.b[0]};
+#pragma unroll
+    for (int s = 1; s < 8; ++s) { acc.r = acc.r + q.r[s]; acc.g = acc.g + q.g[s]; acc.b = acc.b + q.b[s]; }
+    return acc;
+}
 
 // Is tile (tx, ty) inside the tile rectangle of one of the env's mesh entities (env header, mw_geom.hip)?  Those tiles
 // belong to the mesh kernel, all others to K2.
@@ -386,14 +387,13 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     const int gy = H - 1 - py;                              // GL row (the frame buffer's y points up, the image's down)
     const int pxlo = tx * MW_TILE_W, pxhi = pxlo + MW_TILE_W - 1;
     const int gyhi = H - 1 - ty * MW_TILE_H, gylo = gyhi - (MW_TILE_H - 1);
-    const float eo = 0.5f;                                  // multisampled target: attributes at x + 0.5
     RGB out = {0.0f, 0.0f, 0.0f};
     uint32_t z16 = 65535u;
 
     // ============ pass A: "painter without overlap" ==================================
     // As long as no sample is claimed by two triangles, depth is irrelevant: every covered sample belongs to its only
-    // claimant.  A pixel keeps at most three claimants (colour + sample mask each: a quad's diagonal crossing the edge
-    // between two surfaces); a fourth one, or any contention, abandons the tile to pass B (exact keys).
+    // claimant, whose colour goes straight into the sample's registers (one v_cndmask per sample and channel, the
+    // coverage ballots as selectors).  Contention abandons the tile to pass B (exact keys).
     bool exact = (dbg & 4) != 0;
     const bool sorted = SORTED && cx.order[0] != 0 && !(dbg & 64);
     if (SORTED && sorted) exact = true;
@@ -403,12 +403,12 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         for (int s = 0; s < 8; ++s) m |= mesh_key[s] != 0xFFFFFFFFu;
         exact |= __any(m) != 0;
     }
+    Samples smp;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { smp.r[s] = sky.r; smp.g[s] = sky.g; smp.b[s] = sky.b; }
     if (!exact) {
         uint32_t covbits = 0u;
         uint64_t anycov_m = 0ull;
-        RGB col[4] = {sky, sky, sky, sky};
-        uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
-        int nown = 0;
         for (int chunk = 0; chunk < (PRE == 1 ? 1 : ((dbg & 2) ? 0 : nvis)) && !exact; chunk += 64) {
             pmask_t todo, fullm;
             if (have_pre) {
@@ -424,16 +424,15 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 const int bit = ffs_mask(todo) - 1;
                 const int p = chunk + bit;
                 todo &= todo - 1;
-                uint32_t bits;
+                uint64_t in_m[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s) in_m[s] = ~0ull;
                 if ((fullm >> bit) & 1) {
                     if (anycov_m) { exact = true; break; }
-                    bits = 0xFFu;
+                    covbits = 0xFFu;
                     anycov_m = ~0ull;
                 } else {
                     const int *__restrict__ rr = reinterpret_cast<const int *>(rr_env + (size_t)p * MW_RASTER_REC);
-                    uint64_t in_m[8];
-#pragma unroll
-                    for (int s = 0; s < 8; ++s) in_m[s] = ~0ull;
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
                         if (PRE == 1 && !((cx.pre_edges >> (16 * k + (bit & 15))) & 1ull)) continue;   // known from the classification
@@ -446,36 +445,33 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 #pragma unroll
                     for (int s = 0; s < 8; ++s) any_m |= in_m[s];
                     if (!any_m) continue;
-                    bits = 0u;
+                    uint32_t bits = 0u;
 #pragma unroll
                     for (int s = 7; s >= 0; --s)
                         asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(in_m[s]) : "vcc");
                     if (__any((bits & covbits) != 0u)) { exact = true; break; }      // a sample claimed twice
+                    covbits |= bits;
                     anycov_m |= any_m;
                 }
-                if (__any(bits != 0u && nown >= 3)) { exact = true; break; }         // a fourth claimant of a pixel
-                covbits |= bits;
-                if (__any(bits != 0u)) {
-                    const RGB c = shade_uniform(s_shade + p * (MW_SHADE_REC / 4), te, px, gy);
-                    if (bits != 0u) {
-                        if (nown == 0) { col[0] = c; m0 = bits; } else if (nown == 1) { col[1] = c; m1 = bits; } else { col[2] = c; m2 = bits; }
-                        ++nown;
-                        if (has_depth && (bits & 1u)) {
-                            const float4 zp = s_shade[p * (MW_SHADE_REC / 4) + 6];
-                            z16 = depth16(zp.x, zp.y, zp.z, px, gy, 0);
-                        }
-                    }
+                const RGB c = shade_uniform(s_shade + p * (MW_SHADE_REC / 4), te, px, gy);
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    smp.r[s] = sel_mask(in_m[s], c.r, smp.r[s]);
+                    smp.g[s] = sel_mask(in_m[s], c.g, smp.g[s]);
+                    smp.b[s] = sel_mask(in_m[s], c.b, smp.b[s]);
+                }
+                if (has_depth) {
+                    const float4 zp = s_shade[p * (MW_SHADE_REC / 4) + 6];
+                    z16 = sel_mask(in_m[0], depth16(zp.x, zp.y, zp.z, px, gy, 0), z16);
                 }
             }
-        }
-        if (!exact) {
-            if (__all(m0 == 0xFFu)) out = resolve8_one(col[0]);
-            else out = resolve8(col, m0, m1, m2);
         }
     }
 
     // ============ pass B: exact packed-key resolution =================================
     if (exact) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { smp.r[s] = sky.r; smp.g[s] = sky.g; smp.b[s] = sky.b; }
         uint32_t key[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) key[s] = MESH ? mesh_key[s] : 0xFFFFFFFFu;
@@ -534,17 +530,13 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             }
         }
         z16 = key[0] >> 16;
-        // deferred shading: every distinct winner once per pixel (GL multisampling shades a pixel once per triangle), then
-        // the resolve in sample order.  The tile's distinct winners are visited in ascending draw id, each shaded for the
-        // whole wavefront at once (shade_uniform); mesh triangles, which differ from pixel to pixel, per lane.  A pixel
-        // keeps up to three winners (colour + sample mask); a fourth one sends the tile through the per-sample loop below.
+        // deferred shading: every distinct winner once per pixel (GL multisampling shades a pixel once per triangle).  The
+        // tile's distinct winners are visited in ascending draw id, each shaded for the whole wavefront at once
+        // (shade_uniform); mesh triangles, which differ from pixel to pixel, per lane, every lane its own next one.  A
+        // winner's colour goes to the samples it owns.
         uint32_t pid[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) { pid[s] = key[s] & 0xFFFFu; pid[s] = pid[s] == MW_SKY_PID ? 0x10000u : pid[s]; }
-        RGB col[4] = {sky, sky, sky, sky};
-        uint32_t m0 = 0u, m1 = 0u, m2 = 0u;
-        int nown = 0;
-        bool overflow = false;
         for (;;) {
             uint32_t mine = 0x10000u;
 #pragma unroll
@@ -560,52 +552,19 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 1]), nt = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 2]);
                 const bool on = (int)mine < start + nt;      // mine >= id >= start
                 sel = on ? mine : 0x20000u;
-                c = shade_by_draw_id(cx, on ? mine : id, px, gy);
+                c = shade_mesh_winner(cx, mj, on ? mine : id, px, gy);
             } else {
                 c = shade_uniform(s_shade + rec * (MW_SHADE_REC / 4), te, px, gy);
             }
-            uint32_t bits = 0u;
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 const bool eq = pid[s] == sel;
-                bits |= eq ? (1u << s) : 0u;
+                smp.r[s] = eq ? c.r : smp.r[s]; smp.g[s] = eq ? c.g : smp.g[s]; smp.b[s] = eq ? c.b : smp.b[s];
                 pid[s] = eq ? 0x10000u : pid[s];
             }
-            if (bits != 0u) {
-                if (nown == 0) { col[0] = c; m0 = bits; }
-                else if (nown == 1) { col[1] = c; m1 = bits; }
-                else if (nown == 2) { col[2] = c; m2 = bits; }
-                else overflow = true;
-                ++nown;
-            }
-        }
-        if (__any(overflow)) {
-            // four or more surfaces in one pixel: shade per sample (a sample whose winner is the previous sample's reuses
-            // its colour); rare outside the interior of a finely tessellated mesh
-            RGB acc = {0.0f, 0.0f, 0.0f}, last = sky;
-            uint32_t last_id = MW_SKY_PID;
-#pragma unroll 1
-            for (int s = 0; s < 8; ++s) {
-                const uint32_t w = key[0] & 0xFFFFu;
-#pragma unroll
-                for (int i = 0; i < 7; ++i) key[i] = key[i + 1];        // the loop stays rolled: one copy of the shading code
-                const bool need = w != last_id && w != MW_SKY_PID;
-                if (__any(need)) {
-                    RGB cc;
-                    if (MESH) cc = shade_by_draw_id(cx, need ? w : 0u, px, gy);
-                    else cc = shade_frag(s_shade + (need ? w : 0u) * (MW_SHADE_REC / 4), te, px, gy, eo);
-                    if (need) { last = cc; last_id = w; }
-                }
-                if (w == MW_SKY_PID) { last = sky; last_id = MW_SKY_PID; }
-                if (s == 0) acc = last; else { acc.r = acc.r + last.r; acc.g = acc.g + last.g; acc.b = acc.b + last.b; }
-            }
-            out = acc;
-        } else if (__all(m0 == 0xFFu)) {
-            out = resolve8_one(col[0]);
-        } else {
-            out = resolve8(col, m0, m1, m2);
         }
     }
+    out = resolve_samples(smp);
     const uint32_t R = to_u8(out.r), G = to_u8(out.g), B = to_u8(out.b);
 
     // ---- pack.  Output layout (mw_set_obs_layout; the reference's wrappers.py folded into the store):

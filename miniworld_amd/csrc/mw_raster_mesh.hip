@@ -3,12 +3,11 @@
 #include "mw_mesh.h"
 
 // Grid (MW_SCATTER_BLOCKS_X, N): the blocks of row y walk the mesh entities in view of env y, 256 triangles per block and
-// step, one triangle per lane, in the order sorted by face normal (mw_upload_mesh: the 64 triangles of a wavefront face
-// the same way, so back-face culling retires whole waves).  keys: [N][H][W][8] dwords, all 0xFFFFFFFF on entry inside the
+// step, one triangle per lane, read from the mesh's stream in the order sorted by face normal (mw_upload_mesh: the 64
+// triangles of a wavefront face the same way, so back-face culling retires whole waves; 48 contiguous bytes per lane).  keys: [N][H][W][8] dwords, all 0xFFFFFFFF on entry inside the
 // entities' tile rectangles (K2 resets what it reads); planes: [N][plane_cap][MW_PLANE_REC].
 extern "C" __global__ __launch_bounds__(256) void mw_mesh_scatter_kernel(int W, int H, const float *__restrict__ envhdr,
-                                                                        const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
-                                                                        const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv,
+                                                                        const float *__restrict__ mesh_stream, const float *__restrict__ mesh_attr,
                                                                         uint32_t *__restrict__ keys_all, float *__restrict__ plane_cache, int plane_cap,
                                                                         int32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_tris)
 {
@@ -23,10 +22,12 @@ extern "C" __global__ __launch_bounds__(256) void mw_mesh_scatter_kernel(int W, 
         const MeshEnt e = load_ment(hdr + MW_HDR_MESH, j);
         float *cache_e = plane_cache + ((size_t)env * plane_cap + (size_t)__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 25])) * MW_PLANE_REC;
         for (int t = (int)blockIdx.x * 256 + (int)threadIdx.x; t < e.ntris; t += (int)gridDim.x * 256) {
-            const int tri = tri_sorted(mesh_pos, e, t);
-            float pos[9];
-            tri_load(mesh_pos, e, tri, pos);
-            raster_tri_obs(f, e, tri, pos, W, H, keys, mesh_nrm, mesh_rgb, mesh_uv, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS);
+            // record t of the entity's stream: the t-th triangle of the rasterisation order, coalesced
+            const float4 *rec = reinterpret_cast<const float4 *>(mesh_stream) + (size_t)(e.first + t) * 3;
+            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+            const float pos[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+            const int tri = __float_as_int(r2.y);
+            raster_tri_obs(f, e, tri, pos, W, H, keys, reinterpret_cast<const float4 *>(mesh_attr) + (size_t)(e.first + t) * 6, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS);
         }
     }
 }
@@ -289,7 +290,7 @@ __device__ inline void view_tile_body(TileCtx &cx, int tiles_x, const uint32_t *
         const uint32_t w = key[s] & 0xFFFFu;
         const bool need = w != last_id && w != MW_SKY_PID;
         if (__any(need)) {
-            const RGB c = shade_by_draw_id_s<S, false>(cx, need ? w : 0u, px, gy);
+            const RGB c = shade_by_draw_id_s<S>(cx, need ? w : 0u, px, gy);
             if (need) { last = c; last_id = w; }
         }
         if (w == MW_SKY_PID) { last = sky; last_id = MW_SKY_PID; }
