@@ -182,7 +182,7 @@ int k1_threads(const mw_engine *) { return 64; }
 // the agent marker), 8 .. 64
 int geom_lanes(const mw_engine *e)
 {
-    const int items = e->cfg.max_polys + 6 * e->cfg.max_ents + 1;
+    const int items = 2 * (e->cfg.max_polys + 6 * e->cfg.max_ents + 1);      // one triangle per lane
     int L = 8;
     while (L < items && L < 64) L <<= 1;
     return L;
@@ -551,7 +551,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
     {
         const int L = geom_lanes(e), epw = 64 / L;
-        hipLaunchKernelGGL(L == 64 ? mw_geom_big_kernel : mw_geom_kernel, dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags | (getenv("MW_GEOM_DBG") ? atoi(getenv("MW_GEOM_DBG")) : 0), e->cfg.msaa, L, N);
+        hipLaunchKernelGGL(L == 64 ? mw_geom_big_kernel : mw_geom_kernel, dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
     }
     if (do_step && e->cfg.task == MW_TASK_COLLECT)
         hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_collect_respawn_pcg_kernel : mw_collect_respawn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, a);

@@ -15,17 +15,18 @@
 // table), and the entity removals the step left pending (a picked-up object is still drawn in the frame of the step that
 // picked it up: pickupobjects.py:86-88 runs after :717).
 //
-// Lanes: a wavefront serves 64 / L envs, L lanes each (L: the power of two that holds an env's primitives — polygons, six
-// faces per box, the agent marker — or 64, with several rounds).  One GL primitive per lane and round, up to two triangles.
+// Lanes: a wavefront serves 64 / L envs, L lanes each (L: the power of two that holds an env's triangles — two per polygon
+// and box face, the agent marker — or 64, with several rounds).  One triangle per lane and round.
 // A round runs twice over its triangles: pass 1 counts what survives clipping and culling, a segmented scan turns the
 // counts into list positions, pass 2 writes the records.  Unclipped triangles keep their setup in registers between the
 // passes; a triangle that crosses a frustum plane goes through one of kClipSlots work lists in LDS, in both passes.
+#include <cstddef>
 #include "mw_setup_common.h"
 #include "mw_records.h"
 
 namespace {
 
-constexpr int kClipSlots = 32;
+constexpr int kClipSlots = 24;      // work lists of the clipper in LDS: 2 x 10 vertices of 40 bytes each (19 KB)
 
 // exclusive scan inside the env's L-lane group; total: the group's sum
 __device__ inline int group_excl_scan(int v, int sub, int L, int &total)
@@ -37,6 +38,18 @@ __device__ inline int group_excl_scan(int v, int sub, int L, int &total)
     }
     total = __shfl(x, L - 1, L);
     return x - v;
+}
+
+// a work-list vertex with the primitive's flat colour
+__device__ inline mwgl::Vert to_vert(const mwgl::ClipVert &c, const float col[3])
+{
+    mwgl::Vert v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { v.clip[i] = c.clip[i]; v.win[i] = c.win[i]; }
+    v.st[0] = c.st[0]; v.st[1] = c.st[1];
+    v.col[0] = col[0]; v.col[1] = col[1]; v.col[2] = col[2];
+    v.clipmask = 0u;
+    return v;
 }
 
 // does the triangle (window coordinates) leave setup?  (the snapped-area cull of setup_triangle alone)
@@ -107,7 +120,9 @@ __device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float
 template <bool BIG>
 __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, int n_env)
 {
-    __shared__ mwgl::Vert s_clip[kClipSlots][2][MWGL_MAX_CLIP_VERTS];
+    // (201 dwords per slot: consecutive slots start in different LDS banks)
+    struct ClipSlot { mwgl::ClipVert l[2][MWGL_MAX_CLIP_VERTS]; float pad; };
+    __shared__ ClipSlot s_clip[kClipSlots];
     __shared__ int s_pos[8][66];
     __shared__ float s_occ_z[BIG ? MW_OCC_BINS + MW_OCC_BINS / 16 : 1];      // occlusion culling: farthest depth of the nearest wall per column bin, group maxima
     __shared__ float s_occ_wall[BIG ? MW_OCC_CAP * 5 : 1];
@@ -165,9 +180,11 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         }
         mwgl::frame_finish(f, a.W, a.H, lpos, lcol, lamb);
     }
+    const unsigned long long tp0 = a.k1_prof ? __builtin_readcyclecounter() : 0ull;
     mwgl::Xform cam;
     mwgl::make_xform(f, f.view, f.view_flags, cam);
-    if (view_flags & 0x100) { if (sub == 0 && live) a.nvis[env] = (int)cam.mvp.m[0]; return; }
+    unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a.k1_prof) tp[0] = __builtin_readcyclecounter();
 
     const mw_poly *polys = a.polys + (size_t)set * a.max_polys;
     const int np = a.npolys[set];
@@ -404,7 +421,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         __syncthreads();
     }
 
-    if (view_flags & 0x200) { if (sub == 0 && live) a.nvis[env] = total_boxes; return; }
+    if (a.k1_prof) tp[1] = __builtin_readcyclecounter();
     int count = 0;          // the env's list length so far (uniform in the group)
     float stale_n[3] = {0.0f, 1.0f, 0.0f};
     if (np > 0) { stale_n[0] = polys[np - 1].n[0]; stale_n[1] = polys[np - 1].n[1]; stale_n[2] = polys[np - 1].n[2]; }
@@ -418,8 +435,10 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     int *pos = s_pos[grp];
     if (sub == 0) for (int i = 0; i <= (total_boxes < 64 ? total_boxes : 64); ++i) pos[i] = -1;
 
-    for (int r0 = 0; r0 < n_items; r0 += L) {
-        const int item = r0 + sub;
+    // one TRIANGLE per lane: lanes 2k and 2k + 1 of a round hold the two triangles of primitive k (both evaluate its vertex
+    // stage; each sets up, clips and writes its own triangle)
+    for (int r0 = 0; r0 < 2 * n_items; r0 += L) {
+        const int item = (r0 + sub) >> 1, tsel = (r0 + sub) & 1;
         int box_slot = -1, box_idbase = 0;
         if (__any(item >= npd && item < npd + 6 * total_boxes)) find_box(item >= npd ? (item - npd) / 6 : -1, box_slot, box_idbase);
         if (!(item >= npd && item < npd + 6 * total_boxes)) box_slot = -1;
@@ -429,27 +448,38 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         uint32_t id_base = 0u, tag = 0u;
         bool is_box = false, clipped_l = false, in_list = false;
         if (item < npd) {
-            const mw_poly *qp = polys + (sifted ? (int)s_list[item] : item);
-            const int nvf = qp->nv, nv = nvf & 0xFF;
+            // the polygon's 128 bytes in one go: vertices [0..11], uv [12..19], normal [20..22], nv, tex, rgb [25..27], xf [28..31]
+            const float4 *q4 = reinterpret_cast<const float4 *>(polys + (sifted ? (int)s_list[item] : item));
+            float q[32];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float4 w = q4[i]; q[4 * i] = w.x; q[4 * i + 1] = w.y; q[4 * i + 2] = w.z; q[4 * i + 3] = w.w; }
+            static_assert(sizeof(mw_poly) == 128 && offsetof(mw_poly, uv) == 48 && offsetof(mw_poly, n) == 80 && offsetof(mw_poly, nv) == 92 &&
+                          offsetof(mw_poly, tex) == 96 && offsetof(mw_poly, rgb) == 100 && offsetof(mw_poly, xf) == 112, "mw_poly layout");
+            const int nvf = __float_as_int(q[23]), nv = nvf & 0xFF;
             if (!(proxy && (nvf & MW_POLY_ENTITY))) {       // the queries draw rooms only
                 mwgl::Xform ex;
                 const bool own = (nvf & MW_POLY_XF) != 0;
-                if (own) mwgl::entity_xform(f, qp->xf, qp->xf[3], 1.0f, false, ex);
+                const float qxf[4] = {q[28], q[29], q[30], q[31]};
+                if (own) mwgl::entity_xform(f, qxf, qxf[3], 1.0f, false, ex);
                 const mwgl::Xform &x = own ? ex : cam;
                 float col[3];
-                const float qn[3] = {qp->n[0], qp->n[1], qp->n[2]}, qc[3] = {qp->rgb[0], qp->rgb[1], qp->rgb[2]};
+                const float qn[3] = {q[20], q[21], q[22]}, qc[3] = {q[25], q[26], q[27]};
                 mwgl::light_vertex(f, x, qn, proxy ? white : qc, col);
-                tex = proxy ? -1 : qp->tex;
+                tex = proxy ? -1 : __float_as_int(q[24]);
                 // a polygon is the fan (1,2,0) (2,3,0), a quad of the list (0,1,3) (1,2,3): the same triangles of v[] once
                 // the polygon's vertices are taken one further round
                 const bool fan = nv == 3 || !(nvf & MW_POLY_QUAD);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    int sk = fan ? ((k + 1) & 3) : k;
-                    if (nv == 3) sk = k == 0 ? 1 : (k == 1 ? 2 : 0);
-                    const float pk[3] = {qp->v[sk][0], qp->v[sk][1], qp->v[sk][2]};
+                    // source vertex: k for a quad of the list, k + 1 for a polygon, (1, 2, 0, 0) for a triangle
+                    const int ka = k, kb = (k + 1) & 3, kc = k == 0 ? 1 : (k == 1 ? 2 : 0);
+                    float pk[3], st[2];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) pk[c] = nv == 3 ? q[3 * kc + c] : (fan ? q[3 * kb + c] : q[3 * ka + c]);
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) st[c] = nv == 3 ? q[12 + 2 * kc + c] : (fan ? q[12 + 2 * kb + c] : q[12 + 2 * ka + c]);
                     mwgl::transform_vertex(f, x, pk, v[k]);
-                    v[k].st[0] = tex >= 0 ? qp->uv[sk][0] : 0.0f; v[k].st[1] = tex >= 0 ? qp->uv[sk][1] : 0.0f;
+                    v[k].st[0] = tex >= 0 ? st[0] : 0.0f; v[k].st[1] = tex >= 0 ? st[1] : 0.0f;
                     v[k].col[0] = col[0]; v[k].col[1] = col[1]; v[k].col[2] = col[2];
                 }
                 nt = nv == 3 ? 1 : 2;
@@ -529,13 +559,13 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
             bool box_clipped = clipped_l;
             if (is_box) {
                 const int fc = (item - npd) % 6;
-                // the faces of this box in this round: lanes lane - fc .. lane - fc + 5 of the same group (a box may straddle two
+                // the faces of this box in this round: twelve consecutive lanes of the same group (a box may straddle two
                 // rounds: then the other faces' flags are recomputed from the box's vertices — all 8 corners appear in any 2 faces,
                 // so a straddling box is handled by testing the corners directly)
-                const int first = lane - fc;
-                const bool whole = sub - fc >= 0 && sub - fc + 5 < L;
+                const int first = lane - (2 * fc + tsel);
+                const bool whole = sub - (2 * fc + tsel) >= 0 && sub - (2 * fc + tsel) + 11 < L;
                 if (whole) {
-                    box_clipped = ((cm >> first) & 0x3Full) != 0ull;
+                    box_clipped = ((cm >> first) & 0xFFFull) != 0ull;
                 } else {
                     // recompute: any corner of the box clipped?  (faces 0 and 1 hold all eight corners)
                     box_clipped = false;        // filled below by the slow path
@@ -570,61 +600,77 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
             }
         }
 
-        const mwgl::Vert t0c = direct ? v[2] : v[3], t1a = direct ? v[0] : v[1];
-        // ---- pass 1: what survives
-        mwgl::TriSetup ts[2];
-        int cnt[2] = {0, 0};
-        bool clip_t[2] = {false, false};
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            if (t < nt) {
-                const mwgl::Vert &va = t ? t1a : v[0], &vb = t ? v[2] : v[1], &vc = t ? v[3] : t0c;
-                const uint32_t m = va.clipmask | vb.clipmask | vc.clipmask;
-                if (va.clipmask & vb.clipmask & vc.clipmask) continue;
-                if (m == 0u) cnt[t] = mwgl::setup_triangle(va, vb, vc, ms, tex >= 0, ts[t]) ? 1 : 0;
-                else clip_t[t] = true;
-            }
+        if (a.k1_prof) tp[2] = __builtin_readcyclecounter();
+        // this lane's triangle of v[]: (0,1,3) / (1,2,3), or (0,1,2) / (0,2,3) for a direct quad
+        const mwgl::Vert va = tsel ? (direct ? v[0] : v[1]) : v[0], vb = tsel ? v[2] : v[1], vc = tsel ? v[3] : (direct ? v[2] : v[3]);
+        // ---- pass 1: does it survive, and as how many triangles
+        mwgl::TriSetup ts;
+        int cnt = 0;
+        bool clipped = false;
+        if (tsel < nt && !(va.clipmask & vb.clipmask & vc.clipmask)) {
+            if ((va.clipmask | vb.clipmask | vc.clipmask) == 0u) cnt = mwgl::setup_triangle(va, vb, vc, ms, tex >= 0, ts) ? 1 : 0;
+            else clipped = true;
         }
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            uint64_t pend = __ballot(clip_t[t]);
+        if (a.k1_prof) tp[3] = __builtin_readcyclecounter();
+        // A triangle that crosses a frustum plane goes through a work list in LDS.  When the wave has no more of them than
+        // lists (the rule), every one keeps its list — clipped once, here, all lanes side by side — and pass 2 finds the
+        // clipped polygon where pass 1 left it; otherwise they take turns, in both passes.
+        const uint64_t cmask = __ballot(clipped);
+        const uint64_t below = (1ull << lane) - 1ull;
+        const bool keep_lists = (int)__popcll((unsigned long long)cmask) <= kClipSlots;
+        mwgl::ClipVert *kept = nullptr;
+        int kept_n = 0;
+        {
+            uint64_t pend = cmask;
+            if (keep_lists && pend) pend = 1ull;        // one turn for everybody
             while (pend) {
-                uint64_t batch = 0ull, rest = pend;
-                for (int k = 0; k < kClipSlots && rest; ++k) { batch |= rest & (0ull - rest); rest &= rest - 1ull; }
-                if (clip_t[t] && ((batch >> lane) & 1ull)) {
-                    const int slot = __popcll((unsigned long long)(batch & ((1ull << lane) - 1ull)));
-                    mwgl::Vert *r;
-                    const int n = mwgl::clip_triangle<false>(f, t ? t1a : v[0], t ? v[2] : v[1], t ? v[3] : t0c, s_clip[slot][0], s_clip[slot][1], &r);
+                uint64_t batch = ~0ull, rest = 0ull;
+                if (!keep_lists) {
+                    batch = 0ull; rest = pend;
+                    for (int k = 0; k < kClipSlots && rest; ++k) { batch |= rest & (0ull - rest); rest &= rest - 1ull; }
+                }
+                if (clipped && ((batch >> lane) & 1ull)) {
+                    const int slot = (int)__popcll((unsigned long long)((keep_lists ? cmask : batch) & below));
+                    kept_n = mwgl::clip_triangle<false>(f, va, vb, vc, s_clip[slot].l[0], s_clip[slot].l[1], &kept);
                     int c = 0;
-                    for (int i = 2; i < n; ++i) c += tri_front(r[i - 1].win, r[i].win, r[0].win, ms) ? 1 : 0;
-                    cnt[t] = c;
+                    for (int i = 2; i < kept_n; ++i) c += tri_front(kept[i - 1].win, kept[i].win, kept[0].win, ms) ? 1 : 0;
+                    cnt = c;
                 }
                 pend = rest;
             }
         }
-        if (view_flags & 0x400) { if (sub == 0 && live) a.nvis[env] = cnt[0] + cnt[1]; return; }
+        if (a.k1_prof) tp[4] = __builtin_readcyclecounter();
         // ---- list positions
         int total;
-        const int base = count + group_excl_scan(cnt[0] + cnt[1], sub, L, total);
+        const int base = count + group_excl_scan(cnt, sub, L, total);
         count += total;
-        if (base + cnt[0] + cnt[1] > a.max_vis && (cnt[0] | cnt[1])) atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+        if (base + cnt > a.max_vis && cnt) atomicOr(a.status, MW_ST_VIS_OVERFLOW);
+        if (a.k1_prof) tp[5] = __builtin_readcyclecounter();
         // ---- pass 2: the records
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int b0 = base + (t ? cnt[0] : 0);
-            if (cnt[t] == 1 && !clip_t[t] && live && b0 < a.max_vis) mwrec::write_tri(a, env, b0, tag ? tag : (uint32_t)b0 + id_base, ts[t], tex, S);
-            uint64_t pend = __ballot(clip_t[t] && cnt[t] > 0);
+        if (cnt == 1 && !clipped && live && base < a.max_vis) mwrec::write_tri(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex, S);
+        {
+            const bool mine = clipped && cnt > 0;
+            uint64_t pend = __ballot(mine);
+            if (keep_lists && pend) pend = 1ull;
             while (pend) {
-                uint64_t batch = 0ull, rest = pend;
-                for (int k = 0; k < kClipSlots && rest; ++k) { batch |= rest & (0ull - rest); rest &= rest - 1ull; }
-                if (clip_t[t] && cnt[t] > 0 && ((batch >> lane) & 1ull)) {
-                    const int slot = __popcll((unsigned long long)(batch & ((1ull << lane) - 1ull)));
-                    mwgl::Vert *r;
-                    const int n = mwgl::clip_triangle<false>(f, t ? t1a : v[0], t ? v[2] : v[1], t ? v[3] : t0c, s_clip[slot][0], s_clip[slot][1], &r);
-                    int idx = b0;
+                uint64_t batch = ~0ull, rest = 0ull;
+                if (!keep_lists) {
+                    batch = 0ull; rest = pend;
+                    for (int k = 0; k < kClipSlots && rest; ++k) { batch |= rest & (0ull - rest); rest &= rest - 1ull; }
+                }
+                if (mine && ((batch >> lane) & 1ull)) {
+                    const mwgl::ClipVert *r = kept;
+                    int n = kept_n;
+                    if (!keep_lists) {
+                        const int slot = (int)__popcll((unsigned long long)(batch & below));
+                        mwgl::ClipVert *r2;
+                        n = mwgl::clip_triangle<false>(f, va, vb, vc, s_clip[slot].l[0], s_clip[slot].l[1], &r2);
+                        r = r2;
+                    }
+                    int idx = base;
                     for (int i = 2; i < n; ++i) {
                         mwgl::TriSetup t2;
-                        if (mwgl::setup_triangle(r[i - 1], r[i], r[0], ms, tex >= 0, t2)) {
+                        if (mwgl::setup_triangle(to_vert(r[i - 1], va.col), to_vert(r[i], va.col), to_vert(r[0], va.col), ms, tex >= 0, t2)) {
                             if (live && idx < a.max_vis) mwrec::write_tri(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t2, tex, S);
                             ++idx;
                         }
@@ -633,12 +679,18 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
                 pend = rest;
             }
         }
+        if (a.k1_prof) tp[6] = __builtin_readcyclecounter();
         // list positions the meshes' draw ids need
-        if (is_box && (item - npd) % 6 == 0 && (item - npd) / 6 < 64) pos[(item - npd) / 6] = base;
-        if (marker && item == n_items - 1) pos[total_boxes < 64 ? total_boxes : 64] = base;
+        if (is_box && tsel == 0 && (item - npd) % 6 == 0 && (item - npd) / 6 < 64) pos[(item - npd) / 6] = base;
+        if (marker && tsel == 0 && item == n_items - 1) pos[total_boxes < 64 ? total_boxes : 64] = base;
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (a.k1_prof && sub == 0 && live) {
+        unsigned long long *pp = a.k1_prof + (size_t)env * 8;
+        pp[0] = tp[0] - tp0; for (int i = 1; i < 7; ++i) pp[i] = tp[i] - tp[i - 1];
+        pp[7] = __builtin_readcyclecounter() - tp[6];
+    }
     if (sub == 0 && live) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
         a.k3_cost[env] = total_mesh_tris;

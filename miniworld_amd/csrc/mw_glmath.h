@@ -344,7 +344,16 @@ MW_HD void transform_vertex(const Frame &f, const Xform &x, const float p[3], Ve
 // primitive's colour is the same at every vertex and survives the interpolation o + t (c - c) unchanged.
 #define MWGL_MAX_CLIP_VERTS 10
 
-MW_HD float clip_dist(const Vert &v, int plane)
+// the clipper's work-list vertex without the fields a flat-shaded primitive does not need there (colour: the same at every
+// vertex; clip mask: zero for every vertex the clipper makes) — 40 bytes instead of 56 in the geometry kernel's LDS lists
+struct ClipVert {
+    float clip[4];
+    float win[4];
+    float st[2];
+};
+
+template <class V>
+MW_HD float clip_dist(const V &v, int plane)
 {
     // dot4(clip, plane) with the planes (-1,0,0,1) (1,0,0,1) (0,-1,0,1) (0,1,0,1) (0,0,1,1) (0,0,-1,1)
     const float px = plane == 0 ? -1.0f : (plane == 1 ? 1.0f : 0.0f);
@@ -353,32 +362,40 @@ MW_HD float clip_dist(const Vert &v, int plane)
     return ((v.clip[0] * px + v.clip[1] * py) + v.clip[2] * pz) + v.clip[3] * 1.0f;
 }
 
-template <bool GOURAUD>
-MW_HD void clip_interp(const Frame &f, Vert &d, float t, const Vert &out, const Vert &in)
+MW_HD void clip_set_flat(Vert &d, const Vert &src) { for (int i = 0; i < 3; ++i) d.col[i] = src.col[i]; d.clipmask = 0; }
+MW_HD void clip_set_flat(ClipVert &, const ClipVert &) {}
+MW_HD void clip_copy_in(Vert &d, const Vert &s) { d = s; }
+MW_HD void clip_copy_in(ClipVert &d, const Vert &s)
+{
+    for (int i = 0; i < 4; ++i) { d.clip[i] = s.clip[i]; d.win[i] = s.win[i]; }
+    d.st[0] = s.st[0]; d.st[1] = s.st[1];
+}
+
+template <bool GOURAUD, class V>
+MW_HD void clip_interp(const Frame &f, V &d, float t, const V &out, const V &in)
 {
     for (int i = 0; i < 4; ++i) d.clip[i] = out.clip[i] + t * (in.clip[i] - out.clip[i]);
     for (int i = 0; i < 2; ++i) d.st[i] = out.st[i] + t * (in.st[i] - out.st[i]);
-    if (GOURAUD) for (int i = 0; i < 3; ++i) d.col[i] = out.col[i] + t * (in.col[i] - out.col[i]);
-    else for (int i = 0; i < 3; ++i) d.col[i] = out.col[i];
+    if constexpr (GOURAUD) { for (int i = 0; i < 3; ++i) d.col[i] = out.col[i] + t * (in.col[i] - out.col[i]); d.clipmask = 0; }
+    else clip_set_flat(d, out);
     const float oow = 1.0f / d.clip[3];
     d.win[0] = d.clip[0] * oow * f.vp_scale[0] + f.vp_trans[0];
     d.win[1] = d.clip[1] * oow * f.vp_scale[1] + f.vp_trans[1];
     d.win[2] = d.clip[2] * oow * f.vp_scale[2] + f.vp_trans[2];
     d.win[3] = oow;
-    d.clipmask = 0;
 }
 
 // Clips the triangle (a, b, c) against the frustum planes named by the union of the vertices' clip masks, lowest plane
 // first (do_clip_tri).  buf0 / buf1: two work lists of MWGL_MAX_CLIP_VERTS vertices (caller's storage: LDS on the
 // device).  Returns the vertex count n of the result, left in *res (buf0 or buf1): the output triangles are
 // (res[i-1], res[i], res[0]) for i = 2 .. n-1 (emit_poly: the provoking vertex stays last).  n = 0: nothing left.
-template <bool GOURAUD>
-MW_HD int clip_triangle(const Frame &f, const Vert &a, const Vert &b, const Vert &c, Vert *buf0, Vert *buf1, Vert **res)
+template <bool GOURAUD, class V = Vert>
+MW_HD int clip_triangle(const Frame &f, const Vert &a, const Vert &b, const Vert &c, V *buf0, V *buf1, V **res)
 {
     uint32_t clipmask = a.clipmask | b.clipmask | c.clipmask;
     if (a.clipmask & b.clipmask & c.clipmask) { *res = buf0; return 0; }
-    Vert *inl = buf0, *outl = buf1;
-    inl[0] = a; inl[1] = b; inl[2] = c;
+    V *inl = buf0, *outl = buf1;
+    clip_copy_in(inl[0], a); clip_copy_in(inl[1], b); clip_copy_in(inl[2], c);
     int n = 3;
     while (clipmask && n >= 3) {
         int plane = 0;
@@ -402,7 +419,7 @@ MW_HD int clip_triangle(const Frame &f, const Vert &a, const Vert &b, const Vert
             prev = cur;
             dp_prev = dp;
         }
-        Vert *t = inl; inl = outl; outl = t;
+        V *t = inl; inl = outl; outl = t;
         n = oc;
     }
     *res = inl;

@@ -1,0 +1,23 @@
+"""Phase cycle counts of the geometry kernel (MW_K1_PROF hook) for a BASELINE config.  usage: kgprof.py <config>"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+out = "/tmp/kgprof.bin"
+os.environ["MW_K1_PROF"] = out
+import bench
+from miniworld_amd.vec_env import MiniWorldVecEnv
+cfg = sys.argv[1] if len(sys.argv) > 1 else "hallway"
+env_id, _, n, depth, dr, n_act, *_ = bench.CONFIGS[cfg]
+vec = MiniWorldVecEnv(env_id, n, domain_rand=dr, seed=0)
+vec.reset()
+g = torch.Generator(device="cuda").manual_seed(1)
+for t in range(40):
+    vec.step(torch.randint(0, n_act, (n,), generator=g, device="cuda", dtype=torch.int32))
+torch.cuda.synchronize()
+vec.close()
+d = np.fromfile(out, np.uint64).astype(np.float64).reshape(n, 8)
+names = ["xform", "walk/occ/sift", "vertex stage", "pass1 setups", "pass1 clip", "scan", "pass2", "tail"]
+print(cfg, "cycles per phase (mean over envs, last round of the last frame):")
+for k, nm in enumerate(names):
+    print("  %-14s %9.0f" % (nm, d[:, k].mean()))
+print("  sum %.0f cycles = %.1f us at 2.4 GHz" % (d.sum(axis=1).mean(), d.sum(axis=1).mean() / 2400))
