@@ -63,7 +63,7 @@ def test_obs_allgather_over_rccl_world_size_one():
     out = subprocess.run([sys.executable, "-c", WORKER.format(root=ROOT, port=_free_port())], capture_output=True, text=True,
                          timeout=300, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    res = json.loads(out.stdout.strip().splitlines()[-1])
+    res = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])      # (RCCL prints its library path on the way out)
     assert res == {"ok": True, "max": 1.25, "objs": [{"rank": 0}]}
 
 
@@ -72,7 +72,7 @@ def test_bench_force_dist_runs_the_rank_path_on_one_gpu():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--gather-obs", "--steps", "10", "--warmup", "2",
                           "--envs-per-gpu", "256", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads(out.stdout.strip().splitlines()[-1])
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["config"]["torch_distributed"] is True and line["config"]["obs_allgather"] is True
     assert line["value"] > 0 and line["parity_checked"] >= 1
     assert np.isfinite(line["ms_per_step"])
