@@ -432,27 +432,13 @@ static const float CLIP_PLANES[6][4] = {
  * divide and the viewport transform in plain C (two roundings, no fused multiply-add) */
 static void clip_interp(const glstate *st, mwo_vert *dst, float t, const mwo_vert *out, const mwo_vert *in)
 {
-    static int mode = -1;
-    if (mode < 0) mode = getenv("MWO_CLIPMODE") ? atoi(getenv("MWO_CLIPMODE")) : 0;
-    if (mode & 1) {
-    for (int i = 0; i < 4; ++i) dst->clip[i] = fmaf(t, in->clip[i] - out->clip[i], out->clip[i]);
-    for (int i = 0; i < 4; ++i) dst->col[i] = fmaf(t, in->col[i] - out->col[i], out->col[i]);
-    for (int i = 0; i < 2; ++i) dst->st[i] = fmaf(t, in->st[i] - out->st[i], out->st[i]);
-    } else {
     for (int i = 0; i < 4; ++i) dst->clip[i] = out->clip[i] + t * (in->clip[i] - out->clip[i]);
     for (int i = 0; i < 4; ++i) dst->col[i] = out->col[i] + t * (in->col[i] - out->col[i]);
     for (int i = 0; i < 2; ++i) dst->st[i] = out->st[i] + t * (in->st[i] - out->st[i]);
-    }
     float oow = 1.0f / dst->clip[3];
-    if (mode & 2) {
-    dst->win[0] = fmaf(dst->clip[0] * oow, st->vp_scale[0], st->vp_trans[0]);
-    dst->win[1] = fmaf(dst->clip[1] * oow, st->vp_scale[1], st->vp_trans[1]);
-    dst->win[2] = fmaf(dst->clip[2] * oow, st->vp_scale[2], st->vp_trans[2]);
-    } else {
     dst->win[0] = dst->clip[0] * oow * st->vp_scale[0] + st->vp_trans[0];
     dst->win[1] = dst->clip[1] * oow * st->vp_scale[1] + st->vp_trans[1];
     dst->win[2] = dst->clip[2] * oow * st->vp_scale[2] + st->vp_trans[2];
-    }
     dst->win[3] = oow;
     dst->clipmask = 0;
 }

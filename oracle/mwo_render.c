@@ -74,15 +74,11 @@ static inline void coef(plane *p, float a0, float a1, float a2, float dy20_ooa, 
     p->a0 = a0 - (p->dadx * x0c + p->dady * y0c);
 }
 
-static float *dbg_zf = NULL;      /* debug: float z of the winning fragment at sample 0, GL row order */
-void mwo_debug_set_zbuf(float *p) { dbg_zf = p; }
-static int tie_rule = -1;        /* debug: MWO_TIE selects the horizontal-edge ownership */
 
 static int setup(const target *tg, const mwo_tri *tri, setup_tri *s)
 {
     const mwo_vert *v0 = &tri->v[0], *v1 = &tri->v[1], *v2 = &tri->v[2];
     int32_t fx[3], fy[3];
-    if (tie_rule < 0) tie_rule = getenv("MWO_TIE") ? atoi(getenv("MWO_TIE")) : 1;
     /* lp_setup: a single-sampled target shifts the vertices by half a pixel (pixel_offset 0.5: integer coordinates
      * are pixel centres); a multisampled one does not (integer coordinates are pixel corners, the samples sit at
      * their positions inside the pixel and attributes are evaluated at x + 0.5) */
@@ -109,7 +105,7 @@ static int setup(const target *tg, const mwo_tri *tri, setup_tri *s)
         /* fill rule: an edge owns the samples exactly on it when it is a left edge, or a horizontal edge on the side
          * the frame buffer's bottom_edge_rule selects */
         if (s->dcdx[i] < 0) s->c[i]++;
-        else if (s->dcdx[i] == 0 && (tie_rule ? s->dcdy[i] > 0 : s->dcdy[i] < 0)) s->c[i]++;
+        else if (s->dcdx[i] == 0 && s->dcdy[i] > 0) s->c[i]++;
     }
     int minx = fx[0] < fx[1] ? fx[0] : fx[1]; if (fx[2] < minx) minx = fx[2];
     int maxx = fx[0] > fx[1] ? fx[0] : fx[1]; if (fx[2] > maxx) maxx = fx[2];
@@ -218,17 +214,9 @@ static void shade(const mwo_scene *sc, const setup_tri *p, int px, int py, float
     /* lp_build_rho: differences over the quad's first row / first column */
     float qx = (float)(px & ~1) + p->eval_off, qy = (float)(py & ~1) + p->eval_off;
     float s00, t00, s10, t10, s01, t01;
-    static int qmode = -1;
-    if (qmode < 0) qmode = getenv("MWO_QUAD") ? atoi(getenv("MWO_QUAD")) : 0;
-    if (qmode == 1) {
-        tex_coords(p, qx, qy + 1.0f, &s00, &t00);
-        tex_coords(p, qx + 1.0f, qy + 1.0f, &s10, &t10);
-        tex_coords(p, qx, qy, &s01, &t01);
-    } else {
     tex_coords(p, qx, qy, &s00, &t00);
     tex_coords(p, qx + 1.0f, qy, &s10, &t10);
     tex_coords(p, qx, qy + 1.0f, &s01, &t01);
-    }
     float fw = (float)tx->w, fh = (float)tx->h;
     float dsdx = (s10 - s00) * fw, dsdy = (s01 - s00) * fw, dtdx = (t10 - t00) * fh, dtdy = (t01 - t00) * fh;
     float rx = dsdx * dsdx + dtdx * dtdx, ry = dsdy * dsdy + dtdy * dtdy;
@@ -248,14 +236,6 @@ static void shade(const mwo_scene *sc, const setup_tri *p, int px, int py, float
     if (!(rho2 > 0.0f) || ip < 0) { l0 = 0; fp = 0.0f; }         /* magnification (and rho = 0: exponent -127) */
     else if (ip >= last) { l0 = last; fp = 0.0f; }
     w8 = (int)(fp * 256.0f);
-    if (getenv("MWO_DBG_PX")) {
-        int dx, dy;
-        sscanf(getenv("MWO_DBG_PX"), "%d,%d", &dx, &dy);
-        if ((dx & ~1) == (px & ~1) && (dy & ~1) == (py & ~1) && getenv("MWO_W8_DELTA")) w8 += atoi(getenv("MWO_W8_DELTA"));
-        if (dx == px && dy == py)
-            fprintf(stderr, "dbg px %d %d: s %a t %a rho2 %a (rx %a ry %a) lod %a fp*256 %.6f l0 %d w8 %d tex %dx%d dsdx %a dtdx %a dsdy %a dtdy %a\n", px, py, s, t, rho2, rx, ry,
-                    lod, fp * 256.0f, l0, w8, tx->w, tx->h, dsdx, dtdx, dsdy, dtdy);
-    }
     int c0[3], c1[3];
     bilinear8(tx, l0, s, t, c0);
     if (w8 > 0) {
@@ -301,31 +281,12 @@ static int draw_tri(const mwo_scene *sc, target *tg, const setup_tri *p)
                 int in = 1;
                 for (int k = 0; k < 3; ++k)
                     in &= (p->c[k] + (int64_t)p->dcdy[k] * fy - (int64_t)p->dcdx[k] * fx) > 0;
-                if (getenv("MWO_DBG_PX") && s == 0) {
-                    int dx, dy;
-                    sscanf(getenv("MWO_DBG_PX"), "%d,%d", &dx, &dy);
-                    if (dx == px && dy == py)
-                        fprintf(stderr, "dbge px %d %d draw %d in %d E %lld %lld %lld (dcdx %d %d %d)\n", px, py, p->draw, in,
-                                (long long)(p->c[0] + (int64_t)p->dcdy[0] * fy - (int64_t)p->dcdx[0] * fx),
-                                (long long)(p->c[1] + (int64_t)p->dcdy[1] * fy - (int64_t)p->dcdx[1] * fx),
-                                (long long)(p->c[2] + (int64_t)p->dcdy[2] * fy - (int64_t)p->dcdx[2] * fx), p->dcdx[0], p->dcdx[1], p->dcdx[2]);
-                }
                 if (!in) continue;
                 uint16_t z16 = z_to_unorm16(interp(&p->z, xs, ys));
-                if (getenv("MWO_DBG_PX")) {
-                    int dx, dy;
-                    sscanf(getenv("MWO_DBG_PX"), "%d,%d", &dx, &dy);
-                    if (dx == px && dy == py && s == 0) {
-                        float zf = interp(&p->z, xs, ys);
-                        fprintf(stderr, "dbgz px %d %d draw %d z %a (%.9g) z*65535 %.6f scaled %a z16 %d stored %d\n", px, py, p->draw, zf, zf,
-                                (double)zf * 65535.0, zf * (65535.0f / 65536.0f), z16, tg->zbuf[base + s]);
-                    }
-                }
                 if (!(z16 < tg->zbuf[base + s])) continue;        /* GL_LESS */
                 if (!shaded) { shade(sc, p, px, py, col); shaded = 1; }
                 ++passed;
                 tg->zbuf[base + s] = z16;
-                if (dbg_zf && s == 0) dbg_zf[(int64_t)py * tg->W + px] = interp(&p->z, xs, ys);
                 tg->ibuf[base + s] = p->draw;
                 memcpy(&tg->cbuf[(base + s) * 3], col, sizeof col);
             }
@@ -390,16 +351,6 @@ int mwo_render_obs(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out, float *d
             int64_t o = (int64_t)(tg.H - 1 - gy) * tg.W + px;
             for (int c = 0; c < 3; ++c) {
                 float acc = tg.cbuf[base * 3 + c];
-                static int rmode = -1;
-                if (rmode < 0) rmode = getenv("MWO_RESOLVE") ? atoi(getenv("MWO_RESOLVE")) : 0;
-                if (rmode == 1 && tg.S == 4) {
-                    acc = (tg.cbuf[base * 3 + c] + tg.cbuf[(base + 1) * 3 + c]) + (tg.cbuf[(base + 2) * 3 + c] + tg.cbuf[(base + 3) * 3 + c]);
-                } else if (rmode == 2) {
-                    acc = tg.cbuf[base * 3 + c] * inv;
-                    for (int s = 1; s < tg.S; ++s) acc = fmaf(tg.cbuf[(base + s) * 3 + c], inv, acc);
-                    rgb[o * 3 + c] = float_to_unorm8(acc);
-                    continue;
-                } else
                 for (int s = 1; s < tg.S; ++s) acc = acc + tg.cbuf[(base + s) * 3 + c];
                 rgb[o * 3 + c] = float_to_unorm8(acc * inv);
             }
