@@ -514,6 +514,9 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                  float *d_reward, uint8_t *d_term, uint8_t *d_trunc, hipStream_t st)
 {
     if (!d_obs) return fail(e, MW_E_INVALID, "d_obs is null");
+    // (checked before anything is launched or any timing event is taken)
+    if ((e->cfg.msaa != 8 || e->cfg.obs_width > 128 || e->cfg.obs_height > 128) && e->obs_layout != MW_OBS_HWC_U8)
+        return fail(e, MW_E_INVALID, "wrapper layouts need msaa = 8 and observations up to 128 x 128");
     MwArgs a = e->args;
     a.step_override = e->use_step_override ? e->d_step_override : nullptr;
     const int N = e->cfg.num_envs;
@@ -569,7 +572,6 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         // samples) and observations beyond 128 x 128 (the tile kernels' 24-bit edge arithmetic): not the hot path — the
         // generic-resolution kernels, 64-bit edge values, exact packed-key resolution, the whole batch in one grid
         // (blockIdx.y = env)
-        if (e->obs_layout != MW_OBS_HWC_U8) return fail(e, MW_E_INVALID, "wrapper layouts need msaa = 8 and observations up to 128 x 128");
         const int S = e->cfg.msaa;
         uint32_t *keys = nullptr;
         if (e->have_meshes) {

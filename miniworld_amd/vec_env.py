@@ -95,7 +95,7 @@ class MiniWorldVecEnv:
         # placement programs: every room may name its own textures
         prog_names = sorted({n for r in self.template.rooms for n in (r.wall_tex_name, r.floor_tex_name, r.ceil_tex_name)})
         prog_tex_dr = bool(domain_rand) and generator == eng.GEN_PROGRAM and any(len(_assets.texture_variants(n)) > 1 for n in prog_names)
-        shared = generator not in (eng.GEN_NONE, eng.GEN_MAZE) and not tex_dr and not prog_tex_dr
+        shared = generator != eng.GEN_MAZE and not tex_dr and not prog_tex_dr
         P, S, E = len(sc["polys_nv"]), len(sc["wall_segs"]), max(1, len(sc["ents_kind"]))
         pickup_meshes = None
         if cls_name == "PickupObjects":
@@ -120,7 +120,7 @@ class MiniWorldVecEnv:
         cfg.max_episode_steps = int(min(float(self.template.max_episode_steps), 2 ** 30))
         cfg.domain_rand = int(domain_rand)
         cfg.generator = generator
-        cfg.autoreset = eng.AUTORESET_SAME_STEP if (autoreset and generator != eng.GEN_NONE) else eng.AUTORESET_OFF
+        cfg.autoreset = eng.AUTORESET_SAME_STEP if autoreset else eng.AUTORESET_OFF
         cfg.agent_radius = float(self.template.agent.radius)
         if generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM):
             room = self.template.rooms[0]
@@ -178,13 +178,13 @@ class MiniWorldVecEnv:
             # Room._gen_static_data's three rng.integers(0, 1) per room draw nothing (opengl.py:134-138) and the device
             # generator is stream-exact as it is; an asset directory with more variants would need per-room picks
             raise NotImplementedError("Maze with domain_rand and several variants of a room texture is not implemented on the device")
-        pcg_ok = generator != eng.GEN_NONE
+        pcg_ok = True       # every device generator draws numpy's PCG64 stream
         if rng not in ("auto", "pcg64", "philox") or (rng == "pcg64" and not pcg_ok):
             raise ValueError(f"rng={rng!r} is not available for {env_id} (domain_rand={domain_rand})")
         cfg.rng_mode = eng.RNG_PCG64 if (pcg_ok and rng != "philox") else eng.RNG_PHILOX
         self.rng_mode = "pcg64" if cfg.rng_mode == eng.RNG_PCG64 else "philox"
         self.engine = eng.Engine(cfg)
-        self.host_autoreset = autoreset and generator == eng.GEN_NONE
+        self.host_autoreset = False         # every registered id is generated, ruled and auto-reset on the device
         self._upload_assets(sc)
         if cls_name == "RoomObjects":       # any colour of ball / key can be drawn: all twelve meshes are resident
             from .entity import COLOR_NAMES
@@ -268,23 +268,13 @@ class MiniWorldVecEnv:
             self._next_seed = seed
         seeds = np.arange(self.num_envs, dtype=np.uint64) + np.uint64(self._next_seed)
         self._next_seed += self.num_envs
-        if self.generator != eng.GEN_NONE:
-            self.engine.reset(None, seeds)
-        else:
-            self._host_generate(range(self.num_envs), seeds)
+        self.engine.reset(None, seeds)
         self.engine.render(self.obs, self.depth)
         return self.obs
 
     def step(self, actions):
         """actions: integer torch tensor [N] (converted to contiguous int32 on the engine's device if needed)."""
         self.engine.step(actions, self.obs, self.depth, self.reward, self.terminated, self.truncated)
-        if self.host_autoreset:
-            done = (self.terminated | self.truncated).nonzero().flatten().tolist()
-            if done:
-                seeds = np.arange(len(done), dtype=np.uint64) + np.uint64(self._next_seed)
-                self._next_seed += len(done)
-                self._host_generate(done, seeds)
-                self.engine.render(self.obs, self.depth)
         return self.obs, self.reward, self.terminated, self.truncated
 
     def render_top_view(self, render_agent=True):
