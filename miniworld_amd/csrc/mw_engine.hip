@@ -48,8 +48,8 @@ extern "C" __global__ void mw_mesh_scatter_kernel(int W, int H, const float *env
                                                   uint32_t *keys, float *plane_cache, int plane_cap, int32_t *slow_count,
                                                   uint32_t *slow_tris);
 extern "C" __global__ void mw_mesh_slow_kernel(int W, int H, const float *envhdr, const float *mesh_pos, const float *mesh_nrm, const float *mesh_rgb,
-                                               const float *mesh_uv, const uint32_t *texels, int texel_bytes, uint32_t *keys, int32_t *slow_count,
-                                               const uint32_t *slow_tris, int32_t *frag_count, float4 *frags, uint16_t *frag_pix, uint32_t *heads, uint32_t *status, int dbg);
+                                               const float *mesh_uv, const uint32_t *texels, int texel_bytes, uint32_t *keys, int32_t *counts, int N,
+                                               int parity, const uint32_t *slow_tris, float4 *frags, uint32_t *heads, uint32_t stamp, uint32_t *status);
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all, int mark_refill);
 extern "C" __global__ void mw_refill_kernel(MwArgs a);
 extern "C" __global__ void mw_refill_pcg_kernel(MwArgs a);
@@ -102,10 +102,10 @@ struct mw_engine {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *d_mesh_keys = nullptr;    // [N][H][W][8] sample keys of the mesh scatter kernel (all-ones between frames)
     bool mesh_keys_dirty = true;
-    int32_t *d_slow_count = nullptr;    // [2][N] listed triangles, fragments
+    int32_t *d_slow_count = nullptr;    // [2 parities][2][N] listed triangles, fragments
+    uint32_t mesh_frame_seq = 1;
     uint32_t *d_slow_tris = nullptr;
     float4 *d_slow_frags = nullptr;
-    uint16_t *d_slow_pix = nullptr;
     uint32_t *d_slow_head = nullptr;
     float *d_plane_cache = nullptr;     // [N][plane_cap][20] attribute planes of the mesh triangles that win samples (mw_raster_mesh.hip)
     int plane_cap = 0, max_mesh_tris = 0;
@@ -592,6 +592,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                            a.tex, a.texels, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, (const uint32_t *)keys, d_obs, d_depth, e->texel_bytes);
     } else {
         const bool mesh = e->have_meshes;
+        uint32_t mesh_stamp = 0u;
         if (mesh) {
             if (a.W > 255 * MW_TILE_W || a.H > 255 * MW_TILE_H) return fail(e, MW_E_CAPACITY, "frame too large for the mesh tile rectangles");
             // the plane cache: one record per mesh triangle that can be in view (the geometry kernel admits 0xC000 per env);
@@ -607,12 +608,10 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                 if (!e->d_mesh_keys) {
                     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_keys, key_bytes));
                     // triangles that cross a frustum plane and their fragments (mw_mesh_slow_kernel): counts, 1024 / 2048 entries per env
-                    HIP_TRY(e, hipFuncSetAttribute((const void *)mw_mesh_slow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 2 * 10 * 56));
-                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_count, (size_t)N * 2 * 4));
-                    HIP_TRY(e, hipMemset(e->d_slow_count, 0, (size_t)N * 2 * 4));
+                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_count, (size_t)N * 4 * 4));
+                    HIP_TRY(e, hipMemset(e->d_slow_count, 0, (size_t)N * 4 * 4));
                     HIP_TRY(e, hipMalloc((void **)&e->d_slow_tris, (size_t)N * 1024 * 4));
                     HIP_TRY(e, hipMalloc((void **)&e->d_slow_frags, (size_t)N * 8192 * 16));
-                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_pix, (size_t)N * 8192 * 2));
                     HIP_TRY(e, hipMalloc((void **)&e->d_slow_head, (size_t)N * a.W * a.H * 4));
                     HIP_TRY(e, hipMemset(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4));
                 }
@@ -626,11 +625,16 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
             HIP_TRY(e, hipStreamWaitEvent(e->mesh_stream, e->ev_mesh_fork, 0));
             hipStream_t sb = e->mesh_stream;
+            // frame stamp of the slow-fragment chains (16 bits; the heads are wiped when it wraps) and parity of the lists
+            const uint32_t seq = e->mesh_frame_seq++;
+            mesh_stamp = seq & 0xFFFFu;
+            const int parity = (int)(seq & 1u);
+            if (mesh_stamp == 0u) HIP_TRY(e, hipMemsetAsync(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4, sb));
             hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(4, N), dim3(256), 0, sb, a.W, a.H, (const float *)a.envhdr, (const float *)e->d_mesh_stream, (const float *)e->d_mesh_attr,
-                               e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count, e->d_slow_tris);
-            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(N), dim3(64), 64 * 2 * 10 * 56, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
-                               a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, (const uint32_t *)e->d_slow_tris,
-                               e->d_slow_count + N, e->d_slow_frags, e->d_slow_pix, e->d_slow_head, a.status, 0);
+                               e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris);
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(getenv("MW_SLOW_BX") ? atoi(getenv("MW_SLOW_BX")) : 8, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+                               a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, N, parity, (const uint32_t *)e->d_slow_tris,
+                               e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status);
         }
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -649,10 +653,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             k2 = big ? mw_raster_big_mesh_wrap_kernel : (d_depth ? mw_raster_mesh_depth_kernel : mw_raster_mesh_kernel);
             if (general && !big) k2 = mw_raster_mesh_wrap_kernel;
         }
-        const int flags = e->dbg_flags | (e->obs_layout << 8);
+        const int flags = e->dbg_flags | (e->obs_layout << 8) | (int)(mesh_stamp << 16);
         auto launch_k2 = [&](int part_flags) {
-            hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
-                               a.n_tiles, wpe, tpw, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
+            // the second part (the tiles a mesh can touch: few, slow, clustered) spreads over one wave per tile
+            const int wpe2 = (part_flags >> 4) == 2 ? a.n_tiles : wpe, tpw2 = (part_flags >> 4) == 2 ? 1 : tpw;
+            hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe2), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+                               a.n_tiles, wpe2, tpw2, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                                (const int32_t *)a.nvis,
                                (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, flags | part_flags, e->texel_bytes,
                                (const uint16_t *)a.rec_order, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, e->d_mesh_keys,
@@ -837,10 +843,10 @@ void mw_destroy(mw_engine *e)
             if (FILE *f = fopen(getenv("MW_K1_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
     if (getenv("MW_SLOW_STATS") && e->d_slow_count) {      // perf experiments only: the last frame's slow fragments per env
-        std::vector<int32_t> h((size_t)e->cfg.num_envs * 2);
+        std::vector<int32_t> h((size_t)e->cfg.num_envs * 4);
         if (hipMemcpy(h.data(), e->d_slow_count, h.size() * 4, hipMemcpyDeviceToHost) == hipSuccess) {
             long long tot = 0, nz = 0, mx = 0;
-            for (int i = 0; i < e->cfg.num_envs; ++i) { const int v = h[(size_t)e->cfg.num_envs + i]; tot += v; nz += v > 0; mx = std::max<long long>(mx, v); }
+            for (int i = 0; i < e->cfg.num_envs; ++i) { const int v = h[(size_t)e->cfg.num_envs + i] + h[(size_t)e->cfg.num_envs * 3 + i]; tot += v; nz += v > 0; mx = std::max<long long>(mx, v); }
             fprintf(stderr, "slow fragments: total %lld, envs with any %lld of %d, max %lld\n", tot, nz, e->cfg.num_envs, mx);
         }
     }
@@ -850,7 +856,7 @@ void mw_destroy(mw_engine *e)
     if (e->d_view_keys) (void)hipFree(e->d_view_keys);
     if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
     if (e->d_mesh_keys) (void)hipFree(e->d_mesh_keys);
-    for (void *q : {(void *)e->d_slow_count, (void *)e->d_slow_tris, (void *)e->d_slow_frags, (void *)e->d_slow_pix, (void *)e->d_slow_head}) if (q) (void)hipFree(q);
+    for (void *q : {(void *)e->d_slow_count, (void *)e->d_slow_tris, (void *)e->d_slow_frags, (void *)e->d_slow_head}) if (q) (void)hipFree(q);
     if (e->mesh_stream) { (void)hipStreamDestroy(e->mesh_stream); (void)hipEventDestroy(e->ev_mesh_fork); (void)hipEventDestroy(e->ev_mesh_join); }
     if (e->side_stream) { (void)hipStreamDestroy(e->side_stream); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
     for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }

@@ -319,7 +319,8 @@ __device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, 
         // a triangle that crosses a frustum plane: its fragments were shaded by mw_mesh_slow_kernel
         // (the pixel's chain, newest first: the first one appended for this id — the first piece of the fan — counts)
         RGB c = {0.0f, 0.0f, 0.0f};
-        uint32_t k = cx.slow_head[(cx.H - 1 - gy) * cx.W + px];
+        const uint32_t h0 = cx.slow_head[(cx.H - 1 - gy) * cx.W + px];
+        uint32_t k = (h0 >> 16) == cx.slow_stamp ? (h0 & 0xFFFFu) : 0u;        // a head of an earlier frame is empty
         for (int guard = 0; k != 0u && k <= MW_SLOW_FRAGS && guard < MW_SLOW_FRAGS; ++guard) {
             const float4 fr = cx.slow_frags[k - 1u];
             const uint32_t w = __float_as_uint(fr.x);

@@ -84,6 +84,7 @@ __device__ inline void raster_kernel_body(
     cx.planes = MESHAWARE ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
     cx.slow_frags = MESHAWARE ? slow_frags + (size_t)env * MW_SLOW_FRAGS : nullptr;
     cx.slow_head = MESHAWARE ? slow_head + (size_t)env * W * H : nullptr;
+    cx.slow_stamp = (uint32_t)dbg >> 16;
     cx.obs = obs; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3); cx.te = te;
     cx.sky_r = sky_r; cx.sky_g = sky_g; cx.sky_b = sky_b;

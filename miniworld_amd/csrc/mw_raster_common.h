@@ -235,7 +235,8 @@ struct TileCtx {
     const float *mesh_pos, *mesh_nrm, *mesh_rgb, *mesh_uv;
     const float *planes;            // the env's plane cache (mesh-aware K2; null elsewhere)
     const float4 *slow_frags;       // the env's slow-fragment list and its length (mw_mesh_slow_kernel)
-    const uint32_t *slow_head;      // [H][W] newest fragment of the pixel + 1, 0 = none
+    const uint32_t *slow_head;      // [H][W] (frame stamp << 16) | newest fragment of the pixel + 1
+    uint32_t slow_stamp;            // this frame's stamp (bits 16-31 of the launch flags)
     uint8_t *__restrict__ obs;
     float *__restrict__ depth;
     rsrc_t obs_rsrc;                // this env's uint8[H][W][3] frame as a raw buffer (HWC layout only)

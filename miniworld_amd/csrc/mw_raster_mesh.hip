@@ -37,6 +37,8 @@ extern "C" __global__ __launch_bounds__(256) void mw_mesh_scatter_kernel(int W, 
 // (draw id, colour) per pixel with a covered sample, chained per pixel, in fan order — so that neither the scatter kernel
 // nor K2 carries the clipper.  One wavefront per env, a triangle per lane (work lists in LDS); a piece that spans more than
 // 32 pixels is spread over the lanes, a pixel each.  Exits at once for an env without such triangles.
+#define MW_SLOW_LANES 16
+
 namespace {
 
 struct SlowPiece {       // what the pixel loop needs of one set-up piece
@@ -68,21 +70,22 @@ __device__ inline bool slow_cover(const SlowPiece &p, int px, int gy, int W, int
 }
 
 // the piece's fragment of pixel (px, gy) as entry k of the env's list
-__device__ inline void slow_frag(const SlowPiece &p, int px, int gy, int W, int H, const TexEnv &te, int k, float4 *frags, uint16_t *frag_pix,
+// (a pixel's chain head is (frame stamp << 16) | index + 1: heads of earlier frames read as empty, nothing is cleared)
+__device__ inline void slow_frag(const SlowPiece &p, int px, int gy, int W, int H, const TexEnv &te, int k, float4 *frags, uint32_t stamp,
                                  uint32_t *head, uint32_t *status)
 {
     if (k >= MW_SLOW_FRAGS) { atomicOr(status, MW_ST_VIS_OVERFLOW); return; }
     const RGB c = shade_planes(p.w, p.s, p.t, p.r, p.g, p.b, p.tex, te, px, gy, 0.5f);
     const uint32_t pix = (uint32_t)((H - 1 - gy) * W + px);
-    const uint32_t next = atomicExch(head + pix, (uint32_t)k + 1u);
-    frags[k] = make_float4(__uint_as_float((p.id << 16) | (next & 0xFFFFu)), c.r, c.g, c.b);
-    frag_pix[k] = (uint16_t)pix;
+    const uint32_t old = atomicExch(head + pix, (stamp << 16) | ((uint32_t)k + 1u));
+    const uint32_t next = (old >> 16) == stamp ? (old & 0xFFFFu) : 0u;
+    frags[k] = make_float4(__uint_as_float((p.id << 16) | next), c.r, c.g, c.b);
 }
 
 __device__ inline void slow_pixel(const SlowPiece &p, int px, int gy, int W, int H, uint32_t *keys, const TexEnv &te, int32_t *frag_count,
-                                  float4 *frags, uint16_t *frag_pix, uint32_t *head, uint32_t *status)
+                                  float4 *frags, uint32_t stamp, uint32_t *head, uint32_t *status)
 {
-    if (slow_cover(p, px, gy, W, H, keys)) slow_frag(p, px, gy, W, H, te, atomicAdd(frag_count, 1), frags, frag_pix, head, status);
+    if (slow_cover(p, px, gy, W, H, keys)) slow_frag(p, px, gy, W, H, te, atomicAdd(frag_count, 1), frags, stamp, head, status);
 }
 
 __device__ inline int bcast_i(int v, int src) { return __shfl(v, src); }
@@ -92,30 +95,25 @@ __device__ inline mwgl::Plane bcast_p(const mwgl::Plane &q, int src) { return mw
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int H, const float *__restrict__ envhdr, const float *__restrict__ mesh_pos,
-                                                                     const float *__restrict__ mesh_nrm, const float *__restrict__ mesh_rgb,
-                                                                     const float *__restrict__ mesh_uv, const uint32_t *__restrict__ texels, int texel_bytes,
-                                                                     uint32_t *__restrict__ keys_all, int32_t *__restrict__ slow_count,
-                                                                     const uint32_t *__restrict__ slow_tris, int32_t *__restrict__ frag_count,
-                                                                     float4 *__restrict__ frags_all, uint16_t *__restrict__ pix_all,
-                                                                     uint32_t *__restrict__ heads_all, uint32_t *__restrict__ status, int dbg)
+                                                                    const float *__restrict__ mesh_nrm, const float *__restrict__ mesh_rgb,
+                                                                    const float *__restrict__ mesh_uv, const uint32_t *__restrict__ texels, int texel_bytes,
+                                                                    uint32_t *__restrict__ keys_all, int32_t *__restrict__ counts, int N, int parity,
+                                                                    const uint32_t *__restrict__ slow_tris, float4 *__restrict__ frags_all,
+                                                                    uint32_t *__restrict__ heads_all, uint32_t stamp, uint32_t *__restrict__ status)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char slow_smem[];     // the clipper's work lists: [64][2][MWGL_MAX_CLIP_VERTS] vertices
-    const int env = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    // the clipper's work lists: [MW_SLOW_LANES][2][MWGL_MAX_CLIP_VERTS] vertices (18 KB: the grid is mostly empty workgroups, which
+    // must not queue for LDS)
+    __shared__ mwgl::Vert slow_lists[MW_SLOW_LANES][2][MWGL_MAX_CLIP_VERTS];
+    // grid (MW_SLOW_BLOCKS_X, N): the blocks of row y share env y's list, MW_SLOW_LANES triangles per block and turn.
+    // counts: [2 parities][2][N] — listed triangles (the scatter kernel's) and fragments of this frame's parity; the other
+    // parity's are zeroed here for the next frame.
+    const int env = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    int32_t *slow_count = counts + ((size_t)parity * 2 + 0) * N, *frag_count = counts + ((size_t)parity * 2 + 1) * N;
+    if (blockIdx.x == 0 && tid == 0) { counts[((size_t)(parity ^ 1) * 2 + 0) * N + env] = 0; counts[((size_t)(parity ^ 1) * 2 + 1) * N + env] = 0; }
     const int n = slow_count[env];
+    if ((int)blockIdx.x * MW_SLOW_LANES >= n) return;
     uint32_t *head = heads_all + (size_t)env * W * H;
     float4 *frags = frags_all + (size_t)env * MW_SLOW_FRAGS;
-    uint16_t *frag_pix = pix_all + (size_t)env * MW_SLOW_FRAGS;      // the fragments' pixels, for the next frame's clean-up
-    {
-        // the previous frame's chains: every pixel that got a fragment then is emptied now
-        const int prev = min(frag_count[env], MW_SLOW_FRAGS);
-        for (int k = tid; k < prev; k += 64) head[frag_pix[k]] = 0u;
-        __syncthreads();
-        if (tid == 0) frag_count[env] = 0;
-        __threadfence();
-        __syncthreads();
-    }
-    if (n == 0) return;
-    if (dbg & 1) { if (tid == 0) slow_count[env] = 0; return; }
     if (n > MW_SLOW_TRIS && tid == 0) atomicOr(status, MW_ST_VIS_OVERFLOW);
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     uint32_t *keys = keys_all + (size_t)env * W * H * 8;
@@ -127,10 +125,10 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
     mwgl::Frame f;
     frame_lite(hdr, W, H, f);
     const int nn = min(n, MW_SLOW_TRIS);
-    mwgl::Vert *buf0 = reinterpret_cast<mwgl::Vert *>(slow_smem) + (size_t)tid * 2 * MWGL_MAX_CLIP_VERTS, *buf1 = buf0 + MWGL_MAX_CLIP_VERTS;
-    for (int base = 0; base < nn; base += 64) {
+    mwgl::Vert *buf0 = slow_lists[tid & (MW_SLOW_LANES - 1)][0], *buf1 = slow_lists[tid & (MW_SLOW_LANES - 1)][1];
+    for (int base = (int)blockIdx.x * MW_SLOW_LANES; base < nn; base += (int)gridDim.x * MW_SLOW_LANES) {
         const int i = base + tid;
-        const bool valid = i < nn;
+        const bool valid = tid < MW_SLOW_LANES && i < nn;
         mwgl::Vert *r = buf0;
         int nv = 0, tex = -1;
         uint32_t id = 0u;
@@ -154,7 +152,6 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
                 v[k].st[1] = e.tex >= 0 ? uv[k * 2 + 1] : 0.0f;
             }
             nv = mwgl::clip_triangle<true>(f, v[0], v[1], v[2], buf0, buf1, &r);
-            if (dbg & 2) nv = 0;
         }
         // the pieces (r[q-1], r[q], r[0]), q = 2 .. nv - 1, in fan order
         for (int q = 2; __any(q < nv); ++q) {
@@ -173,7 +170,6 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
                     have = p.x0 <= p.x1 && p.y0 <= p.y1;
                 }
             }
-            if (dbg & 4) have = false;
             const int npx = have ? (p.x1 - p.x0 + 1) * (p.y1 - p.y0 + 1) : 0;
             const bool big = npx > 32;
             if (have && !big) {
@@ -185,7 +181,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
                     int k0 = atomicAdd(frag_count + env, __popc(cov));
                     for (uint32_t mm = cov; mm; mm &= mm - 1u, ++k0) {
                         const int k = __ffs((int)mm) - 1;
-                        slow_frag(p, p.x0 + k % bw, p.y0 + k / bw, W, H, te, k0, frags, frag_pix, head, status);
+                        slow_frag(p, p.x0 + k % bw, p.y0 + k / bw, W, H, te, k0, frags, stamp, head, status);
                     }
                 }
             }
@@ -202,12 +198,10 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
                 u.x0 = bcast_i(p.x0, src); u.x1 = bcast_i(p.x1, src); u.y0 = bcast_i(p.y0, src); u.y1 = bcast_i(p.y1, src);
                 u.id = (uint32_t)bcast_i((int)p.id, src); u.tex = bcast_i(p.tex, src);
                 const int bw = u.x1 - u.x0 + 1, tot = bw * (u.y1 - u.y0 + 1);
-                for (int k = lane; k < tot; k += 64) slow_pixel(u, u.x0 + k % bw, u.y0 + k / bw, W, H, keys, te, frag_count + env, frags, frag_pix, head, status);
+                for (int k = lane; k < tot; k += 64) slow_pixel(u, u.x0 + k % bw, u.y0 + k / bw, W, H, keys, te, frag_count + env, frags, stamp, head, status);
             }
         }
     }
-    __syncthreads();
-    if (tid == 0) slow_count[env] = 0;         // the next frame's scatter starts a new list
 }
 
 // ======================================================================================
@@ -340,7 +334,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.te.flat = 0;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
     cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr; cx.tprof = nullptr;
-    cx.planes = nullptr; cx.slow_frags = nullptr; cx.slow_head = nullptr;
+    cx.planes = nullptr; cx.slow_frags = nullptr; cx.slow_head = nullptr; cx.slow_stamp = 0u;
     cx.pre_touch = cx.pre_full = cx.pre_clip = cx.pre_edges = 0ull;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
     else if (S == 4) view_tile_body<4>(cx, tiles_x, mesh_keys);
