@@ -639,9 +639,10 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
         const int groups = (N + 7) / 8;
-        // (MW_RASTER_BIG=1: the variant that never stages records in LDS)
-        const bool big = getenv("MW_RASTER_BIG") && atoi(getenv("MW_RASTER_BIG")) != 0;
-        // the env's records are staged in LDS when there are at most MW_LDS_RECS of them (a wave whose env holds more reads them in place): stage up to MW_LDS_RECS records in LDS (a wave whose env holds more reads them in place)
+        // big scenes (a visiting order exists): records read in place, near to far; otherwise the env's records are staged
+        // in LDS when there are at most MW_LDS_RECS of them (a wave whose env holds more reads them in place).
+        // MW_RASTER_BIG=0 / 1 forces either (A/B runs).
+        const bool big = getenv("MW_RASTER_BIG") ? atoi(getenv("MW_RASTER_BIG")) != 0 : a.rec_order != nullptr;
         const int lds_recs = a.max_vis < MW_LDS_RECS ? a.max_vis : MW_LDS_RECS;
         const size_t lds = big ? 192 : (size_t)lds_recs * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
         // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
@@ -800,6 +801,11 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.rec_shade, (size_t)N * a.max_vis * MW_SHADE_REC);
     ALLOC(a.rec_cull, (size_t)N * a.max_vis * MW_CULL_REC);
     ALLOC(a.k3_cost, (size_t)N); ALLOC(a.k3_order, (size_t)N);
+    if (cfg->max_visible > 64 && !(getenv("MW_SORT_VIS") && atoi(getenv("MW_SORT_VIS")) == 0)) {
+        // big scenes: the visiting order the geometry kernel leaves for K2 (mw_geom.hip)
+        ALLOC(a.rec_order, (size_t)N * (a.max_vis + 1));
+        if (rc == MW_OK) (void)hipMemset(a.rec_order, 0, (size_t)N * (a.max_vis + 1) * 2);
+    }
     ALLOC(a.pending_remove, (size_t)N);
     if (rc == MW_OK) (void)hipMemset(a.pending_remove, 0xFF, 4 * (size_t)N);
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);

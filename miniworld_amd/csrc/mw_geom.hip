@@ -40,6 +40,14 @@ __device__ inline int group_excl_scan(int v, int sub, int L, int &total)
     return x - v;
 }
 
+// a polygon's 128 bytes in one go: vertices [0..11], uv [12..19], normal [20..22], nv, tex, rgb [25..27], xf [28..31]
+__device__ inline void load_poly(const mw_poly *p, float (&q)[32])
+{
+    const float4 *q4 = reinterpret_cast<const float4 *>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const float4 w = q4[i]; q[4 * i] = w.x; q[4 * i + 1] = w.y; q[4 * i + 2] = w.z; q[4 * i + 3] = w.w; }
+}
+
 // a work-list vertex with the primitive's flat colour
 __device__ inline mwgl::Vert to_vert(const mwgl::ClipVert &c, const float col[3])
 {
@@ -79,6 +87,7 @@ __device__ inline bool tri_front(const float wa[4], const float wb[4], const flo
 // tests/test_gpu_env_api.py::test_occlusion_culling_never_changes_a_frame compares MW_OCCLUSION=0 / 1 bit for bit.
 #define MW_OCC_BINS 256
 #define MW_OCC_CAP 192
+#define MW_ORDER_CAP 512       // big scenes: lists up to this length get a near-to-far visiting order
 
 // occ_z[0 .. BINS): the bins; occ_z[BINS .. BINS + BINS / 16): the largest value of every group of 16 bins
 __device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float bins_per_px)
@@ -127,7 +136,8 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     __shared__ float s_occ_z[BIG ? MW_OCC_BINS + MW_OCC_BINS / 16 : 1];      // occlusion culling: farthest depth of the nearest wall per column bin, group maxima
     __shared__ float s_occ_wall[BIG ? MW_OCC_CAP * 5 : 1];
     __shared__ int s_occ_n;
-    __shared__ uint16_t s_list[BIG ? 4096 : 1];      // big scenes: the polygons that pass the cheap tests (frustum, occlusion), in drawing order
+    __shared__ uint16_t s_list[BIG ? 4096 : 1];
+    __shared__ uint32_t s_key[BIG ? MW_ORDER_CAP : 1];        // big scenes: (depth bound << 16 | list index) of every record, for the visiting order      // big scenes: the polygons that pass the cheap tests (frustum, occlusion), in drawing order
     const int lane = threadIdx.x;
     const int epw = 64 / L, sub = lane & (L - 1), grp = lane / L;
     const int rel = (int)blockIdx.x * epw + grp;
@@ -297,10 +307,20 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     if (occ_on) {
         // the slab: lowest and highest point of the room polygons
         float lo = 1e30f, hi = -1e30f;
-        for (int i = lane; i < np; i += 64) {
-            const mw_poly *qp = polys + i;
-            const int nv = qp->nv & 0xFF;
-            for (int k = 0; k < nv; ++k) { lo = fminf(lo, qp->v[k][1]); hi = fmaxf(hi, qp->v[k][1]); }
+        // (the loops over the env's polygons keep the next polygon's 128 bytes in flight while they work on the current one)
+        {
+            float qn[32];
+            if (lane < np) load_poly(polys + lane, qn);
+            for (int i = lane; i < np; i += 64) {
+                float q[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) q[k] = qn[k];
+                if (i + 64 < np) load_poly(polys + i + 64, qn);
+                const int nv = __float_as_int(q[23]) & 0xFF;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < nv) { lo = fminf(lo, q[3 * k + 1]); hi = fmaxf(hi, q[3 * k + 1]); }
+            }
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
@@ -312,14 +332,20 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
             const float *V = f.view.m;          // column major: eye x = V[0] x + V[8] z + V[12], depth = -(V[2] x + V[10] z + V[14])
             const float p00 = f.proj.m[0], halfw = (float)a.W * 0.5f;
             const float inv_p00 = 1.0f / p00, inv_hp = 1.0f / (halfw * p00), px_per_bin = 1.0f / bins_per_px;
+            float qn[32];
+            if (lane < np) load_poly(polys + lane, qn);
             for (int i = lane; i < np; i += 64) {
-                const mw_poly *qp = polys + i;
-                if (qp->nv != 4 && qp->nv != (4 | MW_POLY_QUAD)) continue;      // triangles, and the quads of static entities (flag bits), are no walls
+                float q[32];
+#pragma unroll
+                for (int k = 0; k < 32; ++k) q[k] = qn[k];
+                if (i + 64 < np) load_poly(polys + i + 64, qn);
+                const int nvf = __float_as_int(q[23]);
+                if (nvf != 4 && nvf != (4 | MW_POLY_QUAD)) continue;      // triangles, and the quads of static entities (flag bits), are no walls
                 float vx[4], vy[4], vz[4];
                 bool ys = true;
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    vx[k] = qp->v[k][0]; vy[k] = qp->v[k][1]; vz[k] = qp->v[k][2];
+                    vx[k] = q[3 * k]; vy[k] = q[3 * k + 1]; vz[k] = q[3 * k + 2];
                     ys &= vy[k] == lo || vy[k] == hi;
                 }
                 // a vertical rectangle from lo to hi: two vertical edges
@@ -366,15 +392,24 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         __syncthreads();
         if (occ_on) {
             const int n_occ = s_occ_n < MW_OCC_CAP ? s_occ_n : MW_OCC_CAP;
-            for (int b = lane; b < MW_OCC_BINS; b += 64) {
-                const float xa = (float)b / bins_per_px, xb = (float)(b + 1) / bins_per_px;
-                float z = 1e30f;
-                for (int j = 0; j < n_occ; ++j) {
-                    const float *ow = s_occ_wall + 5 * j;
-                    const float far = ow[4] * fmaxf(__builtin_amdgcn_rcpf(fmaf(ow[2], xa, ow[3])), __builtin_amdgcn_rcpf(fmaf(ow[2], xb, ow[3])));
-                    z = (xa >= ow[0] && xb <= ow[1]) ? fminf(z, far) : z;
+            // (four bins per lane in registers, the walls in the outer loop: one broadcast read of a wall serves them all)
+            static_assert(MW_OCC_BINS == 256, "four column bins per lane");
+            float zb[4] = {1e30f, 1e30f, 1e30f, 1e30f}, xa[4], xb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const int b = lane + 64 * q; xa[q] = (float)b / bins_per_px; xb[q] = (float)(b + 1) / bins_per_px; }
+            for (int j = 0; j < n_occ; ++j) {
+                const float *ow = s_occ_wall + 5 * j;
+                const float o0 = ow[0], o1 = ow[1], o2 = ow[2], o3 = ow[3], o4 = ow[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float far = o4 * fmaxf(__builtin_amdgcn_rcpf(fmaf(o2, xa[q], o3)), __builtin_amdgcn_rcpf(fmaf(o2, xb[q], o3)));
+                    zb[q] = (xa[q] >= o0 && xb[q] <= o1) ? fminf(zb[q], far) : zb[q];
                 }
-                z *= 1.0001f;
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int b = lane + 64 * q;
+                const float z = zb[q] * 1.0001f;
                 s_occ_z[b] = z;
                 // the largest value of every group of 16 bins (= 16 consecutive lanes)
                 float gz = z;
@@ -392,20 +427,24 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     const bool sifted = BIG && L == 64 && np > 64 && np <= 4096;
     if (sifted) {
         int ns = 0;
+        float qn[32];
+        if (lane < np) load_poly(polys + lane, qn);
         for (int base = 0; base < np; base += 64) {
             const int i = base + lane;
             bool keep = false;
+            float q[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) q[k] = qn[k];
+            if (i + 64 < np) load_poly(polys + i + 64, qn);
             if (i < np) {
-                const mw_poly *qp = polys + i;
-                const int nvf = qp->nv, nv = nvf & 0xFF;
+                const int nvf = __float_as_int(q[23]), nv = nvf & 0xFF;
                 keep = !(proxy && (nvf & MW_POLY_ENTITY));
                 if (keep && !(nvf & MW_POLY_XF)) {
                     mwgl::Vert v[4];
                     uint32_t all = 0x3Fu;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const int sk = k < nv ? k : 0;
-                        const float pk[3] = {qp->v[sk][0], qp->v[sk][1], qp->v[sk][2]};
+                        const float pk[3] = {k < nv ? q[3 * k] : q[0], k < nv ? q[3 * k + 1] : q[1], k < nv ? q[3 * k + 2] : q[2]};
                         mwgl::transform_vertex(f, cam, pk, v[k]);
                         all &= v[k].clipmask;
                     }
@@ -449,10 +488,8 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         bool is_box = false, clipped_l = false, in_list = false;
         if (item < npd) {
             // the polygon's 128 bytes in one go: vertices [0..11], uv [12..19], normal [20..22], nv, tex, rgb [25..27], xf [28..31]
-            const float4 *q4 = reinterpret_cast<const float4 *>(polys + (sifted ? (int)s_list[item] : item));
             float q[32];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { const float4 w = q4[i]; q[4 * i] = w.x; q[4 * i + 1] = w.y; q[4 * i + 2] = w.z; q[4 * i + 3] = w.w; }
+            load_poly(polys + (sifted ? (int)s_list[item] : item), q);
             static_assert(sizeof(mw_poly) == 128 && offsetof(mw_poly, uv) == 48 && offsetof(mw_poly, n) == 80 && offsetof(mw_poly, nv) == 92 &&
                           offsetof(mw_poly, tex) == 96 && offsetof(mw_poly, rgb) == 100 && offsetof(mw_poly, xf) == 112, "mw_poly layout");
             const int nvf = __float_as_int(q[23]), nv = nvf & 0xFF;
@@ -647,7 +684,10 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         if (base + cnt > a.max_vis && cnt) atomicOr(a.status, MW_ST_VIS_OVERFLOW);
         if (a.k1_prof) tp[5] = __builtin_readcyclecounter();
         // ---- pass 2: the records
-        if (cnt == 1 && !clipped && live && base < a.max_vis) mwrec::write_tri(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex, S);
+        if (cnt == 1 && !clipped && live && base < a.max_vis) {
+            const uint32_t zlo = mwrec::write_tri(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex, S);
+            if (BIG && base < MW_ORDER_CAP) s_key[base] = (zlo << 16) | (uint32_t)base;
+        }
         {
             const bool mine = clipped && cnt > 0;
             uint64_t pend = __ballot(mine);
@@ -671,7 +711,10 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
                     for (int i = 2; i < n; ++i) {
                         mwgl::TriSetup t2;
                         if (mwgl::setup_triangle(to_vert(r[i - 1], va.col), to_vert(r[i], va.col), to_vert(r[0], va.col), ms, tex >= 0, t2)) {
-                            if (live && idx < a.max_vis) mwrec::write_tri(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t2, tex, S);
+                            if (live && idx < a.max_vis) {
+                                const uint32_t zlo = mwrec::write_tri(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t2, tex, S);
+                                if (BIG && idx < MW_ORDER_CAP) s_key[idx] = (zlo << 16) | (uint32_t)idx;
+                            }
                             ++idx;
                         }
                     }
@@ -686,6 +729,36 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     }
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (BIG && a.rec_order && L < 64) {
+        if (sub == 0 && live) a.rec_order[(size_t)env * (a.max_vis + 1)] = 0;      // no order
+    } else if (BIG && a.rec_order) {
+        // big scenes (one env per wavefront): the records' visiting order by ascending depth bound — K2 visits a tile's
+        // triangles near to far and stops at the first one that lies behind everything the tile holds by then
+        uint16_t *order = a.rec_order + (size_t)env * (a.max_vis + 1);
+        const int n = count;
+        if (n > MW_ORDER_CAP || !live) {
+            if (lane == 0 && live) order[0] = 0;
+        } else {
+            int P = 64;
+            while (P < n) P <<= 1;
+            for (int i = n + lane; i < P; i += 64) s_key[i] = 0xFFFFFFFFu;
+            __syncthreads();
+            for (int k = 2; k <= P; k <<= 1)
+                for (int j = k >> 1; j > 0; j >>= 1) {
+                    for (int i = lane; i < P; i += 64) {
+                        const int l = i ^ j;
+                        if (l > i) {
+                            const uint32_t x = s_key[i], y = s_key[l];
+                            const bool up = (i & k) == 0;
+                            if ((x > y) == up) { s_key[i] = y; s_key[l] = x; }
+                        }
+                    }
+                    __syncthreads();
+                }
+            for (int i = lane; i < n; i += 64) order[1 + i] = (uint16_t)(s_key[i] & 0xFFFFu);
+            if (lane == 0) order[0] = 1;
+        }
+    }
     if (a.k1_prof && sub == 0 && live) {
         unsigned long long *pp = a.k1_prof + (size_t)env * 8;
         pp[0] = tp[0] - tp0; for (int i = 1; i < 7; ++i) pp[i] = tp[i] - tp[i - 1];

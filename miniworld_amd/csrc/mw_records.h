@@ -9,7 +9,6 @@
 //     [16 + 16 k + s]  thr_k[s] = dcdx_k sx_s - dcdy_k sy_s  (sx, sy: the sample's 24.8 offset inside the pixel)
 //   shade (MW_SHADE_REC = 32 dwords, read per lane): w plane + texture id, s, t, r, g, b planes, z plane
 //   cull (MW_CULL_REC = 24 dwords, read per lane): A, B, C, tmin, tmax, tile bounds, 16-bit depth lower bound, C high words
-// A slot the clipper left unused holds a NULL record that touches no tile.
 #pragma once
 #include "mw_device.h"
 #include "mw_glmath.h"
@@ -35,24 +34,6 @@ __device__ inline void sample_offset(int S, int s, int &sx, int &sy)
     sx = kPat[pi][s][0] * 16; sy = kPat[pi][s][1] * 16;
 }
 
-__device__ inline void write_null(const MwArgs &a, int env, int idx)
-{
-    float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
-    float4 *cr = reinterpret_cast<float4 *>(a.rec_cull + ((size_t)env * a.max_vis + idx) * MW_CULL_REC);
-    const float m1 = __int_as_float(-1), big = __int_as_float(0x7fffffff);
-    // A = B = 0, C = -1, thresholds INT_MAX: nothing is ever inside; tile bounds empty
-    cr[0] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0x000000ffu | (0u << 8) | (0xffu << 16) | (0u << 24)));
-    cr[1] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    cr[2] = make_float4(m1, m1, m1, __uint_as_float(0xffffu));
-    cr[3] = make_float4(big, big, big, 0.0f);
-    cr[4] = make_float4(big, big, big, 0.0f);
-    cr[5] = make_float4(m1, m1, m1, 0.0f);
-    rr[0] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    rr[1] = make_float4(0.0f, 0.0f, m1, m1);
-    rr[2] = make_float4(m1, 0.0f, 0.0f, 0.0f);
-    rr[3] = make_float4(0.0f, big, big, big);
-}
-
 // the pattern as compile-time constants (the record writer's thresholds fold to multiply-adds)
 template <int S> struct Pat;
 template <> struct Pat<1> { static constexpr int x[1] = {8}, y[1] = {8}; };
@@ -63,8 +44,9 @@ template <> struct Pat<16> {
 };
 
 // records of one triangle.  S: samples per pixel; draw_id: position in the frame's drawing order
+// (returns the 16-bit lower bound of the triangle's depth, the key of the big scenes' visiting order)
 template <int S>
-__device__ inline void write_tri_s(const MwArgs &a, int env, int idx, uint32_t draw_id, const mwgl::TriSetup &t, int tex)
+__device__ inline uint32_t write_tri_s(const MwArgs &a, int env, int idx, uint32_t draw_id, const mwgl::TriSetup &t, int tex)
 {
     float4 *rr = reinterpret_cast<float4 *>(a.rec_raster + ((size_t)env * a.max_vis + idx) * MW_RASTER_REC);
     float4 *sr = reinterpret_cast<float4 *>(a.rec_shade + ((size_t)env * a.max_vis + idx) * MW_SHADE_REC);
@@ -128,14 +110,15 @@ __device__ inline void write_tri_s(const MwArgs &a, int env, int idx, uint32_t d
     sr[5] = make_float4(t.col[2].a0, t.col[2].dadx, t.col[2].dady, 0.0f);
     sr[6] = make_float4(t.z.a0, t.z.dadx, t.z.dady, 0.0f);
     sr[7] = make_float4(__int_as_float(chi[0]), __int_as_float(chi[1]), __int_as_float(chi[2]), 0.0f);
+    return (uint32_t)zlo;
 }
 
-__device__ inline void write_tri(const MwArgs &a, int env, int idx, uint32_t draw_id, const mwgl::TriSetup &t, int tex, int S)
+__device__ inline uint32_t write_tri(const MwArgs &a, int env, int idx, uint32_t draw_id, const mwgl::TriSetup &t, int tex, int S)
 {
-    if (S == 8) write_tri_s<8>(a, env, idx, draw_id, t, tex);
-    else if (S == 4) write_tri_s<4>(a, env, idx, draw_id, t, tex);
-    else if (S == 1) write_tri_s<1>(a, env, idx, draw_id, t, tex);
-    else write_tri_s<16>(a, env, idx, draw_id, t, tex);
+    if (S == 8) return write_tri_s<8>(a, env, idx, draw_id, t, tex);
+    if (S == 4) return write_tri_s<4>(a, env, idx, draw_id, t, tex);
+    if (S == 1) return write_tri_s<1>(a, env, idx, draw_id, t, tex);
+    return write_tri_s<16>(a, env, idx, draw_id, t, tex);
 }
 
 }  // namespace mwrec
