@@ -10,7 +10,9 @@
 #define MW_RASTER_REC 64     // dwords per raster record
 #define MW_SHADE_REC 32      // dwords per shade record (attribute planes, colour, tex, depth plane)
 #define MW_CULL_REC 24       // a[4] b[4] c[4] tmin[4] tmax[4] flags pad[3]
-#define MW_LDS_RECS 48       // triangle records a small-scene raster wave stages in LDS (10.5 KB)
+#define MW_LDS_RECS 32       // triangle records a small-scene raster wave stages in LDS ...
+#define MW_LDS_SHADE_Q 7      // ... as the quads K2 reads of each: 7 of the shade record's 8,
+#define MW_LDS_CULL_Q 5       //     5 of the classification record's 6 (192 B per triangle: 7.5 KB + 192 B per wave, 5 waves per SIMD)
 #define MW_TILE_W 16
 #define MW_TILE_H 4
 #define MW_SKY_PID 0xFFFFu

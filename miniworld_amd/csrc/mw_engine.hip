@@ -622,17 +622,26 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             // The mesh kernels run on the side stream, beside the first part of K2 (every tile no mesh can touch); the
             // tiles inside the meshes' rectangles follow behind both (part 2).
             if (ensure_mesh_stream(e) != MW_OK) return MW_E_HIP;
-            HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
-            HIP_TRY(e, hipStreamWaitEvent(e->mesh_stream, e->ev_mesh_fork, 0));
-            hipStream_t sb = e->mesh_stream;
             // frame stamp of the slow-fragment chains (16 bits; the heads are wiped when it wraps) and parity of the lists
             const uint32_t seq = e->mesh_frame_seq++;
             mesh_stamp = seq & 0xFFFFu;
             const int parity = (int)(seq & 1u);
-            if (mesh_stamp == 0u) HIP_TRY(e, hipMemsetAsync(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4, sb));
-            hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(4, N), dim3(256), 0, sb, a.W, a.H, (const float *)a.envhdr, (const float *)e->d_mesh_stream, (const float *)e->d_mesh_attr,
+            const bool scatter_first = !(getenv("MW_SCATTER_OVERLAP") && atoi(getenv("MW_SCATTER_OVERLAP")) != 0);
+            if (mesh_stamp == 0u) HIP_TRY(e, hipMemsetAsync(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4, st));
+            // the scatter kernel alone (it is latency bound and would take 2.5x as long beside K2), then the slow path on the
+            // mesh stream beside K2's first part
+            hipStream_t sb = e->mesh_stream;
+            if (!scatter_first) {
+                HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
+                HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
+            }
+            hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(4, N), dim3(256), 0, scatter_first ? st : sb, a.W, a.H, (const float *)a.envhdr, (const float *)e->d_mesh_stream, (const float *)e->d_mesh_attr,
                                e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris);
-            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(getenv("MW_SLOW_BX") ? atoi(getenv("MW_SLOW_BX")) : 8, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+            if (scatter_first) {
+                HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
+                HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
+            }
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(8, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
                                a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, N, parity, (const uint32_t *)e->d_slow_tris,
                                e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status);
         }
@@ -644,7 +653,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         // MW_RASTER_BIG=0 / 1 forces either (A/B runs).
         const bool big = getenv("MW_RASTER_BIG") ? atoi(getenv("MW_RASTER_BIG")) != 0 : a.rec_order != nullptr;
         const int lds_recs = a.max_vis < MW_LDS_RECS ? a.max_vis : MW_LDS_RECS;
-        const size_t lds = big ? 192 : (size_t)lds_recs * (MW_SHADE_REC + MW_CULL_REC) * 4 + 192;
+        const size_t lds = big ? 192 : (size_t)lds_recs * (MW_LDS_SHADE_Q + MW_LDS_CULL_Q) * 16 + 192;
         // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
         // anything else goes to the general kernel
         const bool general = e->obs_layout != MW_OBS_HWC_U8 || e->dbg_flags != 0;

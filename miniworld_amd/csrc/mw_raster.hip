@@ -37,8 +37,8 @@ __device__ inline void raster_kernel_body(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lds_recs = LDS_RECS ? (max_vis < MW_LDS_RECS ? max_vis : MW_LDS_RECS) : 0;
     float4 *s_shade = reinterpret_cast<float4 *>(smem);                                       // [max_vis][8]
-    float4 *s_cull = reinterpret_cast<float4 *>(smem + (size_t)lds_recs * MW_SHADE_REC * 4);  // [max_vis][6]
-    uint8_t *s_pack = smem + (size_t)lds_recs * (MW_SHADE_REC + MW_CULL_REC) * 4;             // 192 B
+    float4 *s_cull = reinterpret_cast<float4 *>(smem + (size_t)lds_recs * MW_LDS_SHADE_Q * 16);       // [lds_recs][5]
+    uint8_t *s_pack = smem + (size_t)lds_recs * (MW_LDS_SHADE_Q + MW_LDS_CULL_Q) * 16;                 // 192 B
 
     // XCD-aware block -> (env, part): the parts of one env run on the same XCD (block b is
     // dispatched to XCD b % 8), adjacent in time, so its records are fetched into one L2 once.
@@ -66,8 +66,9 @@ __device__ inline void raster_kernel_body(
     const float4 *g_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
     const bool in_lds = LDS_RECS && nvis <= lds_recs;
     if (in_lds) {
-        for (int i = lane; i < nvis * (MW_SHADE_REC / 4); i += 64) s_shade[i] = g_shade[i];
-        for (int i = lane; i < nvis * (MW_CULL_REC / 4); i += 64) s_cull[i] = g_cull[i];
+        // (the quads K2 reads: 7 of a shade record's 8, 5 of a classification record's 6)
+        for (int i = lane; i < nvis * MW_LDS_SHADE_Q; i += 64) { const int r = i / MW_LDS_SHADE_Q, q = i - r * MW_LDS_SHADE_Q; s_shade[i] = g_shade[r * (MW_SHADE_REC / 4) + q]; }
+        for (int i = lane; i < nvis * MW_LDS_CULL_Q; i += 64) { const int r = i / MW_LDS_CULL_Q, q = i - r * MW_LDS_CULL_Q; s_cull[i] = g_cull[r * (MW_CULL_REC / 4) + q]; }
         __syncthreads();
     }
     const float sky_r = envhdr[(size_t)env * MW_ENVHDR + 0], sky_g = envhdr[(size_t)env * MW_ENVHDR + 1],
@@ -79,7 +80,8 @@ __device__ inline void raster_kernel_body(
     te.flat = HOT ? 0 : (dbg & 1);
 
     TileCtx cx;
-    cx.s_shade = in_lds ? s_shade : g_shade; cx.s_cull = in_lds ? s_cull : g_cull; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH; cx.tprof = nullptr;
+    cx.s_shade = in_lds ? s_shade : g_shade; cx.s_cull = in_lds ? s_cull : g_cull;
+    cx.shade_stride = in_lds ? MW_LDS_SHADE_Q : MW_SHADE_REC / 4; cx.cull_stride = in_lds ? MW_LDS_CULL_Q : MW_CULL_REC / 4; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH; cx.tprof = nullptr;
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.planes = MESHAWARE ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
     cx.slow_frags = MESHAWARE ? slow_frags + (size_t)env * MW_SLOW_FRAGS : nullptr;
@@ -112,7 +114,7 @@ __device__ inline void raster_kernel_body(
                 G = min(per_group, t_end - tile);
                 gi = 0;
                 uint64_t T, F, Eo[3];
-                classify_group(s_cull, lane, nvis, tile, G, tiles_x, H, T, F, Eo);
+                classify_group(s_cull, MW_LDS_CULL_Q, lane, nvis, tile, G, tiles_x, H, T, F, Eo);
                 const int sh = lane < G ? lane * nvis : 0;
                 vT = (uint32_t)((T >> sh) & prim_mask); vF = (uint32_t)((F >> sh) & prim_mask);
                 if (nvis <= 16) {

@@ -226,8 +226,9 @@ __device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, 
 
 // Everything a wavefront needs to produce one 16x4 tile of one env.
 struct TileCtx {
-    const float4 *s_shade;          // [nvis][8]  shade records (LDS in K2, global in the mesh kernel)
-    const float4 *s_cull;           // [nvis][6]  classification records
+    const float4 *s_shade;          // [nvis][shade_stride]  shade records: in place (stride 8) or staged in LDS (their 7 used quads)
+    const float4 *s_cull;           // [nvis][cull_stride]   classification records: in place (6) or staged (5)
+    int shade_stride, cull_stride;
     const float *__restrict__ rr_env;   // [nvis][64] raster records (scalar loads)
     uint8_t *s_pack;                // 192 B of LDS per wavefront
     const float *hdr;               // env header (mesh kernel only)
@@ -253,11 +254,11 @@ struct TileCtx {
 // Tile classification of triangle lp against the tile whose pixels span [pxlo, pxhi] x [gylo, gyhi] (GL rows): the edge
 // value A px + B gy + C is monotone, so its extremes over the tile's pixels sit at corners:
 //   touch = every edge's maximum exceeds its smallest sample threshold, full = every edge's minimum exceeds its largest.
-__device__ inline void classify_prim(const float4 *s_cull, int lp, int pxlo, int pxhi, int gylo, int gyhi, bool &touch, bool &full,
+__device__ inline void classify_prim(const float4 *cr, int pxlo, int pxhi, int gylo, int gyhi, bool &touch, bool &full,
                                      uint32_t *edge_open = nullptr)
 {
-    const float4 A = s_cull[lp * 6 + 0], B = s_cull[lp * 6 + 1], C = s_cull[lp * 6 + 2];
-    const float4 TMIN = s_cull[lp * 6 + 3], TMAX = s_cull[lp * 6 + 4];
+    const float4 A = cr[0], B = cr[1], C = cr[2];
+    const float4 TMIN = cr[3], TMAX = cr[4];
     const int ea[3] = {__float_as_int(A.x), __float_as_int(A.y), __float_as_int(A.z)};
     const int eb[3] = {__float_as_int(B.x), __float_as_int(B.y), __float_as_int(B.z)};
     const int ec[3] = {__float_as_int(C.x), __float_as_int(C.y), __float_as_int(C.z)};
@@ -276,7 +277,7 @@ __device__ inline void classify_prim(const float4 *s_cull, int lp, int pxlo, int
 }
 
 // Classification of a GROUP of consecutive tiles in one pass, one (tile, triangle) pair per lane.
-__device__ inline void classify_group(const float4 *s_cull, int lane, int nvis, int tile0, int G, int tiles_x, int H,
+__device__ inline void classify_group(const float4 *s_cull, int cull_stride, int lane, int nvis, int tile0, int G, int tiles_x, int H,
                                       uint64_t &T, uint64_t &F, uint64_t (&Eo)[3])
 {
     const uint32_t inv_n = (65536u + (uint32_t)nvis - 1u) / (uint32_t)nvis;      // lane / nvis, exact for lane < 64
@@ -290,7 +291,7 @@ __device__ inline void classify_group(const float4 *s_cull, int lane, int nvis, 
         const uint32_t tx = idx - ty * (uint32_t)tiles_x;
         const int pxlo = (int)(tx * MW_TILE_W), pxhi = pxlo + MW_TILE_W - 1;
         const int gyhi = H - 1 - (int)(ty * MW_TILE_H), gylo = gyhi - (MW_TILE_H - 1);
-        classify_prim(s_cull, p, pxlo, pxhi, gylo, gyhi, touch, full, &eo);
+        classify_prim(s_cull + p * cull_stride, pxlo, pxhi, gylo, gyhi, touch, full, &eo);
     }
     T = __ballot(touch); F = __ballot(full);
 #pragma unroll
@@ -417,7 +418,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             } else {
                 const int lp = chunk + lane;
                 bool touch = lp < nvis, full = touch;
-                if (touch) classify_prim(s_cull, lp, pxlo, pxhi, gylo, gyhi, touch, full);
+                if (touch) classify_prim(s_cull + lp * cx.cull_stride, pxlo, pxhi, gylo, gyhi, touch, full);
                 todo = (pmask_t)__ballot(touch);
                 fullm = (pmask_t)__ballot(full);
             }
@@ -454,7 +455,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     covbits |= bits;
                     anycov_m |= any_m;
                 }
-                const RGB c = shade_uniform(s_shade + p * (MW_SHADE_REC / 4), te, px, gy);
+                const RGB c = shade_uniform(s_shade + p * cx.shade_stride, te, px, gy);
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     smp.r[s] = sel_mask(in_m[s], c.r, smp.r[s]);
@@ -462,7 +463,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     smp.b[s] = sel_mask(in_m[s], c.b, smp.b[s]);
                 }
                 if (has_depth) {
-                    const float4 zp = s_shade[p * (MW_SHADE_REC / 4) + 6];
+                    const float4 zp = s_shade[p * cx.shade_stride + 6];
                     z16 = sel_mask(in_m[0], depth16(zp.x, zp.y, zp.z, px, gy, 0), z16);
                 }
             }
@@ -489,8 +490,8 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 bool touch = lp < nvis, full = false;
                 if (touch) {
                     if (SORTED && sorted) pidx = (int)cx.order[1 + lp];
-                    classify_prim(s_cull, pidx, pxlo, pxhi, gylo, gyhi, touch, full);
-                    if (SORTED && sorted) zlo = __float_as_uint(s_cull[pidx * 6 + 2].w);
+                    classify_prim(s_cull + pidx * cx.cull_stride, pxlo, pxhi, gylo, gyhi, touch, full);
+                    if (SORTED && sorted) zlo = __float_as_uint(s_cull[pidx * cx.cull_stride + 2].w);
                 }
                 todo = (pmask_t)__ballot(touch);
             }
@@ -555,7 +556,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 sel = on ? mine : 0x20000u;
                 c = shade_mesh_winner(cx, mj, on ? mine : id, px, gy);
             } else {
-                c = shade_uniform(s_shade + rec * (MW_SHADE_REC / 4), te, px, gy);
+                c = shade_uniform(s_shade + rec * cx.shade_stride, te, px, gy);
             }
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
