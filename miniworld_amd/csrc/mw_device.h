@@ -18,8 +18,6 @@
 #define MW_SKY_PID 0xFFFFu
 #define MW_ENVHDR 640         // floats per env: sky, light colours, mesh-entity table (geometry kernel -> raster kernels)
 #define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
-#define MW_K3_THREADS 512     // threads of the mesh kernel's workgroup (one per CU: the key buffer fills the LDS): 8 wavefronts, 256 VGPRs each
-#define MW_K3_WAVE_LDS 192     // LDS bytes per wave of the mesh kernel beside the key buffer: its pack buffer
 #define MW_HDR_MESH 32        // first float of the mesh-entity table
 #define MW_HDR_MESH_STRIDE 28 // floats per entry: slot, first draw id, triangles, first triangle, texture, normal scale, light[3], mvp[16]
 
@@ -144,10 +142,6 @@ struct MwArgs {
     uint32_t *refill_mask;  // [N] 0 spare ready, 1 consumed (refill pending), 2 refill running, 3 env regenerating inline
     const MwArgs *gen_live; // device copies of this struct for the generators (live state / spare state): they index
     const MwArgs *gen_spare;//   it dynamically, which a by-value kernarg would turn into a scratch copy
-    // mesh kernel scheduling (longest processing time first): K1 leaves each env's mesh triangles in view,
-    // mw_mesh_order_kernel turns them into the order in which the mesh kernel's blocks take the envs
-    int32_t *k3_cost;       // [N]
-    int32_t *k3_order;      // [N] env ids, heaviest first
     int32_t *pending_remove; // [N] entity slot that leaves the list after this step's frame (-1 none): written by K1, applied by the geometry kernel
     unsigned long long *k1_prof;   // MW_K1_PROF: [N][8] cycle counters of K1's phases (perf experiments only), else null
 };

@@ -809,7 +809,6 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.rec_raster, (size_t)N * a.max_vis * MW_RASTER_REC);
     ALLOC(a.rec_shade, (size_t)N * a.max_vis * MW_SHADE_REC);
     ALLOC(a.rec_cull, (size_t)N * a.max_vis * MW_CULL_REC);
-    ALLOC(a.k3_cost, (size_t)N); ALLOC(a.k3_order, (size_t)N);
     if (cfg->max_visible > 64 && !(getenv("MW_SORT_VIS") && atoi(getenv("MW_SORT_VIS")) == 0)) {
         // big scenes: the visiting order the geometry kernel leaves for K2 (mw_geom.hip)
         ALLOC(a.rec_order, (size_t)N * (a.max_vis + 1));

@@ -26,7 +26,7 @@
 
 namespace {
 
-constexpr int kClipSlots = 24;      // work lists of the clipper in LDS: 2 x 10 vertices of 40 bytes each (19 KB)
+constexpr int kClipSlots = 24;      // work lists of the clipper in LDS: 2 x 10 vertices of 48 bytes each (23 KB)
 
 // exclusive scan inside the env's L-lane group; total: the group's sum
 __device__ inline int group_excl_scan(int v, int sub, int L, int &total)
@@ -129,8 +129,8 @@ __device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float
 template <bool BIG>
 __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, int n_env)
 {
-    // (201 dwords per slot: consecutive slots start in different LDS banks)
-    struct ClipSlot { mwgl::ClipVert l[2][MWGL_MAX_CLIP_VERTS]; float pad; };
+    // (244 dwords per slot: consecutive slots start in different LDS banks)
+    struct ClipSlot { mwgl::ClipVert l[2][MWGL_MAX_CLIP_VERTS]; float pad[4]; };
     __shared__ ClipSlot s_clip[kClipSlots];
     __shared__ int s_pos[8][66];
     __shared__ float s_occ_z[BIG ? MW_OCC_BINS + MW_OCC_BINS / 16 : 1];      // occlusion culling: farthest depth of the nearest wall per column bin, group maxima
@@ -766,7 +766,6 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     }
     if (sub == 0 && live) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
-        a.k3_cost[env] = total_mesh_tris;
         hdr[0] = (float)a.light[(size_t)0 * a.N + env]; hdr[1] = (float)a.light[(size_t)1 * a.N + env]; hdr[2] = (float)a.light[(size_t)2 * a.N + env];
         hdr[3] = __int_as_float(total_meshes);
 #pragma unroll

@@ -346,10 +346,11 @@ MW_HD void transform_vertex(const Frame &f, const Xform &x, const float p[3], Ve
 
 // the clipper's work-list vertex without the fields a flat-shaded primitive does not need there (colour: the same at every
 // vertex; clip mask: zero for every vertex the clipper makes) — 40 bytes instead of 56 in the geometry kernel's LDS lists
-struct ClipVert {
+struct alignas(16) ClipVert {       // (three 16-byte LDS accesses per copy)
     float clip[4];
     float win[4];
     float st[2];
+    float pad[2];
 };
 
 template <class V>
@@ -412,8 +413,10 @@ MW_HD int clip_triangle(const Frame &f, const Vert &a, const Vert &b, const Vert
             if ((dp >= 0.0f) != (dp_prev >= 0.0f)) {
                 // the new vertex is interpolated from the endpoint that is closer to the plane, whichever way the edge
                 // is traversed: both triangles sharing an edge get the same vertex
-                if (fabsf(dp) < fabsf(dp_prev)) clip_interp<GOURAUD>(f, outl[oc], dp / (dp - dp_prev), inl[cur], inl[prev]);
-                else clip_interp<GOURAUD>(f, outl[oc], dp_prev / (dp_prev - dp), inl[prev], inl[cur]);
+                // (one interpolation whichever way round: same arithmetic, half the code)
+                const bool from_cur = fabsf(dp) < fabsf(dp_prev);
+                const float t = from_cur ? dp / (dp - dp_prev) : dp_prev / (dp_prev - dp);
+                clip_interp<GOURAUD>(f, outl[oc], t, inl[from_cur ? cur : prev], inl[from_cur ? prev : cur]);
                 ++oc;
             }
             prev = cur;

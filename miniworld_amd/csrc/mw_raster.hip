@@ -81,7 +81,7 @@ __device__ inline void raster_kernel_body(
 
     TileCtx cx;
     cx.s_shade = in_lds ? s_shade : g_shade; cx.s_cull = in_lds ? s_cull : g_cull;
-    cx.shade_stride = in_lds ? MW_LDS_SHADE_Q : MW_SHADE_REC / 4; cx.cull_stride = in_lds ? MW_LDS_CULL_Q : MW_CULL_REC / 4; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH; cx.tprof = nullptr;
+    cx.shade_stride = in_lds ? MW_LDS_SHADE_Q : MW_SHADE_REC / 4; cx.cull_stride = in_lds ? MW_LDS_CULL_Q : MW_CULL_REC / 4; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH;
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.planes = MESHAWARE ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
     cx.slow_frags = MESHAWARE ? slow_frags + (size_t)env * MW_SLOW_FRAGS : nullptr;

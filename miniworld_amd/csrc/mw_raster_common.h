@@ -247,7 +247,6 @@ struct TileCtx {
     uint64_t pre_touch, pre_full, pre_clip;
     uint64_t pre_edges;
     int have_pre;
-    unsigned long long *tprof;
     const uint16_t *order;          // SORTED kernels: [0] sorted flag, [1 + k] list index of the k-th nearest triangle
 };
 

@@ -333,7 +333,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.te.texd = texd;
     cx.te.flat = 0;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
-    cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr; cx.tprof = nullptr;
+    cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr;
     cx.planes = nullptr; cx.slow_frags = nullptr; cx.slow_head = nullptr; cx.slow_stamp = 0u;
     cx.pre_touch = cx.pre_full = cx.pre_clip = cx.pre_edges = 0ull;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
