@@ -243,3 +243,42 @@ extern "C" int mwhost_render(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out
 
 // glibc's sinf / cosf against the restatement the device uses (exhaustive range test in tests/)
 extern "C" void mwhost_sincosf(float x, float *s, float *c) { sincosf_glibc(x, *s, *c); }
+
+// The geometry kernel clips flat-shaded triangles on compact work-list vertices (mwgl::ClipVert: no colour, no clip mask);
+// this hook runs both instantiations of the clipper on the same clip-space triangle and reports whether vertex count,
+// clip coordinates, window coordinates and texture coordinates agree bit for bit.
+extern "C" int mwhost_clip_variants_agree(const float clip[3][4], const float st[3][2], int W, int H)
+{
+    Frame f{};
+    f.vp_scale[0] = (float)W * 0.5f; f.vp_trans[0] = (float)W * 0.5f;
+    f.vp_scale[1] = (float)H * 0.5f; f.vp_trans[1] = (float)H * 0.5f;
+    f.vp_scale[2] = 0.5f; f.vp_trans[2] = 0.5f;
+    Vert v[3];
+    for (int k = 0; k < 3; ++k) {
+        for (int i = 0; i < 4; ++i) v[k].clip[i] = clip[k][i];
+        const float w = v[k].clip[3];
+        uint32_t m = 0;
+        if (v[k].clip[0] > w) m |= 1u;
+        if (v[k].clip[0] + w < 0.0f) m |= 2u;
+        if (v[k].clip[1] > w) m |= 4u;
+        if (v[k].clip[1] + w < 0.0f) m |= 8u;
+        if (v[k].clip[2] + w < 0.0f) m |= 16u;
+        if (v[k].clip[2] > w) m |= 32u;
+        v[k].clipmask = m;
+        const float oow = 1.0f / w;
+        for (int i = 0; i < 3; ++i) v[k].win[i] = fmaf(v[k].clip[i] * oow, f.vp_scale[i], f.vp_trans[i]);
+        v[k].win[3] = oow;
+        v[k].st[0] = st[k][0]; v[k].st[1] = st[k][1];
+        v[k].col[0] = 0.25f; v[k].col[1] = 0.5f; v[k].col[2] = 0.75f;
+    }
+    Vert a0[MWGL_MAX_CLIP_VERTS], a1[MWGL_MAX_CLIP_VERTS], *ra;
+    ClipVert b0[MWGL_MAX_CLIP_VERTS], b1[MWGL_MAX_CLIP_VERTS], *rb;
+    const int na = clip_triangle<false>(f, v[0], v[1], v[2], a0, a1, &ra);
+    const int nb = clip_triangle<false>(f, v[0], v[1], v[2], b0, b1, &rb);
+    if (na != nb) return 0;
+    for (int i = 0; i < na; ++i) {
+        if (memcmp(ra[i].clip, rb[i].clip, 16) || memcmp(ra[i].win, rb[i].win, 16) || memcmp(ra[i].st, rb[i].st, 8)) return 0;
+        if (ra[i].col[0] != 0.25f || ra[i].col[1] != 0.5f || ra[i].col[2] != 0.75f) return 0;
+    }
+    return 1 + na;
+}

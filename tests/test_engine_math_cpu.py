@@ -73,3 +73,19 @@ def test_device_sinf_cosf_restate_glibc(host):
     for x in xs:
         host.mwhost_sincosf(float(x), C.byref(s), C.byref(c))
         assert s.value == libm.sinf(float(x)) and c.value == libm.cosf(float(x)), float(x)
+
+
+def test_compact_clip_vertices_clip_like_full_ones(host):
+    """The geometry kernel's work lists hold mwgl::ClipVert (clip, window, texture coordinates: a flat primitive's colour
+    stays in registers); the clipper instantiated on them yields the same polygon as on full vertices, bit for bit."""
+    rng = np.random.default_rng(5)
+    host.mwhost_clip_variants_agree.restype = C.c_int
+    clipped = 0
+    for _ in range(4000):
+        clip = rng.normal(0, 1.5, (3, 4)).astype(np.float32)
+        clip[:, 3] = rng.uniform(-0.5, 2.5, 3).astype(np.float32)
+        st = rng.uniform(-2, 2, (3, 2)).astype(np.float32)
+        r = host.mwhost_clip_variants_agree(clip.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), 80, 60)
+        assert r >= 1, (clip, st)
+        clipped += r > 1
+    assert clipped > 500        # plenty of them really went through the planes
