@@ -1,22 +1,21 @@
-// K2 — the dominant kernel: 8x-MSAA coverage + 16-bit depth + deferred trilinear shading +
-// resolve + pack, for every environment.  Replaces what the reference delegates to the GL
-// driver per step: glClear, rasterisation/depth test of display list 1 and the entity
-// draws, GL_MODULATE texturing, FrameBuffer.resolve()'s two blits + glReadPixels + flip
-// (miniworld.py:1064-1086, 1193-1195; opengl.py:339-398) and get_depth_map (opengl.py:400-435).
+// K2 — the dominant kernel: 8x-MSAA coverage + 16-bit depth + GL_LINEAR_MIPMAP_LINEAR shading + resolve + pack, for every
+// environment.  Replaces what the reference delegates to the GL driver per step: glClear, rasterisation / depth test of
+// display list 1 and the entity draws, GL_MODULATE texturing, FrameBuffer.resolve()'s two blits + glReadPixels + flip
+// (miniworld.py:1064-1086, 1193-1195; opengl.py:339-398) and get_depth_map (opengl.py:400-435) — llvmpipe's fragment
+// pipeline (mw_frag.h).
 //
-// Mapping: one 64-lane wavefront (= one workgroup) owns a run of 16x4-pixel tiles of one
-// env; lane l is pixel (l & 15, l >> 4) of the tile and keeps its 8 samples' packed keys
-// (depth16 << 16 | draw index) in 8 VGPRs — no depth buffer in memory at all.
-//   coverage : per (tile, primitive) the 64-dword raster record is wave-uniform and arrives
-//              through scalar loads (SGPRs); a sample is inside edge k iff E_k(pixel centre)
-//              > thr_k[s] (R4/R5: thresholds precomputed by K1 with the top-left rule folded
-//              in), so coverage is 2 FMA + 8 v_cmp per edge with the mask algebra on the SALU.
-//   depth    : GL_LESS with first-drawn-wins == unsigned min of the packed keys (R6).
-//   shading  : deferred — each lane shades each *distinct* winning primitive of its pixel once
-//              at the pixel centre (GL multisample semantics, R9), ascending draw index (R12).
+// Mapping: one 64-lane wavefront (= one workgroup) owns a run of 16x4-pixel tiles of one env; lanes are pixels, quad by
+// quad (mw_raster_common.h), each with its 8 samples' colours — and, where triangles contend for samples, their packed
+// keys (depth16 << 16 | draw id) — in registers: no colour or depth buffer in memory at all.
+//   coverage : per (tile, triangle) the raster record is wave-uniform and arrives through scalar loads (SGPRs); a sample
+//              is inside edge k iff E_k(pixel) > thr_k[s] (integer edge functions, fill rule folded into C_k): 2 mul24 +
+//              8 v_cmp per edge, the mask algebra on the SALU.
+//   depth    : GL_LESS with first-drawn-wins == unsigned min of the packed keys; not needed while no sample is claimed twice.
+//   shading  : each distinct triangle of the tile once for the whole wavefront (GL multisampling shades a pixel once per
+//              triangle, at the pixel centre), the quad's texture-coordinate differences through DPP.
 //   output   : RGB bytes staged through 192 B of LDS so the tile leaves as dword stores.
-// HBM traffic per env-step is the observation (14 400 B, + 19 200 B with depth) plus the
-// K1 records; textures and records are L2-resident.
+// HBM traffic per env-step is the observation (14 400 B, + 19 200 B with depth) plus the geometry kernel's records; textures
+// and records are L2-resident.
 #include "mw_mesh.h"
 
 // LDS_RECS = true : the env's shade / classification records are staged in LDS (small scenes);

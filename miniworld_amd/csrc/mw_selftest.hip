@@ -1,6 +1,6 @@
 // Test hooks that need the GPU but no engine (tests/test_gpu_numerics.py).
 //
-// mw_selftest_rcp: the raster kernels take 1 / W of the perspective-correct interpolation (R7) with rcp_exact()
+// mw_selftest_rcp: the raster kernels take 1 / W of the perspective-correct interpolation with rcp_exact()
 // (mw_raster_common.h: hardware reciprocal estimate + one fused Newton step) instead of the compiler's IEEE division
 // sequence (11 instructions).  "Same result as the oracle's 1.0f / x" is a claim about every float: this kernel
 // evaluates both for ALL 2^32 bit patterns and counts where they differ, per binade, so that the guard range inside
@@ -15,7 +15,7 @@ extern "C" __global__ void mw_selftest_rcp_kernel(unsigned long long *bad_per_ex
     for (uint64_t b = tid; b < (1ull << 32); b += stride) {
         const float x = __uint_as_float((uint32_t)b);
         const float want = 1.0f / x;                 // correctly rounded (hipcc default: -fhip-fp32-correctly-rounded-divide-sqrt)
-        const float got = rcp_domain(x) ? rcp_exact(x) : want;      // the callers' guard (R7)
+        const float got = rcp_domain(x) ? rcp_exact(x) : want;      // the callers' guard
         const bool same = __float_as_uint(want) == __float_as_uint(got) || (want != want && got != got);
         if (!same) {
             atomicAdd(&bad_per_exp[(b >> 23) & 511u], 1ull);           // sign | exponent

@@ -157,10 +157,10 @@ def test_oracle_visible_ents_geometry():
 
 
 def test_polygon_fragments_stay_inside_their_vertex_depth_range():
-    """R6p: the depth plane of a polygon comes from its vertices' window coordinates in binary64, so
-    the 16-bit depth of every fragment lies between the depths of the polygon's nearest and farthest vertex — also for
-    polygons seen edge-on (wall stubs a fraction of a pixel wide, far floors a pixel high), where the 2DH sums of R6 were
-    off by dozens to hundreds of steps.  K1's occlusion culling relies on it (mw_setup.hip)."""
+    """llvmpipe's depth plane comes from the (clipped) vertices' window coordinates, so the
+    16-bit depth of every fragment lies between the depths of the polygon's nearest and farthest vertex — also for polygons
+    seen edge-on (wall stubs a fraction of a pixel wide, far floors a pixel high).  The geometry kernel's occlusion culling
+    relies on it (mw_geom.hip)."""
     sc, _ = _empty_scene()
     rng = np.random.default_rng(7)
     W, H, ch, fov = 160, 120, 1.5, 60.0
