@@ -96,7 +96,7 @@ struct MwArgs {
     int32_t task, goal_ent, num_objs, max_steps;
     int32_t domain_rand, generator, autoreset, tiles_x;
     int32_t tiles_y, n_tiles, goal_ent2, env_base;    // env_base: first env of this launch (0 for the batched step)
-    int32_t rng_mode, occlusion;    // occlusion: K1 of big scenes drops room polygons hidden behind full-height walls (mw_setup.hip; MW_OCCLUSION=0 turns it off)
+    int32_t rng_mode, occlusion;    // occlusion: the geometry kernel of big scenes drops room polygons hidden behind full-height walls (mw_geom.hip; MW_OCCLUSION=0 turns it off)
     double agent_radius, max_forward_step, agent_height;
     mw_range fwd, drift, turn;
     mw_range sky[3], light_pos[3], light_color[3], light_ambient[3], color_bias[3];
@@ -143,5 +143,5 @@ struct MwArgs {
     const MwArgs *gen_live; // device copies of this struct for the generators (live state / spare state): they index
     const MwArgs *gen_spare;//   it dynamically, which a by-value kernarg would turn into a scratch copy
     int32_t *pending_remove; // [N] entity slot that leaves the list after this step's frame (-1 none): written by K1, applied by the geometry kernel
-    unsigned long long *k1_prof;   // MW_K1_PROF: [N][8] cycle counters of K1's phases (perf experiments only), else null
+    unsigned long long *k1_prof;   // MW_K1_PROF: [N][8] cycle counters of the geometry kernel's phases (tools/perf/kgprof.py; perf experiments only), else null
 };

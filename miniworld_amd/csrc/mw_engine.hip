@@ -175,11 +175,8 @@ auto k1_of(const mw_engine *e) -> decltype(&mw_step_setup_kernel)
 
 int k1_threads(const mw_engine *) { return 64; }
 
-// Lanes per env of the dense K1 (mw_setup_dense.hip: one lane per room polygon + six per entity slot), or 0 when the
-// frame has to go through the wave-per-env kernel: big scenes, mesh entities, spare-world mode, other views,
-// or too many primitive slots to pack two envs into a wavefront.  MW_K1_DENSE=0 switches it off (A/B runs).
-// lanes per env of the geometry kernel: the power of two that holds an env's primitives (polygons, six faces per box,
-// the agent marker), 8 .. 64
+// lanes per env of the geometry kernel: the power of two that holds an env's triangles (two per polygon and box face, the
+// agent marker), 8 .. 64
 int geom_lanes(const mw_engine *e)
 {
     const int items = 2 * (e->cfg.max_polys + 6 * e->cfg.max_ents + 1);      // one triangle per lane
@@ -188,6 +185,8 @@ int geom_lanes(const mw_engine *e)
     return L;
 }
 
+// Lanes per env of the dense K1 (mw_setup_dense.hip), or 0 when the step has to go through the wave-per-env kernel: big
+// scenes, CollectHealth, or too many slots to pack two envs into a wavefront.  MW_K1_DENSE=0 switches it off (A/B runs).
 int k1_dense_lanes(const mw_engine *e, int view_flags)
 {
     if (e->args.rec_order || view_flags != 0 || !e->k1_dense || e->cfg.task == MW_TASK_COLLECT) return 0;
@@ -819,7 +818,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
-    if (getenv("MW_K1_PROF")) {     // perf experiments only: per-env cycle stamps of K1's phases, dumped by mw_destroy
+    if (getenv("MW_K1_PROF")) {     // perf experiments only: per-env cycle stamps of the geometry kernel's phases, dumped by mw_destroy
         ALLOC(a.k1_prof, 8 * (size_t)N);
         if (rc == MW_OK) (void)hipMemset(a.k1_prof, 0, 64 * (size_t)N);
     }
@@ -1234,7 +1233,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     MwArgs b = e->args;
     b.step_override = nullptr;
     b.env_base = first_env;
-    // K1 in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
+    // the geometry kernel in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
     {
         const int L = geom_lanes(e), epw = 64 / L;
         hipLaunchKernelGGL(L == 64 ? mw_geom_big_kernel : mw_geom_kernel, dim3((count + epw - 1) / epw), dim3(64), 0, st, b, 4, e->cfg.msaa, L, count);
