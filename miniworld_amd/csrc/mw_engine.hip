@@ -85,7 +85,7 @@ struct mw_engine {
     std::vector<void *> allocs;
     // textures
     std::vector<MwTexDesc> tex_desc;
-    std::vector<std::vector<uint32_t>> tex_data;   // per texture: every level as 16-byte footprint records (build_pyramid)
+    std::vector<std::vector<uint32_t>> tex_data;   // per texture: every level as 32-byte footprint records (build_pyramid)
     uint32_t *d_texels = nullptr;
     MwTexDesc *d_texdesc = nullptr;
     MwMeshDesc *d_meshdesc = nullptr;
@@ -271,20 +271,25 @@ void build_pyramid(const uint8_t *rgb, int w, int h, std::vector<uint32_t> &out,
     desc.w = (uint32_t)w; desc.h = (uint32_t)h; desc.nlevels = 0; desc.pad = 0;
     out.clear();
     for (;;) {
-        // a level is stored as one 16-byte record per texel (i, j): the four texels of its GL_LINEAR footprint
-        // (i, j), (i+1, j), (i, j+1), (i+1, j+1), GL_REPEAT applied — a bilinear tap is ONE 16-byte load and needs
-        // neither the neighbour indices nor their wrap (4x the memory: the coarse levels an 80x60 frame samples stay
-        // cache resident all the same).  Level::off counts these records from the start of the texture.
-        desc.lvl[desc.nlevels++] = MwTexDesc::Level{(uint32_t)(out.size() / 4), (uint32_t)w, (uint32_t)w - 1u, (uint32_t)h - 1u, (float)w, (float)h, (uint32_t)h, 0u};
-        auto texel = [&](int i, int j) {
-            const size_t k = ((size_t)(j % h) * w + (size_t)(i % w)) * 3;
-            return (uint32_t)cur[k] | ((uint32_t)cur[k + 1] << 8) | ((uint32_t)cur[k + 2] << 16) | 0xFF000000u;
-        };
+        // a level is stored as one 32-byte record per texel (i, j): its GL_LINEAR footprint (i, j), (i+1, j), (i, j+1),
+        // (i+1, j+1), GL_REPEAT applied, laid out for the filter's first step.  The lerp along x of a channel's two texels
+        // a, b under the 8-bit weight w, a + ((w (b - a) + 128) >> 8), is ((a * 256 + 128) + w * (b - a)) >> 8 in 16-bit
+        // arithmetic (the sum stays in [128, 65408]); a record holds A = a * 256 + 128 and D = (b - a) mod 2^16, two
+        // channels to a dword: row j as (A_r | A_b << 16, D_r | D_b << 16, A_g, D_g), then row j + 1 the same.  A bilinear
+        // tap is two 16-byte loads, needs neither the neighbours' indices nor their wrap nor any unpacking, and its
+        // x step is one packed multiply-add and one packed shift per pair of channels (8x the memory of the texels: the
+        // coarse levels an 80x60 frame samples stay cache resident all the same).  Level::off counts records from the
+        // start of the pool.
+        desc.lvl[desc.nlevels++] = MwTexDesc::Level{(uint32_t)(out.size() / 8), (uint32_t)w, (uint32_t)w - 1u, (uint32_t)h - 1u, (float)w, (float)h, (uint32_t)h, 0u};
+        auto chan = [&](int i, int j, int c) { return (uint32_t)cur[((size_t)(j % h) * w + (size_t)(i % w)) * 3 + c]; };
+        auto A = [&](int i, int j, int c) { return chan(i, j, c) * 256u + 128u; };
+        auto D = [&](int i, int j, int c) { return (chan(i + 1, j, c) - chan(i, j, c)) & 0xFFFFu; };
         for (int j = 0; j < h; ++j)
-            for (int i = 0; i < w; ++i) {
-                out.push_back(texel(i, j)); out.push_back(texel(i + 1, j));
-                out.push_back(texel(i, j + 1)); out.push_back(texel(i + 1, j + 1));
-            }
+            for (int i = 0; i < w; ++i)
+                for (int r = 0; r < 2; ++r) {
+                    out.push_back(A(i, j + r, 0) | (A(i, j + r, 2) << 16)); out.push_back(D(i, j + r, 0) | (D(i, j + r, 2) << 16));
+                    out.push_back(A(i, j + r, 1)); out.push_back(D(i, j + r, 1));
+                }
         if ((w == 1 && h == 1) || desc.nlevels == MW_MAX_LEVELS) break;
         const int nw = std::max(1, w / 2), nh = std::max(1, h / 2);
         nxt.assign((size_t)nw * nh * 3, 0);
@@ -313,9 +318,9 @@ int upload_textures(mw_engine *e)
     const size_t table = (size_t)MW_MAX_TEX * sizeof(MwTexDesc) / 4;       // dwords
     size_t total = table;
     std::vector<MwTexDesc> descs = e->tex_desc;
-    static_assert((MW_MAX_TEX * sizeof(MwTexDesc)) % 16 == 0, "footprint records are 16-byte aligned behind the table");
+    static_assert((MW_MAX_TEX * sizeof(MwTexDesc)) % 32 == 0, "footprint records are 32-byte aligned behind the table");
     for (size_t i = 0; i < descs.size(); ++i) {
-        for (uint32_t l = 0; l < descs[i].nlevels; ++l) descs[i].lvl[l].off += (uint32_t)(total / 4);      // in 16-byte records
+        for (uint32_t l = 0; l < descs[i].nlevels; ++l) descs[i].lvl[l].off += (uint32_t)(total / 8);      // in 32-byte records
         total += e->tex_data[i].size();
     }
     if (total * 4 > 0xFFFFFFF0ull) return fail(e, MW_E_CAPACITY, "texture pool of %zu bytes exceeds one buffer resource", total * 4);

@@ -138,6 +138,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     __shared__ int s_occ_n;
     __shared__ uint16_t s_list[BIG ? 4096 : 1];
     __shared__ uint32_t s_key[BIG ? MW_ORDER_CAP : 1];        // big scenes: (depth bound << 16 | list index) of every record, for the visiting order      // big scenes: the polygons that pass the cheap tests (frustum, occlusion), in drawing order
+    const unsigned long long tstart = __builtin_readcyclecounter();
     const int lane = threadIdx.x;
     const int epw = 64 / L, sub = lane & (L - 1), grp = lane / L;
     const int rel = (int)blockIdx.x * epw + grp;
@@ -761,7 +762,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     }
     if (a.k1_prof && sub == 0 && live) {
         unsigned long long *pp = a.k1_prof + (size_t)env * 8;
-        pp[0] = tp[0] - tp0; for (int i = 1; i < 7; ++i) pp[i] = tp[i] - tp[i - 1];
+        pp[0] = tp[0] - tstart; (void)tp0; for (int i = 1; i < 7; ++i) pp[i] = tp[i] - tp[i - 1];
         pp[7] = __builtin_readcyclecounter() - tp[6];
     }
     if (sub == 0 && live) {

@@ -55,7 +55,39 @@ struct TexEnv {
     int flat;
 };
 
-// GL_LINEAR lookup on mip level l of the texture whose descriptor starts at dword `desc`: one 16-byte footprint record
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+// mwgl::lerp8 on two 16-bit lanes at once: a + ((w (b - a) + 128) >> 8) == (a (256 - w) + b w + 128) >> 8, which stays
+// below 2^16 for 8-bit a, b, w.  w, iw: the weight and 256 - weight in both halves.
+__device__ inline uint32_t lerp8_pk(uint32_t a, uint32_t b, uint32_t w, uint32_t iw)
+{
+    // (the rounding term comes out of a register the compiler cannot see through: b w + 128 and a iw + that are two
+    // packed multiply-adds; a visible constant is moved to the end of the sum and costs a third instruction)
+    uint32_t half;
+    asm("s_mov_b32 %0, 0x00800080" : "=s"(half));
+    const u16x2 av = __builtin_bit_cast(u16x2, a), bv = __builtin_bit_cast(u16x2, b), wv = __builtin_bit_cast(u16x2, w), iv = __builtin_bit_cast(u16x2, iw);
+    const u16x2 r = (av * iv + (bv * wv + __builtin_bit_cast(u16x2, half))) >> (u16x2)(8);
+    return __builtin_bit_cast(uint32_t, r);
+}
+__device__ inline uint32_t weight_pk(int w) { return (uint32_t)w | ((uint32_t)w << 16); }
+// ... given A = a * 256 + 128 and D = b - a (the footprint records of mw_engine.hip::build_pyramid): (A + w D) >> 8
+__device__ inline uint32_t lerp8_ad(uint32_t A, uint32_t D, uint32_t w)
+{
+    const u16x2 av = __builtin_bit_cast(u16x2, A), dv = __builtin_bit_cast(u16x2, D), wv = __builtin_bit_cast(u16x2, w);
+    const u16x2 r = (dv * wv + av) >> (u16x2)(8);
+    return __builtin_bit_cast(uint32_t, r);
+}
+
+// mwgl::bilerp_rgb on the footprint record whose index in the texel pool is rec: x first, then y; R | B << 16 and G
+__device__ inline void bilerp_rec(const TexEnv &te, uint32_t rec, int wx8, int wy8, uint32_t &rb, uint32_t &g)
+{
+    const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(te.tx, rec << 5, 0, 0);
+    const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(te.tx, (rec << 5) + 16u, 0, 0);
+    const uint32_t wx = weight_pk(wx8), wy = weight_pk(wy8), iy = 0x01000100u - wy;
+    rb = lerp8_pk(lerp8_ad(r0.x, r0.y, wx), lerp8_ad(r1.x, r1.y, wx), wy, iy);
+    g = lerp8_pk(lerp8_ad(r0.z, r0.w, wx), lerp8_ad(r1.z, r1.w, wx), wy, iy);
+}
+
+// GL_LINEAR lookup on mip level l of the texture whose descriptor starts at dword `desc`: one 32-byte footprint record
 // (the texel and its right / upper / diagonal neighbours, GL_REPEAT applied: mw_engine.hip::build_pyramid), 8-bit weights
 __device__ inline void fetch_level(const TexEnv &te, uint32_t desc, int l, float s, float t, int out[3])
 {
@@ -66,8 +98,9 @@ __device__ inline void fetch_level(const TexEnv &te, uint32_t desc, int l, float
     int i0, j0, wx, wy;
     mwgl::linear_coord(s, w, (w & (w - 1)) == 0, i0, wx);
     mwgl::linear_coord(t, h, (h & (h - 1)) == 0, j0, wy);
-    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(te.tx, (a4.x + __umul24((uint32_t)j0, (uint32_t)w) + (uint32_t)i0) << 4, 0, 0);
-    mwgl::bilerp_rgb(q.x, q.y, q.z, q.w, wx, wy, out);
+    uint32_t rb, g;
+    bilerp_rec(te, a4.x + __umul24((uint32_t)j0, (uint32_t)w) + (uint32_t)i0, wx, wy, rb, g);
+    out[0] = (int)(rb & 255u); out[1] = (int)(g & 255u); out[2] = (int)((rb >> 16) & 255u);
 }
 
 // fragment colour from a triangle's attribute planes at GL pixel (px, gy); eo: where the pixel centre sits in the planes'
@@ -141,32 +174,15 @@ template <int L> __device__ inline float quad_bcast(float v)
     return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), L * 0x55, 0xF, 0xF, true));
 }
 
-typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
-// mwgl::lerp8 on two 16-bit lanes at once: a + ((w (b - a) + 128) >> 8) == (a (256 - w) + b w + 128) >> 8, which stays
-// below 2^16 for 8-bit a, b, w.  w, iw: the weight and 256 - weight in both halves.
-__device__ inline uint32_t lerp8_pk(uint32_t a, uint32_t b, uint32_t w, uint32_t iw)
-{
-    const u16x2 av = __builtin_bit_cast(u16x2, a), bv = __builtin_bit_cast(u16x2, b), wv = __builtin_bit_cast(u16x2, w), iv = __builtin_bit_cast(u16x2, iw);
-    const u16x2 r = ((av * iv + (u16x2)(128)) + bv * wv) >> (u16x2)(8);
-    return __builtin_bit_cast(uint32_t, r);
-}
-__device__ inline uint32_t weight_pk(int w) { return (uint32_t)w | ((uint32_t)w << 16); }
-
 // GL_LINEAR on level l of a texture whose level-0 sizes are powers of two (lw0, lh0: their logarithms): result as
 // R | B << 16 and G (low byte) — mwgl::linear_coord / bilerp_rgb with the size scaling as an exponent add
 __device__ inline void fetch_level_pot(const TexEnv &te, uint32_t desc, int lw0, int lh0, int l, float s, float t, uint32_t &rb, uint32_t &ag)
 {
     const uint32_t off = ldw(te.td, desc + 4u + (uint32_t)l * 8u);
-    const int lw = lw0 > l ? lw0 - l : 0, lh = lh0 > l ? lh0 - l : 0;
+    const int lw = max(lw0 - l, 0), lh = max(lh0 - l, 0);
     const int fx = (int)rintf(ldexpf(s, lw + 8)) - 128, fy = (int)rintf(ldexpf(t, lh + 8)) - 128;
     const uint32_t i0 = (uint32_t)(fx >> 8) & ((1u << lw) - 1u), j0 = (uint32_t)(fy >> 8) & ((1u << lh) - 1u);
-    const u32x4 q = __builtin_amdgcn_raw_buffer_load_b128(te.tx, (off + (j0 << lw) + i0) << 4, 0, 0);
-    const uint32_t wx = weight_pk(fx & 255), ix = 0x01000100u - wx, wy = weight_pk(fy & 255), iy = 0x01000100u - wy;
-    const uint32_t M = 0x00FF00FFu;
-    const uint32_t rb0 = lerp8_pk(q.x & M, q.y & M, wx, ix), rb1 = lerp8_pk(q.z & M, q.w & M, wx, ix);
-    const uint32_t ag0 = lerp8_pk((q.x >> 8) & M, (q.y >> 8) & M, wx, ix), ag1 = lerp8_pk((q.z >> 8) & M, (q.w >> 8) & M, wx, ix);
-    rb = lerp8_pk(rb0, rb1, wy, iy);
-    ag = lerp8_pk(ag0, ag1, wy, iy);
+    bilerp_rec(te, off + (j0 << lw) + i0, fx & 255, fy & 255, rb, ag);
 }
 
 // fragment colour of the triangle with shade record sr — the SAME record for all 64 lanes — at the lane's pixel of a
