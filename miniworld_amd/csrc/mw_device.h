@@ -19,6 +19,9 @@
 #define MW_ENVHDR 640         // floats per env: sky, light colours, mesh-entity table (geometry kernel -> raster kernels)
 #define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
 #define MW_HDR_MESH 32        // first float of the mesh-entity table
+#define MW_OCC_CACHE_HDR 8
+// floats per set: header, 8 per wall, 8 per box of eight polygons; whole 128-byte lines
+#define MW_OCC_CACHE_STRIDE(max_polys) ((MW_OCC_CACHE_HDR + 8 * (size_t)(max_polys) + 8 * (size_t)(((max_polys) + 7) / 8) + 31) / 32 * 32)
 #define MW_HDR_MESH_STRIDE 28 // floats per entry: slot, first draw id, triangles, first triangle, texture, normal scale, light[3], mvp[16]
 
 // status bits written by kernels, read by mw_check()
@@ -143,5 +146,9 @@ struct MwArgs {
     const MwArgs *gen_live; // device copies of this struct for the generators (live state / spare state): they index
     const MwArgs *gen_spare;//   it dynamically, which a by-value kernarg would turn into a scratch copy
     int32_t *pending_remove; // [N] entity slot that leaves the list after this step's frame (-1 none): written by K1, applied by the geometry kernel
+    // big scenes: what the geometry kernel's culling derives from a world's polygons alone (mw_geom.hip), kept from frame to
+    // frame.  occ_valid[set]: polygon count + 1 of the world the cache belongs to, 0 after anything rewrote the polygons.
+    int32_t *occ_valid;     // [sets] or null
+    float *occ_cache;       // [sets][MW_OCC_CACHE_STRIDE(max_polys)]
     unsigned long long *k1_prof;   // MW_K1_PROF: [N][8] cycle counters of the geometry kernel's phases (tools/perf/kgprof.py; perf experiments only), else null
 };

@@ -482,7 +482,7 @@ int sync_gen_args(mw_engine *e)
         sa.ax = sp.ax; sa.ay = sp.ay; sa.az = sp.az; sa.adir = sp.adir; sa.cam = sp.cam; sa.light = sp.light; sa.extent = sp.extent;
         sa.ekind = sp.ekind; sa.emesh = sp.emesh; sa.estatic = sp.estatic; sa.epos = sp.epos; sa.edir = sp.edir; sa.egeom = sp.egeom;
         sa.carry = e->d_spare_dummy; sa.step = e->d_spare_dummy + e->cfg.num_envs; sa.picked = e->d_spare_dummy + 2 * (size_t)e->cfg.num_envs;
-        if (!e->cfg.shared_geometry) { sa.polys = sp.polys; sa.npolys = sp.npolys; sa.segs = sp.segs; sa.nsegs = sp.nsegs; }
+        if (!e->cfg.shared_geometry) { sa.polys = sp.polys; sa.npolys = sp.npolys; sa.segs = sp.segs; sa.nsegs = sp.nsegs; sa.occ_valid = nullptr; sa.occ_cache = nullptr; }
         sa.spare = nullptr;
         HIP_TRY(e, hipMemcpy(e->d_gen_spare, &sa, sizeof sa, hipMemcpyHostToDevice));
     }
@@ -645,7 +645,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
                 HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
             }
-            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(8, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(getenv("MW_SLOW_BX") ? atoi(getenv("MW_SLOW_BX")) : 8, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
                                a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, N, parity, (const uint32_t *)e->d_slow_tris,
                                e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status);
         }
@@ -817,6 +817,11 @@ int mw_create(const mw_config *cfg, mw_engine **out)
         // big scenes: the visiting order the geometry kernel leaves for K2 (mw_geom.hip)
         ALLOC(a.rec_order, (size_t)N * (a.max_vis + 1));
         if (rc == MW_OK) (void)hipMemset(a.rec_order, 0, (size_t)N * (a.max_vis + 1) * 2);
+    }
+    if (cfg->max_polys > 64 && !(getenv("MW_OCC_CACHE") && atoi(getenv("MW_OCC_CACHE")) == 0)) {
+        // big scenes: the geometry kernel's per-world culling data (mw_geom.hip), zeroed = nothing cached
+        ALLOC(a.occ_valid, e->n_sets);
+        ALLOC(a.occ_cache, (size_t)e->n_sets * MW_OCC_CACHE_STRIDE(cfg->max_polys));
     }
     ALLOC(a.pending_remove, (size_t)N);
     if (rc == MW_OK) (void)hipMemset(a.pending_remove, 0xFF, 4 * (size_t)N);
@@ -1009,6 +1014,7 @@ int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_p
     }
     HIP_TRY(e, hipMemcpy(const_cast<mw_poly *>(e->args.polys) + (size_t)set * e->cfg.max_polys, polys, sizeof(mw_poly) * (size_t)n_polys, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(const_cast<int32_t *>(e->args.npolys) + set, &n_polys, 4, hipMemcpyHostToDevice));
+    if (e->args.occ_valid) HIP_TRY(e, hipMemset(e->args.occ_valid + set, 0, 4));
     HIP_TRY(e, hipMemcpy(const_cast<double *>(e->args.segs) + (size_t)set * e->cfg.max_segs * 4, segs, 32 * (size_t)n_segs, hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(const_cast<int32_t *>(e->args.nsegs) + set, &n_segs, 4, hipMemcpyHostToDevice));
     return MW_OK;

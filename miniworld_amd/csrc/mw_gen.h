@@ -281,6 +281,7 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
         }
         if (lane == 0) {
             const_cast<int32_t *>(a.npolys)[set] = np_base;
+            if (a.occ_valid) a.occ_valid[set] = 0;
             const_cast<int32_t *>(a.nsegs)[set] = ns_base;
         }
     }
@@ -407,6 +408,7 @@ __device__ inline void prog_static_data(const MwArgs &a, int env, int set, Rng &
     double *sd = const_cast<double *>(a.segs) + (size_t)set * a.max_segs * 4;
     for (int i = 0; i < P.n_segs * 4; ++i) sd[i] = P.segs[i];
     const_cast<int32_t *>(a.npolys)[set] = P.n_polys;
+    if (a.occ_valid) a.occ_valid[set] = 0;
     const_cast<int32_t *>(a.nsegs)[set] = P.n_segs;
     __threadfence();        // the placements below test against these segments
 }
@@ -572,6 +574,7 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
         int np = 0, ns = 0;
         emit_room(a, set, rt, px, pz, 15u, np, ns);
         const_cast<int32_t *>(a.npolys)[set] = np;
+        if (a.occ_valid) a.occ_valid[set] = 0;
         const_cast<int32_t *>(a.nsegs)[set] = ns;
     };
     // PickupObjects draws its first object's kind and colour before the first placement; the Philox
@@ -725,7 +728,7 @@ __device__ inline void take_spare(const MwArgs &a, int env, int lane)
         const double *ss = sp.segs + (size_t)env * a.max_segs * 4;
         double *sd = const_cast<double *>(a.segs) + (size_t)env * a.max_segs * 4;
         for (int i = lane; i < ns * 4; i += 64) sd[i] = ss[i];
-        if (lane == 0) { const_cast<int32_t *>(a.npolys)[env] = np; const_cast<int32_t *>(a.nsegs)[env] = ns; }
+        if (lane == 0) { const_cast<int32_t *>(a.npolys)[env] = np; const_cast<int32_t *>(a.nsegs)[env] = ns; if (a.occ_valid) a.occ_valid[env] = 0; }
     }
 }
 
@@ -787,6 +790,7 @@ __device__ inline void take_spare_lane(const MwArgs &a, int env)
             sd[i * 4] = s0; sd[i * 4 + 1] = s1; sd[i * 4 + 2] = s2; sd[i * 4 + 3] = s3;
         }
         const_cast<int32_t *>(a.npolys)[env] = np; const_cast<int32_t *>(a.nsegs)[env] = ns;
+        if (a.occ_valid) a.occ_valid[env] = 0;
     }
 }
 

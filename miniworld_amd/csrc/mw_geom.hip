@@ -90,17 +90,10 @@ __device__ inline bool tri_front(const float wa[4], const float wb[4], const flo
 #define MW_ORDER_CAP 512       // big scenes: lists up to this length get a near-to-far visiting order
 
 // occ_z[0 .. BINS): the bins; occ_z[BINS .. BINS + BINS / 16): the largest value of every group of 16 bins
-__device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float bins_per_px)
+// Is everything with window x in [xlo, xhi] and depth >= zq hidden?
+__device__ inline bool occluded_span(const float *occ_z, float xlo, float xhi, float zq, float bins_per_px)
 {
-    float zq = 1e30f, xmn = 1e30f, xmx = -1e30f;
-    bool ok = true;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        ok &= v[k].clip[3] >= 0.1f;
-        xmn = fminf(xmn, v[k].win[0]); xmx = fmaxf(xmx, v[k].win[0]); zq = fminf(zq, v[k].clip[3]);
-    }
-    if (!ok) return false;
-    const float fb0 = floorf(fmaxf(xmn - 0.1f, 0.0f) * bins_per_px), fb1 = floorf(fmaxf(xmx + 0.1f, 0.0f) * bins_per_px);
+    const float fb0 = floorf(fmaxf(xlo, 0.0f) * bins_per_px), fb1 = floorf(fmaxf(xhi, 0.0f) * bins_per_px);
     const int b0 = (int)fminf(fb0, (float)(MW_OCC_BINS - 1)), b1 = (int)fminf(fb1, (float)(MW_OCC_BINS - 1));
     const float thr = zq * __builtin_amdgcn_rcpf(fmaf(1.2e-3f, zq, 1.0f)) * 0.9999f;
     // every bin of b0 .. b1 in front of thr: whole groups through their maxima
@@ -119,6 +112,18 @@ __device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float
     return true;
 }
 
+__device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float bins_per_px)
+{
+    float zq = 1e30f, xmn = 1e30f, xmx = -1e30f;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ok &= v[k].clip[3] >= 0.1f;
+        xmn = fminf(xmn, v[k].win[0]); xmx = fmaxf(xmx, v[k].win[0]); zq = fminf(zq, v[k].clip[3]);
+    }
+    return ok && occluded_span(occ_z, xmn - 0.1f, xmx + 0.1f, zq, bins_per_px);
+}
+
 }  // namespace
 
 // view_flags: bit 0 top view, bit 1 draw the agent marker, bit 2 get_visible_ents' proxy pass (rooms untextured + one
@@ -132,7 +137,8 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     // (244 dwords per slot: consecutive slots start in different LDS banks)
     struct ClipSlot { mwgl::ClipVert l[2][MWGL_MAX_CLIP_VERTS]; float pad[4]; };
     __shared__ ClipSlot s_clip[kClipSlots];
-    __shared__ int s_pos[8][66];
+    __shared__ int s_pos[BIG ? 1 : 8][66];       // (the big scenes' kernel serves one env per wavefront: its LDS must stay within a quarter of a CU's)
+    __shared__ uint32_t s_meta[64], s_res[64];      // per work list: owner lane | clip planes << 8; vertices | list << 4 | front-facing fan triangles << 8
     __shared__ float s_occ_z[BIG ? MW_OCC_BINS + MW_OCC_BINS / 16 : 1];      // occlusion culling: farthest depth of the nearest wall per column bin, group maxima
     __shared__ float s_occ_wall[BIG ? MW_OCC_CAP * 5 : 1];
     __shared__ int s_occ_n;
@@ -302,13 +308,20 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         }
     };
 
-    // ---- occlusion culling of big scenes (one env per wavefront): the walls that hide what lies behind them
+    // ---- big scenes (one env per wavefront): what the culling below needs of the world alone — the slab, the full-height
+    // walls, a bounding box for every eight consecutive polygons — is derived once per world and kept (a.occ_cache; a Maze
+    // world lives for hundreds of frames, and three passes over its 65 KB of polygons per frame were a third of this
+    // kernel's time).  Whatever rewrites a set's polygons zeroes occ_valid[set] (mw_gen.h, mw_set_world).
+    const bool sifted = BIG && L == 64 && np > 64 && np <= 4096;
     bool occ_on = BIG && L == 64 && a.occlusion && !top && f.view.m[4] == 0.0f && f.view.m[6] == 0.0f;      // an unpitched camera
-    const float bins_per_px = (float)MW_OCC_BINS / (float)a.W;
-    if (occ_on) {
+    const bool cached = BIG && L == 64 && a.occ_cache != nullptr && np > 0 && np <= a.max_polys;
+    if (!cached) occ_on = false;
+    float *oc = cached ? a.occ_cache + (size_t)set * MW_OCC_CACHE_STRIDE(a.max_polys) : nullptr;
+    float *oc_wall = oc + MW_OCC_CACHE_HDR, *oc_box = oc + MW_OCC_CACHE_HDR + 8 * (size_t)a.max_polys;
+    if (cached && (occ_on || sifted) && a.occ_valid[set] != np + 1) {
         // the slab: lowest and highest point of the room polygons
-        float lo = 1e30f, hi = -1e30f;
         // (the loops over the env's polygons keep the next polygon's 128 bytes in flight while they work on the current one)
+        float lo = 1e30f, hi = -1e30f;
         {
             float qn[32];
             if (lane < np) load_poly(polys + lane, qn);
@@ -325,6 +338,71 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+        int n_walls = 0;
+        float qn[32];
+        if (lane < np) load_poly(polys + lane, qn);
+        for (int base = 0; base < np; base += 64) {
+            const int i = base + lane;
+            float q[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) q[k] = qn[k];
+            if (i + 64 < np) load_poly(polys + i + 64, qn);
+            const int nvf = i < np ? __float_as_int(q[23]) : 0, nv = nvf & 0xFF;
+            // -- a wall that can hide things: a vertical rectangle from lo to hi (triangles, and the quads of static
+            // entities (flag bits), are no walls)
+            bool wall = i < np && (nvf == 4 || nvf == (4 | MW_POLY_QUAD));
+            float vx[4], vy[4], vz[4];
+            bool ys = true;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vx[k] = q[3 * k]; vy[k] = q[3 * k + 1]; vz[k] = q[3 * k + 2];
+                ys &= vy[k] == lo || vy[k] == hi;
+            }
+            const bool pa = vx[0] == vx[1] && vz[0] == vz[1] && vx[2] == vx[3] && vz[2] == vz[3] && vy[0] != vy[1] && vy[2] != vy[3];
+            const bool pb = vx[1] == vx[2] && vz[1] == vz[2] && vx[3] == vx[0] && vz[3] == vz[0] && vy[1] != vy[2] && vy[3] != vy[0];
+            const float bx = pa ? vx[2] : vx[1], bz = pa ? vz[2] : vz[1];
+            wall = wall && ys && (pa || pb) && !(bx == vx[0] && bz == vz[0]);
+            const uint64_t wm = __ballot(wall);
+            if (wall) {
+                float4 *w4 = reinterpret_cast<float4 *>(oc_wall + 8 * (size_t)(n_walls + (int)__popcll((unsigned long long)(wm & ((1ull << lane) - 1ull)))));
+                w4[0] = make_float4(vx[0], vz[0], bx, bz);
+                w4[1] = make_float4(pa ? vy[1] - vy[0] : vy[1] - vy[2], 0.0f, 0.0f, 0.0f);        // which way round the rectangle is drawn
+            }
+            n_walls += (int)__popcll((unsigned long long)wm);
+            // -- the bounding box of polygons 8c .. 8c + 7 (eight consecutive lanes) and what may be concluded from it:
+            // bit 0 every polygon stands in world coordinates (the frustum test applies), bit 1 every polygon is a room
+            // quad (the occlusion test applies)
+            float mn[3] = {1e30f, 1e30f, 1e30f}, mx[3] = {-1e30f, -1e30f, -1e30f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (i < np && k < nv) {
+                    mn[0] = fminf(mn[0], vx[k]); mn[1] = fminf(mn[1], vy[k]); mn[2] = fminf(mn[2], vz[k]);
+                    mx[0] = fmaxf(mx[0], vx[k]); mx[1] = fmaxf(mx[1], vy[k]); mx[2] = fmaxf(mx[2], vz[k]);
+                }
+            int fl = i < np ? (((nvf & MW_POLY_XF) ? 0 : 1) | ((nv == 4 && !(nvf & MW_POLY_XF)) ? 2 : 0)) : 3;
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) { mn[c] = fminf(mn[c], __shfl_xor(mn[c], o)); mx[c] = fmaxf(mx[c], __shfl_xor(mx[c], o)); }
+                fl &= __shfl_xor(fl, o);
+            }
+            if ((lane & 7) == 0 && i < np) {
+                float4 *b4 = reinterpret_cast<float4 *>(oc_box + 8 * (size_t)(i >> 3));
+                b4[0] = make_float4(mn[0], mn[1], mn[2], mx[0]);
+                b4[1] = make_float4(mx[1], mx[2], __int_as_float(fl), 0.0f);
+            }
+        }
+        if (lane == 0) { oc[0] = __int_as_float(n_walls); oc[1] = lo; oc[2] = hi; }
+        __threadfence();
+        __syncthreads();
+        if (lane == 0) a.occ_valid[set] = np + 1;
+    }
+
+    // ---- occlusion culling: the walls that hide what lies behind them
+    const float bins_per_px = (float)MW_OCC_BINS / (float)a.W;
+    if (occ_on) {
+        const float lo = oc[1], hi = oc[2];
+        const int n_walls = __float_as_int(oc[0]);
         if (lane == 0) s_occ_n = 0;
         __syncthreads();
         occ_on = eye_y > lo + 1e-3f && eye_y < hi - 1e-3f;
@@ -333,38 +411,19 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
             const float *V = f.view.m;          // column major: eye x = V[0] x + V[8] z + V[12], depth = -(V[2] x + V[10] z + V[14])
             const float p00 = f.proj.m[0], halfw = (float)a.W * 0.5f;
             const float inv_p00 = 1.0f / p00, inv_hp = 1.0f / (halfw * p00), px_per_bin = 1.0f / bins_per_px;
-            float qn[32];
-            if (lane < np) load_poly(polys + lane, qn);
-            for (int i = lane; i < np; i += 64) {
-                float q[32];
-#pragma unroll
-                for (int k = 0; k < 32; ++k) q[k] = qn[k];
-                if (i + 64 < np) load_poly(polys + i + 64, qn);
-                const int nvf = __float_as_int(q[23]);
-                if (nvf != 4 && nvf != (4 | MW_POLY_QUAD)) continue;      // triangles, and the quads of static entities (flag bits), are no walls
-                float vx[4], vy[4], vz[4];
-                bool ys = true;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    vx[k] = q[3 * k]; vy[k] = q[3 * k + 1]; vz[k] = q[3 * k + 2];
-                    ys &= vy[k] == lo || vy[k] == hi;
-                }
-                // a vertical rectangle from lo to hi: two vertical edges
-                const bool pa = vx[0] == vx[1] && vz[0] == vz[1] && vx[2] == vx[3] && vz[2] == vz[3] && vy[0] != vy[1] && vy[2] != vy[3];
-                const bool pb = vx[1] == vx[2] && vz[1] == vz[2] && vx[3] == vx[0] && vz[3] == vz[0] && vy[1] != vy[2] && vy[3] != vy[0];
-                if (!ys || !(pa || pb)) continue;
-                const float bx = pa ? vx[2] : vx[1], bz = pa ? vz[2] : vz[1];
-                if (bx == vx[0] && bz == vz[0]) continue;
+            for (int i = lane; i < n_walls; i += 64) {
+                const float4 w0 = reinterpret_cast<const float4 *>(oc_wall + 8 * (size_t)i)[0];
+                const float sgn = oc_wall[8 * (size_t)i + 4];
+                const float vx0 = w0.x, vz0 = w0.y, bx = w0.z, bz = w0.w;
                 // drawn at all?  GL_CCW front faces (miniworld.py:512): the winding normal, s * (tz, 0, -tx) for a vertical
                 // rectangle over the foot line B0 -> B1 = (tx, tz), points at the eye — by a centimetre at least
-                const float tx = bx - vx[0], tz = bz - vz[0];
-                const float sgn = pa ? vy[1] - vy[0] : vy[1] - vy[2];
-                const float side = tz * (eye_x - vx[0]) - tx * (eye_z - vz[0]);
+                const float tx = bx - vx0, tz = bz - vz0;
+                const float side = tz * (eye_x - vx0) - tx * (eye_z - vz0);
                 const float facing = sgn > 0.0f ? side : -side;
                 if (!(facing > 0.0f && facing * facing > 1e-4f * (tx * tx + tz * tz))) continue;
                 // its foot line in eye space: (x, depth) of the two vertical edges, cut at depth wc
-                float ea = fmaf(V[0], vx[0], fmaf(V[8], vz[0], V[12]));
-                float wa = -fmaf(V[2], vx[0], fmaf(V[10], vz[0], V[14]));
+                float ea = fmaf(V[0], vx0, fmaf(V[8], vz0, V[12]));
+                float wa = -fmaf(V[2], vx0, fmaf(V[10], vz0, V[14]));
                 float eb = fmaf(V[0], bx, fmaf(V[8], bz, V[12]));
                 float wb = -fmaf(V[2], bx, fmaf(V[10], bz, V[14]));
                 if (!(wa >= wc) && !(wb >= wc)) continue;
@@ -423,31 +482,80 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     }
 
     // ---- big scenes: most polygons lie outside the frustum or behind walls — sift them with the cheap tests first, so that
-    // the rounds below (clipping, setup) run over the survivors only
+    // the rounds below (clipping, setup) run over the survivors only.  First the boxes of eight polygons each: a box
+    // that fails a test takes its polygons along unseen.  A box fails only where each of its polygons would (its margins
+    // are the wider ones), so the list is the one the polygons' own tests leave.
     int n_polys_drawn = np;
-    const bool sifted = BIG && L == 64 && np > 64 && np <= 4096;
     if (sifted) {
-        int ns = 0;
-        float qn[32];
-        if (lane < np) load_poly(polys + lane, qn);
-        for (int base = 0; base < np; base += 64) {
-            const int i = base + lane;
-            bool keep = false;
-            float q[32];
+        uint16_t *s_box = reinterpret_cast<uint16_t *>(s_key);      // the boxes that stay, ascending (s_key is not in use yet)
+        const int nbox = (np + 7) >> 3;
+        int nkept = 0;
+        for (int base = 0; base < nbox; base += 64) {
+            const int c = base + lane;
+            bool keep = c < nbox;
+            if (keep && cached) {
+                const float4 b0 = reinterpret_cast<const float4 *>(oc_box + 8 * (size_t)c)[0], b1 = reinterpret_cast<const float4 *>(oc_box + 8 * (size_t)c)[1];
+                const int fl = __float_as_int(b1.z);
+                if (fl & 1) {
+                    const float mn[3] = {b0.x, b0.y, b0.z}, mx[3] = {b0.w, b1.x, b1.y};
+                    const float *m = cam.mvp.m;
+                    // "outside a plane" with a margin above the rounding of the sums below and of transform_vertex's
+                    // (four roundings of half an ulp of at most mag[i] each, twice): then every vertex inside the box is
+                    // outside that plane in transform_vertex's own arithmetic too
+                    const float R = fmaxf(fmaxf(fmaxf(fabsf(mn[0]), fabsf(mx[0])), fmaxf(fabsf(mn[1]), fabsf(mx[1]))), fmaxf(fabsf(mn[2]), fabsf(mx[2])));
+                    float mag[4];
 #pragma unroll
-            for (int k = 0; k < 32; ++k) q[k] = qn[k];
-            if (i + 64 < np) load_poly(polys + i + 64, qn);
+                    for (int i = 0; i < 4; ++i) mag[i] = ((fabsf(m[i]) + fabsf(m[4 + i])) + fabsf(m[8 + i])) * R + fabsf(m[12 + i]);
+                    const float ex = 4e-6f * (mag[0] + mag[3]), ey = 4e-6f * (mag[1] + mag[3]), ez = 4e-6f * (mag[2] + mag[3]);
+                    uint32_t all = 0x3Fu;
+                    float zq = 1e30f, xmn = 1e30f, xmx = -1e30f;
+                    bool front = true;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float p[3] = {(k & 1) ? mx[0] : mn[0], (k & 2) ? mx[1] : mn[1], (k & 4) ? mx[2] : mn[2]};
+                        float cl[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) cl[i] = ((p[0] * m[i] + p[1] * m[4 + i]) + p[2] * m[8 + i]) + m[12 + i];
+                        const float w = cl[3];
+                        uint32_t mask = 0;
+                        if (cl[0] - w > ex) mask |= 1u;
+                        if (cl[0] + w < -ex) mask |= 2u;
+                        if (cl[1] - w > ey) mask |= 4u;
+                        if (cl[1] + w < -ey) mask |= 8u;
+                        if (cl[2] + w < -ez) mask |= 16u;
+                        if (cl[2] - w > ez) mask |= 32u;
+                        all &= mask;
+                        front &= w >= 0.1f;
+                        const float wx = fmaf(cl[0] * __builtin_amdgcn_rcpf(w), f.vp_scale[0], f.vp_trans[0]);
+                        xmn = fminf(xmn, wx); xmx = fmaxf(xmx, wx); zq = fminf(zq, w);
+                    }
+                    keep = all == 0u;
+                    if (keep && occ_on && (fl & 2) && front && occluded_span(s_occ_z, xmn - 0.15f, xmx + 0.15f, zq * 0.9999f, bins_per_px)) keep = false;
+                }
+            }
+            const uint64_t m = __ballot(keep);
+            if (keep) s_box[nkept + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)))] = (uint16_t)c;
+            nkept += __popcll((unsigned long long)m);
+        }
+        __syncthreads();
+        int ns = 0;
+        for (int base = 0; base < 8 * nkept; base += 64) {
+            const int k = base + lane;
+            const int i = k < 8 * nkept ? 8 * (int)s_box[k >> 3] + (k & 7) : np;
+            bool keep = false;
             if (i < np) {
+                float q[32];
+                load_poly(polys + i, q);
                 const int nvf = __float_as_int(q[23]), nv = nvf & 0xFF;
                 keep = !(proxy && (nvf & MW_POLY_ENTITY));
                 if (keep && !(nvf & MW_POLY_XF)) {
                     mwgl::Vert v[4];
                     uint32_t all = 0x3Fu;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float pk[3] = {k < nv ? q[3 * k] : q[0], k < nv ? q[3 * k + 1] : q[1], k < nv ? q[3 * k + 2] : q[2]};
-                        mwgl::transform_vertex(f, cam, pk, v[k]);
-                        all &= v[k].clipmask;
+                    for (int k2 = 0; k2 < 4; ++k2) {
+                        const float pk[3] = {k2 < nv ? q[3 * k2] : q[0], k2 < nv ? q[3 * k2 + 1] : q[1], k2 < nv ? q[3 * k2 + 2] : q[2]};
+                        mwgl::transform_vertex(f, cam, pk, v[k2]);
+                        all &= v[k2].clipmask;
                     }
                     keep = all == 0u;       // no frustum plane has every vertex outside
                     if (keep && occ_on && nv == 4 && occluded(s_occ_z, v, bins_per_px)) keep = false;
@@ -472,7 +580,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     const int n_items = npd + 6 * total_boxes + marker;
     // list position of each box's first record and of the end of the boxes: a mesh's first draw id is the number of
     // records drawn before it plus the mesh triangles drawn before it
-    int *pos = s_pos[grp];
+    int *pos = s_pos[BIG ? 0 : grp];      // (the big kernel is launched with L = 64 only)
     if (sub == 0) for (int i = 0; i <= (total_boxes < 64 ? total_boxes : 64); ++i) pos[i] = -1;
 
     // one TRIANGLE per lane: lanes 2k and 2k + 1 of a round hold the two triangles of primitive k (both evaluate its vertex
@@ -655,10 +763,80 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         // clipped polygon where pass 1 left it; otherwise they take turns, in both passes.
         const uint64_t cmask = __ballot(clipped);
         const uint64_t below = (1ull << lane) - 1ull;
-        const bool keep_lists = (int)__popcll((unsigned long long)cmask) <= kClipSlots;
+        const int n_clip = (int)__popcll((unsigned long long)cmask);
+        const bool keep_lists = n_clip <= kClipSlots;
+        const uint32_t cm_union = va.clipmask | vb.clipmask | vc.clipmask;
+        // The triangles are clipped eight at a time, eight lanes to a list — lane e owns the polygon's edge e -> e + 1: it passes
+        // vertex e on if that lies inside the plane and makes the crossing's vertex; the coverage ballots give everybody's
+        // place in the output list.  Same arithmetic per vertex as clip_triangle, one step per plane instead of one per
+        // plane and vertex.  (A triangle that crosses all six planes could grow to nine vertices: then
+        // clip_triangle does the work, one lane per triangle.)
+        const bool par = !__any(clipped && __popc(cm_union) == 6);
         mwgl::ClipVert *kept = nullptr;
         int kept_n = 0;
-        {
+        const int cg0 = lane & ~7, ce = lane & 7;
+        const int my_v = (int)__popcll((unsigned long long)(cmask & below));        // this lane's clipped triangle among the wave's
+        // clips triangles v0 .. v0 + kClipSlots - 1 of the wave's clipped ones (list = number - v0) and notes what became of each
+        auto clip_lists = [&](int v0) {
+            if (clipped && my_v >= v0 && my_v < v0 + kClipSlots) {
+                ClipSlot &cs = s_clip[my_v - v0];
+                mwgl::clip_copy_in(cs.l[0][0], va); mwgl::clip_copy_in(cs.l[0][1], vb); mwgl::clip_copy_in(cs.l[0][2], vc);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int nb = n_clip - v0 < kClipSlots ? n_clip - v0 : kClipSlots;
+            for (int b0 = 0; b0 < nb; b0 += 8) {
+                const int slot = b0 + (lane >> 3);
+                const bool valid = slot < nb;
+                ClipSlot &cs = s_clip[valid ? slot : 0];
+                uint32_t cm = valid ? s_meta[v0 + slot] >> 8 : 0u;
+                int n = valid ? 3 : 0, cur = 0;
+                while (__any(cm != 0u && n >= 3)) {
+                    const bool act = cm != 0u && n >= 3;
+                    const int plane = act ? __ffs((int)cm) - 1 : 0;
+                    if (act) cm &= cm - 1u;
+                    const mwgl::ClipVert *in = cs.l[cur];
+                    mwgl::ClipVert *out = cs.l[cur ^ 1];
+                    const bool me = act && ce < n;
+                    const int nxt = ce + 1 < n ? ce + 1 : 0;
+                    mwgl::ClipVert V;
+                    if (me) V = in[ce];
+                    const float dp_prev = me ? mwgl::clip_dist(V, plane) : 0.0f;
+                    const float dp = __shfl(dp_prev, cg0 + nxt);
+                    const bool bad = me && (!(dp_prev == dp_prev) || dp_prev - dp_prev != 0.0f);      // NaN / Inf: the triangle is dropped
+                    const bool emit = me && dp_prev >= 0.0f, cross = me && ((dp >= 0.0f) != (dp_prev >= 0.0f));
+                    const uint32_t bg = (uint32_t)(__ballot(bad) >> cg0) & 0xFFu;
+                    const uint32_t eg = (uint32_t)(__ballot(emit) >> cg0) & 0xFFu, xg = (uint32_t)(__ballot(cross) >> cg0) & 0xFFu;
+                    const uint32_t lowm = (1u << ce) - 1u;
+                    const int pos = __popc(eg & lowm) + __popc(xg & lowm);
+                    if (emit) out[pos] = V;
+                    if (cross) {
+                        const mwgl::ClipVert Vn = in[nxt];
+                        // the new vertex is interpolated from the endpoint that is closer to the plane (clip_triangle)
+                        const bool from_cur = fabsf(dp) < fabsf(dp_prev);
+                        const float t = (from_cur ? dp : dp_prev) / (from_cur ? dp - dp_prev : dp_prev - dp);
+                        mwgl::clip_interp<false>(f, out[pos + (emit ? 1 : 0)], t, from_cur ? Vn : V, from_cur ? V : Vn);
+                    }
+                    if (act) { n = bg ? 0 : __popc(eg) + __popc(xg); cur ^= 1; }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (n < 3) n = 0;
+                // the fan (r[e-1], r[e], r[0]), e = 2 .. n-1: which of its triangles leave setup
+                const mwgl::ClipVert *r = cs.l[cur];
+                bool front = false;
+                if (ce >= 2 && ce < n) front = tri_front(r[ce - 1].win, r[ce].win, r[0].win, ms);
+                const uint32_t fm = (uint32_t)(__ballot(front) >> cg0) & 0xFFu;
+                if (valid && ce == 0) s_res[v0 + slot] = (uint32_t)n | ((uint32_t)cur << 4) | (fm << 8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (par && n_clip) {
+            if (clipped) s_meta[my_v] = (uint32_t)lane | (cm_union << 8);
+            for (int v0 = 0; v0 < n_clip; v0 += kClipSlots) clip_lists(v0);
+            if (clipped) cnt = __popc(s_res[my_v] >> 8);
+        } else {
             uint64_t pend = cmask;
             if (keep_lists && pend) pend = 1ull;        // one turn for everybody
             while (pend) {
@@ -689,7 +867,36 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
             const uint32_t zlo = mwrec::write_tri(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex, S);
             if (BIG && base < MW_ORDER_CAP) s_key[base] = (zlo << 16) | (uint32_t)base;
         }
-        {
+        if (par) {
+            // every triangle of every fan on a lane of its own: list position from the owner's, setup, record
+            // (more clipped triangles than lists: they are clipped again, kClipSlots at a time)
+            for (int v0 = 0; v0 < n_clip; v0 += kClipSlots) {
+                if (!keep_lists) clip_lists(v0);
+                const int nb = n_clip - v0 < kClipSlots ? n_clip - v0 : kClipSlots;
+                for (int b0 = 0; b0 < nb; b0 += 8) {
+                    const int slot = b0 + (lane >> 3);
+                    const bool valid = slot < nb;
+                    const uint32_t res = valid ? s_res[v0 + slot] : 0u;
+                    const int owner = valid ? (int)(s_meta[v0 + slot] & 63u) : 0;
+                    const int n = (int)(res & 15u), cur = (int)((res >> 4) & 1u);
+                    const uint32_t fm = (res >> 8) & 0xFFu;
+                    const int o_base = __shfl(base, owner), o_tex = __shfl(tex, owner), o_env = __shfl(env, owner), o_live = __shfl((int)live, owner);
+                    const uint32_t o_tag = (uint32_t)__shfl((int)tag, owner), o_idb = (uint32_t)__shfl((int)id_base, owner);
+                    const float o_col[3] = {__shfl(va.col[0], owner), __shfl(va.col[1], owner), __shfl(va.col[2], owner)};
+                    if (ce >= 2 && ce < n && ((fm >> ce) & 1u)) {
+                        const mwgl::ClipVert *r = s_clip[slot].l[cur];
+                        const int idx = o_base + __popc(fm & ((1u << ce) - 1u));
+                        mwgl::TriSetup t2;
+                        if (mwgl::setup_triangle(to_vert(r[ce - 1], o_col), to_vert(r[ce], o_col), to_vert(r[0], o_col), ms, o_tex >= 0, t2) && o_live && idx < a.max_vis) {
+                            const uint32_t zlo = mwrec::write_tri(a, o_env, idx, o_tag ? o_tag : (uint32_t)idx + o_idb, t2, o_tex, S);
+                            if (BIG && idx < MW_ORDER_CAP) s_key[idx] = (zlo << 16) | (uint32_t)idx;
+                        }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        } else {
             const bool mine = clipped && cnt > 0;
             uint64_t pend = __ballot(mine);
             if (keep_lists && pend) pend = 1ull;

@@ -35,8 +35,8 @@ extern "C" __global__ __launch_bounds__(256) void mw_mesh_scatter_kernel(int W, 
 // The mesh triangles that cross a frustum plane (a mesh at the frame's edge; the scatter kernel lists them): clipped, every
 // piece set up on its own (llvmpipe's clipper output), its keys scattered and its fragments shaded right here — one entry
 // (draw id, colour) per pixel with a covered sample, chained per pixel, in fan order — so that neither the scatter kernel
-// nor K2 carries the clipper.  One wavefront per env, a triangle per lane (work lists in LDS); a piece that spans more than
-// 32 pixels is spread over the lanes, a pixel each.  Exits at once for an env without such triangles.
+// nor K2 carries the clipper.  A triangle per lane (work lists in LDS) up to the pieces' setup, then a (piece, pixel)
+// pair per lane.  Exits at once for an env without such triangles.
 #define MW_SLOW_LANES 16
 
 namespace {
@@ -88,10 +88,6 @@ __device__ inline void slow_pixel(const SlowPiece &p, int px, int gy, int W, int
     if (slow_cover(p, px, gy, W, H, keys)) slow_frag(p, px, gy, W, H, te, atomicAdd(frag_count, 1), frags, stamp, head, status);
 }
 
-__device__ inline int bcast_i(int v, int src) { return __shfl(v, src); }
-__device__ inline float bcast_f(float v, int src) { return __shfl(v, src); }
-__device__ inline mwgl::Plane bcast_p(const mwgl::Plane &q, int src) { return mwgl::Plane{bcast_f(q.a0, src), bcast_f(q.dadx, src), bcast_f(q.dady, src)}; }
-
 }  // namespace
 
 extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int H, const float *__restrict__ envhdr, const float *__restrict__ mesh_pos,
@@ -104,6 +100,8 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
     // the clipper's work lists: [MW_SLOW_LANES][2][MWGL_MAX_CLIP_VERTS] vertices (18 KB: the grid is mostly empty workgroups, which
     // must not queue for LDS)
     __shared__ mwgl::Vert slow_lists[MW_SLOW_LANES][2][MWGL_MAX_CLIP_VERTS];
+    __shared__ SlowPiece s_piece[MW_SLOW_LANES];        // the pieces of one step of the fans, and where each one's pixels start in the step's pixel list
+    __shared__ int s_pref[MW_SLOW_LANES + 1];
     // grid (MW_SLOW_BLOCKS_X, N): the blocks of row y share env y's list, MW_SLOW_LANES triangles per block and turn.
     // counts: [2 parities][2][N] — listed triangles (the scatter kernel's) and fragments of this frame's parity; the other
     // parity's are zeroed here for the next frame.
@@ -170,36 +168,27 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
                     have = p.x0 <= p.x1 && p.y0 <= p.y1;
                 }
             }
+            // the pixels of all pieces of this step of the fans, one (piece, pixel) pair per lane and turn: a fragment costs
+            // two dependent texture reads, and a lane walking its own piece pays them pixel after pixel
             const int npx = have ? (p.x1 - p.x0 + 1) * (p.y1 - p.y0 + 1) : 0;
-            const bool big = npx > 32;
-            if (have && !big) {
-                // coverage of its (at most 32) pixels first, then one list allocation for the piece
-                const int bw = p.x1 - p.x0 + 1;
-                uint32_t cov = 0u;
-                for (int k = 0; k < npx; ++k) cov |= slow_cover(p, p.x0 + k % bw, p.y0 + k / bw, W, H, keys) ? (1u << k) : 0u;
-                if (cov) {
-                    int k0 = atomicAdd(frag_count + env, __popc(cov));
-                    for (uint32_t mm = cov; mm; mm &= mm - 1u, ++k0) {
-                        const int k = __ffs((int)mm) - 1;
-                        slow_frag(p, p.x0 + k % bw, p.y0 + k / bw, W, H, te, k0, frags, stamp, head, status);
-                    }
-                }
-            }
-            // a piece that spans many pixels: all 64 lanes of the wavefront, a pixel each
-            uint64_t m = __ballot(big);
-            while (m) {
-                const int src = __ffsll((unsigned long long)m) - 1;
-                m &= m - 1;
-                SlowPiece u;
+            int incl = npx;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) { u.dcdx[k] = bcast_i(p.dcdx[k], src); u.dcdy[k] = bcast_i(p.dcdy[k], src); u.c[k] = bcast_i(p.c[k], src); }
-                u.z = bcast_p(p.z, src); u.w = bcast_p(p.w, src); u.s = bcast_p(p.s, src); u.t = bcast_p(p.t, src);
-                u.r = bcast_p(p.r, src); u.g = bcast_p(p.g, src); u.b = bcast_p(p.b, src);
-                u.x0 = bcast_i(p.x0, src); u.x1 = bcast_i(p.x1, src); u.y0 = bcast_i(p.y0, src); u.y1 = bcast_i(p.y1, src);
-                u.id = (uint32_t)bcast_i((int)p.id, src); u.tex = bcast_i(p.tex, src);
-                const int bw = u.x1 - u.x0 + 1, tot = bw * (u.y1 - u.y0 + 1);
-                for (int k = lane; k < tot; k += 64) slow_pixel(u, u.x0 + k % bw, u.y0 + k / bw, W, H, keys, te, frag_count + env, frags, stamp, head, status);
+            for (int off = 1; off < MW_SLOW_LANES; off <<= 1) { const int y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+            if (tid < MW_SLOW_LANES) { s_pref[tid] = incl - npx; if (have) s_piece[tid] = p; }
+            if (tid == MW_SLOW_LANES - 1) s_pref[MW_SLOW_LANES] = incl;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            const int total = s_pref[MW_SLOW_LANES];
+            for (int k = lane; k < total; k += 64) {
+                int j = 0;
+#pragma unroll
+                for (int step = MW_SLOW_LANES / 2; step > 0; step >>= 1) if (s_pref[j + step] <= k) j += step;      // the last piece that starts at or before k
+                const SlowPiece u = s_piece[j];
+                const int kk = k - s_pref[j], bw = u.x1 - u.x0 + 1;
+                slow_pixel(u, u.x0 + kk % bw, u.y0 + kk / bw, W, H, keys, te, frag_count + env, frags, stamp, head, status);
             }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
