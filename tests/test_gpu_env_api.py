@@ -932,16 +932,19 @@ def test_vec_env_fallback_sample_counts_match_oracle(env_id, kw, msaa):
 @pytest.mark.parametrize("env_id,kw", [("MiniWorld-Maze-v0", {"max_episode_steps": 40}), ("MiniWorld-Maze-v0", {"obs_width": 160, "obs_height": 120, "max_episode_steps": 40}),
                                        ("MiniWorld-MazeS3-v0", {"domain_rand": True, "max_episode_steps": 40}), ("MiniWorld-FourRooms-v0", {})])
 def test_occlusion_culling_never_changes_a_frame(env_id, kw, monkeypatch):
-    """K1 of big scenes drops the room polygons that lie behind full-height walls before they cost a record
-    (mw_setup.hip; MW_OCCLUSION=0 keeps them): a dropped polygon owns no sample, so RGB and depth are identical bit for
-    bit, step after step, auto-resets included.  (With domain_rand the camera is pitched and the culling switches itself
+    """The geometry kernel of big scenes drops the room polygons that lie behind full-height walls before they cost a record
+    (mw_geom.hip; MW_OCCLUSION=0 keeps them), and whole boxes of polygons outside the frustum, from data it keeps per world
+    (MW_OCC_CACHE=0: none of it): a dropped polygon owns no sample, so RGB and depth are identical bit for
+    bit, step after step, auto-resets — new worlds behind the same cache — included.  (With domain_rand the camera is pitched and the culling switches itself
     off; FourRooms is a small scene and never had it: both must still agree.)"""
     import torch
     from miniworld_amd.vec_env import MiniWorldVecEnv
     n = 96
     frames = {}
-    for flag in ("0", "1"):
-        monkeypatch.setenv("MW_OCCLUSION", flag)
+    # "plain": without the per-world culling cache (no boxes of polygons, no occlusion test): every polygon sifted on its own
+    for flag in ("0", "1", "plain"):
+        monkeypatch.setenv("MW_OCCLUSION", "0" if flag == "plain" else flag)
+        monkeypatch.setenv("MW_OCC_CACHE", "0" if flag == "plain" else "1")
         vec = MiniWorldVecEnv(env_id, n, seed=11, want_depth=True, **kw)
         vec.reset()
         out = [(vec.obs.cpu().numpy().copy(), vec.depth.cpu().numpy().copy())]
@@ -952,9 +955,10 @@ def test_occlusion_culling_never_changes_a_frame(env_id, kw, monkeypatch):
         vec.engine.check()
         vec.close()
         frames[flag] = out
-    for t, ((o0, d0), (o1, d1)) in enumerate(zip(frames["0"], frames["1"])):
-        assert np.array_equal(o0, o1), (env_id, t, np.nonzero((o0 != o1).any(axis=(1, 2, 3)))[0][:8])
-        assert np.array_equal(d0, d1), (env_id, t)
+    for other in ("1", "plain"):
+        for t, ((o0, d0), (o1, d1)) in enumerate(zip(frames["0"], frames[other])):
+            assert np.array_equal(o0, o1), (env_id, other, t, np.nonzero((o0 != o1).any(axis=(1, 2, 3)))[0][:8])
+            assert np.array_equal(d0, d1), (env_id, other, t)
 
 
 @pytest.mark.gpu
