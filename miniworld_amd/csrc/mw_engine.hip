@@ -182,6 +182,7 @@ int geom_lanes(const mw_engine *e)
     const int items = 2 * (e->cfg.max_polys + 6 * e->cfg.max_ents + 1);      // one triangle per lane
     int L = 8;
     while (L < items && L < 64) L <<= 1;
+    if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) L = v; }
     return L;
 }
 

@@ -750,11 +750,11 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         // this lane's triangle of v[]: (0,1,3) / (1,2,3), or (0,1,2) / (0,2,3) for a direct quad
         const mwgl::Vert va = tsel ? (direct ? v[0] : v[1]) : v[0], vb = tsel ? v[2] : v[1], vc = tsel ? v[3] : (direct ? v[2] : v[3]);
         // ---- pass 1: does it survive, and as how many triangles
-        mwgl::TriSetup ts;
+        // (the setup itself waits for pass 2: nothing of it has to live through the clipper and the scan)
         int cnt = 0;
         bool clipped = false;
         if (tsel < nt && !(va.clipmask & vb.clipmask & vc.clipmask)) {
-            if ((va.clipmask | vb.clipmask | vc.clipmask) == 0u) cnt = mwgl::setup_triangle(va, vb, vc, ms, tex >= 0, ts) ? 1 : 0;
+            if ((va.clipmask | vb.clipmask | vc.clipmask) == 0u) cnt = tri_front(va.win, vb.win, vc.win, ms) ? 1 : 0;
             else clipped = true;
         }
         if (a.k1_prof) tp[3] = __builtin_readcyclecounter();
@@ -864,8 +864,11 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         if (a.k1_prof) tp[5] = __builtin_readcyclecounter();
         // ---- pass 2: the records
         if (cnt == 1 && !clipped && live && base < a.max_vis) {
-            const uint32_t zlo = mwrec::write_tri(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex, S);
-            if (BIG && base < MW_ORDER_CAP) s_key[base] = (zlo << 16) | (uint32_t)base;
+            mwgl::TriSetup ts;
+            if (mwgl::setup_triangle(va, vb, vc, ms, tex >= 0, ts)) {
+                const uint32_t zlo = mwrec::write_tri(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex, S);
+                if (BIG && base < MW_ORDER_CAP) s_key[base] = (zlo << 16) | (uint32_t)base;
+            }
         }
         if (par) {
             // every triangle of every fan on a lane of its own: list position from the owner's, setup, record

@@ -321,10 +321,13 @@ __device__ inline float samp_x8(int s) { return (float)mwrec::kPat[2][s][0] * 0.
 __device__ inline float samp_y8(int s) { return (float)mwrec::kPat[2][s][1] * 0.0625f; }
 
 // 16-bit depth of the triangle with z plane (a0, dadx, dady) at sample s of GL pixel (px, gy)
+// (mwgl::z_to_unorm16 with the clamp as one median instruction: the same value for every z that is not a NaN, and a
+// finite plane has none)
 __device__ inline uint32_t depth16(float a0, float dadx, float dady, int px, int gy, int s)
 {
     const float xs = (float)px + samp_x8(s), ys = (float)gy + samp_y8(s);
-    return mwgl::z_to_unorm16(fmaf(dady, ys, fmaf(dadx, xs, a0)));
+    const float z = __builtin_amdgcn_fmed3f(fmaf(dady, ys, fmaf(dadx, xs, a0)), 0.0f, 1.0f);
+    return __float_as_uint(z * (65535.0f / 65536.0f) + 128.0f) & 0xffffu;
 }
 
 __device__ inline uint32_t to_u8(float acc) { return mwgl::float_to_unorm8(acc * 0.125f); }
@@ -518,27 +521,29 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     if ((uint32_t)__builtin_amdgcn_readlane((int)zlo, bit) > far16) { done = true; break; }
                 }
                 const int *__restrict__ rr = reinterpret_cast<const int *>(rr_env + (size_t)p * MW_RASTER_REC);
-                bool in[8];
+                // (coverage as wave masks in scalar registers, like pass A: one compare per sample and open edge, one select
+                // per sample — no per-lane flags, no branches around the samples)
+                uint64_t in_m[8];
 #pragma unroll
-                for (int s = 0; s < 8; ++s) in[s] = true;
+                for (int s = 0; s < 8; ++s) in_m[s] = ~0ull;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) {
                     if (PRE == 1 && !((cx.pre_edges >> (16 * k + (bit & 15))) & 1ull)) continue;
                     const int E = __mul24(rr[k], px) + __mul24(rr[3 + k], gy) + rr[6 + k];
                     if (__all(E > rr[13 + k])) continue;
 #pragma unroll
-                    for (int s = 0; s < 8; ++s) in[s] &= E > rr[16 + k * 16 + s];
+                    for (int s = 0; s < 8; ++s) in_m[s] &= __ballot(E > rr[16 + k * 16 + s]);
                 }
-                bool any = false;
+                uint64_t any_m = 0ull;
 #pragma unroll
-                for (int s = 0; s < 8; ++s) any |= in[s];
-                if (!__any(any)) continue;
+                for (int s = 0; s < 8; ++s) any_m |= in_m[s];
+                if (!any_m) continue;
                 const float za0 = __int_as_float(rr[10]), zdx = __int_as_float(rr[11]), zdy = __int_as_float(rr[12]);
                 const uint32_t id = MESH ? (uint32_t)rr[9] : (uint32_t)p;           // the mesh kernel's keys carry draw ids
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
                     const uint32_t k = (depth16(za0, zdx, zdy, px, gy, s) << 16) | id;
-                    key[s] = in[s] ? min(key[s], k) : key[s];
+                    key[s] = sel_mask(in_m[s], min(key[s], k), key[s]);
                 }
                 if (SORTED && sorted) {
                     uint32_t m = max(max(max(key[0], key[1]), max(key[2], key[3])), max(max(key[4], key[5]), max(key[6], key[7])));
