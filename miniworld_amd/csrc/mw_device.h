@@ -19,6 +19,7 @@
 #define MW_ENVHDR 640         // floats per env: sky, light colours, mesh-entity table (geometry kernel -> raster kernels)
 #define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
 #define MW_HDR_MESH 32        // first float of the mesh-entity table
+#define MW_K1_PROF_SLOTS 10
 #define MW_OCC_CACHE_HDR 8
 // floats per set: header, 8 per wall, 8 per box of eight polygons; whole 128-byte lines
 #define MW_OCC_CACHE_STRIDE(max_polys) ((MW_OCC_CACHE_HDR + 8 * (size_t)(max_polys) + 8 * (size_t)(((max_polys) + 7) / 8) + 31) / 32 * 32)
@@ -150,5 +151,5 @@ struct MwArgs {
     // frame.  occ_valid[set]: polygon count + 1 of the world the cache belongs to, 0 after anything rewrote the polygons.
     int32_t *occ_valid;     // [sets] or null
     float *occ_cache;       // [sets][MW_OCC_CACHE_STRIDE(max_polys)]
-    unsigned long long *k1_prof;   // MW_K1_PROF: [N][8] cycle counters of the geometry kernel's phases (tools/perf/kgprof.py; perf experiments only), else null
+    unsigned long long *k1_prof;   // MW_K1_PROF: [N][MW_K1_PROF_SLOTS] cycle counters of the geometry kernel's phases, start and end time of the env's wavefront (tools/perf/kgprof.py; perf experiments only), else null
 };

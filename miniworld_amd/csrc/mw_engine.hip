@@ -830,8 +830,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
     if (getenv("MW_K1_PROF")) {     // perf experiments only: per-env cycle stamps of the geometry kernel's phases, dumped by mw_destroy
-        ALLOC(a.k1_prof, 8 * (size_t)N);
-        if (rc == MW_OK) (void)hipMemset(a.k1_prof, 0, 64 * (size_t)N);
+        ALLOC(a.k1_prof, MW_K1_PROF_SLOTS * (size_t)N);
+        if (rc == MW_OK) (void)hipMemset(a.k1_prof, 0, 8 * MW_K1_PROF_SLOTS * (size_t)N);
     }
 #undef ALLOC
     if (rc != MW_OK) { g_create_error = e->err; mw_destroy(e); return rc; }
@@ -862,7 +862,7 @@ void mw_destroy(mw_engine *e)
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipDeviceSynchronize();
     if (e->args.k1_prof) {
-        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 8);
+        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * MW_K1_PROF_SLOTS);
         if (hipMemcpy(h.data(), e->args.k1_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(getenv("MW_K1_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }

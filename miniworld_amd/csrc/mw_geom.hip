@@ -71,6 +71,17 @@ __device__ inline bool tri_front(const float wa[4], const float wb[4], const flo
     return dx01 * dy20 - dx20 * dy01 < 0;
 }
 
+// Would tri_front say no whatever the rounding of the snap does?  In units of 1/256 px the snapped coordinates differ from
+// the exact ones by at most a half each, the edge differences by at most one, the area by at most the sum of the four
+// differences plus two; the float products below add their own rounding (1e-6 of their size, generously).
+__device__ inline bool clearly_back(const float wa[4], const float wb[4], const float wc[4])
+{
+    const float dx01 = (wa[0] - wb[0]) * 256.0f, dy01 = (wa[1] - wb[1]) * 256.0f, dx20 = (wc[0] - wa[0]) * 256.0f, dy20 = (wc[1] - wa[1]) * 256.0f;
+    const float p = dx01 * dy20, q = dx20 * dy01;
+    const float margin = (fabsf(dx01) + fabsf(dy20)) + (fabsf(dx20) + fabsf(dy01)) + 4.0f + 1e-6f * (fabsf(p) + fabsf(q));
+    return p - q > margin;
+}
+
 // ---------------------------------------------------------------- occlusion culling (big scenes)
 // A Maze view holds ~95 front-facing polygons inside the frustum and ~13 that own a sample: everything else lies behind
 // walls.  With an unpitched camera a wall that spans the whole height of the world (the slab [lo, hi] of all room
@@ -145,6 +156,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     __shared__ uint16_t s_list[BIG ? 4096 : 1];
     __shared__ uint32_t s_key[BIG ? MW_ORDER_CAP : 1];        // big scenes: (depth bound << 16 | list index) of every record, for the visiting order      // big scenes: the polygons that pass the cheap tests (frustum, occlusion), in drawing order
     const unsigned long long tstart = __builtin_readcyclecounter();
+    const unsigned long long rt_start = a.k1_prof ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz, the same clock on every CU
     const int lane = threadIdx.x;
     const int epw = 64 / L, sub = lane & (L - 1), grp = lane / L;
     const int rel = (int)blockIdx.x * epw + grp;
@@ -559,6 +571,16 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
                     }
                     keep = all == 0u;       // no frustum plane has every vertex outside
                     if (keep && occ_on && nv == 4 && occluded(s_occ_z, v, bins_per_px)) keep = false;
+                    // seen from behind — the other side of most walls of other rooms: with no vertex clipped its two
+                    // triangles are the ones the rounds would set up, and when both are back-facing by more than snapping
+                    // the vertices can change (clearly_back), setup would drop both: no record either way
+                    if (keep && (v[0].clipmask | v[1].clipmask | v[2].clipmask | v[3].clipmask) == 0u) {
+                        const bool fan = nv == 3 || !(nvf & MW_POLY_QUAD);
+                        // v[] holds the polygon's own vertices k (v[3] = v[0] for a triangle): fan (1,2,0) (2,3,0), list quad (0,1,3) (1,2,3)
+                        const bool b0 = fan ? clearly_back(v[1].win, v[2].win, v[0].win) : clearly_back(v[0].win, v[1].win, v[3].win);
+                        const bool b1 = nv == 3 || (fan ? clearly_back(v[2].win, v[3].win, v[0].win) : clearly_back(v[1].win, v[2].win, v[3].win));
+                        if (b0 && b1) keep = false;
+                    }
                 }
             }
             const uint64_t m = __ballot(keep);
@@ -832,10 +854,46 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
         };
+        // the records of the fans in lists 0 .. of triangles v0 ..: every triangle of every fan on a lane of its own — list
+        // position from the owner's (base_now), setup, record
+        auto emit_fans = [&](int v0, int base_now) {
+            const int nb = n_clip - v0 < kClipSlots ? n_clip - v0 : kClipSlots;
+            for (int b0 = 0; b0 < nb; b0 += 8) {
+                const int slot = b0 + (lane >> 3);
+                const bool valid = slot < nb;
+                const uint32_t res = valid ? s_res[v0 + slot] : 0u;
+                const int owner = valid ? (int)(s_meta[v0 + slot] & 63u) : 0;
+                const int n = (int)(res & 15u), cur = (int)((res >> 4) & 1u);
+                const uint32_t fm = (res >> 8) & 0xFFu;
+                const int o_base = __shfl(base_now, owner), o_tex = __shfl(tex, owner), o_env = __shfl(env, owner), o_live = __shfl((int)live, owner);
+                const uint32_t o_tag = (uint32_t)__shfl((int)tag, owner), o_idb = (uint32_t)__shfl((int)id_base, owner);
+                const float o_col[3] = {__shfl(va.col[0], owner), __shfl(va.col[1], owner), __shfl(va.col[2], owner)};
+                if (ce >= 2 && ce < n && ((fm >> ce) & 1u)) {
+                    const mwgl::ClipVert *r = s_clip[slot].l[cur];
+                    const int idx = o_base + __popc(fm & ((1u << ce) - 1u));
+                    mwgl::TriSetup t2;
+                    if (mwgl::setup_triangle(to_vert(r[ce - 1], o_col), to_vert(r[ce], o_col), to_vert(r[0], o_col), ms, o_tex >= 0, t2) && o_live && idx < a.max_vis) {
+                        const uint32_t zlo = mwrec::write_tri(a, o_env, idx, o_tag ? o_tag : (uint32_t)idx + o_idb, t2, o_tex, S);
+                        if (BIG && idx < MW_ORDER_CAP) s_key[idx] = (zlo << 16) | (uint32_t)idx;
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        };
+        int total = 0, base = 0;
+        bool scanned = false;
         if (par && n_clip) {
+            // kClipSlots triangles at a time: clipped, counted, placed (the scan sees zero for the clipped triangles still
+            // to come: they lie behind these in the list), written — then the lists serve the next ones
             if (clipped) s_meta[my_v] = (uint32_t)lane | (cm_union << 8);
-            for (int v0 = 0; v0 < n_clip; v0 += kClipSlots) clip_lists(v0);
-            if (clipped) cnt = __popc(s_res[my_v] >> 8);
+            for (int v0 = 0; v0 < n_clip; v0 += kClipSlots) {
+                clip_lists(v0);
+                if (clipped && my_v >= v0 && my_v < v0 + kClipSlots) cnt = __popc(s_res[my_v] >> 8);
+                base = count + group_excl_scan(cnt, sub, L, total);
+                emit_fans(v0, base);
+            }
+            scanned = true;     // the last scan saw every count
         } else {
             uint64_t pend = cmask;
             if (keep_lists && pend) pend = 1ull;        // one turn for everybody
@@ -857,8 +915,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         }
         if (a.k1_prof) tp[4] = __builtin_readcyclecounter();
         // ---- list positions
-        int total;
-        const int base = count + group_excl_scan(cnt, sub, L, total);
+        if (!scanned) base = count + group_excl_scan(cnt, sub, L, total);
         count += total;
         if (base + cnt > a.max_vis && cnt) atomicOr(a.status, MW_ST_VIS_OVERFLOW);
         if (a.k1_prof) tp[5] = __builtin_readcyclecounter();
@@ -870,36 +927,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
                 if (BIG && base < MW_ORDER_CAP) s_key[base] = (zlo << 16) | (uint32_t)base;
             }
         }
-        if (par) {
-            // every triangle of every fan on a lane of its own: list position from the owner's, setup, record
-            // (more clipped triangles than lists: they are clipped again, kClipSlots at a time)
-            for (int v0 = 0; v0 < n_clip; v0 += kClipSlots) {
-                if (!keep_lists) clip_lists(v0);
-                const int nb = n_clip - v0 < kClipSlots ? n_clip - v0 : kClipSlots;
-                for (int b0 = 0; b0 < nb; b0 += 8) {
-                    const int slot = b0 + (lane >> 3);
-                    const bool valid = slot < nb;
-                    const uint32_t res = valid ? s_res[v0 + slot] : 0u;
-                    const int owner = valid ? (int)(s_meta[v0 + slot] & 63u) : 0;
-                    const int n = (int)(res & 15u), cur = (int)((res >> 4) & 1u);
-                    const uint32_t fm = (res >> 8) & 0xFFu;
-                    const int o_base = __shfl(base, owner), o_tex = __shfl(tex, owner), o_env = __shfl(env, owner), o_live = __shfl((int)live, owner);
-                    const uint32_t o_tag = (uint32_t)__shfl((int)tag, owner), o_idb = (uint32_t)__shfl((int)id_base, owner);
-                    const float o_col[3] = {__shfl(va.col[0], owner), __shfl(va.col[1], owner), __shfl(va.col[2], owner)};
-                    if (ce >= 2 && ce < n && ((fm >> ce) & 1u)) {
-                        const mwgl::ClipVert *r = s_clip[slot].l[cur];
-                        const int idx = o_base + __popc(fm & ((1u << ce) - 1u));
-                        mwgl::TriSetup t2;
-                        if (mwgl::setup_triangle(to_vert(r[ce - 1], o_col), to_vert(r[ce], o_col), to_vert(r[0], o_col), ms, o_tex >= 0, t2) && o_live && idx < a.max_vis) {
-                            const uint32_t zlo = mwrec::write_tri(a, o_env, idx, o_tag ? o_tag : (uint32_t)idx + o_idb, t2, o_tex, S);
-                            if (BIG && idx < MW_ORDER_CAP) s_key[idx] = (zlo << 16) | (uint32_t)idx;
-                        }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            }
-        } else {
+        if (!par) {
             const bool mine = clipped && cnt > 0;
             uint64_t pend = __ballot(mine);
             if (keep_lists && pend) pend = 1ull;
@@ -971,9 +999,10 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         }
     }
     if (a.k1_prof && sub == 0 && live) {
-        unsigned long long *pp = a.k1_prof + (size_t)env * 8;
+        unsigned long long *pp = a.k1_prof + (size_t)env * MW_K1_PROF_SLOTS;
         pp[0] = tp[0] - tstart; (void)tp0; for (int i = 1; i < 7; ++i) pp[i] = tp[i] - tp[i - 1];
         pp[7] = __builtin_readcyclecounter() - tp[6];
+        pp[8] = rt_start; pp[9] = __builtin_amdgcn_s_memrealtime();
     }
     if (sub == 0 && live) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;

@@ -15,9 +15,19 @@ for t in range(40):
     vec.step(torch.randint(0, n_act, (n,), generator=g, device="cuda", dtype=torch.int32))
 torch.cuda.synchronize()
 vec.close()
-d = np.fromfile(out, np.uint64).astype(np.float64).reshape(n, 8)
+raw = np.fromfile(out, np.uint64).reshape(n, 10)
+d = raw[:, :8].astype(np.float64)
 names = ["xform", "walk/occ/sift", "vertex stage", "pass1 setups", "pass1 clip", "scan", "pass2", "tail"]
 print(cfg, "cycles per phase (mean over envs, last round of the last frame):")
 for k, nm in enumerate(names):
     print("  %-14s %9.0f" % (nm, d[:, k].mean()))
 print("  sum %.0f cycles = %.1f us at 2.4 GHz" % (d.sum(axis=1).mean(), d.sum(axis=1).mean() / 2400))
+# the wavefronts in time (s_memrealtime, 100 MHz): when they start, how long they run — the kernel lasts until the slowest ends
+st = raw[:, 8].astype(np.int64); en = raw[:, 9].astype(np.int64)
+t0 = st.min(); st = (st - t0) / 100.0; en = (en - t0) / 100.0; dur = en - st
+print("  wavefronts: start median %.1f max %.1f us; duration median %.1f p95 %.1f max %.1f us; last end %.1f us" %
+      (np.median(st), st.max(), np.median(dur), np.percentile(dur, 95), dur.max(), en.max()))
+h, edges = np.histogram(dur, bins=8)
+print("  duration histogram (us):", ", ".join("%.0f-%.0f: %d" % (edges[i], edges[i + 1], h[i]) for i in range(len(h))))
+slow = dur >= np.percentile(dur, 97)
+print("  slowest 3 %%: phases %s" % " ".join("%s %.0f" % (names[k].split("/")[0], d[slow, k].mean()) for k in range(8)))
