@@ -82,6 +82,45 @@ __device__ inline bool clearly_back(const float wa[4], const float wb[4], const 
     return p - q > margin;
 }
 
+// Bitonic sort of the n <= 64 R keys in keys[] (ascending; unused places count as the largest key) by one wavefront, the
+// low halves of the sorted keys stored to order[1 ..].
+template <int R>
+__device__ inline void sort_store_keys(const uint32_t *keys, int n, int lane, uint16_t *order)
+{
+    uint32_t x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = 64 * r + lane < n ? keys[64 * r + lane] : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                // partners in two registers of the same lane
+                const int jj = j >> 6;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    if (r & jj) continue;
+                    const bool up = ((64 * r) & k) == 0;        // (k >= 128: the lane's bits do not matter)
+                    const uint32_t lo = min(x[r], x[r ^ jj]), hi = max(x[r], x[r ^ jj]);
+                    x[r] = up ? lo : hi; x[r ^ jj] = up ? hi : lo;
+                }
+            } else {
+                // partners in two lanes, the same register
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const uint32_t y = (uint32_t)__shfl_xor((int)x[r], j);
+                    const bool up = (((64 * r) | lane) & k) == 0;
+                    const bool keep_min = ((lane & j) == 0) == up;
+                    x[r] = keep_min ? min(x[r], y) : max(x[r], y);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+        if (64 * r + lane < n) order[1 + 64 * r + lane] = (uint16_t)(x[r] & 0xFFFFu);
+}
+
 // ---------------------------------------------------------------- occlusion culling (big scenes)
 // A Maze view holds ~95 front-facing polygons inside the frustum and ~13 that own a sample: everything else lies behind
 // walls.  With an unpitched camera a wall that spans the whole height of the world (the slab [lo, hi] of all room
@@ -551,13 +590,18 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         }
         __syncthreads();
         int ns = 0;
+        // (the next turn's polygon is in flight while this turn's is tested)
+        auto cand = [&](int k) { return k < 8 * nkept ? 8 * (int)s_box[k >> 3] + (k & 7) : np; };
+        float qn[32];
+        if (cand(lane) < np) load_poly(polys + cand(lane), qn);
         for (int base = 0; base < 8 * nkept; base += 64) {
-            const int k = base + lane;
-            const int i = k < 8 * nkept ? 8 * (int)s_box[k >> 3] + (k & 7) : np;
+            const int i = cand(base + lane);
             bool keep = false;
+            float q[32];
+#pragma unroll
+            for (int k = 0; k < 32; ++k) q[k] = qn[k];
+            if (cand(base + 64 + lane) < np) load_poly(polys + cand(base + 64 + lane), qn);
             if (i < np) {
-                float q[32];
-                load_poly(polys + i, q);
                 const int nvf = __float_as_int(q[23]), nv = nvf & 0xFF;
                 keep = !(proxy && (nvf & MW_POLY_ENTITY));
                 if (keep && !(nvf & MW_POLY_XF)) {
@@ -978,23 +1022,13 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         if (n > MW_ORDER_CAP || !live) {
             if (lane == 0 && live) order[0] = 0;
         } else {
-            int P = 64;
-            while (P < n) P <<= 1;
-            for (int i = n + lane; i < P; i += 64) s_key[i] = 0xFFFFFFFFu;
             __syncthreads();
-            for (int k = 2; k <= P; k <<= 1)
-                for (int j = k >> 1; j > 0; j >>= 1) {
-                    for (int i = lane; i < P; i += 64) {
-                        const int l = i ^ j;
-                        if (l > i) {
-                            const uint32_t x = s_key[i], y = s_key[l];
-                            const bool up = (i & k) == 0;
-                            if ((x > y) == up) { s_key[i] = y; s_key[l] = x; }
-                        }
-                    }
-                    __syncthreads();
-                }
-            for (int i = lane; i < n; i += 64) order[1 + i] = (uint16_t)(s_key[i] & 0xFFFFu);
+            // (64 R keys in R registers per lane, key i = 64 r + lane: the network's exchanges are lane shuffles and
+            // register swaps — no LDS round trip per stage)
+            if (n <= 64) sort_store_keys<1>(s_key, n, lane, order);
+            else if (n <= 128) sort_store_keys<2>(s_key, n, lane, order);
+            else if (n <= 256) sort_store_keys<4>(s_key, n, lane, order);
+            else sort_store_keys<8>(s_key, n, lane, order);
             if (lane == 0) order[0] = 1;
         }
     }
