@@ -638,10 +638,10 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     if (a.k1_prof) tp[1] = __builtin_readcyclecounter();
     int count = 0;          // the env's list length so far (uniform in the group)
     float stale_n[3] = {0.0f, 1.0f, 0.0f};
-    if (np > 0) { stale_n[0] = polys[np - 1].n[0]; stale_n[1] = polys[np - 1].n[1]; stale_n[2] = polys[np - 1].n[2]; }
+    const int marker = (view_flags & 2) ? 1 : 0;
+    if (marker && np > 0) { stale_n[0] = polys[np - 1].n[0]; stale_n[1] = polys[np - 1].n[1]; stale_n[2] = polys[np - 1].n[2]; }      // (only the marker is lit by it)
     if (total_boxes > 0) { stale_n[0] = 0.0f; stale_n[1] = -1.0f; stale_n[2] = 0.0f; }     // drawBox ends with glNormal3f(0, -1, 0)
     const float white[3] = {1.0f, 1.0f, 1.0f};
-    const int marker = (view_flags & 2) ? 1 : 0;
     const int npd = n_polys_drawn;      // polygons among the items
     const int n_items = npd + 6 * total_boxes + marker;
     // list position of each box's first record and of the end of the boxes: a mesh's first draw id is the number of
