@@ -123,7 +123,7 @@ __device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const
 #define MW_PLANE_REC 20         // (w plane, tex) (r plane, state) (g plane, s.a0) (b plane, s.dadx) (s.dady, t plane)
 #define MW_PLANE_SLOW 2         // state: the triangle crosses a frustum plane — its fragments come from the env's slow-fragment list
 #define MW_SLOW_TRIS 1024       // per env: mesh triangles that cross a frustum plane (a mesh at the frame's edge)
-#define MW_SLOW_FRAGS 8192      // per env: their fragments, (draw id << 16 | next fragment of the pixel + 1, r, g, b), chained per pixel
+#define MW_SLOW_FRAGS 8191      // per env: their fragments, (draw id << 16 | piece of the fan << 13 | next fragment of the pixel + 1, r, g, b), chained per pixel
 
 __device__ inline bool scatter_tri_narrow(const int dcdx[3], const int dcdy[3], const int c[3], const mwgl::Plane &zp, int minx, int maxx,
                                           int miny, int maxy, int W, int H, uint32_t id, uint32_t *keys)
@@ -317,15 +317,16 @@ __device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, 
     const int tex = cx.te.flat ? -1 : __float_as_int(q0.w);
     if (__float_as_int(q1.w) == MW_PLANE_SLOW) {
         // a triangle that crosses a frustum plane: its fragments were shaded by mw_mesh_slow_kernel
-        // (the pixel's chain, newest first: the first one appended for this id — the first piece of the fan — counts)
+        // (the pixel's chain: of the entries for this id — pieces of the triangle's fan — the first piece's counts)
         RGB c = {0.0f, 0.0f, 0.0f};
         const uint32_t h0 = cx.slow_head[(cx.H - 1 - gy) * cx.W + px];
         uint32_t k = (h0 >> 16) == cx.slow_stamp ? (h0 & 0xFFFFu) : 0u;        // a head of an earlier frame is empty
+        uint32_t best = 8u;
         for (int guard = 0; k != 0u && k <= MW_SLOW_FRAGS && guard < MW_SLOW_FRAGS; ++guard) {
             const float4 fr = cx.slow_frags[k - 1u];
-            const uint32_t w = __float_as_uint(fr.x);
-            if ((w >> 16) == id) c = RGB{fr.y, fr.z, fr.w};
-            k = w & 0xFFFFu;
+            const uint32_t w = __float_as_uint(fr.x), piece = (w >> 13) & 7u;
+            if ((w >> 16) == id && piece < best) { c = RGB{fr.y, fr.z, fr.w}; best = piece; }
+            k = w & 0x1FFFu;
         }
         return c;
     }

@@ -34,10 +34,12 @@ extern "C" __global__ __launch_bounds__(256) void mw_mesh_scatter_kernel(int W, 
 
 // The mesh triangles that cross a frustum plane (a mesh at the frame's edge; the scatter kernel lists them): clipped, every
 // piece set up on its own (llvmpipe's clipper output), its keys scattered and its fragments shaded right here — one entry
-// (draw id, colour) per pixel with a covered sample, chained per pixel, in fan order — so that neither the scatter kernel
-// nor K2 carries the clipper.  A triangle per lane (work lists in LDS) up to the pieces' setup, then a (piece, pixel)
-// pair per lane.  Exits at once for an env without such triangles.
-#define MW_SLOW_LANES 16
+// (draw id, piece, colour) per pixel with a covered sample, chained per pixel — so that neither the scatter kernel nor K2
+// carries the clipper.  A wavefront takes eight triangles at a time, eight lanes to a triangle: a vertex per lane
+// (transform, light), an edge of the clipped polygon per lane (the geometry kernel's clipper, with colours), a piece of the
+// fan per lane (setup), then a (piece, pixel) pair per lane over all pieces of the eight.  Exits at once for an env without
+// such triangles.
+#define MW_SLOW_GROUPS 8        // triangles per wavefront and turn
 
 namespace {
 
@@ -45,7 +47,7 @@ struct SlowPiece {       // what the pixel loop needs of one set-up piece
     int dcdx[3], dcdy[3], c[3];
     mwgl::Plane z, w, s, t, r, g, b;
     int x0, x1, y0, y1;
-    uint32_t id;
+    uint32_t id;        // draw id << 16 | piece of the fan << 13
     int tex;
 };
 
@@ -62,7 +64,7 @@ __device__ inline bool slow_cover(const SlowPiece &p, int px, int gy, int W, int
         for (int k = 0; k < 3; ++k) in &= p.c[k] + __mul24(p.dcdy[k], fy) - __mul24(p.dcdx[k], fx) > 0;
         if (in) {
             const float xs = (float)px + samp_fx<8>(s), ys = (float)gy + samp_fy<8>(s);
-            atomicMin(kp + s, (mwgl::z_to_unorm16(mwgl::plane_at(p.z, xs, ys)) << 16) | p.id);
+            atomicMin(kp + s, (mwgl::z_to_unorm16(mwgl::plane_at(p.z, xs, ys)) << 16) | (p.id >> 16));
             any = true;
         }
     }
@@ -79,7 +81,7 @@ __device__ inline void slow_frag(const SlowPiece &p, int px, int gy, int W, int 
     const uint32_t pix = (uint32_t)((H - 1 - gy) * W + px);
     const uint32_t old = atomicExch(head + pix, (stamp << 16) | ((uint32_t)k + 1u));
     const uint32_t next = (old >> 16) == stamp ? (old & 0xFFFFu) : 0u;
-    frags[k] = make_float4(__uint_as_float((p.id << 16) | next), c.r, c.g, c.b);
+    frags[k] = make_float4(__uint_as_float(p.id | next), c.r, c.g, c.b);
 }
 
 __device__ inline void slow_pixel(const SlowPiece &p, int px, int gy, int W, int H, uint32_t *keys, const TexEnv &te, int32_t *frag_count,
@@ -97,22 +99,22 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
                                                                     const uint32_t *__restrict__ slow_tris, float4 *__restrict__ frags_all,
                                                                     uint32_t *__restrict__ heads_all, uint32_t stamp, uint32_t *__restrict__ status)
 {
-    // the clipper's work lists: [MW_SLOW_LANES][2][MWGL_MAX_CLIP_VERTS] vertices (18 KB: the grid is mostly empty workgroups, which
-    // must not queue for LDS)
-    __shared__ mwgl::Vert slow_lists[MW_SLOW_LANES][2][MWGL_MAX_CLIP_VERTS];
-    __shared__ SlowPiece s_piece[MW_SLOW_LANES];        // the pieces of one step of the fans, and where each one's pixels start in the step's pixel list
-    __shared__ int s_pref[MW_SLOW_LANES + 1];
-    // grid (MW_SLOW_BLOCKS_X, N): the blocks of row y share env y's list, MW_SLOW_LANES triangles per block and turn.
+    // the clipper's work lists, the pieces of one turn, where each piece's pixels start in the turn's pixel list (18 KB: the
+    // grid is mostly empty workgroups, which must not queue for LDS)
+    __shared__ mwgl::Vert s_list[MW_SLOW_GROUPS][2][MWGL_MAX_CLIP_VERTS];
+    __shared__ SlowPiece s_piece[64];
+    __shared__ int s_pref[65];
+    // grid (x, N): the blocks of row y share env y's list, MW_SLOW_GROUPS triangles per block and turn.
     // counts: [2 parities][2][N] — listed triangles (the scatter kernel's) and fragments of this frame's parity; the other
     // parity's are zeroed here for the next frame.
-    const int env = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int env = blockIdx.y, lane = threadIdx.x;
     int32_t *slow_count = counts + ((size_t)parity * 2 + 0) * N, *frag_count = counts + ((size_t)parity * 2 + 1) * N;
-    if (blockIdx.x == 0 && tid == 0) { counts[((size_t)(parity ^ 1) * 2 + 0) * N + env] = 0; counts[((size_t)(parity ^ 1) * 2 + 1) * N + env] = 0; }
+    if (blockIdx.x == 0 && lane == 0) { counts[((size_t)(parity ^ 1) * 2 + 0) * N + env] = 0; counts[((size_t)(parity ^ 1) * 2 + 1) * N + env] = 0; }
     const int n = slow_count[env];
-    if ((int)blockIdx.x * MW_SLOW_LANES >= n) return;
+    if ((int)blockIdx.x * MW_SLOW_GROUPS >= n) return;
     uint32_t *head = heads_all + (size_t)env * W * H;
     float4 *frags = frags_all + (size_t)env * MW_SLOW_FRAGS;
-    if (n > MW_SLOW_TRIS && tid == 0) atomicOr(status, MW_ST_VIS_OVERFLOW);
+    if (n > MW_SLOW_TRIS && lane == 0) atomicOr(status, MW_ST_VIS_OVERFLOW);
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     uint32_t *keys = keys_all + (size_t)env * W * H * 8;
     TexEnv te;
@@ -123,73 +125,117 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
     mwgl::Frame f;
     frame_lite(hdr, W, H, f);
     const int nn = min(n, MW_SLOW_TRIS);
-    mwgl::Vert *buf0 = slow_lists[tid & (MW_SLOW_LANES - 1)][0], *buf1 = slow_lists[tid & (MW_SLOW_LANES - 1)][1];
-    for (int base = (int)blockIdx.x * MW_SLOW_LANES; base < nn; base += (int)gridDim.x * MW_SLOW_LANES) {
-        const int i = base + tid;
-        const bool valid = tid < MW_SLOW_LANES && i < nn;
-        mwgl::Vert *r = buf0;
-        int nv = 0, tex = -1;
-        uint32_t id = 0u;
-        if (valid) {
-            const uint32_t it = slow_tris[(size_t)env * MW_SLOW_TRIS + i];
-            const MeshEnt e = load_ment(hdr + MW_HDR_MESH, (int)(it >> 16));
-            const int tri = (int)(it & 0xFFFFu);
-            id = (uint32_t)(e.start + tri);
-            tex = e.tex;
-            float pos[9];
-            tri_load(mesh_pos, e, tri, pos);
-            const float *nrm = mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = mesh_rgb + (size_t)(e.first + tri) * 9;
-            const float *uv = mesh_uv + (size_t)(e.first + tri) * 6;
-            mwgl::Vert v[3];
-            for (int k = 0; k < 3; ++k) {
-                const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
-                mwgl::transform_vertex(f, e.x, p, v[k]);
-                const float nv3[3] = {nrm[k * 3], nrm[k * 3 + 1], nrm[k * 3 + 2]}, c[3] = {rgb[k * 3], rgb[k * 3 + 1], rgb[k * 3 + 2]};
-                mwgl::light_vertex(f, e.x, nv3, c, v[k].col);
-                v[k].st[0] = e.tex >= 0 ? uv[k * 2] : 0.0f;
-                v[k].st[1] = e.tex >= 0 ? uv[k * 2 + 1] : 0.0f;
-            }
-            nv = mwgl::clip_triangle<true>(f, v[0], v[1], v[2], buf0, buf1, &r);
+    const int g = lane >> 3, e = lane & 7, g0 = lane & ~7;
+    mwgl::Vert (&L)[2][MWGL_MAX_CLIP_VERTS] = s_list[g];
+    for (int base = (int)blockIdx.x * MW_SLOW_GROUPS; base < nn; base += (int)gridDim.x * MW_SLOW_GROUPS) {
+        const int i = base + g;
+        const bool valid = i < nn;
+        // ---- a vertex per lane (lanes 0 .. 2 of the group)
+        const uint32_t it = valid ? slow_tris[(size_t)env * MW_SLOW_TRIS + i] : 0u;
+        const MeshEnt me = load_ment(hdr + MW_HDR_MESH, (int)(it >> 16));
+        const int tri = (int)(it & 0xFFFFu), tex = me.tex;
+        const uint32_t id = (uint32_t)(me.start + tri);
+        uint32_t cmv = 0u;
+        if (valid && e < 3) {
+            const float *ps = mesh_pos + (size_t)(me.first + tri) * MW_MESH_POS_STRIDE + 3 * e;
+            const float *nrm = mesh_nrm + (size_t)(me.first + tri) * 9 + 3 * e, *rgb = mesh_rgb + (size_t)(me.first + tri) * 9 + 3 * e;
+            const float *uv = mesh_uv + (size_t)(me.first + tri) * 6 + 2 * e;
+            const float p[3] = {ps[0], ps[1], ps[2]}, nv3[3] = {nrm[0], nrm[1], nrm[2]}, c[3] = {rgb[0], rgb[1], rgb[2]};
+            mwgl::Vert v;
+            mwgl::transform_vertex(f, me.x, p, v);
+            mwgl::light_vertex(f, me.x, nv3, c, v.col);
+            v.st[0] = tex >= 0 ? uv[0] : 0.0f;
+            v.st[1] = tex >= 0 ? uv[1] : 0.0f;
+            cmv = v.clipmask;
+            L[0][e] = v;
         }
-        // the pieces (r[q-1], r[q], r[0]), q = 2 .. nv - 1, in fan order
-        for (int q = 2; __any(q < nv); ++q) {
-            SlowPiece p;
-            bool have = false;
-            if (q < nv) {
-                mwgl::TriSetup ts;
-                if (mwgl::setup_triangle(r[q - 1], r[q], r[0], true, tex >= 0, ts)) {
-                    have = true;
-#pragma unroll
-                    for (int k = 0; k < 3; ++k) { p.dcdx[k] = ts.dcdx[k]; p.dcdy[k] = ts.dcdy[k]; p.c[k] = (int)ts.c[k]; }
-                    p.z = ts.z; p.w = ts.w; p.s = ts.s; p.t = ts.t; p.r = ts.col[0]; p.g = ts.col[1]; p.b = ts.col[2];
-                    p.x0 = max(ts.minx >> 8, 0); p.x1 = min(ts.maxx >> 8, W - 1);
-                    p.y0 = max(ts.miny >> 8, 0); p.y1 = min(ts.maxy >> 8, H - 1);
-                    p.id = id; p.tex = tex;
-                    have = p.x0 <= p.x1 && p.y0 <= p.y1;
-                }
+        const uint32_t c0 = (uint32_t)__shfl((int)cmv, g0), c1 = (uint32_t)__shfl((int)cmv, g0 + 1), c2 = (uint32_t)__shfl((int)cmv, g0 + 2);
+        uint32_t cm = valid && !(c0 & c1 & c2) ? (c0 | c1 | c2) : 0u;
+        int nvx = valid && !(c0 & c1 & c2) ? 3 : 0, cur = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // ---- an edge per lane: the clipper (mw_geom.hip's, with the colours clipped like the texture coordinates).  A
+        // triangle across all six planes can grow to nine vertices: clip_triangle then, on the group's first lane.
+        const bool six = __popc(cm) == 6;
+        if (six) {
+            if (e == 0) {
+                mwgl::Vert *r;
+                const mwgl::Vert a = L[0][0], b = L[0][1], c = L[0][2];
+                nvx = mwgl::clip_triangle<true>(f, a, b, c, L[0], L[1], &r);
+                cur = r == L[1] ? 1 : 0;
             }
-            // the pixels of all pieces of this step of the fans, one (piece, pixel) pair per lane and turn: a fragment costs
-            // two dependent texture reads, and a lane walking its own piece pays them pixel after pixel
-            const int npx = have ? (p.x1 - p.x0 + 1) * (p.y1 - p.y0 + 1) : 0;
-            int incl = npx;
-#pragma unroll
-            for (int off = 1; off < MW_SLOW_LANES; off <<= 1) { const int y = __shfl_up(incl, off); if (lane >= off) incl += y; }
-            if (tid < MW_SLOW_LANES) { s_pref[tid] = incl - npx; if (have) s_piece[tid] = p; }
-            if (tid == MW_SLOW_LANES - 1) s_pref[MW_SLOW_LANES] = incl;
+            nvx = __shfl(nvx, g0); cur = __shfl(cur, g0);
+            cm = 0u;
+        }
+        while (__any(cm != 0u && nvx >= 3)) {
+            const bool act = cm != 0u && nvx >= 3;
+            const int plane = act ? __ffs((int)cm) - 1 : 0;
+            if (act) cm &= cm - 1u;
+            const mwgl::Vert *in = L[cur];
+            mwgl::Vert *out = L[cur ^ 1];
+            const bool mine = act && e < nvx;
+            const int nxt = e + 1 < nvx ? e + 1 : 0;
+            mwgl::Vert V;
+            if (mine) V = in[e];
+            const float dp_prev = mine ? mwgl::clip_dist(V, plane) : 0.0f;
+            const float dp = __shfl(dp_prev, g0 + nxt);
+            const bool bad = mine && (!(dp_prev == dp_prev) || dp_prev - dp_prev != 0.0f);
+            const bool emit = mine && dp_prev >= 0.0f, cross = mine && ((dp >= 0.0f) != (dp_prev >= 0.0f));
+            const uint32_t bg = (uint32_t)(__ballot(bad) >> g0) & 0xFFu;
+            const uint32_t eg = (uint32_t)(__ballot(emit) >> g0) & 0xFFu, xg = (uint32_t)(__ballot(cross) >> g0) & 0xFFu;
+            const uint32_t lowm = (1u << e) - 1u;
+            const int pos = __popc(eg & lowm) + __popc(xg & lowm);
+            if (emit) out[pos] = V;
+            if (cross) {
+                const mwgl::Vert Vn = in[nxt];
+                const bool from_cur = fabsf(dp) < fabsf(dp_prev);
+                const float t = (from_cur ? dp : dp_prev) / (from_cur ? dp - dp_prev : dp_prev - dp);
+                mwgl::clip_interp<true>(f, out[pos + (emit ? 1 : 0)], t, from_cur ? Vn : V, from_cur ? V : Vn);
+            }
+            if (act) { nvx = bg ? 0 : __popc(eg) + __popc(xg); cur ^= 1; }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             __builtin_amdgcn_wave_barrier();
-            const int total = s_pref[MW_SLOW_LANES];
-            for (int k = lane; k < total; k += 64) {
-                int j = 0;
-#pragma unroll
-                for (int step = MW_SLOW_LANES / 2; step > 0; step >>= 1) if (s_pref[j + step] <= k) j += step;      // the last piece that starts at or before k
-                const SlowPiece u = s_piece[j];
-                const int kk = k - s_pref[j], bw = u.x1 - u.x0 + 1;
-                slow_pixel(u, u.x0 + kk % bw, u.y0 + kk / bw, W, H, keys, te, frag_count + env, frags, stamp, head, status);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
         }
+        if (nvx < 3) nvx = 0;
+        // ---- a piece per lane: (r[q-1], r[q], r[0]), q = e + 2
+        const mwgl::Vert *r = L[cur];
+        const int q = e + 2;
+        SlowPiece p;
+        bool have = false;
+        if (q < nvx) {
+            mwgl::TriSetup ts;
+            if (mwgl::setup_triangle(r[q - 1], r[q], r[0], true, tex >= 0, ts)) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { p.dcdx[k] = ts.dcdx[k]; p.dcdy[k] = ts.dcdy[k]; p.c[k] = (int)ts.c[k]; }
+                p.z = ts.z; p.w = ts.w; p.s = ts.s; p.t = ts.t; p.r = ts.col[0]; p.g = ts.col[1]; p.b = ts.col[2];
+                p.x0 = max(ts.minx >> 8, 0); p.x1 = min(ts.maxx >> 8, W - 1);
+                p.y0 = max(ts.miny >> 8, 0); p.y1 = min(ts.maxy >> 8, H - 1);
+                p.id = (id << 16) | ((uint32_t)(q - 2) << 13); p.tex = tex;
+                have = p.x0 <= p.x1 && p.y0 <= p.y1;
+            }
+        }
+        // ---- a (piece, pixel) pair per lane and turn over all pieces: a fragment costs two dependent texture reads, and a
+        // lane walking its own piece would pay them pixel after pixel
+        const int npx = have ? (p.x1 - p.x0 + 1) * (p.y1 - p.y0 + 1) : 0;
+        int incl = npx;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const int y = __shfl_up(incl, off); if (lane >= off) incl += y; }
+        s_pref[lane] = incl - npx;
+        if (have) s_piece[lane] = p;
+        if (lane == 63) s_pref[64] = incl;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const int total = s_pref[64];
+        for (int k = lane; k < total; k += 64) {
+            int j = 0;
+#pragma unroll
+            for (int step = 32; step > 0; step >>= 1) if (s_pref[j + step] <= k) j += step;      // the last piece that starts at or before k
+            const SlowPiece u = s_piece[j];
+            const int kk = k - s_pref[j], bw = u.x1 - u.x0 + 1;
+            slow_pixel(u, u.x0 + kk % bw, u.y0 + kk / bw, W, H, keys, te, frag_count + env, frags, stamp, head, status);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
