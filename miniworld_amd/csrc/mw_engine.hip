@@ -26,7 +26,9 @@ extern "C" __global__ void mw_step_setup_dense_kernel(MwArgs a, int do_step, int
 extern "C" __global__ void mw_step_setup_dense_pcg_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
                                                            float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
+extern "C" __global__ void mw_geom_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
 extern "C" __global__ void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
+extern "C" __global__ void mw_geom_big_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
 #define MW_RASTER_DECL(name) \
     extern "C" __global__ void name(int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave, \
                                     const float *rec_raster, const float *rec_shade, const float *rec_cull, const int32_t *nvis, \
@@ -174,6 +176,14 @@ auto k1_of(const mw_engine *e) -> decltype(&mw_step_setup_kernel)
 }
 
 int k1_threads(const mw_engine *) { return 64; }
+
+// the geometry kernel: big scenes (one env per wavefront) or small, 8 samples per pixel (compiled in) or any
+auto geom_kernel_of(int L, int msaa) -> void (*)(MwArgs, int, int, int, int)
+{
+    const bool fixed8 = msaa == 8 && !getenv("MW_GEOM_ANY");       // (MW_GEOM_ANY: A/B runs)
+    if (L == 64) return fixed8 ? mw_geom_big_kernel : mw_geom_big_any_kernel;
+    return fixed8 ? mw_geom_kernel : mw_geom_any_kernel;
+}
 
 // lanes per env of the geometry kernel: the power of two that holds an env's triangles (two per polygon and box face, the
 // agent marker), 8 .. 64
@@ -559,7 +569,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
     {
         const int L = geom_lanes(e), epw = 64 / L;
-        hipLaunchKernelGGL(L == 64 ? mw_geom_big_kernel : mw_geom_kernel, dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
+        hipLaunchKernelGGL(geom_kernel_of(L, e->cfg.msaa), dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
     }
     if (do_step && e->cfg.task == MW_TASK_COLLECT)
         hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_collect_respawn_pcg_kernel : mw_collect_respawn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, a);
@@ -1193,7 +1203,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     b.W = width; b.H = height;
     b.tiles_x = width / MW_TILE_W; b.tiles_y = height / MW_TILE_H; b.n_tiles = b.tiles_x * b.tiles_y;
     b.env_base = env;
-    hipLaunchKernelGGL(mw_geom_big_kernel, dim3(1), dim3(64), 0, st, b, view_flags, msaa, 64, 1);
+    hipLaunchKernelGGL(geom_kernel_of(64, msaa), dim3(1), dim3(64), 0, st, b, view_flags, msaa, 64, 1);
     uint32_t *keys = nullptr;
     if (e->have_meshes) {
         const size_t need = (size_t)width * height * msaa * 4;
@@ -1248,7 +1258,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     // the geometry kernel in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
     {
         const int L = geom_lanes(e), epw = 64 / L;
-        hipLaunchKernelGGL(L == 64 ? mw_geom_big_kernel : mw_geom_kernel, dim3((count + epw - 1) / epw), dim3(64), 0, st, b, 4, e->cfg.msaa, L, count);
+        hipLaunchKernelGGL(geom_kernel_of(L, e->cfg.msaa), dim3((count + epw - 1) / epw), dim3(64), 0, st, b, 4, e->cfg.msaa, L, count);
     }
     if (!e->visible_attr_set) {
         HIP_TRY(e, hipFuncSetAttribute((const void *)mw_visible_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -181,9 +181,12 @@ __device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float
 // (8, 16, 32 or 64); n_env: envs a.env_base .. a.env_base + n_env - 1.
 // BIG: one env per wavefront (L = 64) with the sifting and occlusion culling of big scenes — their LDS stays out of the
 // small scenes' kernel, whose workgroups then fit four to a CU.
-template <bool BIG>
-__device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, int n_env)
+// SFIX: the target's samples per pixel when fixed at compile time (8: the observation path — a quarter of the record
+// writer's code, 36 registers less), 0: taken from the launch
+template <bool BIG, int SFIX>
+__device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L, int n_env)
 {
+    const int S = SFIX ? SFIX : S_;
     // (244 dwords per slot: consecutive slots start in different LDS banks)
     struct ClipSlot { mwgl::ClipVert l[2][MWGL_MAX_CLIP_VERTS]; float pad[4]; };
     __shared__ ClipSlot s_clip[kClipSlots];
@@ -917,7 +920,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
                     const int idx = o_base + __popc(fm & ((1u << ce) - 1u));
                     mwgl::TriSetup t2;
                     if (mwgl::setup_triangle(to_vert(r[ce - 1], o_col), to_vert(r[ce], o_col), to_vert(r[0], o_col), ms, o_tex >= 0, t2) && o_live && idx < a.max_vis) {
-                        const uint32_t zlo = mwrec::write_tri(a, o_env, idx, o_tag ? o_tag : (uint32_t)idx + o_idb, t2, o_tex, S);
+                        const uint32_t zlo = (SFIX == 8 ? mwrec::write_tri_s<8>(a, o_env, idx, o_tag ? o_tag : (uint32_t)idx + o_idb, t2, o_tex) : mwrec::write_tri(a, o_env, idx, o_tag ? o_tag : (uint32_t)idx + o_idb, t2, o_tex, S));
                         if (BIG && idx < MW_ORDER_CAP) s_key[idx] = (zlo << 16) | (uint32_t)idx;
                     }
                 }
@@ -967,7 +970,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
         if (cnt == 1 && !clipped && live && base < a.max_vis) {
             mwgl::TriSetup ts;
             if (mwgl::setup_triangle(va, vb, vc, ms, tex >= 0, ts)) {
-                const uint32_t zlo = mwrec::write_tri(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex, S);
+                const uint32_t zlo = (SFIX == 8 ? mwrec::write_tri_s<8>(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex) : mwrec::write_tri(a, env, base, tag ? tag : (uint32_t)base + id_base, ts, tex, S));
                 if (BIG && base < MW_ORDER_CAP) s_key[base] = (zlo << 16) | (uint32_t)base;
             }
         }
@@ -995,7 +998,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
                         mwgl::TriSetup t2;
                         if (mwgl::setup_triangle(to_vert(r[i - 1], va.col), to_vert(r[i], va.col), to_vert(r[0], va.col), ms, tex >= 0, t2)) {
                             if (live && idx < a.max_vis) {
-                                const uint32_t zlo = mwrec::write_tri(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t2, tex, S);
+                                const uint32_t zlo = (SFIX == 8 ? mwrec::write_tri_s<8>(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t2, tex) : mwrec::write_tri(a, env, idx, tag ? tag : (uint32_t)idx + id_base, t2, tex, S));
                                 if (BIG && idx < MW_ORDER_CAP) s_key[idx] = (zlo << 16) | (uint32_t)idx;
                             }
                             ++idx;
@@ -1064,5 +1067,8 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S, int L, 
     }
 }
 
-extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false>(a, view_flags, S, L, n_env); }
-extern "C" __global__ __launch_bounds__(64) void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true>(a, view_flags, S, L, n_env); }
+extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false, 8>(a, view_flags, S, L, n_env); }
+extern "C" __global__ __launch_bounds__(64) void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true, 8>(a, view_flags, S, L, n_env); }
+// ... for frame buffers with 1, 4 or 16 samples per pixel
+extern "C" __global__ __launch_bounds__(64) void mw_geom_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false, 0>(a, view_flags, S, L, n_env); }
+extern "C" __global__ __launch_bounds__(64) void mw_geom_big_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true, 0>(a, view_flags, S, L, n_env); }
