@@ -20,6 +20,13 @@
 #define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
 #define MW_HDR_MESH 32        // first float of the mesh-entity table
 #define MW_K1_PROF_SLOTS 10
+// mesh path (mw_mesh.h, mw_raster_mesh.hip)
+#define MW_PLANE_REC 20         // (w plane, tex) (r plane, state) (g plane, s.a0) (b plane, s.dadx) (s.dady, t plane)
+#define MW_PLANE_SLOW 2         // state: the triangle crosses a frustum plane — its fragments come from the env's slow-fragment list
+#define MW_SLOW_TRIS 1024       // per env: mesh triangles that cross a frustum plane (a mesh at the frame's edge)
+#define MW_SLOW_FRAGS 8191      // per env: their fragments, (draw id << 16 | piece of the fan << 13 | next fragment of the pixel + 1, piece's record), chained per pixel
+#define MW_SLOW_PIECES (MW_SLOW_TRIS * 7)       // per env: the attribute planes of the pieces of their fans (plane-cache records), 7 places per listed triangle
+#define MW_SLOW_STRIDE (MW_SLOW_FRAGS + 1 + MW_SLOW_PIECES * (MW_PLANE_REC / 4))       // float4s per env: fragments, then pieces
 #define MW_OCC_CACHE_HDR 8
 // floats per set: header, 8 per wall, 8 per box of eight polygons; whole 128-byte lines
 #define MW_OCC_CACHE_STRIDE(max_polys) ((MW_OCC_CACHE_HDR + 8 * (size_t)(max_polys) + 8 * (size_t)(((max_polys) + 7) / 8) + 31) / 32 * 32)

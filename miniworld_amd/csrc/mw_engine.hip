@@ -625,8 +625,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                     // triangles that cross a frustum plane and their fragments (mw_mesh_slow_kernel): counts, 1024 / 2048 entries per env
                     HIP_TRY(e, hipMalloc((void **)&e->d_slow_count, (size_t)N * 4 * 4));
                     HIP_TRY(e, hipMemset(e->d_slow_count, 0, (size_t)N * 4 * 4));
-                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_tris, (size_t)N * 1024 * 4));
-                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_frags, (size_t)N * 8192 * 16));
+                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_tris, (size_t)N * MW_SLOW_TRIS * 4));
+                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_frags, (size_t)N * MW_SLOW_STRIDE * 16));
                     HIP_TRY(e, hipMalloc((void **)&e->d_slow_head, (size_t)N * a.W * a.H * 4));
                     HIP_TRY(e, hipMemset(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4));
                 }

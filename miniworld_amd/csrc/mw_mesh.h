@@ -120,10 +120,6 @@ __device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const
 // mw_mesh_slow_kernel.  A triangle that covers a sample leaves its attribute planes in the env's plane
 // cache (MW_PLANE_REC floats per mesh triangle in view, indexed like the draw ids), so that the tile phase shades a mesh
 // winner with a 80-byte lookup instead of re-deriving its three vertices.
-#define MW_PLANE_REC 20         // (w plane, tex) (r plane, state) (g plane, s.a0) (b plane, s.dadx) (s.dady, t plane)
-#define MW_PLANE_SLOW 2         // state: the triangle crosses a frustum plane — its fragments come from the env's slow-fragment list
-#define MW_SLOW_TRIS 1024       // per env: mesh triangles that cross a frustum plane (a mesh at the frame's edge)
-#define MW_SLOW_FRAGS 8191      // per env: their fragments, (draw id << 16 | piece of the fan << 13 | next fragment of the pixel + 1, r, g, b), chained per pixel
 
 __device__ inline bool scatter_tri_narrow(const int dcdx[3], const int dcdy[3], const int c[3], const mwgl::Plane &zp, int minx, int maxx,
                                           int miny, int maxy, int W, int H, uint32_t id, uint32_t *keys)
@@ -313,23 +309,23 @@ __device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, 
 {
     const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 1]);
     const float4 *q = reinterpret_cast<const float4 *>(cx.planes + ((size_t)__float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 25]) + ((int)id - start)) * MW_PLANE_REC);
-    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
-    const int tex = cx.te.flat ? -1 : __float_as_int(q0.w);
-    if (__float_as_int(q1.w) == MW_PLANE_SLOW) {
-        // a triangle that crosses a frustum plane: its fragments were shaded by mw_mesh_slow_kernel
-        // (the pixel's chain: of the entries for this id — pieces of the triangle's fan — the first piece's counts)
-        RGB c = {0.0f, 0.0f, 0.0f};
+    if (__float_as_int(q[1].w) == MW_PLANE_SLOW) {
+        // a triangle that crosses a frustum plane: mw_mesh_slow_kernel clipped it and left, per pixel, a chain of the pieces
+        // of its fan that cover a sample there, and the pieces' planes (of the entries for this id the first piece's counts)
         const uint32_t h0 = cx.slow_head[(cx.H - 1 - gy) * cx.W + px];
         uint32_t k = (h0 >> 16) == cx.slow_stamp ? (h0 & 0xFFFFu) : 0u;        // a head of an earlier frame is empty
-        uint32_t best = 8u;
+        uint32_t best = 8u, piece = 0xFFFFFFFFu;
         for (int guard = 0; k != 0u && k <= MW_SLOW_FRAGS && guard < MW_SLOW_FRAGS; ++guard) {
             const float4 fr = cx.slow_frags[k - 1u];
-            const uint32_t w = __float_as_uint(fr.x), piece = (w >> 13) & 7u;
-            if ((w >> 16) == id && piece < best) { c = RGB{fr.y, fr.z, fr.w}; best = piece; }
+            const uint32_t w = __float_as_uint(fr.x), pc = (w >> 13) & 7u;
+            if ((w >> 16) == id && pc < best) { piece = __float_as_uint(fr.y); best = pc; }
             k = w & 0x1FFFu;
         }
-        return c;
+        if (piece >= (uint32_t)MW_SLOW_PIECES) return RGB{0.0f, 0.0f, 0.0f};
+        q = cx.slow_frags + (MW_SLOW_FRAGS + 1) + (size_t)piece * (MW_PLANE_REC / 4);
     }
+    const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+    const int tex = cx.te.flat ? -1 : __float_as_int(q0.w);
     const mwgl::Plane wp = {q0.x, q0.y, q0.z}, pr = {q1.x, q1.y, q1.z}, pg = {q2.x, q2.y, q2.z}, pb = {q3.x, q3.y, q3.z};
     if (tex < 0) {      // an untextured mesh (the common case): three planes over 1 / w
         const float x = (float)px + 0.5f, y = (float)gy + 0.5f;

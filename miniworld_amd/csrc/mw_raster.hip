@@ -83,7 +83,7 @@ __device__ inline void raster_kernel_body(
     cx.shade_stride = in_lds ? MW_LDS_SHADE_Q : MW_SHADE_REC / 4; cx.cull_stride = in_lds ? MW_LDS_CULL_Q : MW_CULL_REC / 4; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH;
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.planes = MESHAWARE ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
-    cx.slow_frags = MESHAWARE ? slow_frags + (size_t)env * MW_SLOW_FRAGS : nullptr;
+    cx.slow_frags = MESHAWARE ? slow_frags + (size_t)env * MW_SLOW_STRIDE : nullptr;
     cx.slow_head = MESHAWARE ? slow_head + (size_t)env * W * H : nullptr;
     cx.slow_stamp = (uint32_t)dbg >> 16;
     cx.obs = obs; cx.depth = depth;

@@ -33,9 +33,9 @@ extern "C" __global__ __launch_bounds__(256) void mw_mesh_scatter_kernel(int W, 
 }
 
 // The mesh triangles that cross a frustum plane (a mesh at the frame's edge; the scatter kernel lists them): clipped, every
-// piece set up on its own (llvmpipe's clipper output), its keys scattered and its fragments shaded right here — one entry
-// (draw id, piece, colour) per pixel with a covered sample, chained per pixel — so that neither the scatter kernel nor K2
-// carries the clipper.  A wavefront takes eight triangles at a time, eight lanes to a triangle: a vertex per lane
+// piece set up on its own (llvmpipe's clipper output), its keys scattered, its attribute planes left in the env's piece
+// table and one entry (draw id, piece) per pixel with a covered sample chained to the pixel — K2 shades what wins from
+// there — so that neither the scatter kernel nor K2 carries the clipper.  A wavefront takes eight triangles at a time, eight lanes to a triangle: a vertex per lane
 // (transform, light), an edge of the clipped polygon per lane (the geometry kernel's clipper, with colours), a piece of the
 // fan per lane (setup), then a (piece, pixel) pair per lane over all pieces of the eight.  Exits at once for an env without
 // such triangles.
@@ -45,10 +45,10 @@ namespace {
 
 struct SlowPiece {       // what the pixel loop needs of one set-up piece
     int dcdx[3], dcdy[3], c[3];
-    mwgl::Plane z, w, s, t, r, g, b;
+    mwgl::Plane z;
     int x0, x1, y0, y1;
     uint32_t id;        // draw id << 16 | piece of the fan << 13
-    int tex;
+    uint32_t rec;       // the piece's record (attribute planes) in the env's piece table
 };
 
 // the piece's samples in pixel (px, gy): keys scattered; true if any
@@ -71,23 +71,19 @@ __device__ inline bool slow_cover(const SlowPiece &p, int px, int gy, int W, int
     return any;
 }
 
-// the piece's fragment of pixel (px, gy) as entry k of the env's list
+// the piece covers a sample of pixel (px, gy): entry k of the env's list, chained to the pixel (K2 shades it from the
+// piece's record if it wins)
 // (a pixel's chain head is (frame stamp << 16) | index + 1: heads of earlier frames read as empty, nothing is cleared)
-__device__ inline void slow_frag(const SlowPiece &p, int px, int gy, int W, int H, const TexEnv &te, int k, float4 *frags, uint32_t stamp,
-                                 uint32_t *head, uint32_t *status)
+__device__ inline void slow_pixel(const SlowPiece &p, int px, int gy, int W, int H, uint32_t *keys, int32_t *frag_count,
+                                  float4 *frags, uint32_t stamp, uint32_t *head, uint32_t *status)
 {
+    if (!slow_cover(p, px, gy, W, H, keys)) return;
+    const int k = atomicAdd(frag_count, 1);
     if (k >= MW_SLOW_FRAGS) { atomicOr(status, MW_ST_VIS_OVERFLOW); return; }
-    const RGB c = shade_planes(p.w, p.s, p.t, p.r, p.g, p.b, p.tex, te, px, gy, 0.5f);
     const uint32_t pix = (uint32_t)((H - 1 - gy) * W + px);
     const uint32_t old = atomicExch(head + pix, (stamp << 16) | ((uint32_t)k + 1u));
     const uint32_t next = (old >> 16) == stamp ? (old & 0xFFFFu) : 0u;
-    frags[k] = make_float4(__uint_as_float(p.id | next), c.r, c.g, c.b);
-}
-
-__device__ inline void slow_pixel(const SlowPiece &p, int px, int gy, int W, int H, uint32_t *keys, const TexEnv &te, int32_t *frag_count,
-                                  float4 *frags, uint32_t stamp, uint32_t *head, uint32_t *status)
-{
-    if (slow_cover(p, px, gy, W, H, keys)) slow_frag(p, px, gy, W, H, te, atomicAdd(frag_count, 1), frags, stamp, head, status);
+    frags[k] = make_float4(__uint_as_float(p.id | next), __uint_as_float(p.rec), 0.0f, 0.0f);
 }
 
 }  // namespace
@@ -113,15 +109,12 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
     const int n = slow_count[env];
     if ((int)blockIdx.x * MW_SLOW_GROUPS >= n) return;
     uint32_t *head = heads_all + (size_t)env * W * H;
-    float4 *frags = frags_all + (size_t)env * MW_SLOW_FRAGS;
+    float4 *frags = frags_all + (size_t)env * MW_SLOW_STRIDE;
+    float *pieces = reinterpret_cast<float *>(frags + (MW_SLOW_FRAGS + 1));
     if (n > MW_SLOW_TRIS && lane == 0) atomicOr(status, MW_ST_VIS_OVERFLOW);
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     uint32_t *keys = keys_all + (size_t)env * W * H * 8;
-    TexEnv te;
-    te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
-    te.td = te.tx;
-    te.texd = reinterpret_cast<const MwTexDesc *>(texels);
-    te.flat = 0;
+    (void)texels; (void)texel_bytes;
     mwgl::Frame f;
     frame_lite(hdr, W, H, f);
     const int nn = min(n, MW_SLOW_TRIS);
@@ -207,15 +200,16 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
             if (mwgl::setup_triangle(r[q - 1], r[q], r[0], true, tex >= 0, ts)) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { p.dcdx[k] = ts.dcdx[k]; p.dcdy[k] = ts.dcdy[k]; p.c[k] = (int)ts.c[k]; }
-                p.z = ts.z; p.w = ts.w; p.s = ts.s; p.t = ts.t; p.r = ts.col[0]; p.g = ts.col[1]; p.b = ts.col[2];
+                p.z = ts.z;
                 p.x0 = max(ts.minx >> 8, 0); p.x1 = min(ts.maxx >> 8, W - 1);
                 p.y0 = max(ts.miny >> 8, 0); p.y1 = min(ts.maxy >> 8, H - 1);
-                p.id = (id << 16) | ((uint32_t)(q - 2) << 13); p.tex = tex;
+                p.id = (id << 16) | ((uint32_t)(q - 2) << 13);
+                p.rec = (uint32_t)(i * 7 + (q - 2));
                 have = p.x0 <= p.x1 && p.y0 <= p.y1;
+                if (have) store_planes(pieces + (size_t)p.rec * MW_PLANE_REC, ts, tex, 1);
             }
         }
-        // ---- a (piece, pixel) pair per lane and turn over all pieces: a fragment costs two dependent texture reads, and a
-        // lane walking its own piece would pay them pixel after pixel
+        // ---- a (piece, pixel) pair per lane and turn over all pieces
         const int npx = have ? (p.x1 - p.x0 + 1) * (p.y1 - p.y0 + 1) : 0;
         int incl = npx;
 #pragma unroll
@@ -232,7 +226,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
             for (int step = 32; step > 0; step >>= 1) if (s_pref[j + step] <= k) j += step;      // the last piece that starts at or before k
             const SlowPiece u = s_piece[j];
             const int kk = k - s_pref[j], bw = u.x1 - u.x0 + 1;
-            slow_pixel(u, u.x0 + kk % bw, u.y0 + kk / bw, W, H, keys, te, frag_count + env, frags, stamp, head, status);
+            slow_pixel(u, u.x0 + kk % bw, u.y0 + kk / bw, W, H, keys, frag_count + env, frags, stamp, head, status);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
