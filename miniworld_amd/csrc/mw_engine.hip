@@ -43,6 +43,8 @@ MW_RASTER_DECL(mw_raster_big_depth_kernel);
 MW_RASTER_DECL(mw_raster_wrap_kernel);
 MW_RASTER_DECL(mw_raster_big_wrap_kernel);
 MW_RASTER_DECL(mw_raster_mesh_kernel);
+MW_RASTER_DECL(mw_raster_nomesh_kernel);
+MW_RASTER_DECL(mw_raster_nomesh_depth_kernel);
 MW_RASTER_DECL(mw_raster_mesh_depth_kernel);
 MW_RASTER_DECL(mw_raster_mesh_wrap_kernel);
 MW_RASTER_DECL(mw_raster_big_mesh_wrap_kernel);
@@ -656,7 +658,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
                 HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
             }
-            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(getenv("MW_SLOW_BX") ? atoi(getenv("MW_SLOW_BX")) : 16, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(getenv("MW_SLOW_BX") ? atoi(getenv("MW_SLOW_BX")) : 16, N), dim3(64), 0, getenv("MW_SLOW_SERIAL") ? st : sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
                                a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, N, parity, (const uint32_t *)e->d_slow_tris,
                                e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status);
         }
@@ -679,10 +681,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             if (general && !big) k2 = mw_raster_mesh_wrap_kernel;
         }
         const int flags = e->dbg_flags | (e->obs_layout << 8) | (int)(mesh_stamp << 16);
+        // K2's first part of a frame with meshes never enters a mesh tile: the plain tile code with the skip (the small-scene observation path only)
+        auto k2_first = (mesh && !big && !general && !getenv("MW_K2_FIRST_FULL")) ? (d_depth ? mw_raster_nomesh_depth_kernel : mw_raster_nomesh_kernel) : k2;
         auto launch_k2 = [&](int part_flags) {
             // the second part (the tiles a mesh can touch: few, slow, clustered) spreads over one wave per tile
             const int wpe2 = (part_flags >> 4) == 2 ? a.n_tiles : wpe, tpw2 = (part_flags >> 4) == 2 ? 1 : tpw;
-            hipLaunchKernelGGL(k2, dim3(groups * 8 * wpe2), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+            hipLaunchKernelGGL((part_flags >> 4) == 1 ? k2_first : k2, dim3(groups * 8 * wpe2), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                                a.n_tiles, wpe2, tpw2, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                                (const int32_t *)a.nvis,
                                (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, flags | part_flags, e->texel_bytes,

@@ -23,7 +23,7 @@
 //                   visible primitives (Maze) would not leave room for enough resident waves.
 // MESHAWARE   : envs may hold mesh entities — the tiles inside a mesh entity's tile rectangle (env header) start from the
 //               sample keys the scatter kernel left (mw_raster_mesh.hip) and give them back cleared.
-template <bool LDS_RECS, int FMT, int HOT = 0, bool MESHAWARE = false>
+template <bool LDS_RECS, int FMT, int HOT = 0, int MESHAWARE = 0>
 __device__ inline void raster_kernel_body(
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave,
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
@@ -49,7 +49,7 @@ __device__ inline void raster_kernel_body(
     const int lane = threadIdx.x;
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     const bool mesh_env = MESHAWARE && __float_as_int(hdr[3]) != 0;
-    uint32_t *env_keys = MESHAWARE ? mesh_keys + (size_t)env * W * H * 8 : nullptr;
+    uint32_t *env_keys = MESHAWARE == 1 ? mesh_keys + (size_t)env * W * H * 8 : nullptr;
     // mesh-aware launches come in two parts (launch flags bits 4-5): 1 = every tile but those a mesh can touch — they need
     // nothing of the mesh kernels and run beside them —, 2 = those tiles only, behind the mesh kernels; 0 = all tiles
     const int part_mode = MESHAWARE ? (dbg >> 4) & 3 : 0;
@@ -82,9 +82,9 @@ __device__ inline void raster_kernel_body(
     cx.s_shade = in_lds ? s_shade : g_shade; cx.s_cull = in_lds ? s_cull : g_cull;
     cx.shade_stride = in_lds ? MW_LDS_SHADE_Q : MW_SHADE_REC / 4; cx.cull_stride = in_lds ? MW_LDS_CULL_Q : MW_CULL_REC / 4; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH;
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
-    cx.planes = MESHAWARE ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
-    cx.slow_frags = MESHAWARE ? slow_frags + (size_t)env * MW_SLOW_STRIDE : nullptr;
-    cx.slow_head = MESHAWARE ? slow_head + (size_t)env * W * H : nullptr;
+    cx.planes = MESHAWARE == 1 ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
+    cx.slow_frags = MESHAWARE == 1 ? slow_frags + (size_t)env * MW_SLOW_STRIDE : nullptr;
+    cx.slow_head = MESHAWARE == 1 ? slow_head + (size_t)env * W * H : nullptr;
     cx.slow_stamp = (uint32_t)dbg >> 16;
     cx.obs = obs; cx.depth = depth;
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3); cx.te = te;
@@ -127,8 +127,9 @@ __device__ inline void raster_kernel_body(
             cx.pre_full = (uint32_t)__builtin_amdgcn_readlane((int)vF, gi);
             ++gi;
             const bool mesh_tile = MESHAWARE && mesh_env && tile_in_mesh_rect(hdr, tx, ty);
+            if (MESHAWARE == 2 && mesh_tile) continue;
             if (MESHAWARE && part_mode != 0 && mesh_tile != (part_mode == 2)) continue;
-            if (MESHAWARE && mesh_tile) {
+            if (MESHAWARE == 1 && mesh_tile) {
                 uint32_t mk[8];
                 take_mesh_keys(env_keys, W, tx, ty, lane, mk);
                 raster_tile_fmt<true, FMT, false, HOT, 1>(cx, tx, ty, mk);
@@ -140,8 +141,9 @@ __device__ inline void raster_kernel_body(
     }
     for (int tile = t_begin; tile < t_end; ++tile, tx = (tx + 1 == tiles_x) ? 0 : tx + 1, ty += (tx == 0)) {
         const bool mesh_tile = MESHAWARE && mesh_env && tile_in_mesh_rect(hdr, tx, ty);
+        if (MESHAWARE == 2 && mesh_tile) continue;
         if (MESHAWARE && part_mode != 0 && mesh_tile != (part_mode == 2)) continue;
-        if (MESHAWARE && mesh_tile) {
+        if (MESHAWARE == 1 && mesh_tile) {
             uint32_t mk[8];
             take_mesh_keys(env_keys, W, tx, ty, lane, mk);
             raster_tile_fmt<true, FMT, false, HOT, 0>(cx, tx, ty, mk);
@@ -199,7 +201,11 @@ extern "C" __global__ __launch_bounds__(64) void mw_raster_big_wrap_kernel(MW_RA
 }
 
 // the same for envs that may hold mesh entities (PickupObjects, Sign, CollectHealth, ...)
-extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 1, true>(MW_RASTER_FWD); }
-extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_depth_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 2, true>(MW_RASTER_FWD); }
-extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, -1, 0, true>(MW_RASTER_FWD); }
-extern "C" __global__ __launch_bounds__(64) void mw_raster_big_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<false, -1, 0, true>(MW_RASTER_FWD); }
+// ... the tiles no mesh can touch, of envs that hold mesh entities (K2's first part, beside the mesh kernels): the plain tile code,
+// at the plain kernels' register count
+extern "C" __global__ __launch_bounds__(64) void mw_raster_nomesh_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 1, 2>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64) void mw_raster_nomesh_depth_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 2, 2>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 1, 1>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_depth_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 2, 1>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, -1, 0, 1>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64) void mw_raster_big_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<false, -1, 0, 1>(MW_RASTER_FWD); }
