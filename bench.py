@@ -39,7 +39,7 @@ CONFIGS = {
     "hallway": ("MiniWorld-Hallway-v0", "Hallway", 4096, False, False, 3, 1, 14540, "mw_raster_kernel"),
     "oneroom_rgbd": ("MiniWorld-OneRoom-v0", "OneRoom", 4096, True, False, 3, 1, 33740, "mw_raster_depth_kernel"),
     "maze": ("MiniWorld-Maze-v0", "Maze", 1024, False, False, 3, 1, 30860, "mw_raster_big_kernel"),
-    "pickup_dr": ("MiniWorld-PickupObjects-v0", "PickupObjects", 2048, False, True, 5, 2, 14800, "mw_raster_mesh_kernel"),
+    "pickup_dr": ("MiniWorld-PickupObjects-v0", "PickupObjects", 2048, False, True, 5, 2, 14800, "mw_raster_nomesh_kernel"),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PREWARM_S = 0.5             # untimed steps before the W warm-up steps: clocks and caches of a cold box (reported)
