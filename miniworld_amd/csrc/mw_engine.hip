@@ -658,7 +658,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
                 HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
             }
-            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(getenv("MW_SLOW_BX") ? atoi(getenv("MW_SLOW_BX")) : 16, N), dim3(64), 0, getenv("MW_SLOW_SERIAL") ? st : sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(getenv("MW_SLOW_BX") ? atoi(getenv("MW_SLOW_BX")) : 16, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
                                a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, N, parity, (const uint32_t *)e->d_slow_tris,
                                e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status);
         }

@@ -451,6 +451,8 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         __syncthreads();
         if (lane == 0) a.occ_valid[set] = np + 1;
     }
+    // (acquire: the cache is read behind the flag — a shared set may have been filled by another wavefront of this launch)
+    if (cached) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
     // ---- occlusion culling: the walls that hide what lies behind them
     const float bins_per_px = (float)MW_OCC_BINS / (float)a.W;
