@@ -183,7 +183,7 @@ __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, in
     const uint32_t id = (uint32_t)(e.start + tri);
     float *rec = cache + (size_t)tri * MW_PLANE_REC;
     if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) != 0u) {
-        // crosses a frustum plane (rare): left to mw_mesh_slow_kernel, which clips it, scatters its keys and shades its fragments
+        // crosses a frustum plane (rare): left to mw_mesh_slow_kernel, which clips it, scatters its keys and lists its fragments
         const int k = atomicAdd(slow_count, 1);
         if (k < MW_SLOW_TRIS) slow_tris[k] = ((uint32_t)j << 16) | (uint32_t)tri;
         reinterpret_cast<float4 *>(rec)[1] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(MW_PLANE_SLOW));
