@@ -71,17 +71,6 @@ __device__ inline bool tri_front(const float wa[4], const float wb[4], const flo
     return dx01 * dy20 - dx20 * dy01 < 0;
 }
 
-// Would tri_front say no whatever the rounding of the snap does?  In units of 1/256 px the snapped coordinates differ from
-// the exact ones by at most a half each, the edge differences by at most one, the area by at most the sum of the four
-// differences plus two; the float products below add their own rounding (1e-6 of their size, generously).
-__device__ inline bool clearly_back(const float wa[4], const float wb[4], const float wc[4])
-{
-    const float dx01 = (wa[0] - wb[0]) * 256.0f, dy01 = (wa[1] - wb[1]) * 256.0f, dx20 = (wc[0] - wa[0]) * 256.0f, dy20 = (wc[1] - wa[1]) * 256.0f;
-    const float p = dx01 * dy20, q = dx20 * dy01;
-    const float margin = (fabsf(dx01) + fabsf(dy20)) + (fabsf(dx20) + fabsf(dy01)) + 4.0f + 1e-6f * (fabsf(p) + fabsf(q));
-    return p - q > margin;
-}
-
 // Bitonic sort of the n <= 64 R keys in keys[] (ascending; unused places count as the largest key) by one wavefront, the
 // low halves of the sorted keys stored to order[1 ..].
 template <int R>
@@ -626,8 +615,8 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                     if (keep && (v[0].clipmask | v[1].clipmask | v[2].clipmask | v[3].clipmask) == 0u) {
                         const bool fan = nv == 3 || !(nvf & MW_POLY_QUAD);
                         // v[] holds the polygon's own vertices k (v[3] = v[0] for a triangle): fan (1,2,0) (2,3,0), list quad (0,1,3) (1,2,3)
-                        const bool b0 = fan ? clearly_back(v[1].win, v[2].win, v[0].win) : clearly_back(v[0].win, v[1].win, v[3].win);
-                        const bool b1 = nv == 3 || (fan ? clearly_back(v[2].win, v[3].win, v[0].win) : clearly_back(v[1].win, v[2].win, v[3].win));
+                        const bool b0 = fan ? mwgl::clearly_back(v[1].win, v[2].win, v[0].win) : mwgl::clearly_back(v[0].win, v[1].win, v[3].win);
+                        const bool b1 = nv == 3 || (fan ? mwgl::clearly_back(v[2].win, v[3].win, v[0].win) : mwgl::clearly_back(v[1].win, v[2].win, v[3].win));
                         if (b0 && b1) keep = false;
                     }
                 }

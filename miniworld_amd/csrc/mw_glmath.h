@@ -450,6 +450,17 @@ MW_HD void plane_coef(Plane &p, float a0, float a1, float a2, float dy20_ooa, fl
     p.a0 = a0 - (p.dadx * x0c + p.dady * y0c);
 }
 
+// Would the setup's area test (on the snapped vertices) drop the triangle whatever the rounding of the snap does?  In units
+// of 1/256 px the snapped coordinates differ from the exact ones by at most a half each, the edge differences by at most one, the area by at most the sum of the four
+// differences plus two; the float products below add their own rounding (1e-6 of their size, generously).
+MW_HD bool clearly_back(const float wa[4], const float wb[4], const float wc[4])
+{
+    const float dx01 = (wa[0] - wb[0]) * 256.0f, dy01 = (wa[1] - wb[1]) * 256.0f, dx20 = (wc[0] - wa[0]) * 256.0f, dy20 = (wc[1] - wa[1]) * 256.0f;
+    const float p = dx01 * dy20, q = dx20 * dy01;
+    const float margin = (fabsf(dx01) + fabsf(dy20)) + (fabsf(dx20) + fabsf(dy01)) + 4.0f + 1e-6f * (fabsf(p) + fabsf(q));
+    return p - q > margin;
+}
+
 // The position-only part of the setup (edges + depth plane): what a kernel that only needs coverage and depth keys pays.
 struct TriEdges {
     int32_t dcdx[3], dcdy[3];

@@ -282,3 +282,90 @@ extern "C" int mwhost_clip_variants_agree(const float clip[3][4], const float st
     }
     return 1 + na;
 }
+
+// The big scenes' sift drops a polygon whose triangles are "clearly back-facing" (mw_glmath.h: the float area beyond what
+// snapping the vertices to 1/256 px can change).  Returns 1 if the claim and the exact test disagree: clearly_back says
+// yes although the setup (snapped integers) keeps the triangle.
+extern "C" int mwhost_clearly_back_is_wrong(const float win[3][4], int multisampled)
+{
+    TriEdges te;
+    const bool kept = setup_triangle_pos(win[0], win[1], win[2], multisampled != 0, te);
+    return clearly_back(win[0], win[1], win[2]) && kept ? 1 : 0;
+}
+
+extern "C" int mwhost_clearly_back(const float win[3][4]) { return clearly_back(win[0], win[1], win[2]) ? 1 : 0; }
+
+// The geometry kernel's clipper works eight lanes to a triangle: lane e owns the polygon's edge e -> e + 1, passes vertex e
+// on if it is inside the plane and makes the crossing's vertex; everybody's place in the output list is the number of
+// vertices the lanes before it put out.  This is that algorithm with the lanes as a loop, on the same per-vertex functions:
+// it must give clip_triangle's polygon bit for bit (vertex count, order, coordinates).  Returns 1 + n on agreement, 0 else.
+extern "C" int mwhost_edge_parallel_clip_agrees(const float clip[3][4], const float st[3][2], int W, int H)
+{
+    Frame f{};
+    f.vp_scale[0] = (float)W * 0.5f; f.vp_trans[0] = (float)W * 0.5f;
+    f.vp_scale[1] = (float)H * 0.5f; f.vp_trans[1] = (float)H * 0.5f;
+    f.vp_scale[2] = 0.5f; f.vp_trans[2] = 0.5f;
+    Vert v[3];
+    uint32_t un = 0u, in = 0x3Fu;
+    for (int k = 0; k < 3; ++k) {
+        for (int i = 0; i < 4; ++i) v[k].clip[i] = clip[k][i];
+        const float w = v[k].clip[3];
+        uint32_t m = 0;
+        if (v[k].clip[0] > w) m |= 1u;
+        if (v[k].clip[0] + w < 0.0f) m |= 2u;
+        if (v[k].clip[1] > w) m |= 4u;
+        if (v[k].clip[1] + w < 0.0f) m |= 8u;
+        if (v[k].clip[2] + w < 0.0f) m |= 16u;
+        if (v[k].clip[2] > w) m |= 32u;
+        v[k].clipmask = m; un |= m; in &= m;
+        const float oow = 1.0f / w;
+        for (int i = 0; i < 3; ++i) v[k].win[i] = fmaf(v[k].clip[i] * oow, f.vp_scale[i], f.vp_trans[i]);
+        v[k].win[3] = oow;
+        v[k].st[0] = st[k][0]; v[k].st[1] = st[k][1];
+        v[k].col[0] = v[k].col[1] = v[k].col[2] = 0.5f;
+    }
+    ClipVert a0[MWGL_MAX_CLIP_VERTS], a1[MWGL_MAX_CLIP_VERTS], *ra;
+    const int na = clip_triangle<false>(f, v[0], v[1], v[2], a0, a1, &ra);
+    if (in) return na == 0 ? 1 : 0;
+    // the lanes' version
+    ClipVert l[2][MWGL_MAX_CLIP_VERTS + 2];
+    for (int k = 0; k < 3; ++k) clip_copy_in(l[0][k], v[k]);
+    int n = 3, cur = 0;
+    uint32_t cm = un;
+    while (cm != 0u && n >= 3) {
+        int plane = 0;
+        while (!((cm >> plane) & 1u)) ++plane;
+        cm &= cm - 1u;
+        const ClipVert *inl = l[cur];
+        ClipVert *out = l[cur ^ 1];
+        float dpv[MWGL_MAX_CLIP_VERTS + 2];
+        bool bad = false;
+        for (int e = 0; e < n; ++e) { dpv[e] = clip_dist(inl[e], plane); bad |= !(dpv[e] == dpv[e]) || dpv[e] - dpv[e] != 0.0f; }
+        int total = 0;
+        for (int e = 0; e < n; ++e) {       // "lane" e: its place = what the lanes before it put out
+            const int nxt = e + 1 < n ? e + 1 : 0;
+            const float dp_prev = dpv[e], dp = dpv[nxt];
+            const bool emit = dp_prev >= 0.0f, cross = (dp >= 0.0f) != (dp_prev >= 0.0f);
+            int pos = 0;
+            for (int b = 0; b < e; ++b) {
+                const int bn = b + 1 < n ? b + 1 : 0;
+                pos += (dpv[b] >= 0.0f ? 1 : 0) + (((dpv[bn] >= 0.0f) != (dpv[b] >= 0.0f)) ? 1 : 0);
+            }
+            if (emit) out[pos] = inl[e];
+            if (cross) {
+                const bool from_cur = fabsf(dp) < fabsf(dp_prev);
+                const float t = (from_cur ? dp : dp_prev) / (from_cur ? dp - dp_prev : dp_prev - dp);
+                clip_interp<false>(f, out[pos + (emit ? 1 : 0)], t, from_cur ? inl[nxt] : inl[e], from_cur ? inl[e] : inl[nxt]);
+            }
+            total += (emit ? 1 : 0) + (cross ? 1 : 0);
+        }
+        n = bad ? 0 : total;
+        cur ^= 1;
+    }
+    if (n < 3) n = 0;
+    if (n != na) return 0;
+    for (int i = 0; i < n; ++i)
+        if (memcmp(l[cur][i].clip, ra[i].clip, 16) || memcmp(l[cur][i].win, ra[i].win, 16) || memcmp(l[cur][i].st, ra[i].st, 8)) return 0;
+    return 1 + n;
+}
+

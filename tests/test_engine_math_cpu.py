@@ -89,3 +89,54 @@ def test_compact_clip_vertices_clip_like_full_ones(host):
         assert r >= 1, (clip, st)
         clipped += r > 1
     assert clipped > 500        # plenty of them really went through the planes
+
+
+def test_edge_parallel_clipper_gives_the_serial_clippers_polygon(host):
+    """The geometry kernel clips with eight lanes to a triangle, an edge of the polygon per lane, one step per frustum
+    plane (mw_geom.hip); that algorithm, with the lanes as a loop over the same per-vertex functions, yields
+    clip_triangle's polygon bit for bit — vertex count, order, clip / window / texture coordinates."""
+    rng = np.random.default_rng(9)
+    host.mwhost_edge_parallel_clip_agrees.restype = C.c_int
+    clipped = many = 0
+    for _ in range(6000):
+        clip = rng.normal(0, 1.5, (3, 4)).astype(np.float32)
+        clip[:, 3] = rng.uniform(-0.5, 2.5, 3).astype(np.float32)
+        if rng.random() < 0.2:      # big triangles around the whole frustum: many planes, many vertices
+            clip[:, :3] *= 6.0
+        st = rng.uniform(-2, 2, (3, 2)).astype(np.float32)
+        r = host.mwhost_edge_parallel_clip_agrees(clip.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p), 80, 60)
+        assert r >= 1, (clip, st)
+        clipped += r > 1
+        many += r > 6
+    assert clipped > 1000 and many > 20
+
+
+def test_clearly_back_facing_triangles_never_leave_setup(host):
+    """Big scenes drop polygons seen from behind while sifting (mw_geom.hip): `clearly_back` must only say yes where the
+    setup's own test on the snapped vertices drops the triangle — also for slivers, sub-pixel triangles and vertices a hair
+    apart, where snapping to 1/256 px can turn the area's sign."""
+    rng = np.random.default_rng(10)
+    host.mwhost_clearly_back_is_wrong.restype = C.c_int
+    host.mwhost_clearly_back.restype = C.c_int
+    said_yes = 0
+    for k in range(30000):
+        kind = k % 4
+        if kind == 0:       # anything on the 80 x 60 frame
+            w = rng.uniform(-5, 85, (3, 2))
+        elif kind == 1:     # slivers: the third vertex a hair off the line through the first two
+            a, b = rng.uniform(0, 80, 2), rng.uniform(0, 80, 2)
+            t = rng.uniform(0, 1)
+            n = np.array([-(b - a)[1], (b - a)[0]]) / max(np.linalg.norm(b - a), 1e-6)
+            w = np.stack([a, b, a + t * (b - a) + n * rng.normal(0, 3e-3)])
+        elif kind == 2:     # sub-pixel triangles
+            w = rng.uniform(0, 80, 2) + rng.normal(0, 5e-3, (3, 2))
+        else:               # on the snapping grid's half steps
+            w = (np.round(rng.uniform(0, 80, (3, 2)) * 256) + rng.choice([0.0, 0.5, 0.4999, 0.5001], (3, 2))) / 256
+        win = np.zeros((3, 4), np.float32)
+        win[:, :2] = w
+        win[:, 2] = 0.5; win[:, 3] = 1.0
+        for ms in (0, 1):
+            assert host.mwhost_clearly_back_is_wrong(win.ctypes.data_as(C.c_void_p), ms) == 0, (win, ms)
+        said_yes += host.mwhost_clearly_back(win.ctypes.data_as(C.c_void_p))
+    assert said_yes > 3000      # and it does say yes for ordinary back faces
+
