@@ -543,37 +543,10 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                 const int fl = __float_as_int(b1.z);
                 if (fl & 1) {
                     const float mn[3] = {b0.x, b0.y, b0.z}, mx[3] = {b0.w, b1.x, b1.y};
-                    const float *m = cam.mvp.m;
-                    // "outside a plane" with a margin above the rounding of the sums below and of transform_vertex's
-                    // (four roundings of half an ulp of at most mag[i] each, twice): then every vertex inside the box is
-                    // outside that plane in transform_vertex's own arithmetic too
-                    const float R = fmaxf(fmaxf(fmaxf(fabsf(mn[0]), fabsf(mx[0])), fmaxf(fabsf(mn[1]), fabsf(mx[1]))), fmaxf(fabsf(mn[2]), fabsf(mx[2])));
-                    float mag[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) mag[i] = ((fabsf(m[i]) + fabsf(m[4 + i])) + fabsf(m[8 + i])) * R + fabsf(m[12 + i]);
-                    const float ex = 4e-6f * (mag[0] + mag[3]), ey = 4e-6f * (mag[1] + mag[3]), ez = 4e-6f * (mag[2] + mag[3]);
-                    uint32_t all = 0x3Fu;
-                    float zq = 1e30f, xmn = 1e30f, xmx = -1e30f;
-                    bool front = true;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float p[3] = {(k & 1) ? mx[0] : mn[0], (k & 2) ? mx[1] : mn[1], (k & 4) ? mx[2] : mn[2]};
-                        float cl[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) cl[i] = ((p[0] * m[i] + p[1] * m[4 + i]) + p[2] * m[8 + i]) + m[12 + i];
-                        const float w = cl[3];
-                        uint32_t mask = 0;
-                        if (cl[0] - w > ex) mask |= 1u;
-                        if (cl[0] + w < -ex) mask |= 2u;
-                        if (cl[1] - w > ey) mask |= 4u;
-                        if (cl[1] + w < -ey) mask |= 8u;
-                        if (cl[2] + w < -ez) mask |= 16u;
-                        if (cl[2] - w > ez) mask |= 32u;
-                        all &= mask;
-                        front &= w >= 0.1f;
-                        const float wx = fmaf(cl[0] * __builtin_amdgcn_rcpf(w), f.vp_scale[0], f.vp_trans[0]);
-                        xmn = fminf(xmn, wx); xmx = fmaxf(xmx, wx); zq = fminf(zq, w);
-                    }
+                    const mwgl::BoxView bv = mwgl::box_view(mn, mx, cam.mvp.m, f.vp_scale[0], f.vp_trans[0]);
+                    const uint32_t all = bv.all;
+                    const bool front = bv.front;
+                    const float xmn = bv.xmn, xmx = bv.xmx, zq = bv.zq;
                     keep = all == 0u;
                     if (keep && occ_on && (fl & 2) && front && occluded_span(s_occ_z, xmn - 0.15f, xmx + 0.15f, zq * 0.9999f, bins_per_px)) keep = false;
                 }

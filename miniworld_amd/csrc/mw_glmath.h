@@ -339,6 +339,50 @@ MW_HD void transform_vertex(const Frame &f, const Xform &x, const float p[3], Ve
     v.win[3] = oow;
 }
 
+// ---------------------------------------------------------------- boxes of polygons (big scenes' culling, mw_geom.hip)
+// An axis-aligned box under the MVP matrix m: the frustum planes every corner lies outside of, whether it lies in front
+// of the eye throughout (w >= 0.1), its extent in window x and its smallest w.
+// "Outside a plane" carries a margin above the rounding of the sums below and of transform_vertex's (four roundings of half an
+// ulp of at most mag[i] each, twice): every vertex inside the box is then outside that plane in transform_vertex's own
+// arithmetic too, so a box may stand for its polygons in the frustum test (tests/test_engine_math_cpu.py).
+struct BoxView { uint32_t all; bool front; float xmn, xmx, zq; };
+
+MW_HD float rcp_estimate(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+
+MW_HD BoxView box_view(const float mn[3], const float mx[3], const float *m, float vp_scale_x, float vp_trans_x)
+{
+    const float R = fmaxf(fmaxf(fmaxf(fabsf(mn[0]), fabsf(mx[0])), fmaxf(fabsf(mn[1]), fabsf(mx[1]))), fmaxf(fabsf(mn[2]), fabsf(mx[2])));
+    float mag[4];
+    for (int i = 0; i < 4; ++i) mag[i] = ((fabsf(m[i]) + fabsf(m[4 + i])) + fabsf(m[8 + i])) * R + fabsf(m[12 + i]);
+    const float ex = 4e-6f * (mag[0] + mag[3]), ey = 4e-6f * (mag[1] + mag[3]), ez = 4e-6f * (mag[2] + mag[3]);
+    BoxView b = {0x3Fu, true, 1e30f, -1e30f, 1e30f};
+    for (int k = 0; k < 8; ++k) {
+        const float p[3] = {(k & 1) ? mx[0] : mn[0], (k & 2) ? mx[1] : mn[1], (k & 4) ? mx[2] : mn[2]};
+        float cl[4];
+        for (int i = 0; i < 4; ++i) cl[i] = ((p[0] * m[i] + p[1] * m[4 + i]) + p[2] * m[8 + i]) + m[12 + i];
+        const float w = cl[3];
+        uint32_t mask = 0;
+        if (cl[0] - w > ex) mask |= 1u;
+        if (cl[0] + w < -ex) mask |= 2u;
+        if (cl[1] - w > ey) mask |= 4u;
+        if (cl[1] + w < -ey) mask |= 8u;
+        if (cl[2] + w < -ez) mask |= 16u;
+        if (cl[2] - w > ez) mask |= 32u;
+        b.all &= mask;
+        b.front &= w >= 0.1f;
+        const float wx = fmaf(cl[0] * rcp_estimate(w), vp_scale_x, vp_trans_x);
+        b.xmn = fminf(b.xmn, wx); b.xmx = fmaxf(b.xmx, wx); b.zq = fminf(b.zq, w);
+    }
+    return b;
+}
+
 // ---------------------------------------------------------------- clipper (draw_pipe_clip.c)
 // GOURAUD: the colour varies over the primitive (meshes) and is clipped like the texture coordinates; a flat
 // primitive's colour is the same at every vertex and survives the interpolation o + t (c - c) unchanged.

@@ -369,3 +369,30 @@ extern "C" int mwhost_edge_parallel_clip_agrees(const float clip[3][4], const fl
     return 1 + n;
 }
 
+// Big scenes test a bounding box of eight polygons against the frustum before the polygons themselves (mw_geom.hip,
+// box_view): for every plane the box is found outside of, every point inside the box must be outside in
+// transform_vertex's own arithmetic.  Camera as render_obs builds it (eye, direction of view in the xz plane + pitch).
+// Returns the number of points that contradict the box; *planes gets the box's plane mask.
+extern "C" int mwhost_box_cull_contradictions(const double eye[3], const double at[3], double fov_y_deg, int W, int H, const float mn[3],
+                                              const float mx[3], const float *pts, int n, int *planes)
+{
+    Frame f;
+    double sf, cf;
+    mwo_sincos(fov_y_deg / 2 * 3.14159265358979323846 / 180, &sf, &cf);
+    frame_perspective(f, eye, at, cf / sf, W, H);
+    const double lp[3] = {0, 2.5, 0}, lc[3] = {0.7, 0.7, 0.7}, la[3] = {0.45, 0.45, 0.45};
+    frame_finish(f, W, H, lp, lc, la);
+    Xform cam;
+    make_xform(f, f.view, f.view_flags, cam);
+    const BoxView b = box_view(mn, mx, cam.mvp.m, f.vp_scale[0], f.vp_trans[0]);
+    *planes = (int)b.all;
+    int bad = 0;
+    for (int i = 0; i < n; ++i) {
+        Vert v;
+        transform_vertex(f, cam, pts + 3 * i, v);
+        if ((v.clipmask & b.all) != b.all) ++bad;
+        if (b.front && (v.win[0] < b.xmn - 0.05f || v.win[0] > b.xmx + 0.05f || v.clip[3] < b.zq * 0.9999f)) ++bad;
+    }
+    return bad;
+}
+

@@ -140,3 +140,31 @@ def test_clearly_back_facing_triangles_never_leave_setup(host):
         said_yes += host.mwhost_clearly_back(win.ctypes.data_as(C.c_void_p))
     assert said_yes > 3000      # and it does say yes for ordinary back faces
 
+
+def test_a_box_outside_the_frustum_holds_only_vertices_outside_it(host):
+    """Big scenes sift boxes of eight polygons before the polygons (mw_geom.hip, mwgl::box_view): a plane the box is
+    outside of (with box_view's margin) has every point of the box outside in transform_vertex's arithmetic — the box may
+    stand for its polygons —, and a box in front of the eye bounds its points' window x and depth (the occlusion test)."""
+    rng = np.random.default_rng(11)
+    host.mwhost_box_cull_contradictions.restype = C.c_int
+    culled = 0
+    for k in range(3000):
+        eye = np.array([rng.uniform(-30, 30), rng.uniform(0.5, 2.5), rng.uniform(-30, 30)])
+        yaw, pitch = rng.uniform(0, 2 * np.pi), rng.uniform(-0.5, 0.5) * (k % 3 == 0)
+        d = np.array([np.cos(yaw) * np.cos(pitch), np.sin(pitch), -np.sin(yaw) * np.cos(pitch)])
+        at = eye + d
+        c = eye + rng.normal(0, 12, 3) if k % 2 else eye + d * rng.uniform(-3, 30) + rng.normal(0, 4, 3)
+        half = rng.uniform(0.05, 4, 3)
+        # boxes that graze a frustum plane are the interesting ones: shift some so that a face lies almost in a plane
+        mn, mx = (c - half).astype(np.float32), (c + half).astype(np.float32)
+        n = 64
+        pts = rng.uniform(mn, mx, (n, 3)).astype(np.float32)
+        pts[:8] = [[(mx if (j >> a) & 1 else mn)[a] for a in range(3)] for j in range(8)]       # the corners themselves
+        planes = C.c_int(0)
+        bad = host.mwhost_box_cull_contradictions(eye.ctypes.data_as(C.c_void_p), at.ctypes.data_as(C.c_void_p), C.c_double(60.0), 80, 60,
+                                                  mn.ctypes.data_as(C.c_void_p), mx.ctypes.data_as(C.c_void_p),
+                                                  pts.ctypes.data_as(C.c_void_p), n, C.byref(planes))
+        assert bad == 0, (eye, at, mn, mx, planes.value)
+        culled += planes.value != 0
+    assert 500 < culled < 2900      # both outcomes occur
+
