@@ -241,6 +241,25 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     const int nlink = *s_nlink;
+    // ---- texture variants: with domain randomisation every room draws its wall, floor and ceiling variant, in that order,
+    // rooms in list order (Room._gen_static_data with an rng, miniworld.py:295-297, run for all rooms inside the first
+    // place_entity: after the carving, before the placement; a texture with one variant draws nothing, opengl.py:134-138).
+    // Lane 0 draws; the picks (a nibble each) go where the carving's stack was.
+    const bool tex_var = a.domain_rand != 0 && (a.gt->tex_nvar[0] > 1 || a.gt->tex_nvar[1] > 1 || a.gt->tex_nvar[2] > 1);
+    unsigned char *picks = ws + 192;        // 3 nibbles per room, 127 rooms: 191 bytes
+    if (tex_var) {
+        if (lane == 0) {
+            for (int i = 0; i < 192; ++i) picks[i] = 0;
+            for (int room = 0; room < ncell + nlink; ++room)
+                for (int k = 0; k < 3; ++k) {
+                    const uint32_t nv = (uint32_t)a.gt->tex_nvar[k];
+                    const uint32_t pk = nv > 1u ? rng_below(r, nv) : 0u;
+                    picks[(3 * room + k) >> 1] |= (unsigned char)(pk << (4 * ((3 * room + k) & 1)));
+                }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
     // ---- geometry: one room per lane, offsets from an ordered prefix sum over the rooms ------
     RoomTex rt;
     rt.floor = (int)a.gt->gen_tab[5]; rt.ceil = (int)a.gt->gen_tab[6]; rt.wall = (int)a.gt->gen_tab[7];
@@ -275,7 +294,17 @@ __device__ inline void gen_maze(const MwArgs &a, int env, int set, Rng &r, unsig
                 if (lane >= off) incl += up;
             }
             int np = np_base + ((incl - cnt) & 0xFFFF), ns = ns_base + ((incl - cnt) >> 16);
-            if (room < nroom) emit_room(a, set, rt, px, pz, keep, np, ns);
+            if (room < nroom) {
+                RoomTex rr = rt;
+                if (tex_var) {
+                    int pk[3];
+                    for (int k = 0; k < 3; ++k) pk[k] = (picks[(3 * room + k) >> 1] >> (4 * ((3 * room + k) & 1))) & 15;
+                    rr.wall = a.gt->tex_var_id[0][pk[0]]; rr.wu = a.gt->tex_var_scale[0][pk[0]][0]; rr.wv = a.gt->tex_var_scale[0][pk[0]][1];
+                    rr.floor = a.gt->tex_var_id[1][pk[1]]; rr.fu = a.gt->tex_var_scale[1][pk[1]][0]; rr.fv = a.gt->tex_var_scale[1][pk[1]][1];
+                    rr.ceil = a.gt->tex_var_id[2][pk[2]]; rr.cu = a.gt->tex_var_scale[2][pk[2]][0]; rr.cv = a.gt->tex_var_scale[2][pk[2]][1];
+                }
+                emit_room(a, set, rr, px, pz, keep, np, ns);
+            }
             const int tot = __shfl(incl, 63);
             np_base += tot & 0xFFFF; ns_base += tot >> 16;
         }

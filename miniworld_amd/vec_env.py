@@ -91,7 +91,7 @@ class MiniWorldVecEnv:
         room0 = self.template.rooms[0]
         tex_slots = [room0.wall_tex_name, room0.floor_tex_name, room0.ceil_tex_name]
         variants = [_assets.texture_variants(t) for t in tex_slots]
-        tex_dr = bool(domain_rand) and generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM, eng.GEN_PICKUP) and any(len(v) > 1 for v in variants)
+        tex_dr = bool(domain_rand) and generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM, eng.GEN_PICKUP, eng.GEN_MAZE) and any(len(v) > 1 for v in variants)
         # placement programs: every room may name its own textures
         prog_names = sorted({n for r in self.template.rooms for n in (r.wall_tex_name, r.floor_tex_name, r.ceil_tex_name)})
         prog_tex_dr = bool(domain_rand) and generator == eng.GEN_PROGRAM and any(len(_assets.texture_variants(n)) > 1 for n in prog_names)
@@ -173,11 +173,6 @@ class MiniWorldVecEnv:
             self._tex_dr_variants = names
             cfg.room_wall_height = float(room0.wall_height)
             cfg.room_no_ceiling = int(bool(room0.no_ceiling))
-        if generator == eng.GEN_MAZE and domain_rand and any(len(v) > 1 for v in variants):
-            # the reference's Maze textures (brick_wall, floor_tiles_bw, concrete_tiles) exist in one variant each, so
-            # Room._gen_static_data's three rng.integers(0, 1) per room draw nothing (opengl.py:134-138) and the device
-            # generator is stream-exact as it is; an asset directory with more variants would need per-room picks
-            raise NotImplementedError("Maze with domain_rand and several variants of a room texture is not implemented on the device")
         pcg_ok = True       # every device generator draws numpy's PCG64 stream
         if rng not in ("auto", "pcg64", "philox") or (rng == "pcg64" and not pcg_ok):
             raise ValueError(f"rng={rng!r} is not available for {env_id} (domain_rand={domain_rand})")

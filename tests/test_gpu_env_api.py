@@ -666,6 +666,63 @@ def test_device_reset_reference_stream_all_generators(env_id, cls_name, dr):
     vec.close()
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,cls_name", [("MiniWorld-MazeS3-v0", "MazeS3"), ("MiniWorld-Maze-v0", "Maze")])
+def test_maze_with_domain_rand_draws_a_texture_variant_per_room(env_id, cls_name, monkeypatch):
+    """Room._gen_static_data with an rng draws a wall, a floor and a ceiling variant for EVERY room of a maze, inside the
+    first place_entity (miniworld.py:295-297, 856-857; opengl.py:134-138).  The Maze's own textures exist in one variant
+    each, so here the asset inventory is given more (sizes differ: the texture coordinates follow): the device generator
+    draws them in the reference's order — worlds, polygons (texture ids, texture coordinates) and the stream behind them
+    are the host's, episode after episode."""
+    import torch
+    from miniworld_amd import assets, envs
+    from miniworld_amd.scene import polys_array, scene_from_env
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    real = assets.texture_variants
+    more = {"brick_wall": ["brick_wall_1", "concrete_1", "concrete_3", "asphalt_1"], "floor_tiles_bw": ["floor_tiles_bw_1", "concrete_2"],
+            "concrete_tiles": ["concrete_tiles_1", "concrete_4", "brick_wall_1"]}
+    monkeypatch.setattr(assets, "texture_variants", lambda name: more.get(name, real(name)))
+    n, s, k_steps = 16, 31, 5
+    vec = MiniWorldVecEnv(env_id, n, seed=s, domain_rand=True, autoreset=False)
+    assert vec.rng_mode == "pcg64"
+    vec.reset()
+    hosts = [getattr(envs, cls_name)(host_only=True, domain_rand=True) for _ in range(n)]
+    for i, h in enumerate(hosts):
+        h.reset(seed=s + i)
+    seen = set()
+    for episode in (1, 2):
+        st = vec.engine.get_state()
+        for i, h in enumerate(hosts):
+            _assert_same_world(vec, st, i, h, f"episode {episode}")
+            polys, segs = vec.engine.get_geometry(i)
+            sc = scene_from_env(h)
+            want = polys_array(sc, {k: vec.tex_ids[str(v)] for k, v in enumerate(sc["tex_names"])})
+            assert len(polys) == len(want), (i, len(polys), len(want))
+            for f in ("v", "uv", "n", "nv", "tex"):
+                assert np.array_equal(polys[f], want[f]), (episode, i, f)
+            seen |= {str(v) for v in sc["tex_names"]}
+        if episode == 1:
+            g = torch.Generator(device="cuda").manual_seed(8)
+            for t in range(k_steps):
+                vec.step(torch.randint(0, 3, (n,), generator=g, device="cuda", dtype=torch.int32))
+            vec.engine.reset(None, None)
+            for h in hosts:
+                for t in range(k_steps):
+                    for name in ("forward_step", "forward_drift", "turn_step"):
+                        h.params.sample(h.np_random, name)
+                h.reset()
+    assert len(seen) >= 6       # the variants really were drawn
+    # and the frames are the oracle's for such a world
+    import pyoracle
+    vec.step(torch.zeros(n, dtype=torch.int32, device="cuda"))
+    st = vec.engine.get_state()
+    for i in (0, n - 1):
+        want = pyoracle.render(helpers.scene_of_vec_env(vec, st, i))
+        assert np.array_equal(vec.obs[i].cpu().numpy(), want["rgb"]), i
+    vec.engine.check()
+    vec.close()
+
+
 _DEVICE_FAMILIES = {"Hallway": "MiniWorld-Hallway-v0", "OneRoom": "MiniWorld-OneRoom-v0", "Maze": "MiniWorld-Maze-v0",
                     "MazeS3": "MiniWorld-MazeS3-v0", "PickupObjects": "MiniWorld-PickupObjects-v0"}
 _DEVICE_FAMILIES.update({c: f"MiniWorld-{c}-v0" for c in _PROGRAM_FAMILIES})
