@@ -17,9 +17,12 @@
 //
 // Lanes: a wavefront serves 64 / L envs, L lanes each (L: the power of two that holds an env's triangles — two per polygon
 // and box face, the agent marker — or 64, with several rounds).  One triangle per lane and round.
-// A round runs twice over its triangles: pass 1 counts what survives clipping and culling, a segmented scan turns the
-// counts into list positions, pass 2 writes the records.  Unclipped triangles keep their setup in registers between the
-// passes; a triangle that crosses a frustum plane goes through one of kClipSlots work lists in LDS, in both passes.
+// A round runs twice over its triangles: pass 1 counts what survives clipping and culling (the snapped-area test only), a
+// segmented scan turns the counts into list positions, pass 2 sets the survivors up and writes the records.  A triangle
+// that crosses a frustum plane goes through one of kClipSlots work lists in LDS, eight lanes to a list: an edge of the
+// polygon per lane and one step per plane, then a triangle of the fan per lane (setup, record).
+// Big scenes (one env per wavefront): the polygons are sifted first — boxes of eight polygons, then the polygons, against
+// the frustum, full-height walls in front of them and their own facing — from data kept per world (occ_cache).
 #include <cstddef>
 #include "mw_setup_common.h"
 #include "mw_records.h"
