@@ -794,9 +794,9 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             else clipped = true;
         }
         if (a.k1_prof) tp[3] = __builtin_readcyclecounter();
-        // A triangle that crosses a frustum plane goes through a work list in LDS.  When the wave has no more of them than
-        // lists (the rule), every one keeps its list — clipped once, here, all lanes side by side — and pass 2 finds the
-        // clipped polygon where pass 1 left it; otherwise they take turns, in both passes.
+        // A triangle that crosses a frustum plane goes through a work list in LDS: kClipSlots of the wave's clipped
+        // triangles at a time are clipped, counted, placed in the env's list and written (the serial form, for a triangle
+        // across all six planes: clipped in pass 1, and again in pass 2 when the wave has more of them than lists).
         const uint64_t cmask = __ballot(clipped);
         const uint64_t below = (1ull << lane) - 1ull;
         const int n_clip = (int)__popcll((unsigned long long)cmask);
