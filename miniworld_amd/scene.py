@@ -32,8 +32,12 @@ def scene_from_env(env) -> dict:
 
     def add_poly(verts, texcs, normal, tex, rgb=(1, 1, 1), flags=0, xf=(0, 0, 0, 0)):
         n = len(verts)
-        if n not in (3, 4):
-            raise NotImplementedError("room outlines with more than 4 corners are not supported yet")
+        if n > 4:
+            # GL_POLYGON with n vertices: the driver's triangles are (i, i + 1, 0), i = 1 .. n - 2 — and a polygon with three
+            # vertices (p0, p1, p2) is drawn as (p1, p2, p0): one triangle polygon per fan triangle (tests/golden/gl_ngon_*.npz)
+            for i in range(1, n - 1):
+                add_poly([verts[0], verts[i], verts[i + 1]], [texcs[0], texcs[i], texcs[i + 1]], normal, tex, rgb, flags, xf)
+            return
         v = np.zeros((4, 3), np.float32)
         uv = np.zeros((4, 2), np.float32)
         v[:n], uv[:n] = _f32(verts), _f32(texcs)

@@ -244,3 +244,37 @@ def test_placement_programs_compile_for_every_fixed_floorplan_family():
         assert (room >= 0).sum() >= 5 and len(polys) == len(sc["polys_nv"]) and len(segs) == len(sc["wall_segs"])
         n += 1
     assert n == 14
+
+
+def test_rooms_with_more_than_four_corners_are_the_references():
+    """Room accepts any outline (miniworld.py:127-176); floor and ceiling are then GL_POLYGONs of that many vertices, which
+    the driver draws as the triangles (i, i + 1, 0).  tests/golden/gl_ngon_*.npz are the reference's own frames of a hexagonal
+    and a heptagonal room on llvmpipe (tools/gen_gl_fixtures.py: EXTRA; the pixel tests take them like every other fixture);
+    here: the host classes build that world from the same seed, and the scene the engine gets — one triangle polygon per
+    fan triangle — is the fixture's."""
+    from miniworld_amd.entity import Box
+    from miniworld_amd.miniworld import MiniWorldEnv
+    from miniworld_amd.scene import scene_from_env
+
+    class NGonRooms(MiniWorldEnv):
+        def __init__(self, **kw):
+            super().__init__(max_episode_steps=200, **kw)
+
+        def _gen_world(self):
+            def ring(cx, cz, r, n, t0):
+                return np.array([[cx + r * np.cos(t0 + 2 * np.pi * k / n), cz - r * np.sin(t0 + 2 * np.pi * k / n)] for k in range(n)])
+            self.add_room(outline=ring(0.0, 0.0, 4.5, 6, 0.3))
+            self.add_room(outline=ring(12.0, 1.0, 3.5, 7, 1.1), wall_tex="brick_wall", floor_tex="asphalt", no_ceiling=True)
+            self.box = self.place_entity(Box(color="red"), room=self.rooms[0])
+            self.box2 = self.place_entity(Box(color="blue", size=0.5), room=self.rooms[1])
+            self.place_agent(room=self.rooms[0])
+
+    env = NGonRooms(host_only=True)
+    env.reset(seed=0)
+    sc = scene_from_env(env)
+    d = np.load(os.path.join(helpers.GOLDEN, "gl_ngon_s0.npz"))
+    assert sc["polys_v"].shape[0] == 26        # 4 + 4 fan triangles + 6 walls; 5 fan triangles + 7 walls
+    for k in ("polys_v", "polys_uv", "polys_n", "polys_nv", "polys_tex", "polys_rgb", "agent_pos", "agent_dir", "ents_pos", "ents_dir",
+              "ents_size", "ents_color", "wall_segs"):
+        assert np.array_equal(np.asarray(sc[k]), d["gl/0/scene/" + k]), k
+

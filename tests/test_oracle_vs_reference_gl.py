@@ -1,7 +1,7 @@
 """The pixel oracle against the REFERENCE ITSELF on real OpenGL (CPU; no GPU, no /root/reference needed).
 
 tests/golden/gl_*.npz hold what /root/reference/miniworld produces, unmodified, on Mesa llvmpipe — the reference's CI
-driver family — for 94 states of every env family (tools/refshim_gl.py + tools/gen_gl_fixtures.py; the reference asks
+driver family — for 101 states of every env family and of rooms with six and seven corners (tools/refshim_gl.py + tools/gen_gl_fixtures.py; the reference asks
 for 8 / 16 samples and gets GL_MAX_SAMPLES = 4, opengl.py:229-231, so these are 4-sample frames):
 render_obs(), the resolved 16-bit depth buffer, render_depth(), render_top_view(), get_visible_ents(), and render() at
 800x600 for four states.
@@ -40,7 +40,7 @@ def test_fixtures_come_from_the_driver_the_oracle_names():
     assert "llvmpipe" in str(m["renderer"]) and "Mesa 23.2.1" in str(m["version"])
     # glGetMultisamplefv(GL_SAMPLE_POSITION) of the 4-sample FBO: the pattern mwo_render.c's PAT4 restates (1/16 px, y up)
     assert np.array_equal(np.round(m["sample_positions_4"] * 16).astype(int), [[6, 2], [14, 6], [2, 10], [10, 14]])
-    assert len(gl_cases()) >= 38
+    assert len(gl_cases()) >= 40
 
 
 @pytest.mark.parametrize("case", gl_cases())

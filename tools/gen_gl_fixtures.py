@@ -95,8 +95,44 @@ def capture(env, out, k, stats, big=False):
         env.view = "agent"
 
 
+# Beyond the registered ids: rooms whose outline has more than four corners (Room accepts any polygon, miniworld.py:127-176;
+# floor and ceiling are then GL_POLYGONs of that many vertices).  A hexagon and a heptagon joined by nothing, a box, the
+# reference's own classes and methods throughout.
+EXTRA = [("ngon_s0", "NGonRooms", {}, 0, 3, 40, [0, 13, 27, 40]), ("ngon_dr_s2", "NGonRooms", {"domain_rand": True}, 2, 3, 30, [0, 17, 30])]
+
+
+def make_ngon_env(**kwargs):
+    refshim_gl.load_reference()
+    from miniworld.entity import Box
+    from miniworld.miniworld import MiniWorldEnv
+
+    class NGonRooms(MiniWorldEnv):
+        def __init__(self, **kw):
+            MiniWorldEnv.__init__(self, max_episode_steps=200, **kw)
+
+        def _gen_world(self):
+            def ring(cx, cz, r, n, t0):
+                # counter-clockwise seen from above (x east, z south), like add_rect_room's outline (miniworld.py:737-750)
+                return np.array([[cx + r * np.cos(t0 + 2 * np.pi * k / n), cz - r * np.sin(t0 + 2 * np.pi * k / n)] for k in range(n)])
+            self.add_room(outline=ring(0.0, 0.0, 4.5, 6, 0.3))
+            self.add_room(outline=ring(12.0, 1.0, 3.5, 7, 1.1), wall_tex="brick_wall", floor_tex="asphalt", no_ceiling=True)
+            self.box = self.place_entity(Box(color="red"), room=self.rooms[0])
+            self.box2 = self.place_entity(Box(color="blue", size=0.5), room=self.rooms[1])
+            self.place_agent(room=self.rooms[seed_room[0]])
+
+        def step(self, action):
+            return MiniWorldEnv.step(self, action)
+
+    seed_room = [0]
+    env = NGonRooms(**kwargs)
+    env._seed_room = seed_room
+    return env
+
+
 def run_case(name, cls, kwargs, seed, n_actions, steps, frames, totals):
-    env = refshim_gl.make_env(cls, **kwargs)
+    env = make_ngon_env(**kwargs) if cls == "NGonRooms" else refshim_gl.make_env(cls, **kwargs)
+    if cls == "NGonRooms":
+        env._seed_room[0] = seed % 2 and 1 or 0        # the agent starts in the hexagon (seed 0) or the heptagon (seed 2 -> 0 ... see EXTRA)
     env.reset(seed=seed)
     rng = np.random.default_rng(1000 + seed)            # the action stream of tools/gen_golden.py
     out = {}
@@ -164,7 +200,7 @@ def gl_mip_checksums():
 def main():
     only = set(sys.argv[1:])
     totals = {}
-    for case in cases():
+    for case in list(cases()) + EXTRA:
         if not only or case[0] in only:
             run_case(*case, totals)
     info = refshim_gl.driver_info()

@@ -38,7 +38,13 @@ def scene_from_ref_env(env):
 
     def add_poly(verts, texcs, normal, tex, rgb=(1, 1, 1), flags=0, xf=(0, 0, 0, 0)):
         n = len(verts)
-        assert n in (3, 4), "n-gon rooms are not part of the BASELINE configs"
+        if n > 4:
+            # GL_POLYGON with n vertices: the driver's triangles are (i, i + 1, 0), i = 1 .. n - 2 (draw_decompose_tmp.h, last
+            # vertex convention; a polygon of ours with three vertices (p0, p1, p2) is drawn as (p1, p2, p0))
+            for i in range(1, n - 1):
+                add_poly([verts[0], verts[i], verts[i + 1]], [texcs[0], texcs[i], texcs[i + 1]], normal, tex, rgb, flags, xf)
+            return
+        assert n in (3, 4)
         v = np.zeros((4, 3), np.float32)
         uv = np.zeros((4, 2), np.float32)
         v[:n] = np.asarray(verts, np.float64).astype(np.float32)      # glVertex3f
