@@ -278,3 +278,23 @@ def test_rooms_with_more_than_four_corners_are_the_references():
               "ents_size", "ents_color", "wall_segs"):
         assert np.array_equal(np.asarray(sc[k]), d["gl/0/scene/" + k]), k
 
+
+def test_footprint_record_operands_reproduce_the_8_8_lerp_for_every_input():
+    """The engine's texture footprint records hold, per channel and texel pair, A = 256 a + 128 and D = (b - a) mod 2^16
+    (mw_engine.hip::build_pyramid); the raster kernel's x lerp is one packed 16-bit multiply-add and a shift,
+    (A + w D) mod 2^16 >> 8 (mw_raster_common.h::lerp8_ad).  Exhaustively over a, b, w in 0 .. 255 that is llvmpipe's
+    a + ((w (b - a) + 128) >> 8) — and so is the three-instruction form of the other lerps, (a (256 - w) + (b w + 128)) >> 8,
+    whose sums stay below 2^16."""
+    a = np.arange(256, dtype=np.int64)[:, None, None]
+    b = np.arange(256, dtype=np.int64)[None, :, None]
+    w = np.arange(256, dtype=np.int64)[None, None, :]
+    want = a + ((w * (b - a) + 128) >> 8)                     # arithmetic shift: mwgl::lerp8
+    A, D = (a * 256 + 128) & 0xFFFF, (b - a) & 0xFFFF
+    got = ((A + D * w) & 0xFFFF) >> 8
+    assert np.array_equal(got, np.broadcast_to(want, got.shape))
+    s1 = b * w + 128
+    s2 = a * (256 - w) + s1
+    assert s1.max() < 65536 and s2.max() < 65536
+    assert np.array_equal(s2 >> 8, np.broadcast_to(want, got.shape))
+    assert want.min() >= 0 and want.max() <= 255
+
