@@ -298,3 +298,43 @@ def test_footprint_record_operands_reproduce_the_8_8_lerp_for_every_input():
     assert np.array_equal(s2 >> 8, np.broadcast_to(want, got.shape))
     assert want.min() >= 0 and want.max() <= 255
 
+
+def test_register_bitonic_network_of_the_visiting_order_sorts():
+    """Big scenes' geometry kernel sorts up to 512 (depth bound << 16 | list index) keys with a bitonic network whose keys
+    live in registers — key i = 64 r + lane in register r of the lane — so that a stage is either a lane shuffle
+    (partner lane ^ j) or a register swap (partner r ^ (j / 64)); K2's early exit relies on the result being ascending.
+    This is mw_geom.hip::sort_store_keys<R> statement for statement (the direction of every compare-exchange is the part
+    that is easy to get wrong), run for R = 1, 2, 4, 8 and list lengths that leave padding."""
+    def network_sort(keys, R):
+        n = len(keys)
+        x = np.full((R, 64), 0xFFFFFFFF, np.uint64)
+        x.reshape(-1)[:n] = keys                                  # x[r][lane] = keys[64 r + lane]
+        lanes = np.arange(64)
+        k = 2
+        while k <= 64 * R:
+            j = k >> 1
+            while j > 0:
+                if j >= 64:                                         # partners in two registers of the same lane
+                    jj = j >> 6
+                    for r in range(R):
+                        if r & jj:
+                            continue
+                        up = ((64 * r) & k) == 0
+                        lo, hi = np.minimum(x[r], x[r ^ jj]), np.maximum(x[r], x[r ^ jj])
+                        x[r], x[r ^ jj] = (lo, hi) if up else (hi, lo)
+                else:                                               # partners in two lanes, the same register
+                    for r in range(R):
+                        y = x[r][lanes ^ j]
+                        up = (((64 * r) | lanes) & k) == 0
+                        keep_min = ((lanes & j) == 0) == up
+                        x[r] = np.where(keep_min, np.minimum(x[r], y), np.maximum(x[r], y))
+                j >>= 1
+            k <<= 1
+        return x.reshape(-1)[:n]
+
+    rng = np.random.default_rng(0)
+    for R in (1, 2, 4, 8):
+        for n in [64 * R, 64 * R - 1, 32 * R + 1] + [int(v) for v in rng.integers(32 * R + 1, 64 * R + 1, 12)]:
+            keys = (rng.integers(0, 65536, n).astype(np.uint64) << 16) | np.arange(n, dtype=np.uint64)
+            assert np.array_equal(network_sort(keys, R), np.sort(keys)), (R, n)
+
