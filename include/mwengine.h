@@ -314,6 +314,9 @@ int mw_pcg64_draws(uint64_t seed, int32_t n, const int32_t *bounds, double *out)
  * *n = their total), mw_selftest_div over 2^32 pseudo-random pairs of its domain. */
 int mw_selftest_rcp(unsigned long long *bad_per_exp, uint32_t *examples, uint32_t *n);
 int mw_selftest_div(unsigned long long *n_bad, uint32_t *examples);
+/* ... and the geometry kernel's visiting-order sort (mw_geom.hip: up to 512 keys per block, bitonic, in registers) on the
+ * caller's keys: keys[blocks][512], n[blocks], order[blocks][513] (order[b][1 + k] = low 16 bits of block b's k-th smallest key). */
+int mw_selftest_sort(const uint32_t *keys, const int32_t *n, int32_t blocks, uint16_t *order);
 
 /* render_obs / render_depth only (miniworld.py:1177-1236) */
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);

@@ -1039,3 +1039,35 @@ extern "C" __global__ __launch_bounds__(64) void mw_geom_big_kernel(MwArgs a, in
 // ... for frame buffers with 1, 4 or 16 samples per pixel
 extern "C" __global__ __launch_bounds__(64) void mw_geom_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false, 0>(a, view_flags, S, L, n_env); }
 extern "C" __global__ __launch_bounds__(64) void mw_geom_big_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true, 0>(a, view_flags, S, L, n_env); }
+
+// mw_selftest_sort: the visiting order's sort on keys of the caller's (tests/test_gpu_numerics.py): block b sorts the
+// n[b] <= 512 keys at keys + 512 b into order + 513 b (order[0] unused, then the keys' low halves in ascending key order)
+extern "C" __global__ __launch_bounds__(64) void mw_selftest_sort_kernel(const uint32_t *keys, const int32_t *n, uint16_t *order)
+{
+    __shared__ uint32_t s_key[MW_ORDER_CAP];
+    const int lane = threadIdx.x, cnt = n[blockIdx.x];
+    for (int i = lane; i < cnt; i += 64) s_key[i] = keys[(size_t)blockIdx.x * MW_ORDER_CAP + i];
+    __syncthreads();
+    uint16_t *out = order + (size_t)blockIdx.x * (MW_ORDER_CAP + 1);
+    if (cnt <= 64) sort_store_keys<1>(s_key, cnt, lane, out);
+    else if (cnt <= 128) sort_store_keys<2>(s_key, cnt, lane, out);
+    else if (cnt <= 256) sort_store_keys<4>(s_key, cnt, lane, out);
+    else sort_store_keys<8>(s_key, cnt, lane, out);
+}
+
+extern "C" int mw_selftest_sort(const uint32_t *host_keys /*[blocks][512]*/, const int32_t *host_n /*[blocks]*/, int32_t blocks, uint16_t *host_order /*[blocks][513]*/)
+{
+    uint32_t *d_keys = nullptr; int32_t *d_n = nullptr; uint16_t *d_order = nullptr;
+    const size_t kb = (size_t)blocks * MW_ORDER_CAP * 4, ob = (size_t)blocks * (MW_ORDER_CAP + 1) * 2;
+    if (blocks <= 0 || hipMalloc((void **)&d_keys, kb) != hipSuccess || hipMalloc((void **)&d_n, (size_t)blocks * 4) != hipSuccess ||
+        hipMalloc((void **)&d_order, ob) != hipSuccess) return -1;
+    (void)hipMemcpy(d_keys, host_keys, kb, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d_n, host_n, (size_t)blocks * 4, hipMemcpyHostToDevice);
+    (void)hipMemset(d_order, 0, ob);
+    hipLaunchKernelGGL(mw_selftest_sort_kernel, dim3(blocks), dim3(64), 0, 0, d_keys, d_n, d_order);
+    const int rc = hipDeviceSynchronize() == hipSuccess ? 0 : -2;
+    (void)hipMemcpy(host_order, d_order, ob, hipMemcpyDeviceToHost);
+    (void)hipFree(d_keys); (void)hipFree(d_n); (void)hipFree(d_order);
+    return rc;
+}
+

@@ -32,3 +32,26 @@ def test_fast_division_equals_ieee_division_on_its_domain():
     assert lib.mw_selftest_div(C.byref(n), ex) == 0
     pairs = np.array(ex[:], np.uint32).view(np.float32).reshape(-1, 2)[:min(int(n.value), 32)]
     assert n.value == 0, f"{n.value} quotients differ, e.g. (a, b) = {pairs[:6].tolist()}"
+
+
+def test_visiting_order_sort_sorts():
+    """Big scenes' geometry kernel leaves K2 a near-to-far visiting order; K2 stops at the first triangle that lies behind
+    everything its tile holds, which is only right if the order is ascending.  mw_selftest_sort runs the kernel's own sort
+    (bitonic network, keys in registers: mw_geom.hip::sort_store_keys) on random keys of every length class."""
+    from miniworld_amd import engine
+    lib = engine.load_library()
+    rng = np.random.default_rng(3)
+    lens = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 300, 511, 512] + [int(v) for v in rng.integers(1, 513, 50)]
+    blocks = len(lens)
+    keys = np.zeros((blocks, 512), np.uint32)
+    for b, n in enumerate(lens):
+        # (depth bound << 16 | list index): the indices make the keys distinct, the bounds repeat
+        keys[b, :n] = (rng.integers(0, 400, n).astype(np.uint32) << 16) | rng.permutation(n).astype(np.uint32)
+    n_arr = np.array(lens, np.int32)
+    order = np.zeros((blocks, 513), np.uint16)
+    lib.mw_selftest_sort.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    assert lib.mw_selftest_sort(keys.ctypes.data, n_arr.ctypes.data, blocks, order.ctypes.data) == 0
+    for b, n in enumerate(lens):
+        want = (np.sort(keys[b, :n]) & 0xFFFF).astype(np.uint16)
+        assert np.array_equal(order[b, 1:1 + n], want), (n, order[b, 1:9], want[:8])
+
