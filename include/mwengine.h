@@ -317,6 +317,11 @@ int mw_selftest_div(unsigned long long *n_bad, uint32_t *examples);
 /* ... and the geometry kernel's visiting-order sort (mw_geom.hip: up to 512 keys per block, bitonic, in registers) on the
  * caller's keys: keys[blocks][512], n[blocks], order[blocks][513] (order[b][1 + k] = low 16 bits of block b's k-th smallest key). */
 int mw_selftest_sort(const uint32_t *keys, const int32_t *n, int32_t blocks, uint16_t *order);
+/* ... and two shortcuts of the quad raster kernel (mw_rasterq.hip) for all 2^32 floats: n_bad[0] = inputs where
+ * v_cvt_pk_u8_f32(x * (255 / S)) differs from FrameBuffer.resolve()'s unorm8 conversion of x * (1 / S) (S = 4, 8);
+ * n_bad[1] = inputs where the lod taken from rho^2's bits differs from llvmpipe's float arithmetic (pyramids of 1 .. 12
+ * levels); examples[2][32] = the first offending bit patterns of each. */
+int mw_selftest_q(unsigned long long *n_bad, uint32_t *examples);
 
 /* render_obs / render_depth only (miniworld.py:1177-1236) */
 int mw_render(mw_engine *e, uint8_t *d_obs, float *d_depth, void *stream);

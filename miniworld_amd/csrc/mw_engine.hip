@@ -48,6 +48,14 @@ MW_RASTER_DECL(mw_raster_nomesh_depth_kernel);
 MW_RASTER_DECL(mw_raster_mesh_depth_kernel);
 MW_RASTER_DECL(mw_raster_mesh_wrap_kernel);
 MW_RASTER_DECL(mw_raster_big_mesh_wrap_kernel);
+#define MW_RASTERQ_DECL(name) \
+    extern "C" __global__ void name(int N, int W, int H, int max_vis, int tiles_x, int n_tiles, const float *rec_raster, const float *rec_shade, \
+                                    const float *rec_cull, const int32_t *nvis, const float *envhdr, const uint32_t *texels, uint8_t *obs, \
+                                    float *depth, int dbg, int texel_bytes, unsigned long long *prof)
+MW_RASTERQ_DECL(mw_rasterq_kernel);
+MW_RASTERQ_DECL(mw_rasterq4_kernel);
+extern "C" int mw_rasterq_lds_bytes(int S, int W, int H, int n_tiles, int depth);
+#define MW_RASTERQ_THREADS 512
 extern "C" __global__ void mw_mesh_scatter_kernel(int W, int H, const float *envhdr, const float *mesh_stream, const float *mesh_attr,
                                                   uint32_t *keys, float *plane_cache, int plane_cap, int32_t *slow_count,
                                                   uint32_t *slow_tris);
@@ -133,6 +141,17 @@ struct mw_engine {
     MwProgram *d_prog = nullptr;        // placement program (mw_set_gen_program)
     int texel_bytes = 4;
     int dbg_flags = 0;       // MW_DEBUG_FLAGS: perf experiments only (bit0: flat shading)
+    // A/B switches, read once by mw_create (the launch path never touches the environment)
+    bool use_k2q = true;        // MW_K2Q=0: the tile kernels of mw_raster.hip for small scenes too
+    bool k2q_ok = false;        // the frame fits the quad kernel's LDS plan
+    bool generic_raster = false;    // MW_GENERIC_RASTER=1: msaa = 4 frames through the generic-resolution kernel (tests run both)
+    bool geom_any = false;      // MW_GEOM_ANY
+    int geom_lanes_override = 0;    // MW_GEOM_LANES
+    bool scatter_overlap = false;   // MW_SCATTER_OVERLAP
+    int slow_bx = 16;           // MW_SLOW_BX
+    int raster_big = -1;        // MW_RASTER_BIG
+    bool k2_first_full = false; // MW_K2_FIRST_FULL
+    unsigned long long *d_k2q_prof = nullptr;   // MW_K2Q_PROF=<file>: s_memtime stamps of the quad kernel's phases, [N][8 waves][8], dumped by mw_destroy
 };
 
 namespace {
@@ -180,9 +199,9 @@ auto k1_of(const mw_engine *e) -> decltype(&mw_step_setup_kernel)
 int k1_threads(const mw_engine *) { return 64; }
 
 // the geometry kernel: big scenes (one env per wavefront) or small, 8 samples per pixel (compiled in) or any
-auto geom_kernel_of(int L, int msaa) -> void (*)(MwArgs, int, int, int, int)
+auto geom_kernel_of(const mw_engine *e, int L, int msaa) -> void (*)(MwArgs, int, int, int, int)
 {
-    const bool fixed8 = msaa == 8 && !getenv("MW_GEOM_ANY");       // (MW_GEOM_ANY: A/B runs)
+    const bool fixed8 = msaa == 8 && !e->geom_any;       // (MW_GEOM_ANY: A/B runs)
     if (L == 64) return fixed8 ? mw_geom_big_kernel : mw_geom_big_any_kernel;
     return fixed8 ? mw_geom_kernel : mw_geom_any_kernel;
 }
@@ -194,7 +213,7 @@ int geom_lanes(const mw_engine *e)
     const int items = 2 * (e->cfg.max_polys + 6 * e->cfg.max_ents + 1);      // one triangle per lane
     int L = 8;
     while (L < items && L < 64) L <<= 1;
-    if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) L = v; }
+    if (e->geom_lanes_override) L = e->geom_lanes_override;
     return L;
 }
 
@@ -571,7 +590,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
     {
         const int L = geom_lanes(e), epw = 64 / L;
-        hipLaunchKernelGGL(geom_kernel_of(L, e->cfg.msaa), dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
+        hipLaunchKernelGGL(geom_kernel_of(e, L, e->cfg.msaa), dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
     }
     if (do_step && e->cfg.task == MW_TASK_COLLECT)
         hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_collect_respawn_pcg_kernel : mw_collect_respawn_kernel, dim3((N + 63) / 64), dim3(64), 0, st, a);
@@ -584,7 +603,22 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         e->side_refill_pending = true;
     }
     bool forked = false;
-    if (e->cfg.msaa != 8 || a.W > 128 || a.H > 128) {
+    // the quad kernel (mw_rasterq.hip): small scenes without a visiting order, frames that fit its LDS plan — 8 samples (the
+    // hot path) and 4 (llvmpipe's GL_MAX_SAMPLES: the reference's own frames run through the same code); with mesh entities
+    // it draws the tiles no mesh can touch (8 samples only)
+    const bool big_scene = e->raster_big >= 0 ? e->raster_big != 0 : a.rec_order != nullptr;
+    const bool k2q = e->use_k2q && e->k2q_ok && !big_scene && !(e->cfg.msaa == 4 && (e->have_meshes || e->generic_raster));
+    auto launch_k2q = [&](int part_flags) {
+        const int S = e->cfg.msaa;
+        const int lds = mw_rasterq_lds_bytes(S, a.W, a.H, a.n_tiles, d_depth ? 1 : 0);
+        const int flags = (e->dbg_flags & 0x1C0F) | (e->obs_layout << 8) | part_flags;
+        hipLaunchKernelGGL(S == 8 ? mw_rasterq_kernel : mw_rasterq4_kernel, dim3(N), dim3(MW_RASTERQ_THREADS), (size_t)lds, st, a.N, a.W, a.H, a.max_vis,
+                           a.tiles_x, a.n_tiles, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
+                           (const int32_t *)a.nvis, (const float *)a.envhdr, a.texels, d_obs, d_depth, flags, e->texel_bytes, e->d_k2q_prof);
+    };
+    if (k2q && e->cfg.msaa == 4) {
+        launch_k2q(0);
+    } else if (e->cfg.msaa != 8 || a.W > 128 || a.H > 128) {
         // FrameBuffer's fallback sample counts (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES gets 4 or 1
         // samples) and observations beyond 128 x 128 (the tile kernels' 24-bit edge arithmetic): not the hot path — the
         // generic-resolution kernels, 64-bit edge values, exact packed-key resolution, the whole batch in one grid
@@ -643,7 +677,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             const uint32_t seq = e->mesh_frame_seq++;
             mesh_stamp = seq & 0xFFFFu;
             const int parity = (int)(seq & 1u);
-            const bool scatter_first = !(getenv("MW_SCATTER_OVERLAP") && atoi(getenv("MW_SCATTER_OVERLAP")) != 0);
+            const bool scatter_first = !e->scatter_overlap;
             if (mesh_stamp == 0u) HIP_TRY(e, hipMemsetAsync(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4, st));
             // the scatter kernel alone (it is latency bound and would take 2.5x as long beside K2), then the slow path on the
             // mesh stream beside K2's first part
@@ -658,7 +692,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
                 HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
             }
-            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(getenv("MW_SLOW_BX") ? atoi(getenv("MW_SLOW_BX")) : 16, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(e->slow_bx, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
                                a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, N, parity, (const uint32_t *)e->d_slow_tris,
                                e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status);
         }
@@ -668,7 +702,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         // big scenes (a visiting order exists): records read in place, near to far; otherwise the env's records are staged
         // in LDS when there are at most MW_LDS_RECS of them (a wave whose env holds more reads them in place).
         // MW_RASTER_BIG=0 / 1 forces either (A/B runs).
-        const bool big = getenv("MW_RASTER_BIG") ? atoi(getenv("MW_RASTER_BIG")) != 0 : a.rec_order != nullptr;
+        const bool big = e->raster_big >= 0 ? e->raster_big != 0 : a.rec_order != nullptr;
         const int lds_recs = a.max_vis < MW_LDS_RECS ? a.max_vis : MW_LDS_RECS;
         const size_t lds = big ? 192 : (size_t)lds_recs * (MW_LDS_SHADE_Q + MW_LDS_CULL_Q) * 16 + 192;
         // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
@@ -682,7 +716,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         }
         const int flags = e->dbg_flags | (e->obs_layout << 8) | (int)(mesh_stamp << 16);
         // K2's first part of a frame with meshes never enters a mesh tile: the plain tile code with the skip (the small-scene observation path only)
-        auto k2_first = (mesh && !big && !general && !getenv("MW_K2_FIRST_FULL")) ? (d_depth ? mw_raster_nomesh_depth_kernel : mw_raster_nomesh_kernel) : k2;
+        auto k2_first = (mesh && !big && !general && !e->k2_first_full) ? (d_depth ? mw_raster_nomesh_depth_kernel : mw_raster_nomesh_kernel) : k2;
         auto launch_k2 = [&](int part_flags) {
             // the second part (the tiles a mesh can touch: few, slow, clustered) spreads over one wave per tile
             const int wpe2 = (part_flags >> 4) == 2 ? a.n_tiles : wpe, tpw2 = (part_flags >> 4) == 2 ? 1 : tpw;
@@ -694,10 +728,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                                (const float *)e->d_plane_cache, e->plane_cap, (const float4 *)e->d_slow_frags, (const uint32_t *)e->d_slow_head);
         };
         if (mesh) {
-            launch_k2(1 << 4);
+            if (k2q) launch_k2q(1 << 4); else launch_k2(1 << 4);
             HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
             HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
             launch_k2(2 << 4);
+        } else if (k2q) {
+            launch_k2q(0);
         } else {
             launch_k2(0);
         }
@@ -864,6 +900,21 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
+    if (const char *s = getenv("MW_K2Q")) e->use_k2q = atoi(s) != 0;
+    if (const char *s = getenv("MW_GENERIC_RASTER")) e->generic_raster = atoi(s) != 0;
+    e->geom_any = getenv("MW_GEOM_ANY") != nullptr;
+    if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
+    if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;
+    if (const char *s = getenv("MW_SLOW_BX")) { const int v = atoi(s); if (v > 0) e->slow_bx = v; }
+    if (const char *s = getenv("MW_RASTER_BIG")) e->raster_big = atoi(s) != 0 ? 1 : 0;
+    e->k2_first_full = getenv("MW_K2_FIRST_FULL") != nullptr;
+    if (getenv("MW_K2Q_PROF")) { if (dev_alloc(e, &e->d_k2q_prof, (size_t)N * 64) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
+    {
+        // the quad kernel (mw_rasterq.hip) keeps an env's frame, quad lists and triangle records in LDS: frames up to 8192 pixels
+        const int S = cfg->msaa == 4 ? 4 : 8;
+        const int lds = mw_rasterq_lds_bytes(S, a.W, a.H, a.n_tiles, 1);
+        e->k2q_ok = (cfg->msaa == 8 || cfg->msaa == 4) && a.W <= 128 && a.H <= 128 && a.W * a.H <= 8192 && lds <= 64 * 1024;
+    }
     if (const char *s = getenv("MW_K1_DENSE")) e->k1_dense = atoi(s) != 0;
     if (sync_gen_args(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     *out = e;
@@ -875,6 +926,11 @@ void mw_destroy(mw_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipDeviceSynchronize();
+    if (e->d_k2q_prof) {
+        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 64);
+        if (hipMemcpy(h.data(), e->d_k2q_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = fopen(getenv("MW_K2Q_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
     if (e->args.k1_prof) {
         std::vector<unsigned long long> h((size_t)e->cfg.num_envs * MW_K1_PROF_SLOTS);
         if (hipMemcpy(h.data(), e->args.k1_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -1207,7 +1263,7 @@ int mw_render_view(mw_engine *e, int32_t env, int32_t view_flags, int32_t width,
     b.W = width; b.H = height;
     b.tiles_x = width / MW_TILE_W; b.tiles_y = height / MW_TILE_H; b.n_tiles = b.tiles_x * b.tiles_y;
     b.env_base = env;
-    hipLaunchKernelGGL(geom_kernel_of(64, msaa), dim3(1), dim3(64), 0, st, b, view_flags, msaa, 64, 1);
+    hipLaunchKernelGGL(geom_kernel_of(e, 64, msaa), dim3(1), dim3(64), 0, st, b, view_flags, msaa, 64, 1);
     uint32_t *keys = nullptr;
     if (e->have_meshes) {
         const size_t need = (size_t)width * height * msaa * 4;
@@ -1262,7 +1318,7 @@ int mw_visible_ents(mw_engine *e, int32_t first_env, int32_t count, uint8_t *d_v
     // the geometry kernel in proxy mode (view_flags bit 2): room polygons + one tagged proxy box per entity
     {
         const int L = geom_lanes(e), epw = 64 / L;
-        hipLaunchKernelGGL(geom_kernel_of(L, e->cfg.msaa), dim3((count + epw - 1) / epw), dim3(64), 0, st, b, 4, e->cfg.msaa, L, count);
+        hipLaunchKernelGGL(geom_kernel_of(e, L, e->cfg.msaa), dim3((count + epw - 1) / epw), dim3(64), 0, st, b, 4, e->cfg.msaa, L, count);
     }
     if (!e->visible_attr_set) {
         HIP_TRY(e, hipFuncSetAttribute((const void *)mw_visible_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -1,0 +1,793 @@
+// K2Q — the raster kernel of small scenes, organised by 2x2-pixel QUADS instead of 16x4 tiles.
+//
+// Same work as mw_raster.hip (glClear, rasterisation / depth test of display list 1 and the entity draws, GL_MODULATE
+// texturing, FrameBuffer.resolve()'s blits + glReadPixels + flip, get_depth_map: miniworld.py:1064-1086, 1193-1195;
+// opengl.py:339-435), same arithmetic (mw_frag.h: llvmpipe's fragment pipeline), another mapping.  The tile kernel shades
+// every triangle that touches a 16x4 tile on all 64 lanes: 2.15 shading events per Hallway tile, more than half of the
+// shaded lanes discarded.  But GL shades per 2x2 quad, and 79 % of the quads of a Hallway / OneRoom frame are covered
+// completely by ONE triangle: they need no coverage test, no depth, no per-sample select — only that triangle's colour.
+//
+// One workgroup (MWQ_THREADS lanes) per env:
+//   0  the env's triangle records are staged in LDS (at most MWQ_CAP; the texture's level-0 geometry is folded in)
+//   A  (tile, triangle) pairs, one per lane: touch / full by the edge functions' extremes over the tile
+//   B  (quad, triangle) pairs of the tiles a triangle touches without covering them: 16-bit touch / full masks
+//   C  every quad collects its triangles (at most four 6-bit ids) and is filed under a class:
+//        TRIV  one triangle, every sample of the four pixels inside it          -> shade, sum, store
+//        P1-4  n triangles, no quad-level evidence of overlap                   -> "painter without overlap": coverage
+//              as wave masks, a contested sample sends the quad to the exact list
+//        EXACT overlap (a covering triangle and another one)                    -> packed keys depth16 << 16 | id
+//        BIG   more than four triangles: the exact path over the tile's list    FALLBACK: over all triangles
+//   D  wavefronts draw batches of 16 quads of one class (heaviest classes first); lanes 4j .. 4j+3 are quad j, every quad
+//      with its OWN triangle: records come per lane from LDS, coverage masks stay wave masks in SGPRs (a v_cmp does not
+//      care that the lanes' operands belong to different triangles), the lod's texture-coordinate differences are DPP
+//      moves inside the quad.  Bytes go to the env's frame in LDS.
+//   E  the frame leaves as 16-byte stores (or in the wrappers' layouts, mw_set_obs_layout).
+// Results do not depend on the order in which atomics file triangles and quads: unclaimed-sample selection is
+// disjoint, the exact path is an unsigned minimum.  Instantiated for 8 samples (the hot path) and for 4 (llvmpipe's
+// GL_MAX_SAMPLES, opengl.py:229-231: the reference's own frames in tests/golden/gl_*.npz run through this very code).
+#include "mw_mesh.h"
+
+#define MWQ_THREADS 512
+#define MWQ_WAVES (MWQ_THREADS / 64)
+#define MWQ_CAP 48            // triangle records staged per env
+#define MWQ_SLOTS 16          // triangles listed per tile
+#define MWQ_EMPTY 63u
+#ifndef MWQ_OCC
+#define MWQ_OCC 6           // wavefronts per SIMD the register allocation aims at (3 workgroups per CU)
+#endif
+
+namespace {
+
+enum { QC_FALLBACK = 0, QC_BIG, QC_EXACT, QC_P4, QC_P3, QC_P2, QC_P1, QC_TRIV, QC_SKY, QC_NCLS, QC_NONE = 15 };
+
+// LDS record of one triangle, in 16-byte quads:
+//   [0..3]   raster record quads 0-3: A[3] B[3] C[3] id z-plane tmax[3]      (mw_records.h)
+//   [4 ..]   thresholds, TQ quads per edge
+//   [SH ..]  shade record quads 0-5: (w plane, tex) (s plane, texture info) (t plane, fw) (r plane, fh) (g plane, byte offset
+//            of the texture's level table) (b plane)
+//   [TMIN]   classification record quad 3: tmin[3]
+template <int S> struct QRec {
+    static constexpr int TQ = (S + 3) / 4;
+    static constexpr int SH = 4 + 3 * TQ;
+    static constexpr int TMIN = SH + 6;
+    static constexpr int NQ = TMIN + 1;       // 17 quads for S = 8: 68 dwords, consecutive records 4 banks apart
+};
+
+// LDS plan of one workgroup (host and device compute the same offsets)
+struct QPlan {
+    int rec, frame, zbuf, qids, queue, xq, tcnt, tlist, tmask, pe, misc, btab, scratch, total;
+};
+__host__ __device__ inline QPlan q_plan(int S, int W, int H, int n_tiles, bool depth)
+{
+    const int NQ = S == 8 ? QRec<8>::NQ : QRec<4>::NQ;
+    const int nquads = (W / 2) * (H / 2);
+    QPlan p;
+    int o = 0;
+    auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
+    p.rec = take(MWQ_CAP * NQ * 16);
+    p.frame = take(W * H * 3);
+    p.zbuf = depth ? take(W * H * 2) : 0;
+    p.qids = take(nquads * 4);
+    p.queue = take((nquads + 16 * QC_NCLS) * 2);
+    p.tcnt = take(n_tiles * 4);
+    p.tlist = take(n_tiles * MWQ_SLOTS);
+    p.tmask = take(n_tiles * MWQ_SLOTS * 4);
+    p.pe = take(n_tiles * MWQ_SLOTS * 2);           // partial (tile, triangle) events: phases A -> B only ...
+    p.xq = p.pe;                                    // ... then the exact list of phase D (a tile is 16 quads: same size)
+    p.misc = take(64 * 4);
+    p.btab = take((nquads / 16 + QC_NCLS) * 2);     // per batch: class | quads << 8
+    p.scratch = p.rec;                              // one record per wavefront (envs with more than MWQ_CAP triangles, 4 samples: no staged records then)
+    p.total = o;
+    return p;
+}
+
+struct QCtx {
+    const float4 *s_rec;
+    uint8_t *s_frame;
+    uint16_t *s_z;
+    TexEnv te;
+    float sky_r, sky_g, sky_b;
+    int W, H;
+    bool depth;
+};
+
+// ---- classification ---------------------------------------------------------------------------------------------------------
+template <int S>
+__device__ inline void classify_rec(const float4 *rec, int pxlo, int pxhi, int gylo, int gyhi, bool &touch, bool &full)
+{
+    const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], tm = rec[QRec<S>::TMIN];
+    const int ea[3] = {__float_as_int(a0.x), __float_as_int(a0.y), __float_as_int(a0.z)};
+    const int eb[3] = {__float_as_int(a0.w), __float_as_int(a1.x), __float_as_int(a1.y)};
+    const int ec[3] = {__float_as_int(a1.z), __float_as_int(a1.w), __float_as_int(a2.x)};
+    const int tmx[3] = {__float_as_int(a3.y), __float_as_int(a3.z), __float_as_int(a3.w)};
+    const int tmn[3] = {__float_as_int(tm.x), __float_as_int(tm.y), __float_as_int(tm.z)};
+    touch = true; full = true;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int emax = __mul24(ea[k], ea[k] > 0 ? pxhi : pxlo) + __mul24(eb[k], eb[k] > 0 ? gyhi : gylo) + ec[k];
+        const int emin = __mul24(ea[k], ea[k] > 0 ? pxlo : pxhi) + __mul24(eb[k], eb[k] > 0 ? gylo : gyhi) + ec[k];
+        touch &= emax > tmn[k];
+        full &= emin > tmx[k];
+    }
+}
+
+// ---- coverage of the lane's pixel by the lane's triangle, as wave masks ------------------------------------------------------
+template <int S>
+__device__ inline void cover_lane(const float4 *rec, int px, int gy, uint64_t valid_m, uint64_t (&in_m)[S])
+{
+    const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3];
+    const int A[3] = {__float_as_int(a0.x), __float_as_int(a0.y), __float_as_int(a0.z)};
+    const int B[3] = {__float_as_int(a0.w), __float_as_int(a1.x), __float_as_int(a1.y)};
+    const int C[3] = {__float_as_int(a1.z), __float_as_int(a1.w), __float_as_int(a2.x)};
+    const int TM[3] = {__float_as_int(a3.y), __float_as_int(a3.z), __float_as_int(a3.w)};
+#pragma unroll
+    for (int s = 0; s < S; ++s) in_m[s] = valid_m;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int E = __mul24(A[k], px) + __mul24(B[k], gy) + C[k];
+        if (__all(E > TM[k])) continue;                 // every lane's pixel strictly inside its triangle's edge k
+        int thr[S];
+#pragma unroll
+        for (int q = 0; q < QRec<S>::TQ; ++q) {
+            const float4 t = rec[4 + k * QRec<S>::TQ + q];
+            thr[4 * q] = __float_as_int(t.x);
+            if (4 * q + 1 < S) thr[4 * q + 1] = __float_as_int(t.y);
+            if (4 * q + 2 < S) thr[4 * q + 2] = __float_as_int(t.z);
+            if (4 * q + 3 < S) thr[4 * q + 3] = __float_as_int(t.w);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) in_m[s] &= __ballot(E > thr[s]);
+    }
+}
+
+template <int S> __device__ inline float samp_ox(int s) { return (float)mwrec::Pat<S>::x[s] * 0.0625f; }
+template <int S> __device__ inline float samp_oy(int s) { return (float)mwrec::Pat<S>::y[s] * 0.0625f; }
+
+// 16-bit depth at sample s of the pixel whose integer coordinates are (fx, fy) as floats (mwgl::z_to_unorm16)
+template <int S>
+__device__ inline uint32_t depth16_s(float a0, float dadx, float dady, float fx, float fy, int s)
+{
+    const float xs = fx + samp_ox<S>(s), ys = fy + samp_oy<S>(s);
+    const float z = __builtin_amdgcn_fmed3f(fmaf(dady, ys, fmaf(dadx, xs, a0)), 0.0f, 1.0f);
+    return __float_as_uint(z * (65535.0f / 65536.0f) + 128.0f) & 0xffffu;
+}
+
+// ---- fragment colour of the lane's triangle at the lane's pixel (x, y: pixel centre) ----------------------------------------
+// The four lanes of a quad hold the same triangle, so the quad's corner coordinates are the neighbours' own values.
+
+// w | w << 16 of the low byte of v: one byte permute
+__device__ inline uint32_t weight_pk8(uint32_t v) { return __builtin_amdgcn_perm(0u, v, 0x0C000C00u); }
+
+// GL_LINEAR on the level whose first record is `off`, lw x lh texels (logarithms; powers of two): R | B << 16 and G
+__device__ inline void fetch_pot(const TexEnv &te, uint32_t off, uint32_t lw, uint32_t lh, float s, float t, uint32_t &rb, uint32_t &g)
+{
+    const int fx = (int)rintf(ldexpf(s, (int)lw + 8)) - 128, fy = (int)rintf(ldexpf(t, (int)lh + 8)) - 128;
+    const uint32_t i0 = __builtin_amdgcn_ubfe((uint32_t)fx, 8u, lw), j0 = __builtin_amdgcn_ubfe((uint32_t)fy, 8u, lh);
+    const uint32_t rec = ((j0 << lw) + i0 + off) << 5;
+    const u32x4 r0 = __builtin_amdgcn_raw_buffer_load_b128(te.tx, rec, 0, 0);
+    const u32x4 r1 = __builtin_amdgcn_raw_buffer_load_b128(te.tx, rec + 16u, 0, 0);
+    const uint32_t wx = weight_pk8((uint32_t)fx), wy = weight_pk8((uint32_t)fy), iy = 0x01000100u - wy;
+    rb = lerp8_pk(lerp8_ad(r0.x, r0.y, wx), lerp8_ad(r1.x, r1.y, wx), wy, iy);
+    g = lerp8_pk(lerp8_ad(r0.z, r0.w, wx), lerp8_ad(r1.z, r1.w, wx), wy, iy);
+}
+
+__device__ inline RGB shade_lane(const float4 *sr, const TexEnv &te, float x, float y)
+{
+    const float4 q0 = sr[0], qr = sr[3], qg = sr[4], qb = sr[5];
+    const float wv = fmaf(q0.z, y, fmaf(q0.y, x, q0.x));
+    const bool fast = __all(rcp_domain(wv));
+    const float oow = fast ? rcp_exact(wv) : 1.0f / wv;
+    RGB c = {fmaf(qr.z, y, fmaf(qr.y, x, qr.x)) * oow, fmaf(qg.z, y, fmaf(qg.y, x, qg.x)) * oow, fmaf(qb.z, y, fmaf(qb.y, x, qb.x)) * oow};
+    const int tex = __float_as_int(q0.w);
+    if (te.flat || !__any(tex >= 0)) return c;
+    if (tex >= 0) {
+        const float4 q1 = sr[1], q2 = sr[2];
+        // (with every wv inside rcp_exact's domain the quotient wv * (1 / wv) is within an ulp of 1: inside it too)
+        const float qq = wv * oow;
+        const float invq = fast ? rcp_exact(qq) : 1.0f / qq;
+        const float s = (fmaf(q1.z, y, fmaf(q1.y, x, q1.x)) * oow) * invq, t = (fmaf(q2.z, y, fmaf(q2.y, x, q2.x)) * oow) * invq;
+        const float s00 = quad_bcast<2>(s), s10 = quad_bcast<3>(s), s01 = quad_bcast<0>(s);
+        const float t00 = quad_bcast<2>(t), t10 = quad_bcast<3>(t), t01 = quad_bcast<0>(t);
+        const uint32_t info = __float_as_uint(q1.w);      // lw0 | lh0 << 5 | nlevels << 10 | both sizes powers of two << 15
+        const int nlevels = (int)((info >> 10) & 31u);
+        const float rho2 = mwgl::lod_rho2(s00, t00, s10, t10, s01, t01, q2.w, qr.w);
+        int l0, w8;
+        mwgl::lod_from_rho2_bits(rho2, nlevels, l0, w8);
+        const int l1 = min(l0 + 1, nlevels - 1);
+        uint32_t rb, ag;
+        if (__all((info >> 15) & 1u)) {
+            const uint32_t dbase = __float_as_uint(qg.w);         // byte offset of lvl[0].off in the descriptor table
+            const uint32_t off0 = __builtin_amdgcn_raw_buffer_load_b32(te.td, dbase + ((uint32_t)l0 << 5), 0, 0);
+            const uint32_t off1 = __builtin_amdgcn_raw_buffer_load_b32(te.td, dbase + ((uint32_t)l1 << 5), 0, 0);
+            const int lw0 = (int)(info & 31u), lh0 = (int)((info >> 5) & 31u);
+            fetch_pot(te, off0, (uint32_t)max(lw0 - l0, 0), (uint32_t)max(lh0 - l0, 0), s, t, rb, ag);
+            if (__any(w8 > 0)) {
+                uint32_t rb1, ag1;
+                fetch_pot(te, off1, (uint32_t)max(lw0 - l1, 0), (uint32_t)max(lh0 - l1, 0), s, t, rb1, ag1);
+                const uint32_t wl = weight_pk8((uint32_t)w8), il = 0x01000100u - wl;
+                rb = lerp8_pk(rb, rb1, wl, il);
+                ag = lerp8_pk(ag, ag1, wl, il);
+            }
+        } else {
+            const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4);
+            int c0[3];
+            fetch_level(te, desc, l0, s, t, c0);
+            if (__any(w8 > 0)) {
+                int c1[3];
+                fetch_level(te, desc, l1, s, t, c1);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) c0[k] = mwgl::lerp8(c0[k], c1[k], w8);
+            }
+            rb = (uint32_t)c0[0] | ((uint32_t)c0[2] << 16); ag = (uint32_t)c0[1];
+        }
+        c.r = ((float)(rb & 0xFFu) * (1.0f / 255.0f)) * c.r;
+        c.g = ((float)(ag & 0xFFu) * (1.0f / 255.0f)) * c.g;
+        c.b = ((float)((rb >> 16) & 0xFFu) * (1.0f / 255.0f)) * c.b;
+    }
+    return c;
+}
+
+template <int S> struct SmpQ { float r[S], g[S], b[S]; };
+
+// mwgl::float_to_unorm8(acc * (1 / S)) in two instructions: the scaling by a power of two is exact, so acc * (255 / S) is
+// the same single rounding as (acc * (1 / S)) * 255, and v_cvt_pk_u8_f32 rounds to nearest even and saturates to 0 .. 255
+// like the clamp before it would (NaN -> 0).  mw_selftest_unorm8 compares the two for all 2^32 floats.
+template <int S> __device__ inline uint32_t resolve_u8(float acc)
+{
+    return __builtin_amdgcn_cvt_pk_u8_f32(acc * (255.0f / S), 0u, 0u);
+}
+
+// resolve in sample order (u_blitter's resolve shader), unorm8, bytes into the env's frame; depth = sample 0
+template <int S>
+__device__ inline void store_pixel(const QCtx &cx, const SmpQ<S> &q, uint32_t z16, int px, int py, bool on)
+{
+    RGB acc = {q.r[0], q.g[0], q.b[0]};
+#pragma unroll
+    for (int s = 1; s < S; ++s) { acc.r = acc.r + q.r[s]; acc.g = acc.g + q.g[s]; acc.b = acc.b + q.b[s]; }
+    const uint32_t R = resolve_u8<S>(acc.r), G = resolve_u8<S>(acc.g), B = resolve_u8<S>(acc.b);
+    if (on) {
+        const int pix = py * cx.W + px;
+        uint8_t *dst = cx.s_frame + pix * 3;
+        dst[0] = (uint8_t)R; dst[1] = (uint8_t)G; dst[2] = (uint8_t)B;
+        if (cx.depth) cx.s_z[pix] = (uint16_t)z16;
+    }
+}
+
+__device__ inline bool quad_any(bool v)
+{
+    const int x = v ? 1 : 0;
+    const int r = x | __builtin_amdgcn_mov_dpp(x, 0x00, 0xF, 0xF, true) | __builtin_amdgcn_mov_dpp(x, 0x55, 0xF, 0xF, true) |
+                  __builtin_amdgcn_mov_dpp(x, 0xAA, 0xF, 0xF, true) | __builtin_amdgcn_mov_dpp(x, 0xFF, 0xF, 0xF, true);
+    return r != 0;
+}
+
+// ---- batch kinds ------------------------------------------------------------------------------------------------------------
+// TRIV: one triangle covers every sample of the quad
+template <int S>
+__device__ inline void batch_trivial(const QCtx &cx, uint32_t ids, int px, int py, bool on)
+{
+    const int gy = cx.H - 1 - py;
+    const float fx = (float)px, fy = (float)gy;
+    const float4 *rec = cx.s_rec + (ids & 63u) * QRec<S>::NQ;
+    const RGB c = shade_lane(rec + QRec<S>::SH, cx.te, fx + 0.5f, fy + 0.5f);
+    SmpQ<S> q;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { q.r[s] = c.r; q.g[s] = c.g; q.b[s] = c.b; }
+    uint32_t z16 = 65535u;
+    if (cx.depth) {
+        const float4 a2 = rec[2], a3 = rec[3];
+        z16 = depth16_s<S>(a2.z, a2.w, a3.x, fx, fy, 0);
+    }
+    store_pixel<S>(cx, q, z16, px, py, on);
+}
+
+// SKY: nothing touches the quad
+template <int S>
+__device__ inline void batch_sky(const QCtx &cx, int px, int py, bool on)
+{
+    SmpQ<S> q;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { q.r[s] = cx.sky_r; q.g[s] = cx.sky_g; q.b[s] = cx.sky_b; }
+    store_pixel<S>(cx, q, 65535u, px, py, on);
+}
+
+// P1-P4: "painter without overlap" — while no sample is claimed twice depth is irrelevant and a claimant's colour goes
+// straight to the samples it covers.  A contested sample sends the quad to the exact list (returns true for its lanes).
+template <int S>
+__device__ inline bool batch_partial(const QCtx &cx, uint32_t ids, int n, int px, int py, bool on)
+{
+    const int gy = cx.H - 1 - py;
+    const float fx = (float)px, fy = (float)gy;
+    SmpQ<S> q;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { q.r[s] = cx.sky_r; q.g[s] = cx.sky_g; q.b[s] = cx.sky_b; }
+    uint32_t z16 = 65535u, covbits = 0u;
+    bool cont = false;
+    for (int k = 0; k < n; ++k) {
+        const float4 *rec = cx.s_rec + ((ids >> (6 * k)) & 63u) * QRec<S>::NQ;
+        uint64_t in_m[S];
+        cover_lane<S>(rec, px, gy, ~0ull, in_m);
+        uint64_t any_m = 0ull;
+#pragma unroll
+        for (int s = 0; s < S; ++s) any_m |= in_m[s];
+        if (!any_m) continue;
+        uint32_t bits = 0u;
+#pragma unroll
+        for (int s = S - 1; s >= 0; --s)
+            asm("v_addc_co_u32_e64 %0, vcc, %0, %0, %1" : "+v"(bits) : "s"(in_m[s]) : "vcc");
+        cont |= (bits & covbits) != 0u;
+        covbits |= bits;
+        const RGB c = shade_lane(rec + QRec<S>::SH, cx.te, fx + 0.5f, fy + 0.5f);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            q.r[s] = sel_mask(in_m[s], c.r, q.r[s]);
+            q.g[s] = sel_mask(in_m[s], c.g, q.g[s]);
+            q.b[s] = sel_mask(in_m[s], c.b, q.b[s]);
+        }
+        if (cx.depth) {
+            const float4 a2 = rec[2], a3 = rec[3];
+            z16 = sel_mask(in_m[0], depth16_s<S>(a2.z, a2.w, a3.x, fx, fy, 0), z16);
+        }
+    }
+    const bool qc = __any(cont) ? quad_any(cont) : false;
+    store_pixel<S>(cx, q, z16, px, py, on && !qc);
+    return qc;
+}
+
+// EXACT / BIG / FALLBACK: packed keys depth16 << 16 | triangle, unsigned min = GL_LESS with first drawn wins (the list
+// index of a triangle is its place in the drawing order); then every triangle that owns a sample of the quad is shaded
+// once (GL multisampling shades a pixel once per triangle) for the samples it owns.
+//   tri(k, p): the lane's k-th candidate (false: none); recp(p): its record
+template <int S, class Tri, class RecOf>
+__device__ inline void batch_exact(const QCtx &cx, int kmax, Tri tri, RecOf recp, int px, int py, bool on)
+{
+    const int gy = cx.H - 1 - py;
+    const float fx = (float)px, fy = (float)gy;
+    uint32_t key[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) key[s] = 0xFFFFFFFFu;
+    for (int k = 0; k < kmax; ++k) {
+        int p = 0;
+        const bool valid = tri(k, p);
+        const uint64_t vm = __ballot(valid);
+        if (!vm) continue;
+        const float4 *rec = recp(valid ? p : 0);
+        uint64_t in_m[S];
+        cover_lane<S>(rec, px, gy, vm, in_m);
+        uint64_t any_m = 0ull;
+#pragma unroll
+        for (int s = 0; s < S; ++s) any_m |= in_m[s];
+        if (!any_m) continue;
+        const float4 a2 = rec[2], a3 = rec[3];
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const uint32_t kk = (depth16_s<S>(a2.z, a2.w, a3.x, fx, fy, s) << 16) | (uint32_t)p;
+            key[s] = sel_mask(in_m[s], min(key[s], kk), key[s]);
+        }
+    }
+    SmpQ<S> q;
+#pragma unroll
+    for (int s = 0; s < S; ++s) { q.r[s] = cx.sky_r; q.g[s] = cx.sky_g; q.b[s] = cx.sky_b; }
+    uint32_t pid[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) pid[s] = key[s] == 0xFFFFFFFFu ? 0x10000u : (key[s] & 0xFFFFu);
+    for (int k = 0; k < kmax; ++k) {
+        int p = 0;
+        const bool valid = tri(k, p);
+        bool wins = false;
+#pragma unroll
+        for (int s = 0; s < S; ++s) wins |= pid[s] == (uint32_t)p;
+        wins &= valid;
+        if (!__any(wins)) continue;
+        // (a quad shades a triangle where any of its pixels holds one of its samples; the other lanes' colour goes nowhere)
+        const float4 *rec = recp(valid ? p : 0);
+        const RGB c = shade_lane(rec + QRec<S>::SH, cx.te, fx + 0.5f, fy + 0.5f);
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const bool eq = valid && pid[s] == (uint32_t)p;
+            q.r[s] = eq ? c.r : q.r[s]; q.g[s] = eq ? c.g : q.g[s]; q.b[s] = eq ? c.b : q.b[s];
+        }
+    }
+    store_pixel<S>(cx, q, key[0] >> 16, px, py, on);
+}
+
+// ---- the kernel -------------------------------------------------------------------------------------------------------------
+template <int S>
+__device__ inline void rasterq_body(
+    int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
+    const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
+    const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const uint32_t *__restrict__ texels,
+    uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, unsigned long long *__restrict__ prof)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    typedef QRec<S> R;
+    const int env = blockIdx.x;
+    if (env >= N) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool has_depth = depth != nullptr;
+    const QPlan pl = q_plan(S, W, H, n_tiles, has_depth);
+    float4 *s_rec = reinterpret_cast<float4 *>(smem + pl.rec);
+    uint8_t *s_frame = smem + pl.frame;
+    uint16_t *s_z = reinterpret_cast<uint16_t *>(smem + pl.zbuf);
+    uint32_t *s_qids = reinterpret_cast<uint32_t *>(smem + pl.qids);
+    uint16_t *s_queue = reinterpret_cast<uint16_t *>(smem + pl.queue);
+    uint16_t *s_xq = reinterpret_cast<uint16_t *>(smem + pl.xq);
+    uint32_t *s_tcnt = reinterpret_cast<uint32_t *>(smem + pl.tcnt);
+    uint8_t *s_tlist = smem + pl.tlist;
+    uint32_t *s_tmask = reinterpret_cast<uint32_t *>(smem + pl.tmask);
+    uint16_t *s_pe = reinterpret_cast<uint16_t *>(smem + pl.pe);
+    uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + pl.misc);     // [0..8] class counts, [16] partial events, [17] next batch, [18] exact list, [19] next exact batch
+    uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_frame);            // (the frame is not written before phase D)
+    uint16_t *s_btab = reinterpret_cast<uint16_t *>(smem + pl.btab);
+    const int QW = W / 2, QH = H / 2, nquads = QW * QH;
+    // x / d for x < 2^16 as a multiply (the divisors are launch constants)
+    const uint32_t m_qw = 0xFFFFFFFFu / (uint32_t)QW + 1u, m_tx = 0xFFFFFFFFu / (uint32_t)tiles_x + 1u;
+    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
+    const int nvis = nvis_arr[env];
+    const int part_mode = (dbg >> 4) & 3;        // 1: every tile but those a mesh entity can touch (the mesh-aware tile kernel draws those)
+    const bool mesh_env = part_mode == 1 && __float_as_int(hdr[3]) != 0;
+    const float *g_rr = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
+    const float4 *g_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
+    const float4 *g_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
+    const MwTexDesc *texd = reinterpret_cast<const MwTexDesc *>(texels);
+
+    // MW_K2Q_PROF (perf experiments only): s_memtime at the phase boundaries of every wavefront, [env][wave][8]
+    auto stamp = [&](int k) { if (prof && lane == 0) prof[((size_t)env * MWQ_WAVES + wave) * 8 + k] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
+    QCtx cx;
+    cx.s_rec = s_rec; cx.s_frame = s_frame; cx.s_z = s_z;
+    cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
+    cx.te.td = cx.te.tx; cx.te.texd = texd; cx.te.flat = dbg & 1;
+    cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
+    cx.W = W; cx.H = H; cx.depth = has_depth;
+
+    // one record quad from the global records into the LDS layout (q: quad of the LDS record)
+    auto stage_quad = [&](int p, int q, float4 *dst, bool with_tex) {
+        float4 v;
+        if (q < 4) v = reinterpret_cast<const float4 *>(g_rr + (size_t)p * MW_RASTER_REC)[q];
+        else if (q < R::SH) { const int k = (q - 4) / R::TQ, j = (q - 4) % R::TQ; v = reinterpret_cast<const float4 *>(g_rr + (size_t)p * MW_RASTER_REC)[4 + 4 * k + j]; }
+        else if (q < R::TMIN) {
+            const int j = q - R::SH;
+            v = g_shade[(size_t)p * (MW_SHADE_REC / 4) + j];
+            if (with_tex && j >= 1 && j <= 4) {
+                const int tex = __float_as_int(g_shade[(size_t)p * (MW_SHADE_REC / 4)].w);
+                uint32_t w0 = 1u, h0 = 1u, nl = 1u;
+                if (tex >= 0) { w0 = texd[tex].w; h0 = texd[tex].h; nl = texd[tex].nlevels; }
+                if (j == 1) {
+                    const uint32_t pot = ((w0 & (w0 - 1u)) | (h0 & (h0 - 1u))) == 0u ? 1u : 0u;
+                    v.w = __uint_as_float((uint32_t)(31 - __builtin_clz(w0)) | ((uint32_t)(31 - __builtin_clz(h0)) << 5) | (nl << 10) | (pot << 15));
+                } else if (j == 4) v.w = __uint_as_float(tex >= 0 ? ((uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4) + 4u) * 4u : 0u);
+                else v.w = j == 2 ? (float)w0 : (float)h0;
+            }
+        } else v = g_cull[(size_t)p * (MW_CULL_REC / 4) + 3];
+        *dst = v;
+    };
+
+    // ---- envs with more triangles than the LDS records hold ---------------------------------------------------------------
+    if (nvis > MWQ_CAP) {
+        if constexpr (S == 8) {
+            // the tile code of mw_raster.hip, records read in place; every wavefront takes every MWQ_WAVES-th tile
+            TileCtx tc;
+            tc.s_shade = g_shade; tc.s_cull = g_cull; tc.shade_stride = MW_SHADE_REC / 4; tc.cull_stride = MW_CULL_REC / 4;
+            tc.rr_env = g_rr; tc.s_pack = smem + wave * 192; tc.hdr = hdr; tc.ment = hdr + MW_HDR_MESH;
+            tc.mesh_pos = tc.mesh_nrm = tc.mesh_rgb = tc.mesh_uv = nullptr; tc.planes = nullptr; tc.slow_frags = nullptr; tc.slow_head = nullptr;
+            tc.slow_stamp = 0u; tc.obs = obs; tc.depth = depth;
+            tc.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3);
+            tc.te = cx.te; tc.sky_r = cx.sky_r; tc.sky_g = cx.sky_g; tc.sky_b = cx.sky_b;
+            tc.env = env; tc.nvis = nvis; tc.W = W; tc.H = H; tc.dbg = dbg & ~0xF0; tc.lane = lane;
+            tc.pre_touch = tc.pre_full = tc.pre_clip = tc.pre_edges = 0ull; tc.have_pre = 0; tc.order = nullptr;
+            for (int tile = wave; tile < n_tiles; tile += MWQ_WAVES) {
+                const int tx = tile % tiles_x, ty = tile / tiles_x;
+                if (mesh_env && tile_in_mesh_rect(hdr, tx, ty)) continue;
+                raster_tile_fmt<false, -1, false, 0, 0>(tc, tx, ty, nullptr);
+            }
+            return;
+        }
+        // 4 samples (not a hot path): every quad through the exact path over all triangles, a record at a time in the
+        // wavefront's scratch
+        float4 *scr = reinterpret_cast<float4 *>(smem + pl.scratch) + wave * R::NQ;
+        cx.s_rec = scr;
+        for (int b = wave; b * 16 < nquads; b += MWQ_WAVES) {
+            const int Q = b * 16 + (lane >> 2);
+            const bool on = Q < nquads;
+            const int Qc = on ? Q : 0;
+            const int qy = (int)__umulhi((uint32_t)Qc, m_qw), qx = Qc - qy * QW;
+            const int px = qx * 2 + (lane & 1), py = qy * 2 + ((lane >> 1) & 1);
+            auto tri = [&](int k, int &p) { p = k; return true; };
+            auto recp = [&](int p) {
+                const int pu = __builtin_amdgcn_readfirstlane(p);
+                __builtin_amdgcn_wave_barrier();
+                if (lane < R::NQ) stage_quad(pu, lane, scr + lane, true);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                return (const float4 *)scr;
+            };
+            batch_exact<S>(cx, nvis, tri, recp, px, py, on);
+        }
+        __syncthreads();
+    } else {
+        // ---- 0: records -> LDS -------------------------------------------------------------------------------------------
+        // (the texture's level-0 geometry follows during phase A: a dependent load that need not hold the copy up)
+        for (int i = tid; i < nvis * R::NQ; i += MWQ_THREADS) { const int p = i / R::NQ, q = i - p * R::NQ; stage_quad(p, q, s_rec + i, false); }
+        for (int i = tid; i < n_tiles; i += MWQ_THREADS) s_tcnt[i] = 0u;
+        if (tid < 64) s_misc[tid] = 0u;
+        __syncthreads();
+        stamp(1);
+
+        // ---- A: (tile, triangle) pairs -------------------------------------------------------------------------------------
+        const bool force_fallback = (dbg & 8) != 0;
+        int my_tex = -1;
+        uint32_t my_w = 1u, my_h = 1u, my_nl = 1u;
+        if (tid < nvis) {
+            my_tex = __float_as_int(s_rec[tid * R::NQ + R::SH].w);
+            if (my_tex >= 0) { my_w = texd[my_tex].w; my_h = texd[my_tex].h; my_nl = texd[my_tex].nlevels; }
+        }
+        const uint32_t m_nvis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / (uint32_t)max(nvis, 1) + 1u));
+        for (int i = tid; i < n_tiles * nvis; i += MWQ_THREADS) {
+            const int t = (int)__umulhi((uint32_t)i, m_nvis), p = i - t * nvis;
+            const int ty = (int)__umulhi((uint32_t)t, m_tx), tx = t - ty * tiles_x;
+            const int pxlo = tx * MW_TILE_W, pxhi = pxlo + MW_TILE_W - 1;
+            const int gyhi = H - 1 - ty * MW_TILE_H, gylo = gyhi - (MW_TILE_H - 1);
+            bool touch, full;
+            classify_rec<S>(s_rec + p * R::NQ, pxlo, pxhi, gylo, gyhi, touch, full);
+            if (touch) {
+                const uint32_t slot = atomicAdd(&s_tcnt[t], 1u);
+                if (slot < MWQ_SLOTS) {
+                    const uint32_t e = (uint32_t)t * MWQ_SLOTS + slot;
+                    s_tlist[e] = (uint8_t)p;
+                    if (full) s_tmask[e] = 0xFFFFFFFFu;
+                    else s_pe[atomicAdd(&s_misc[16], 1u)] = (uint16_t)e;
+                }
+            }
+        }
+        if (tid < nvis) {
+            float *r = reinterpret_cast<float *>(s_rec + tid * R::NQ + R::SH);
+            const uint32_t pot = ((my_w & (my_w - 1u)) | (my_h & (my_h - 1u))) == 0u ? 1u : 0u;
+            r[4 + 3] = __uint_as_float((uint32_t)(31 - __builtin_clz(my_w)) | ((uint32_t)(31 - __builtin_clz(my_h)) << 5) | (my_nl << 10) | (pot << 15));
+            r[8 + 3] = (float)my_w;
+            r[12 + 3] = (float)my_h;
+            r[16 + 3] = __uint_as_float(my_tex >= 0 ? ((uint32_t)my_tex * (uint32_t)(sizeof(MwTexDesc) / 4) + 4u) * 4u : 0u);
+        }
+        __syncthreads();
+
+        stamp(2);
+        // ---- B: (quad, triangle) pairs of the tiles a triangle crosses -----------------------------------------------------
+        const int npe = __builtin_amdgcn_readfirstlane((int)s_misc[16]);
+        for (int i = tid; i < ((npe * 16 + 63) & ~63); i += MWQ_THREADS) {
+            const int j = i >> 4, qi = i & 15;
+            bool touch = false, full = false;
+            uint32_t e = 0u;
+            if (j < npe) {
+                e = s_pe[j];
+                const int t = (int)(e / MWQ_SLOTS), p = s_tlist[e];
+                const int ty = (int)__umulhi((uint32_t)t, m_tx), tx = t - ty * tiles_x;
+                const int pxlo = tx * MW_TILE_W + (qi & 7) * 2, py0 = ty * MW_TILE_H + (qi >> 3) * 2;
+                const int gyhi = H - 1 - py0;
+                classify_rec<S>(s_rec + p * R::NQ, pxlo, pxlo + 1, gyhi - 1, gyhi, touch, full);
+            }
+            const uint64_t tm = __ballot(touch), fm = __ballot(full);
+            const int sh = lane & 48;
+            if (j < npe && qi == 0) s_tmask[e] = (uint32_t)((tm >> sh) & 0xFFFFull) | ((uint32_t)((fm >> sh) & 0xFFFFull) << 16);
+        }
+        __syncthreads();
+
+        stamp(3);
+        // ---- C1: every quad collects its triangles and takes a class --------------------------------------------------------
+        for (int Q = tid; Q < nquads; Q += MWQ_THREADS) {
+            const int qy = (int)__umulhi((uint32_t)Q, m_qw), qx = Q - qy * QW;
+            const int tx = qx >> 3, ty = qy >> 1, t = ty * tiles_x + tx, bit = ((qy & 1) << 3) | (qx & 7);
+            const uint32_t cnt = s_tcnt[t];
+            uint32_t ids = 0u, n = 0u;
+            bool anyfull = false;
+            int cls;
+            if (mesh_env && tile_in_mesh_rect(hdr, tx, ty)) cls = QC_NONE;
+            else if (cnt > MWQ_SLOTS || force_fallback) cls = QC_FALLBACK;
+            else {
+                for (uint32_t k = 0; k < cnt; ++k) {
+                    const uint32_t m = s_tmask[t * MWQ_SLOTS + k];
+                    if ((m >> bit) & 1u) {
+                        if (n < 4u) ids |= (uint32_t)s_tlist[t * MWQ_SLOTS + k] << (6u * n);
+                        ++n;
+                        anyfull |= ((m >> (16 + bit)) & 1u) != 0u;
+                    }
+                }
+                for (uint32_t k = n; k < 4u; ++k) ids |= MWQ_EMPTY << (6u * k);
+                if (n == 0u) cls = QC_SKY;
+                else if (n == 1u && anyfull && !(dbg & 4)) cls = QC_TRIV;
+                else if (n > 4u) cls = QC_BIG;
+                else if ((n >= 2u && anyfull) || (dbg & 4)) cls = QC_EXACT;
+                else cls = QC_P1 + 1 - (int)n;
+            }
+            s_qids[Q] = ids | ((uint32_t)cls << 24);
+            // place within the class: one LDS atomic per wavefront for the class nearly every quad is in, one per lane otherwise
+            const uint64_t tm = __ballot(cls == QC_TRIV);
+            uint32_t tbase = 0u;
+            if (tm != 0ull) {
+                const int leader = __ffsll((unsigned long long)tm) - 1;
+                if (lane == leader) tbase = atomicAdd(&s_misc[QC_TRIV], (uint32_t)__popcll(tm));
+                tbase = (uint32_t)__builtin_amdgcn_readlane((int)tbase, leader);
+            }
+            if (cls == QC_TRIV) s_rank[Q] = (uint16_t)(tbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(tm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)tm, 0u)));
+            else if (cls != QC_NONE) s_rank[Q] = (uint16_t)atomicAdd(&s_misc[cls], 1u);
+        }
+        __syncthreads();
+
+        // ---- C2: class queues, whole batches of 16 quads per class ----------------------------------------------------------
+        uint32_t cnt_c[QC_NCLS], first_b[QC_NCLS + 1];
+        first_b[0] = 0u;
+#pragma unroll
+        for (int c = 0; c < QC_NCLS; ++c) { cnt_c[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[c]); first_b[c + 1] = first_b[c] + (cnt_c[c] + 15u) / 16u; }
+        for (int Q = tid; Q < nquads; Q += MWQ_THREADS) {
+            const uint32_t cls = s_qids[Q] >> 24;
+            if (cls == QC_NONE) continue;
+            uint32_t base = 0u;
+#pragma unroll
+            for (int c = 0; c < QC_NCLS; ++c) base = cls == (uint32_t)c ? first_b[c] : base;
+            s_queue[base * 16u + s_rank[Q]] = (uint16_t)Q;
+        }
+        for (uint32_t b = tid; b < first_b[QC_NCLS]; b += MWQ_THREADS) {
+            uint32_t cls = 0u;
+#pragma unroll
+            for (int c = 1; c < QC_NCLS; ++c) cls += b >= first_b[c] ? 1u : 0u;
+            uint32_t cfirst = 0u, ccnt = 0u;
+#pragma unroll
+            for (int c = 0; c < QC_NCLS; ++c) { cfirst = cls == (uint32_t)c ? first_b[c] : cfirst; ccnt = cls == (uint32_t)c ? cnt_c[c] : ccnt; }
+            s_btab[b] = (uint16_t)(cls | (min(16u, ccnt - (b - cfirst) * 16u) << 8));
+        }
+        __syncthreads();
+
+        stamp(4);
+        // ---- D: batches ------------------------------------------------------------------------------------------------------
+        const uint32_t n_batches = (dbg & 0x400) ? 0u : first_b[QC_NCLS];      // (0x400, 0x800, 0x1000: phase timing experiments, frames invalid)
+        for (;;) {
+            uint32_t b = 0u;
+            if (lane == 0) b = atomicAdd(&s_misc[17], 1u);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (b >= n_batches) break;
+            const uint32_t be = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_btab[b]);
+            const int cls = (int)(be & 255u);
+            const bool on = (uint32_t)(lane >> 2) < (be >> 8);
+            const int Q = on ? (int)s_queue[b * 16u + (uint32_t)(lane >> 2)] : 0;
+            const int qy = (int)__umulhi((uint32_t)Q, m_qw), qx = Q - qy * QW;
+            const int px = qx * 2 + (lane & 1), py = qy * 2 + ((lane >> 1) & 1);
+            const uint32_t ids = on ? s_qids[Q] : 0u;
+            if ((dbg & 0x800) && cls != QC_TRIV) continue;
+            if ((dbg & 0x1000) && cls == QC_TRIV) continue;
+            if (cls == QC_TRIV) batch_trivial<S>(cx, ids, px, py, on);
+            else if (cls == QC_SKY) batch_sky<S>(cx, px, py, on);
+            else if (cls >= QC_P4) {
+                const bool qc = batch_partial<S>(cx, ids, QC_P1 + 1 - cls, px, py, on);
+                if (qc && on && (lane & 3) == 0) s_xq[atomicAdd(&s_misc[18], 1u)] = (uint16_t)Q;
+            } else if (cls == QC_EXACT) {
+                auto tri = [&](int k, int &p) { p = (int)((ids >> (6 * k)) & 63u); return p != (int)MWQ_EMPTY; };
+                auto recp = [&](int p) { return (const float4 *)(s_rec + p * R::NQ); };
+                batch_exact<S>(cx, 4, tri, recp, px, py, on);
+            } else if (cls == QC_BIG) {
+                const int tx = qx >> 3, ty = qy >> 1, t = ty * tiles_x + tx, bit = ((qy & 1) << 3) | (qx & 7);
+                const int cnt = on ? (int)s_tcnt[t] : 0;
+                int kmax = cnt;
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) kmax = max(kmax, __shfl_xor(kmax, o));
+                auto tri = [&](int k, int &p) {
+                    if (k >= cnt) { p = 0; return false; }
+                    p = s_tlist[t * MWQ_SLOTS + k];
+                    return ((s_tmask[t * MWQ_SLOTS + k] >> bit) & 1u) != 0u;
+                };
+                auto recp = [&](int p) { return (const float4 *)(s_rec + p * R::NQ); };
+                batch_exact<S>(cx, kmax, tri, recp, px, py, on);
+            } else {
+                auto tri = [&](int k, int &p) { p = k; return true; };
+                auto recp = [&](int p) { return (const float4 *)(s_rec + p * R::NQ); };
+                batch_exact<S>(cx, nvis, tri, recp, px, py, on);
+            }
+        }
+        stamp(5);
+        __syncthreads();
+        stamp(6);
+
+        // ---- D2: the quads whose samples turned out to be contested ---------------------------------------------------------
+        const uint32_t nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[18]);
+        for (;;) {
+            uint32_t b = 0u;
+            if (lane == 0) b = atomicAdd(&s_misc[19], 1u);
+            b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            if (b * 16u >= nx) break;
+            const bool on = b * 16u + (uint32_t)(lane >> 2) < nx;
+            const int Q = on ? (int)s_xq[b * 16u + (uint32_t)(lane >> 2)] : 0;
+            const int qy = (int)__umulhi((uint32_t)Q, m_qw), qx = Q - qy * QW;
+            const int px = qx * 2 + (lane & 1), py = qy * 2 + ((lane >> 1) & 1);
+            const uint32_t ids = on ? s_qids[Q] : 0u;
+            auto tri = [&](int k, int &p) { p = (int)((ids >> (6 * k)) & 63u); return p != (int)MWQ_EMPTY; };
+            auto recp = [&](int p) { return (const float4 *)(s_rec + p * R::NQ); };
+            batch_exact<S>(cx, 4, tri, recp, px, py, on);
+        }
+        __syncthreads();
+    }
+
+    // ---- E: the frame leaves ------------------------------------------------------------------------------------------------
+    // Output layouts (mw_set_obs_layout; the reference's wrappers.py folded into the store):
+    //   0  uint8 [H][W][3]      the observation itself
+    //   1  uint8 [3][W][H]      PyTorchObsWrapper: observation.transpose(2, 1, 0)   (wrappers.py:24)
+    //   2  double[H][W][1]      GreyscaleWrapper: 0.30 R + 0.59 G + 0.11 B in numpy's float64 (wrappers.py:44)
+    const int fmt = (dbg >> 8) & 3;
+    const int npix = W * H;
+    auto in_mesh_tile = [&](int px, int py) { return mesh_env && tile_in_mesh_rect(hdr, px / MW_TILE_W, py / MW_TILE_H); };
+    if (fmt == 0) {
+        uint8_t *dst = obs + (size_t)env * npix * 3;
+        if (!mesh_env && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0u) {
+            const uint4 *src = reinterpret_cast<const uint4 *>(s_frame);
+            for (int i = tid; i < npix * 3 / 16; i += MWQ_THREADS) reinterpret_cast<uint4 *>(dst)[i] = src[i];
+        } else if ((reinterpret_cast<uintptr_t>(dst) & 3u) == 0u) {
+            // (dwords never straddle a tile: a tile row is 48 bytes)
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(s_frame);
+            for (int i = tid; i < npix * 3 / 4; i += MWQ_THREADS) {
+                const int pix = (i * 4) / 3;
+                if (!in_mesh_tile(pix % W, pix / W)) reinterpret_cast<uint32_t *>(dst)[i] = src[i];
+            }
+        } else {
+            for (int i = tid; i < npix * 3; i += MWQ_THREADS) {
+                const int pix = i / 3;
+                if (!in_mesh_tile(pix % W, pix / W)) dst[i] = s_frame[i];
+            }
+        }
+    } else if (fmt == 1) {
+        uint8_t *dst = obs + (size_t)env * npix * 3;
+        for (int i = tid; i < npix * 3; i += MWQ_THREADS) {
+            const int ch = i / npix, r = i - ch * npix, x = r / H, y = r - x * H;
+            if (!in_mesh_tile(x, y)) dst[i] = s_frame[(y * W + x) * 3 + ch];
+        }
+    } else {
+        double *dst = reinterpret_cast<double *>(obs) + (size_t)env * npix;
+        for (int i = tid; i < npix; i += MWQ_THREADS) {
+            if (in_mesh_tile(i % W, i / W)) continue;
+            const double Rv = (double)s_frame[i * 3], Gv = (double)s_frame[i * 3 + 1], Bv = (double)s_frame[i * 3 + 2];
+            dst[i] = (0.30 * Rv + 0.59 * Gv) + 0.11 * Bv;
+        }
+    }
+    stamp(7);
+    if (has_depth) {
+        // get_depth_map in float32 as numpy evaluates it (opengl.py:426-431)
+        float *dst = depth + (size_t)env * npix;
+        for (int i = tid; i < npix; i += MWQ_THREADS) {
+            if (in_mesh_tile(i % W, i / W)) continue;
+            const float z = (float)s_z[i];
+            const float d = z / 65535.0f;
+            const float clip = (d - 0.5f) * 2.0f;
+            const float den = clip * (float)(100.0 - 0.04) - (float)(100.0 + 0.04);
+            dst[i] = (float)(-2.0 * 100.0 * 0.04) / den;
+        }
+    }
+}
+
+}  // namespace
+
+#define MWQ_ARGS \
+    int N, int W, int H, int max_vis, int tiles_x, int n_tiles, \
+    const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull, \
+    const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const uint32_t *__restrict__ texels, \
+    uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, unsigned long long *__restrict__ prof
+#define MWQ_FWD N, W, H, max_vis, tiles_x, n_tiles, rec_raster, rec_shade, rec_cull, nvis_arr, envhdr, texels, obs, depth, dbg, texel_bytes, prof
+
+extern "C" __global__ __launch_bounds__(MWQ_THREADS, MWQ_OCC) void mw_rasterq_kernel(MWQ_ARGS) { rasterq_body<8>(MWQ_FWD); }
+extern "C" __global__ __launch_bounds__(MWQ_THREADS) void mw_rasterq4_kernel(MWQ_ARGS) { rasterq_body<4>(MWQ_FWD); }
+
+// bytes of dynamic LDS a launch needs (mw_engine.hip)
+extern "C" int mw_rasterq_lds_bytes(int S, int W, int H, int n_tiles, int depth) { return q_plan(S, W, H, n_tiles, depth != 0).total; }
+
+#ifdef MWQ_PROBE
+// static ISA inspection only (tools/perf/isa_k2q.sh): the trivial batch on its own
+extern "C" __global__ __launch_bounds__(MWQ_THREADS) void mwq_probe_trivial(const uint32_t *texels, int texel_bytes, int W, int H, const uint32_t *ids_in, float sky, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    QCtx cx;
+    cx.s_rec = reinterpret_cast<float4 *>(smem); cx.s_frame = smem + 20000; cx.s_z = reinterpret_cast<uint16_t *>(smem + 40000);
+    cx.te.tx = __builtin_amdgcn_make_buffer_rsrc((void *)texels, 0, texel_bytes, MW_RSRC_WORD3);
+    cx.te.td = cx.te.tx; cx.te.texd = nullptr; cx.te.flat = dbg & 1;
+    cx.sky_r = cx.sky_g = cx.sky_b = sky; cx.W = W; cx.H = H; cx.depth = false;
+    const int lane = threadIdx.x & 63;
+    const uint32_t ids = ids_in[threadIdx.x >> 2];
+    const int Q = (int)(ids >> 8);
+    const int qy = Q / 40, qx = Q - qy * 40;
+    batch_trivial<8>(cx, ids, qx * 2 + (lane & 1), qy * 2 + ((lane >> 1) & 1), true);
+}
+#endif

@@ -81,3 +81,40 @@ extern "C" int mw_selftest_div(unsigned long long *host_n_bad, uint32_t *host_ex
     (void)hipFree(d_n); (void)hipFree(d_ex);
     return 0;
 }
+
+// mw_selftest_unorm8: the quad kernel converts a pixel's resolved sum with v_cvt_pk_u8_f32(acc * (255 / S)) instead of
+// mwgl::float_to_unorm8(acc * (1 / S)) (clamp, * 255, rint, convert).  Compared here for ALL 2^32 floats, S = 4 and 8.
+// mw_selftest_lod: mwgl::lod_from_rho2 (llvmpipe's lod arithmetic as the oracle states it) against lod_from_rho2_bits (the
+// quad kernel's form on the float's bits) for all 2^32 floats and pyramids of 1 .. 12 levels.
+extern "C" __global__ void mw_selftest_q_kernel(unsigned long long *n_bad /*[2]*/, uint32_t *examples /*[2][32]*/)
+{
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (uint64_t b = tid; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const bool bad_u8 = mwgl::float_to_unorm8(x * 0.125f) != __builtin_amdgcn_cvt_pk_u8_f32(x * (255.0f / 8), 0u, 0u) ||
+                            mwgl::float_to_unorm8(x * 0.25f) != __builtin_amdgcn_cvt_pk_u8_f32(x * (255.0f / 4), 0u, 0u);
+        if (bad_u8) { const unsigned long long k = atomicAdd(&n_bad[0], 1ull); if (k < 32ull) examples[k] = (uint32_t)b; }
+        bool bad_lod = false;
+        for (int nl = 1; nl <= 12; ++nl) {
+            int l0, w8, l0b, w8b;
+            mwgl::lod_from_rho2(x, nl, l0, w8);
+            mwgl::lod_from_rho2_bits(x, nl, l0b, w8b);
+            bad_lod |= l0 != l0b || w8 != w8b;
+        }
+        if (bad_lod) { const unsigned long long k = atomicAdd(&n_bad[1], 1ull); if (k < 32ull) examples[32 + k] = (uint32_t)b; }
+    }
+}
+
+extern "C" int mw_selftest_q(unsigned long long *host_n_bad /*[2]*/, uint32_t *host_examples /*[64]*/)
+{
+    unsigned long long *d_n = nullptr;
+    uint32_t *d_ex = nullptr;
+    if (hipMalloc((void **)&d_n, 16) != hipSuccess || hipMalloc((void **)&d_ex, 64 * 4) != hipSuccess) return -1;
+    (void)hipMemset(d_n, 0, 16); (void)hipMemset(d_ex, 0, 64 * 4);
+    hipLaunchKernelGGL(mw_selftest_q_kernel, dim3(256 * 32), dim3(256), 0, 0, d_n, d_ex);
+    if (hipDeviceSynchronize() != hipSuccess) return -2;
+    (void)hipMemcpy(host_n_bad, d_n, 16, hipMemcpyDeviceToHost);
+    (void)hipMemcpy(host_examples, d_ex, 64 * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d_n); (void)hipFree(d_ex);
+    return 0;
+}

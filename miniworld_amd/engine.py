@@ -33,7 +33,7 @@ EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
     "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms",
-    "mw_set_gen_program", "mw_selftest_rcp", "mw_selftest_div", "mw_selftest_sort",
+    "mw_set_gen_program", "mw_selftest_rcp", "mw_selftest_div", "mw_selftest_sort", "mw_selftest_q",
 ]
 
 

@@ -34,6 +34,20 @@ def test_fast_division_equals_ieee_division_on_its_domain():
     assert n.value == 0, f"{n.value} quotients differ, e.g. (a, b) = {pairs[:6].tolist()}"
 
 
+def test_quad_kernel_shortcuts_equal_the_pinned_arithmetic_for_every_float():
+    """mw_rasterq.hip: v_cvt_pk_u8_f32(acc * (255 / S)) == float_to_unorm8(acc * (1 / S)) (S = 4, 8), and the lod taken from
+    rho^2's bits == mwgl::lod_from_rho2's float arithmetic (1 .. 12 levels) — for all 2^32 inputs."""
+    from miniworld_amd import engine
+    lib = engine.load_library()
+    n = (C.c_uint64 * 2)()
+    ex = (C.c_uint32 * 64)()
+    lib.mw_selftest_q.argtypes = [C.c_void_p, C.c_void_p]
+    assert lib.mw_selftest_q(n, ex) == 0
+    ex = np.array(ex[:], np.uint32)
+    assert n[0] == 0, f"unorm8: {n[0]} inputs differ, e.g. {ex[:8].view(np.float32).tolist()}"
+    assert n[1] == 0, f"lod: {n[1]} inputs differ, e.g. {ex[32:40].view(np.float32).tolist()}"
+
+
 def test_visiting_order_sort_sorts():
     """Big scenes' geometry kernel leaves K2 a near-to-far visiting order; K2 stops at the first triangle that lies behind
     everything its tile holds, which is only right if the order is ascending.  mw_selftest_sort runs the kernel's own sort
