@@ -29,14 +29,21 @@
 
 #define MWQ_THREADS 512
 #define MWQ_WAVES (MWQ_THREADS / 64)
-#define MWQ_CAP 48            // triangle records staged per env
+#define MWQ_CAP_MAX 48        // triangle records staged per env: 48, or 40 with a depth channel (three workgroups per CU either way)
 #define MWQ_SLOTS 16          // triangles listed per tile
 #define MWQ_EMPTY 63u
+#ifndef MWQ_TILE_FALLBACK
+#define MWQ_TILE_FALLBACK 1
+#endif
 #ifndef MWQ_OCC
 #define MWQ_OCC 6           // wavefronts per SIMD the register allocation aims at (3 workgroups per CU)
 #endif
 
 namespace {
+
+// votes straight from the compare's lane mask (hip's __all / __any go through an integer per lane: two more VALU instructions)
+__device__ inline bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_read_exec(); }
+__device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 
 enum { QC_FALLBACK = 0, QC_BIG, QC_EXACT, QC_P4, QC_P3, QC_P2, QC_P1, QC_TRIV, QC_SKY, QC_NCLS, QC_NONE = 15 };
 
@@ -45,18 +52,22 @@ enum { QC_FALLBACK = 0, QC_BIG, QC_EXACT, QC_P4, QC_P3, QC_P2, QC_P1, QC_TRIV, Q
 //   [4 ..]   thresholds, TQ quads per edge
 //   [SH ..]  shade record quads 0-5: (w plane, tex) (s plane, texture info) (t plane, fw) (r plane, fh) (g plane, byte offset
 //            of the texture's level table) (b plane)
-//   [TMIN]   classification record quad 3: tmin[3]
+//   [CT ..]  classification thresholds of the edge values at a tile's / a quad's first pixel (pxlo, gylo):
+//            touch iff E_k > T_k for all k, covered iff E_k > F_k:  Tt[3] Ft[3] (16x4 tile)  Tq[3] Fq[3] (2x2 quad)
+//              T_k = tmin_k - max(A_k, 0) (w - 1) - max(B_k, 0) (h - 1),  F_k = tmax_k - min(A_k, 0) (w - 1) - min(B_k, 0) (h - 1)
+//            (the edge value is monotone along x and y: its extremes over the rectangle sit at corners)
 template <int S> struct QRec {
     static constexpr int TQ = (S + 3) / 4;
     static constexpr int SH = 4 + 3 * TQ;
-    static constexpr int TMIN = SH + 6;
-    static constexpr int NQ = TMIN + 1;       // 17 quads for S = 8: 68 dwords, consecutive records 4 banks apart
+    static constexpr int CT = SH + 6;
+    static constexpr int NQ = CT + 3;         // 19 quads for S = 8: 76 dwords, 16 consecutive records' quads fall into 16 different bank groups
 };
 
 // LDS plan of one workgroup (host and device compute the same offsets)
 struct QPlan {
-    int rec, frame, zbuf, qids, queue, xq, tcnt, tlist, tmask, pe, misc, btab, scratch, total;
+    int rec, frame, zbuf, qids, queue, xq, tcnt, tfull, tlist, tmask, pe, misc, btab, scratch, total;
 };
+__host__ __device__ inline int q_cap(bool depth) { return depth ? 40 : MWQ_CAP_MAX; }
 __host__ __device__ inline QPlan q_plan(int S, int W, int H, int n_tiles, bool depth)
 {
     const int NQ = S == 8 ? QRec<8>::NQ : QRec<4>::NQ;
@@ -64,16 +75,17 @@ __host__ __device__ inline QPlan q_plan(int S, int W, int H, int n_tiles, bool d
     QPlan p;
     int o = 0;
     auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
-    p.rec = take(MWQ_CAP * NQ * 16);
+    p.rec = take(q_cap(depth) * NQ * 16);
     p.frame = take(W * H * 3);
     p.zbuf = depth ? take(W * H * 2) : 0;
     p.qids = take(nquads * 4);
     p.queue = take((nquads + 16 * QC_NCLS) * 2);
     p.tcnt = take(n_tiles * 4);
+    p.tfull = take(n_tiles * 4);                    // triangles that cover the whole tile: count | three ids << 8, 16, 24
     p.tlist = take(n_tiles * MWQ_SLOTS);
     p.tmask = take(n_tiles * MWQ_SLOTS * 4);
-    p.pe = take(n_tiles * MWQ_SLOTS * 2);           // partial (tile, triangle) events: phases A -> B only ...
-    p.xq = p.pe;                                    // ... then the exact list of phase D (a tile is 16 quads: same size)
+    p.pe = p.frame;                                 // partial (tile, triangle) events, phases A -> B: in the frame (W H 3 >= tiles x 64 bytes), which phase D writes first
+    p.xq = take(nquads * 2);                        // the exact list of phase D
     p.misc = take(64 * 4);
     p.btab = take((nquads / 16 + QC_NCLS) * 2);     // per batch: class | quads << 8
     p.scratch = p.rec;                              // one record per wavefront (envs with more than MWQ_CAP triangles, 4 samples: no staged records then)
@@ -92,23 +104,34 @@ struct QCtx {
 };
 
 // ---- classification ---------------------------------------------------------------------------------------------------------
-template <int S>
-__device__ inline void classify_rec(const float4 *rec, int pxlo, int pxhi, int gylo, int gyhi, bool &touch, bool &full)
+// ... of the rectangle whose first pixel is (pxlo, gylo) against the lane's triangle: T, F = the rectangle size's thresholds
+__device__ inline void classify_at(const float4 &a0, const float4 &a1, const float4 &a2, int pxlo, int gylo, const int (&T)[3], const int (&F)[3],
+                                    bool &touch, bool &full)
 {
-    const float4 a0 = rec[0], a1 = rec[1], a2 = rec[2], a3 = rec[3], tm = rec[QRec<S>::TMIN];
     const int ea[3] = {__float_as_int(a0.x), __float_as_int(a0.y), __float_as_int(a0.z)};
     const int eb[3] = {__float_as_int(a0.w), __float_as_int(a1.x), __float_as_int(a1.y)};
     const int ec[3] = {__float_as_int(a1.z), __float_as_int(a1.w), __float_as_int(a2.x)};
-    const int tmx[3] = {__float_as_int(a3.y), __float_as_int(a3.z), __float_as_int(a3.w)};
-    const int tmn[3] = {__float_as_int(tm.x), __float_as_int(tm.y), __float_as_int(tm.z)};
     touch = true; full = true;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int emax = __mul24(ea[k], ea[k] > 0 ? pxhi : pxlo) + __mul24(eb[k], eb[k] > 0 ? gyhi : gylo) + ec[k];
-        const int emin = __mul24(ea[k], ea[k] > 0 ? pxlo : pxhi) + __mul24(eb[k], eb[k] > 0 ? gylo : gyhi) + ec[k];
-        touch &= emax > tmn[k];
-        full &= emin > tmx[k];
+        const int E = __mul24(ea[k], pxlo) + __mul24(eb[k], gylo) + ec[k];
+        touch &= E > T[k];
+        full &= E > F[k];
     }
+}
+template <int S>
+__device__ inline void classify_tile(const float4 *rec, int pxlo, int gylo, bool &touch, bool &full)
+{
+    const float4 c0 = rec[QRec<S>::CT], c1 = rec[QRec<S>::CT + 1];
+    const int T[3] = {__float_as_int(c0.x), __float_as_int(c0.y), __float_as_int(c0.z)}, F[3] = {__float_as_int(c0.w), __float_as_int(c1.x), __float_as_int(c1.y)};
+    classify_at(rec[0], rec[1], rec[2], pxlo, gylo, T, F, touch, full);
+}
+template <int S>
+__device__ inline void classify_quad(const float4 *rec, int pxlo, int gylo, bool &touch, bool &full)
+{
+    const float4 c1 = rec[QRec<S>::CT + 1], c2 = rec[QRec<S>::CT + 2];
+    const int T[3] = {__float_as_int(c1.z), __float_as_int(c1.w), __float_as_int(c2.x)}, F[3] = {__float_as_int(c2.y), __float_as_int(c2.z), __float_as_int(c2.w)};
+    classify_at(rec[0], rec[1], rec[2], pxlo, gylo, T, F, touch, full);
 }
 
 // ---- coverage of the lane's pixel by the lane's triangle, as wave masks ------------------------------------------------------
@@ -125,7 +148,7 @@ __device__ inline void cover_lane(const float4 *rec, int px, int gy, uint64_t va
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         const int E = __mul24(A[k], px) + __mul24(B[k], gy) + C[k];
-        if (__all(E > TM[k])) continue;                 // every lane's pixel strictly inside its triangle's edge k
+        if (wave_all(E > TM[k])) continue;                 // every lane's pixel strictly inside its triangle's edge k
         int thr[S];
 #pragma unroll
         for (int q = 0; q < QRec<S>::TQ; ++q) {
@@ -175,11 +198,12 @@ __device__ inline RGB shade_lane(const float4 *sr, const TexEnv &te, float x, fl
 {
     const float4 q0 = sr[0], qr = sr[3], qg = sr[4], qb = sr[5];
     const float wv = fmaf(q0.z, y, fmaf(q0.y, x, q0.x));
-    const bool fast = __all(rcp_domain(wv));
+    // (one vote per compare: the votes of a conjunction would go through an integer per lane)
+    const bool fast = (__builtin_amdgcn_ballot_w64(fabsf(wv) >= MW_RCP_LO) & __builtin_amdgcn_ballot_w64(fabsf(wv) <= MW_RCP_HI)) == __builtin_amdgcn_read_exec();
     const float oow = fast ? rcp_exact(wv) : 1.0f / wv;
     RGB c = {fmaf(qr.z, y, fmaf(qr.y, x, qr.x)) * oow, fmaf(qg.z, y, fmaf(qg.y, x, qg.x)) * oow, fmaf(qb.z, y, fmaf(qb.y, x, qb.x)) * oow};
     const int tex = __float_as_int(q0.w);
-    if (te.flat || !__any(tex >= 0)) return c;
+    if (te.flat || !wave_any(tex >= 0)) return c;
     if (tex >= 0) {
         const float4 q1 = sr[1], q2 = sr[2];
         // (with every wv inside rcp_exact's domain the quotient wv * (1 / wv) is within an ulp of 1: inside it too)
@@ -195,13 +219,13 @@ __device__ inline RGB shade_lane(const float4 *sr, const TexEnv &te, float x, fl
         mwgl::lod_from_rho2_bits(rho2, nlevels, l0, w8);
         const int l1 = min(l0 + 1, nlevels - 1);
         uint32_t rb, ag;
-        if (__all((info >> 15) & 1u)) {
+        if (wave_all((info >> 15) & 1u)) {
             const uint32_t dbase = __float_as_uint(qg.w);         // byte offset of lvl[0].off in the descriptor table
             const uint32_t off0 = __builtin_amdgcn_raw_buffer_load_b32(te.td, dbase + ((uint32_t)l0 << 5), 0, 0);
             const uint32_t off1 = __builtin_amdgcn_raw_buffer_load_b32(te.td, dbase + ((uint32_t)l1 << 5), 0, 0);
             const int lw0 = (int)(info & 31u), lh0 = (int)((info >> 5) & 31u);
             fetch_pot(te, off0, (uint32_t)max(lw0 - l0, 0), (uint32_t)max(lh0 - l0, 0), s, t, rb, ag);
-            if (__any(w8 > 0)) {
+            if (wave_any(w8 > 0)) {
                 uint32_t rb1, ag1;
                 fetch_pot(te, off1, (uint32_t)max(lw0 - l1, 0), (uint32_t)max(lh0 - l1, 0), s, t, rb1, ag1);
                 const uint32_t wl = weight_pk8((uint32_t)w8), il = 0x01000100u - wl;
@@ -212,7 +236,7 @@ __device__ inline RGB shade_lane(const float4 *sr, const TexEnv &te, float x, fl
             const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4);
             int c0[3];
             fetch_level(te, desc, l0, s, t, c0);
-            if (__any(w8 > 0)) {
+            if (wave_any(w8 > 0)) {
                 int c1[3];
                 fetch_level(te, desc, l1, s, t, c1);
 #pragma unroll
@@ -329,7 +353,7 @@ __device__ inline bool batch_partial(const QCtx &cx, uint32_t ids, int n, int px
             z16 = sel_mask(in_m[0], depth16_s<S>(a2.z, a2.w, a3.x, fx, fy, 0), z16);
         }
     }
-    const bool qc = __any(cont) ? quad_any(cont) : false;
+    const bool qc = wave_any(cont) ? quad_any(cont) : false;
     store_pixel<S>(cx, q, z16, px, py, on && !qc);
     return qc;
 }
@@ -378,7 +402,7 @@ __device__ inline void batch_exact(const QCtx &cx, int kmax, Tri tri, RecOf recp
 #pragma unroll
         for (int s = 0; s < S; ++s) wins |= pid[s] == (uint32_t)p;
         wins &= valid;
-        if (!__any(wins)) continue;
+        if (!wave_any(wins)) continue;
         // (a quad shades a triangle where any of its pixels holds one of its samples; the other lanes' colour goes nowhere)
         const float4 *rec = recp(valid ? p : 0);
         const RGB c = shade_lane(rec + QRec<S>::SH, cx.te, fx + 0.5f, fy + 0.5f);
@@ -413,11 +437,12 @@ __device__ inline void rasterq_body(
     uint16_t *s_queue = reinterpret_cast<uint16_t *>(smem + pl.queue);
     uint16_t *s_xq = reinterpret_cast<uint16_t *>(smem + pl.xq);
     uint32_t *s_tcnt = reinterpret_cast<uint32_t *>(smem + pl.tcnt);
+    uint32_t *s_tfull = reinterpret_cast<uint32_t *>(smem + pl.tfull);
     uint8_t *s_tlist = smem + pl.tlist;
     uint32_t *s_tmask = reinterpret_cast<uint32_t *>(smem + pl.tmask);
-    uint16_t *s_pe = reinterpret_cast<uint16_t *>(smem + pl.pe);
+    uint32_t *s_pe = reinterpret_cast<uint32_t *>(smem + pl.pe);
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + pl.misc);     // [0..8] class counts, [16] partial events, [17] next batch, [18] exact list, [19] next exact batch
-    uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_frame);            // (the frame is not written before phase D)
+    uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_frame);            // phase C only (the partial events are done with, the frame is not written before phase D)
     uint16_t *s_btab = reinterpret_cast<uint16_t *>(smem + pl.btab);
     const int QW = W / 2, QH = H / 2, nquads = QW * QH;
     // x / d for x < 2^16 as a multiply (the divisors are launch constants)
@@ -446,7 +471,7 @@ __device__ inline void rasterq_body(
         float4 v;
         if (q < 4) v = reinterpret_cast<const float4 *>(g_rr + (size_t)p * MW_RASTER_REC)[q];
         else if (q < R::SH) { const int k = (q - 4) / R::TQ, j = (q - 4) % R::TQ; v = reinterpret_cast<const float4 *>(g_rr + (size_t)p * MW_RASTER_REC)[4 + 4 * k + j]; }
-        else if (q < R::TMIN) {
+        else if (q < R::CT) {
             const int j = q - R::SH;
             v = g_shade[(size_t)p * (MW_SHADE_REC / 4) + j];
             if (with_tex && j >= 1 && j <= 4) {
@@ -459,13 +484,30 @@ __device__ inline void rasterq_body(
                 } else if (j == 4) v.w = __uint_as_float(tex >= 0 ? ((uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4) + 4u) * 4u : 0u);
                 else v.w = j == 2 ? (float)w0 : (float)h0;
             }
-        } else v = g_cull[(size_t)p * (MW_CULL_REC / 4) + 3];
+        } else {
+            const float4 *rr = reinterpret_cast<const float4 *>(g_rr + (size_t)p * MW_RASTER_REC);
+            const float4 r0 = rr[0], r1 = rr[1], r3 = rr[3], tm = g_cull[(size_t)p * (MW_CULL_REC / 4) + 3];
+            const int A[3] = {__float_as_int(r0.x), __float_as_int(r0.y), __float_as_int(r0.z)}, B[3] = {__float_as_int(r0.w), __float_as_int(r1.x), __float_as_int(r1.y)};
+            const int tmx[3] = {__float_as_int(r3.y), __float_as_int(r3.z), __float_as_int(r3.w)}, tmn[3] = {__float_as_int(tm.x), __float_as_int(tm.y), __float_as_int(tm.z)};
+            int c[12];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int ap = max(A[k], 0), an = min(A[k], 0), bp = max(B[k], 0), bn = min(B[k], 0);
+                c[k] = tmn[k] - ap * (MW_TILE_W - 1) - bp * (MW_TILE_H - 1);
+                c[3 + k] = tmx[k] - an * (MW_TILE_W - 1) - bn * (MW_TILE_H - 1);
+                c[6 + k] = tmn[k] - ap - bp;
+                c[9 + k] = tmx[k] - an - bn;
+            }
+            const int j = q - R::CT;
+            v = make_float4(__int_as_float(j == 0 ? c[0] : (j == 1 ? c[4] : c[8])), __int_as_float(j == 0 ? c[1] : (j == 1 ? c[5] : c[9])),
+                            __int_as_float(j == 0 ? c[2] : (j == 1 ? c[6] : c[10])), __int_as_float(j == 0 ? c[3] : (j == 1 ? c[7] : c[11])));
+        }
         *dst = v;
     };
 
     // ---- envs with more triangles than the LDS records hold ---------------------------------------------------------------
-    if (nvis > MWQ_CAP) {
-        if constexpr (S == 8) {
+    if (nvis > q_cap(has_depth)) {
+        if constexpr (S == 8 && MWQ_TILE_FALLBACK) {
             // the tile code of mw_raster.hip, records read in place; every wavefront takes every MWQ_WAVES-th tile
             TileCtx tc;
             tc.s_shade = g_shade; tc.s_cull = g_cull; tc.shade_stride = MW_SHADE_REC / 4; tc.cull_stride = MW_CULL_REC / 4;
@@ -509,7 +551,8 @@ __device__ inline void rasterq_body(
         // ---- 0: records -> LDS -------------------------------------------------------------------------------------------
         // (the texture's level-0 geometry follows during phase A: a dependent load that need not hold the copy up)
         for (int i = tid; i < nvis * R::NQ; i += MWQ_THREADS) { const int p = i / R::NQ, q = i - p * R::NQ; stage_quad(p, q, s_rec + i, false); }
-        for (int i = tid; i < n_tiles; i += MWQ_THREADS) s_tcnt[i] = 0u;
+        for (int i = tid; i < n_tiles; i += MWQ_THREADS) { s_tcnt[i] = 0u; s_tfull[i] = 0u; }
+        for (int i = tid; i < nquads; i += MWQ_THREADS) s_qids[i] = 0u;
         if (tid < 64) s_misc[tid] = 0u;
         __syncthreads();
         stamp(1);
@@ -526,17 +569,19 @@ __device__ inline void rasterq_body(
         for (int i = tid; i < n_tiles * nvis; i += MWQ_THREADS) {
             const int t = (int)__umulhi((uint32_t)i, m_nvis), p = i - t * nvis;
             const int ty = (int)__umulhi((uint32_t)t, m_tx), tx = t - ty * tiles_x;
-            const int pxlo = tx * MW_TILE_W, pxhi = pxlo + MW_TILE_W - 1;
-            const int gyhi = H - 1 - ty * MW_TILE_H, gylo = gyhi - (MW_TILE_H - 1);
             bool touch, full;
-            classify_rec<S>(s_rec + p * R::NQ, pxlo, pxhi, gylo, gyhi, touch, full);
+            classify_tile<S>(s_rec + p * R::NQ, tx * MW_TILE_W, H - MW_TILE_H - ty * MW_TILE_H, touch, full);
             if (touch) {
                 const uint32_t slot = atomicAdd(&s_tcnt[t], 1u);
                 if (slot < MWQ_SLOTS) {
                     const uint32_t e = (uint32_t)t * MWQ_SLOTS + slot;
                     s_tlist[e] = (uint8_t)p;
                     if (full) s_tmask[e] = 0xFFFFFFFFu;
-                    else s_pe[atomicAdd(&s_misc[16], 1u)] = (uint16_t)e;
+                    else s_pe[atomicAdd(&s_misc[16], 1u)] = e | ((uint32_t)p << 16);
+                }
+                if (full) {
+                    const uint32_t f = atomicAdd(&s_tfull[t], 1u) & 255u;
+                    if (f < 3u) atomicOr(&s_tfull[t], (uint32_t)p << (8u + 8u * f));
                 }
             }
         }
@@ -558,12 +603,19 @@ __device__ inline void rasterq_body(
             bool touch = false, full = false;
             uint32_t e = 0u;
             if (j < npe) {
-                e = s_pe[j];
-                const int t = (int)(e / MWQ_SLOTS), p = s_tlist[e];
+                const uint32_t ep = s_pe[j];
+                e = ep & 0xFFFFu;
+                const int t = (int)(e / MWQ_SLOTS), p = (int)(ep >> 16);
                 const int ty = (int)__umulhi((uint32_t)t, m_tx), tx = t - ty * tiles_x;
-                const int pxlo = tx * MW_TILE_W + (qi & 7) * 2, py0 = ty * MW_TILE_H + (qi >> 3) * 2;
-                const int gyhi = H - 1 - py0;
-                classify_rec<S>(s_rec + p * R::NQ, pxlo, pxlo + 1, gyhi - 1, gyhi, touch, full);
+                const int qx = tx * 8 + (qi & 7), qy = ty * 2 + (qi >> 3);
+                classify_quad<S>(s_rec + p * R::NQ, qx * 2, H - 2 - qy * 2, touch, full);
+                if (touch) {
+                    // the quad's own list: a place by the counter in bits 24-30, the id into it (four 6-bit places), bit 31 = covered by some triangle
+                    uint32_t *qd = s_qids + qy * QW + qx;
+                    const uint32_t slot = (atomicAdd(qd, 1u << 24) >> 24) & 127u;
+                    const uint32_t v = (full ? 0x80000000u : 0u) | (slot < 4u ? (uint32_t)p << (6u * slot) : 0u);
+                    if (v) atomicOr(qd, v);
+                }
             }
             const uint64_t tm = __ballot(touch), fm = __ballot(full);
             const int sh = lane & 48;
@@ -575,29 +627,23 @@ __device__ inline void rasterq_body(
         // ---- C1: every quad collects its triangles and takes a class --------------------------------------------------------
         for (int Q = tid; Q < nquads; Q += MWQ_THREADS) {
             const int qy = (int)__umulhi((uint32_t)Q, m_qw), qx = Q - qy * QW;
-            const int tx = qx >> 3, ty = qy >> 1, t = ty * tiles_x + tx, bit = ((qy & 1) << 3) | (qx & 7);
-            const uint32_t cnt = s_tcnt[t];
-            uint32_t ids = 0u, n = 0u;
-            bool anyfull = false;
+            const int tx = qx >> 3, ty = qy >> 1, t = ty * tiles_x + tx;
+            const uint32_t v = s_qids[Q], tf = s_tfull[t];
+            const uint32_t np = (v >> 24) & 127u, nf = tf & 255u, n = np + nf;
+            const bool anyfull = (v >> 31) != 0u || nf != 0u;
+            uint32_t ids = v & 0xFFFFFFu;
+#pragma unroll
+            for (uint32_t j = 0; j < 3u; ++j)
+                if (j < nf && np + j < 4u) ids |= ((tf >> (8u + 8u * j)) & 63u) << (6u * (np + j));
+            ids |= (0xFFFFFFu << (6u * min(n, 4u))) & 0xFFFFFFu;          // the places behind the list: MWQ_EMPTY
             int cls;
             if (mesh_env && tile_in_mesh_rect(hdr, tx, ty)) cls = QC_NONE;
-            else if (cnt > MWQ_SLOTS || force_fallback) cls = QC_FALLBACK;
-            else {
-                for (uint32_t k = 0; k < cnt; ++k) {
-                    const uint32_t m = s_tmask[t * MWQ_SLOTS + k];
-                    if ((m >> bit) & 1u) {
-                        if (n < 4u) ids |= (uint32_t)s_tlist[t * MWQ_SLOTS + k] << (6u * n);
-                        ++n;
-                        anyfull |= ((m >> (16 + bit)) & 1u) != 0u;
-                    }
-                }
-                for (uint32_t k = n; k < 4u; ++k) ids |= MWQ_EMPTY << (6u * k);
-                if (n == 0u) cls = QC_SKY;
-                else if (n == 1u && anyfull && !(dbg & 4)) cls = QC_TRIV;
-                else if (n > 4u) cls = QC_BIG;
-                else if ((n >= 2u && anyfull) || (dbg & 4)) cls = QC_EXACT;
-                else cls = QC_P1 + 1 - (int)n;
-            }
+            else if (s_tcnt[t] > MWQ_SLOTS || force_fallback) cls = QC_FALLBACK;
+            else if (n == 0u) cls = QC_SKY;
+            else if (n == 1u && anyfull && !(dbg & 4)) cls = QC_TRIV;
+            else if (n > 4u || nf > 3u) cls = QC_BIG;
+            else if ((n >= 2u && anyfull) || (dbg & 4)) cls = QC_EXACT;
+            else cls = QC_P1 + 1 - (int)n;
             s_qids[Q] = ids | ((uint32_t)cls << 24);
             // place within the class: one LDS atomic per wavefront for the class nearly every quad is in, one per lane otherwise
             const uint64_t tm = __ballot(cls == QC_TRIV);
