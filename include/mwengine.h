@@ -351,6 +351,20 @@ int mw_check(mw_engine *e, void *stream);
  * `launches` is the number of launches measured.  Returns <0 on error. */
 int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *setup_ms, int64_t *launches);
 
+/* Which raster kernels drew the last frame (the FrameBuffer half of render_obs, opengl.py:202-398) — so that a test can say
+ * which code its fixtures exercised: MW_PATH_QUAD the quad kernel (mw_rasterq.hip: small scenes, 8 or 4 samples),
+ * MW_PATH_QUAD_MESH the same for every tile no mesh entity can touch + the mesh-aware tile kernel for the others,
+ * MW_PATH_TILE the tile kernels (mw_raster.hip: big scenes, MW_K2Q=0), MW_PATH_GENERIC the generic-resolution kernels
+ * (other sample counts, frames beyond 128 x 128, MW_GENERIC_RASTER=1); -1 before the first frame. */
+/* The `info` dict of the envs' step() as device arrays, asynchronous on `stream` (either pointer may be NULL):
+ *   d_health  int32[N]     CollectHealth: info["health"] (collecthealth.py:100)
+ *   d_ent_pos double[N][3] position of entity slot `ent_slot`: TMaze / YMaze info["goal_pos"] = box.pos (tmaze.py:89, ymaze.py:125)
+ * Values are those of the state the device holds: with MW_AUTORESET_SAME_STEP an env that just finished reports its new episode. */
+int mw_get_info(mw_engine *e, int32_t *d_health, double *d_ent_pos, int32_t ent_slot, void *stream);
+
+enum { MW_PATH_TILE = 0, MW_PATH_QUAD = 1, MW_PATH_QUAD_MESH = 2, MW_PATH_GENERIC = 3 };
+int mw_raster_path(const mw_engine *e);
+
 #ifdef __cplusplus
 }
 #endif

@@ -79,6 +79,16 @@ extern "C" __global__ void mw_visible_kernel(int env_base, int W, int H, int S, 
 
 #define MW_TIMING_STRIDE 8
 
+// mw_get_info: what the envs' step() returns in `info` beside the observation (collecthealth.py:100, tmaze.py:89, ymaze.py:125)
+extern "C" __global__ void mw_info_kernel(int N, int E, const int32_t *health, const double *epos, int slot, int32_t *out_health, double *out_pos)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    if (out_health) out_health[i] = health[i];
+    if (out_pos)
+        for (int c = 0; c < 3; ++c) out_pos[(size_t)i * 3 + c] = epos[((size_t)c * E + slot) * N + i];
+}
+
 namespace {
 thread_local std::string g_create_error;
 }
@@ -141,6 +151,7 @@ struct mw_engine {
     MwProgram *d_prog = nullptr;        // placement program (mw_set_gen_program)
     int texel_bytes = 4;
     int dbg_flags = 0;       // MW_DEBUG_FLAGS: perf experiments only (bit0: flat shading)
+    int last_raster_path = -1;  // mw_raster_path
     // A/B switches, read once by mw_create (the launch path never touches the environment)
     bool use_k2q = true;        // MW_K2Q=0: the tile kernels of mw_raster.hip for small scenes too
     bool k2q_ok = false;        // the frame fits the quad kernel's LDS plan
@@ -546,6 +557,53 @@ int ensure_mesh_stream(mw_engine *e)
     return MW_OK;
 }
 
+// Everything a frame with mesh entities needs beyond the triangle records — the plane cache (one record per mesh triangle that
+// can be in view: the geometry kernel admits 0xC000 per env), the sample keys of the tiles a mesh can touch, the slow-path
+// lists, the mesh stream; for the generic-resolution path the view keys.  Called by mw_upload_mesh (a synchronous entry point):
+// a frame never allocates, never synchronises.  Failure-atomic: either every buffer of a group is there or none.
+int ensure_mesh_buffers(mw_engine *e)
+{
+    const MwArgs &a = e->args;
+    const size_t N = (size_t)e->cfg.num_envs;
+    if (ensure_mesh_stream(e) != MW_OK) return MW_E_HIP;
+    if (e->cfg.msaa != 8 || a.W > 128 || a.H > 128) {       // the generic-resolution path
+        const size_t need = N * a.W * a.H * e->cfg.msaa * 4;
+        if (need > e->view_keys_bytes) {
+            uint32_t *nk = nullptr;
+            if (hipMalloc((void **)&nk, need) != hipSuccess) return fail(e, MW_E_NOMEM, "hipMalloc(%zu) for the view keys failed", need);
+            (void)hipDeviceSynchronize();
+            if (e->d_view_keys) (void)hipFree(e->d_view_keys);
+            e->d_view_keys = nk; e->view_keys_bytes = need;
+        }
+        return MW_OK;
+    }
+    if (a.W > 255 * MW_TILE_W || a.H > 255 * MW_TILE_H) return fail(e, MW_E_CAPACITY, "frame too large for the mesh tile rectangles");
+    const long long want = std::min<long long>(0xC000, (long long)e->cfg.max_ents * e->max_mesh_tris);
+    if ((int)want > e->plane_cap) {
+        float *np = nullptr;
+        if (hipMalloc((void **)&np, N * (size_t)want * MW_PLANE_REC * 4) != hipSuccess) return fail(e, MW_E_NOMEM, "hipMalloc for the plane cache (%lld records per env) failed", want);
+        (void)hipDeviceSynchronize();
+        if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
+        e->d_plane_cache = np; e->plane_cap = (int)want;
+    }
+    if (!e->d_mesh_keys) {
+        const size_t key_bytes = N * a.W * a.H * 8 * 4, head_bytes = N * a.W * a.H * 4;
+        void *keys = nullptr, *cnt = nullptr, *tris = nullptr, *frags = nullptr, *head = nullptr;
+        // triangles that cross a frustum plane and their fragments (mw_mesh_slow_kernel): counts, 1024 / 2048 entries per env
+        const bool ok = hipMalloc(&keys, key_bytes) == hipSuccess && hipMalloc(&cnt, N * 4 * 4) == hipSuccess && hipMalloc(&tris, N * MW_SLOW_TRIS * 4) == hipSuccess &&
+                        hipMalloc(&frags, N * MW_SLOW_STRIDE * 16) == hipSuccess && hipMalloc(&head, head_bytes) == hipSuccess &&
+                        hipMemset(cnt, 0, N * 4 * 4) == hipSuccess && hipMemset(head, 0, head_bytes) == hipSuccess && hipMemset(keys, 0xFF, key_bytes) == hipSuccess;
+        if (!ok) {
+            for (void *p : {keys, cnt, tris, frags, head}) if (p) (void)hipFree(p);
+            return fail(e, MW_E_NOMEM, "hipMalloc for the mesh path's buffers failed");
+        }
+        e->d_mesh_keys = (uint32_t *)keys; e->d_slow_count = (int32_t *)cnt; e->d_slow_tris = (uint32_t *)tris;
+        e->d_slow_frags = (float4 *)frags; e->d_slow_head = (uint32_t *)head;
+        e->mesh_keys_dirty = false;
+    }
+    return MW_OK;
+}
+
 int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_actions, uint8_t *d_obs, float *d_depth,
                  float *d_reward, uint8_t *d_term, uint8_t *d_trunc, hipStream_t st)
 {
@@ -618,6 +676,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     };
     if (k2q && e->cfg.msaa == 4) {
         launch_k2q(0);
+        e->last_raster_path = MW_PATH_QUAD;
     } else if (e->cfg.msaa != 8 || a.W > 128 || a.H > 128) {
         // FrameBuffer's fallback sample counts (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES gets 4 or 1
         // samples) and observations beyond 128 x 128 (the tile kernels' 24-bit edge arithmetic): not the hot path — the
@@ -627,17 +686,12 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         uint32_t *keys = nullptr;
         if (e->have_meshes) {
             const size_t need = (size_t)N * a.W * a.H * S * 4;
-            if (need > e->view_keys_bytes) {
-                HIP_TRY(e, hipStreamSynchronize(st));
-                if (e->d_view_keys) (void)hipFree(e->d_view_keys);
-                e->d_view_keys = nullptr; e->view_keys_bytes = 0;
-                HIP_TRY(e, hipMalloc((void **)&e->d_view_keys, need));
-                e->view_keys_bytes = need;
-            }
+            if (need > e->view_keys_bytes) return fail(e, MW_E_INVALID, "view keys missing (mw_upload_mesh allocates them)");
             keys = e->d_view_keys;
             HIP_TRY(e, hipMemsetAsync(keys, 0xFF, need, st));
             hipLaunchKernelGGL(mw_view_mesh_kernel, dim3(32, N), dim3(256), 0, st, a.W, a.H, S, 0, (const float *)a.envhdr, a.mesh_pos, keys);
         }
+        e->last_raster_path = MW_PATH_GENERIC;
         hipLaunchKernelGGL(mw_view_raster_kernel, dim3(a.n_tiles, N), dim3(64), 0, st, 0, a.W, a.H, S, a.max_vis, a.tiles_x,
                            (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull, (const int32_t *)a.nvis, (const float *)a.envhdr,
                            a.tex, a.texels, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, (const uint32_t *)keys, d_obs, d_depth, e->texel_bytes);
@@ -645,34 +699,14 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const bool mesh = e->have_meshes;
         uint32_t mesh_stamp = 0u;
         if (mesh) {
-            if (a.W > 255 * MW_TILE_W || a.H > 255 * MW_TILE_H) return fail(e, MW_E_CAPACITY, "frame too large for the mesh tile rectangles");
-            // the plane cache: one record per mesh triangle that can be in view (the geometry kernel admits 0xC000 per env);
-            // the sample keys of the tiles a mesh can touch: all-ones between frames (K2 clears what it reads)
-            const long long want = std::min<long long>(0xC000, (long long)e->cfg.max_ents * e->max_mesh_tris);
+            // (plane cache, sample keys — all-ones between frames, K2 clears what it reads —, slow-path lists, mesh stream:
+            // ensure_mesh_buffers, at upload time)
+            if (!e->d_mesh_keys || !e->d_plane_cache || !e->mesh_stream) return fail(e, MW_E_INVALID, "mesh buffers missing (mw_upload_mesh allocates them)");
             const size_t key_bytes = (size_t)N * a.W * a.H * 8 * 4;
-            if ((int)want > e->plane_cap || !e->d_mesh_keys) {
-                HIP_TRY(e, hipStreamSynchronize(st));
-                if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
-                e->d_plane_cache = nullptr; e->plane_cap = 0;
-                HIP_TRY(e, hipMalloc((void **)&e->d_plane_cache, (size_t)N * (size_t)want * 20 * 4));
-                e->plane_cap = (int)want;
-                if (!e->d_mesh_keys) {
-                    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_keys, key_bytes));
-                    // triangles that cross a frustum plane and their fragments (mw_mesh_slow_kernel): counts, 1024 / 2048 entries per env
-                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_count, (size_t)N * 4 * 4));
-                    HIP_TRY(e, hipMemset(e->d_slow_count, 0, (size_t)N * 4 * 4));
-                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_tris, (size_t)N * MW_SLOW_TRIS * 4));
-                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_frags, (size_t)N * MW_SLOW_STRIDE * 16));
-                    HIP_TRY(e, hipMalloc((void **)&e->d_slow_head, (size_t)N * a.W * a.H * 4));
-                    HIP_TRY(e, hipMemset(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4));
-                }
-                e->mesh_keys_dirty = true;
-            }
             if (e->mesh_keys_dirty) HIP_TRY(e, hipMemsetAsync(e->d_mesh_keys, 0xFF, key_bytes, st));
             e->mesh_keys_dirty = true;      // until the raster kernel that clears them again has been enqueued
             // The mesh kernels run on the side stream, beside the first part of K2 (every tile no mesh can touch); the
             // tiles inside the meshes' rectangles follow behind both (part 2).
-            if (ensure_mesh_stream(e) != MW_OK) return MW_E_HIP;
             // frame stamp of the slow-fragment chains (16 bits; the heads are wiped when it wraps) and parity of the lists
             const uint32_t seq = e->mesh_frame_seq++;
             mesh_stamp = seq & 0xFFFFu;
@@ -727,6 +761,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                                (const uint16_t *)a.rec_order, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, e->d_mesh_keys,
                                (const float *)e->d_plane_cache, e->plane_cap, (const float4 *)e->d_slow_frags, (const uint32_t *)e->d_slow_head);
         };
+        e->last_raster_path = k2q ? (mesh ? MW_PATH_QUAD_MESH : MW_PATH_QUAD) : MW_PATH_TILE;
         if (mesh) {
             if (k2q) launch_k2q(1 << 4); else launch_k2(1 << 4);
             HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
@@ -1061,7 +1096,7 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
     if (e->d_gen_live && sync_gen_args(e) != MW_OK) return MW_E_HIP;
     e->have_meshes = true;
     e->max_mesh_tris = std::max(e->max_mesh_tris, (int)ntris);
-    return MW_OK;
+    return ensure_mesh_buffers(e);
 }
 
 int mw_set_geometry(mw_engine *e, int32_t env, const mw_poly *polys, int32_t n_polys, const double *segs, int32_t n_segs)
@@ -1339,6 +1374,21 @@ int mw_check(mw_engine *e, void *stream)
     HIP_TRY(e, hipMemcpy(&st, e->args.status, 4, hipMemcpyDeviceToHost));
     if (st & MW_ST_VIS_OVERFLOW) return fail(e, MW_E_OVERFLOW, "more than max_visible=%d visible primitives in some env", e->cfg.max_visible);
     if (st & MW_ST_PLACEMENT_FAIL) return fail(e, MW_E_OVERFLOW, "device-side placement did not converge in some env");
+    return MW_OK;
+}
+
+int mw_raster_path(const mw_engine *e) { return e ? e->last_raster_path : MW_E_INVALID; }
+
+int mw_get_info(mw_engine *e, int32_t *d_health, double *d_ent_pos, int32_t ent_slot, void *stream)
+{
+    if (!e) return MW_E_INVALID;
+    if (!d_health && !d_ent_pos) return fail(e, MW_E_INVALID, "mw_get_info: nothing asked for");
+    if (d_ent_pos && (ent_slot < 0 || ent_slot >= e->args.E)) return fail(e, MW_E_INVALID, "mw_get_info: entity slot %d out of range", ent_slot);
+    ON_DEVICE(e);
+    const int N = e->cfg.num_envs;
+    hipLaunchKernelGGL(mw_info_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, e->args.E, (const int32_t *)e->args.health,
+                       (const double *)e->args.epos, d_ent_pos ? ent_slot : 0, d_health, d_ent_pos);
+    HIP_TRY(e, hipGetLastError());
     return MW_OK;
 }
 

@@ -989,7 +989,9 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         // triangles near to far and stops at the first one that lies behind everything the tile holds by then
         uint16_t *order = a.rec_order + (size_t)env * (a.max_vis + 1);
         const int n = count;
-        if (n > MW_ORDER_CAP || !live) {
+        // (a list that overflowed its capacity has no order either: the records behind max_vis were never written, their keys
+        // never set, and the order array holds max_vis entries — mw_check reports the overflow, the frame stays in bounds)
+        if (n > MW_ORDER_CAP || n > a.max_vis || !live) {
             if (lane == 0 && live) order[0] = 0;
         } else {
             __syncthreads();

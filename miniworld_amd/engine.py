@@ -28,11 +28,12 @@ PROG_MAX_ROOMS, PROG_MAX_TEX, PROG_MAX_OPS, PROG_MAX_ENTS = 16, 8, 48, 64
 AUTORESET_OFF, AUTORESET_SAME_STEP = 0, 1
 OBS_HWC_U8, OBS_CWH_U8, OBS_GREY_F64 = 0, 1, 2
 RNG_PHILOX, RNG_PCG64 = 0, 1
+PATH_TILE, PATH_QUAD, PATH_QUAD_MESH, PATH_GENERIC = 0, 1, 2, 3
 
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms",
+    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms", "mw_raster_path", "mw_get_info",
     "mw_set_gen_program", "mw_selftest_rcp", "mw_selftest_div", "mw_selftest_sort", "mw_selftest_q",
 ]
 
@@ -184,6 +185,8 @@ def load_library():
     L.mw_pcg64_draws.argtypes = [C.c_uint64, i32, vp, vp]
     L.mw_check.argtypes = [vp, vp]
     L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    L.mw_raster_path.argtypes = [vp]
+    L.mw_get_info.argtypes = [vp, vp, vp, i32, vp]
     _lib = L
     return L
 
@@ -381,6 +384,20 @@ class Engine:
 
     def check(self):
         self._check(self.lib.mw_check(self.h, _stream_ptr(self.device)), "mw_check")
+
+    def get_info(self, health=None, ent_pos=None, ent_slot=0):
+        """Fills the caller's device tensors: health int32[N] (CollectHealth's info["health"]) and / or ent_pos float64[N, 3]
+        (position of entity slot ent_slot: TMaze / YMaze info["goal_pos"])."""
+        import torch
+        for t, dt, shape in ((health, torch.int32, (self.N,)), (ent_pos, torch.float64, (self.N, 3))):
+            if t is not None:
+                assert t.is_cuda and t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous()
+        self._check(self.lib.mw_get_info(self.h, health.data_ptr() if health is not None else None,
+                                         ent_pos.data_ptr() if ent_pos is not None else None, int(ent_slot), _stream_ptr(self.device)), "mw_get_info")
+
+    def raster_path(self):
+        """Which raster kernels drew the last frame: PATH_TILE / PATH_QUAD / PATH_QUAD_MESH / PATH_GENERIC (mwengine.h)."""
+        return int(self.lib.mw_raster_path(self.h))
 
     def kernel_time_ms(self, reset=0):
         """(raster ms, setup ms, launches measured) since the last call; reset = k > 0: time one launch in k from now

@@ -210,6 +210,11 @@ class MiniWorldVecEnv:
         self.truncated = torch.zeros(num_envs, dtype=torch.uint8, device=dev)
         self._host_envs = None
         self._next_seed = seed
+        # what the env's step() reports in `info` beside the observation (collecthealth.py:100, tmaze.py:89, ymaze.py:125)
+        self._info_kind = {"CollectHealth": "health", "TMaze": "goal_pos", "TMazeLeft": "goal_pos", "TMazeRight": "goal_pos",
+                           "YMaze": "goal_pos", "YMazeLeft": "goal_pos", "YMazeRight": "goal_pos"}.get(cls_name)
+        self._info_slot = int(cfg.goal_ent)
+        self._info_buf = None
 
     # ------------------------------------------------------------------ assets / worlds
     def _upload_assets(self, sc):
@@ -271,6 +276,24 @@ class MiniWorldVecEnv:
         """actions: integer torch tensor [N] (converted to contiguous int32 on the engine's device if needed)."""
         self.engine.step(actions, self.obs, self.depth, self.reward, self.terminated, self.truncated)
         return self.obs, self.reward, self.terminated, self.truncated
+
+    def infos(self):
+        """The batched `info` of the last step as device tensors: {"health": int32[N]} for CollectHealth (collecthealth.py:100),
+        {"goal_pos": float64[N, 3]} for TMaze / YMaze (the box's position, tmaze.py:89, ymaze.py:125), {} for the other envs
+        (miniworld.py:730 returns an empty dict).  One small gather kernel on the engine's stream; the values are those of the
+        state the device holds (with the same-step auto-reset an env that just finished reports its new episode)."""
+        if self._info_kind is None:
+            return {}
+        torch = self.torch
+        if self._info_buf is None:
+            dev = self.engine.device
+            self._info_buf = (torch.zeros(self.num_envs, dtype=torch.int32, device=dev) if self._info_kind == "health"
+                              else torch.zeros((self.num_envs, 3), dtype=torch.float64, device=dev))
+        if self._info_kind == "health":
+            self.engine.get_info(health=self._info_buf)
+        else:
+            self.engine.get_info(ent_pos=self._info_buf, ent_slot=self._info_slot)
+        return {self._info_kind: self._info_buf}
 
     def render_top_view(self, render_agent=True):
         """uint8[N,H,W,3] map views (render_top_view, miniworld.py:1088-1175) of every env."""

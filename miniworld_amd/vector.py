@@ -36,6 +36,10 @@ class MiniWorldVectorEnv:
     def _out(self, t):
         return t.cpu().numpy() if self.to_numpy else t
 
+    def _infos(self):
+        """gymnasium's batched info convention: one array per key (health / goal_pos: MiniWorldVecEnv.infos)."""
+        return {k: self._out(v) for k, v in self.vec.infos().items()}
+
     def reset(self, *, seed: int | None = None, options: dict | None = None):
         """Env i is seeded with seed + i (gymnasium's convention for an integer seed)."""
         obs = self.vec.reset(seed)
@@ -47,7 +51,7 @@ class MiniWorldVectorEnv:
             actions = torch.as_tensor(np.asarray(actions), device=self.vec.engine.device)
         actions = actions.to(device=self.vec.engine.device, dtype=torch.int32)
         obs, rew, term, trunc = self.vec.step(actions)
-        return self._out(obs), self._out(rew), self._out(term.bool()), self._out(trunc.bool()), {}
+        return self._out(obs), self._out(rew), self._out(term.bool()), self._out(trunc.bool()), self._infos()
 
     def render(self):
         """Tuple-free batched render: the map view of every env (uint8[N, H, W, 3])."""

@@ -16,7 +16,7 @@ def pytest_configure(config):
 
 
 def golden_cases():
-    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("meshes.npz", "screenshots.npz") and not f.startswith("gl_"))
+    return sorted(f[:-4] for f in os.listdir(GOLDEN) if f.endswith(".npz") and f not in ("meshes.npz", "screenshots.npz") and not f.startswith(("gl_", "gl1_")))
 
 
 @pytest.fixture(scope="session")

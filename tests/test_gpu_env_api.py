@@ -593,6 +593,49 @@ def test_vector_env_adapter_follows_gymnasium_convention():
     envs.close()
 
 
+def test_batched_info_matches_the_host_classes():
+    """The batched API's `info` (MiniWorldVecEnv.infos / the VectorEnv adapter's fifth value) against the env classes' own
+    step(): info["goal_pos"] of TMaze / YMaze (tmaze.py:89, ymaze.py:125) and info["health"] of CollectHealth
+    (collecthealth.py:100), env i of a batch seeded with s being env.reset(seed=s + i)."""
+    from miniworld_amd import envs as host_envs
+    from miniworld_amd.vector import MiniWorldVectorEnv
+    for env_id, cls in (("MiniWorld-TMaze-v0", "TMaze"), ("MiniWorld-YMazeLeft-v0", "YMazeLeft")):
+        envs = MiniWorldVectorEnv(env_id, 6, to_numpy=True, seed=40, autoreset=False)
+        envs.reset(seed=40)
+        _, _, _, _, infos = envs.step(np.zeros(6, np.int64))
+        assert set(infos) == {"goal_pos"} and infos["goal_pos"].shape == (6, 3) and infos["goal_pos"].dtype == np.float64
+        for i in range(6):
+            h = getattr(host_envs, cls)()
+            h.reset(seed=40 + i)
+            _, _, _, _, hi = h.step(0)
+            h.close()
+            assert np.array_equal(infos["goal_pos"][i], np.asarray(hi["goal_pos"], np.float64)), (env_id, i)
+        envs.close()
+    envs = MiniWorldVectorEnv("MiniWorld-CollectHealth-v0", 5, to_numpy=True, seed=7, autoreset=False)
+    envs.reset(seed=7)
+    hosts = []
+    for i in range(5):
+        h = host_envs.CollectHealth()
+        h.reset(seed=7 + i)
+        hosts.append(h)
+    rng = np.random.default_rng(5)
+    for t in range(12):
+        a = rng.integers(0, 3, 5)
+        _, _, term, _, infos = envs.step(a)
+        assert set(infos) == {"health"} and infos["health"].dtype == np.int32
+        for i, h in enumerate(hosts):
+            _, _, hterm, _, hi = h.step(int(a[i]))
+            assert int(infos["health"][i]) == int(hi["health"]) and bool(term[i]) == bool(hterm), (t, i)
+    envs.close()
+    for h in hosts:
+        h.close()
+    # every other env: an empty dict, like miniworld.py:730
+    envs = MiniWorldVectorEnv("MiniWorld-Hallway-v0", 2, seed=0)
+    envs.reset(seed=0)
+    assert envs.step(np.zeros(2, np.int64))[4] == {}
+    envs.close()
+
+
 def _assert_same_world(vec, st, i, h, tag):
     """Device state of env i == host env h (same seed, same episode): poses, entity table, per-episode parameters."""
     from miniworld_amd.entity import Box, MeshEnt
@@ -799,6 +842,77 @@ def test_capacity_overflow_is_reported_not_silent():
     with pytest.raises(eng.EngineError, match="max_visible"):
         e.check()
     e.close()
+
+
+def test_capacity_overflow_with_a_visiting_order_stays_in_bounds():
+    """Big scenes (max_visible > 64) keep a near-to-far visiting order of max_vis + 1 entries per env.  A list longer than
+    max_vis (but within the sort's 512 keys) must not be sorted into it: the neighbouring env's order and frame stay what
+    they are, and mw_check reports the overflow.  Scene: a stack of 230 small quads in front of env 0's camera (460
+    triangles + the room's, more than the 390 records of max_visible = 65), env 1 looks the other way."""
+    import pyoracle
+    import torch
+    from miniworld_amd import engine as eng
+    s0, tr, meta, obs = helpers.load_case("hallway_s0")
+    base = helpers.frame_scene(s0, obs[sorted(obs)[0]])
+    d = float(base["agent_dir"])
+    fwd, right = np.array([np.cos(d), 0.0, -np.sin(d)]), np.array([np.sin(d), 0.0, np.cos(d)])
+    eye = np.array(base["agent_pos"], np.float64) + np.array([0.0, float(base["cam_height"]), 0.0])
+    overflowed = False
+    for winding in (1, -1):                                   # one of the two faces the camera
+        sc = {k: np.array(v, copy=True) for k, v in base.items()}
+        n = 230
+        quads = np.zeros((n, 4, 3), np.float32)
+        for j in range(n):
+            c = eye + fwd * (0.6 + 0.0005 * j)
+            corners = [(-1, -1), (1, -1), (1, 1), (-1, 1)][::winding]
+            quads[j] = [c + right * (0.05 * u) + np.array([0.0, 0.05 * v, 0.0]) for u, v in corners]
+        sc["polys_v"] = np.concatenate([base["polys_v"], quads])
+        sc["polys_uv"] = np.concatenate([base["polys_uv"], np.tile(base["polys_uv"][2:3], (n, 1, 1))])
+        sc["polys_n"] = np.concatenate([base["polys_n"], np.tile((-fwd).astype(np.float32), (n, 1))])
+        sc["polys_nv"] = np.concatenate([base["polys_nv"], np.full(n, 4, np.int32)])
+        sc["polys_tex"] = np.concatenate([base["polys_tex"], np.full(n, base["polys_tex"][2], np.int32)])
+        sc["polys_rgb"] = np.concatenate([base["polys_rgb"], np.ones((n, 3), np.float32)])
+        sc["polys_xf"] = np.concatenate([base["polys_xf"], np.tile(base["polys_xf"][2:3], (n, 1))])
+        away = {k: np.array(v, copy=True) for k, v in sc.items()}
+        away["agent_dir"] = np.array(d + np.pi)
+        want = pyoracle.render(away)["rgb"]
+        e = helpers.make_engine_for_scene(sc, 2, max_visible=65)          # 390 records per env, visiting order on
+        e.set_state(helpers.scene_state_arrays([sc, away]))
+        rgb = torch.zeros((2, 60, 80, 3), dtype=torch.uint8, device="cuda")
+        e.render(rgb, None)
+        try:
+            e.check()
+        except eng.EngineError as exc:
+            assert "max_visible" in str(exc)
+            overflowed = True
+        assert np.array_equal(rgb[1].cpu().numpy(), want), "the env beside the overflowing one lost its frame"
+        e.close()
+    assert overflowed, "neither winding of the stack overflowed the 390 records"
+
+
+def test_first_mesh_frame_does_not_synchronise():
+    """include/mwengine.h: "all device work is enqueued on the stream, nothing synchronises unless documented".  The mesh path's
+    buffers (plane cache, sample keys, slow lists) are allocated by mw_upload_mesh, not inside the first frame: with the
+    stream kept busy by unrelated work, the very first mw_step of an engine with mesh entities returns while that work is
+    still running."""
+    import torch
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    vec = MiniWorldVecEnv("MiniWorld-PickupObjects-v0", 64, seed=2)
+    seeds = np.arange(64, dtype=np.uint64) + np.uint64(2)
+    vec.engine.reset(None, seeds)                             # worlds only: no frame has been drawn yet
+    x = torch.randn((8192, 8192), device="cuda")
+    torch.cuda.synchronize()
+    for _ in range(40):                                       # a few hundred milliseconds of matrix products queued ahead
+        y = x @ x
+    busy = torch.cuda.Event()
+    busy.record()
+    act = torch.zeros(64, dtype=torch.int32, device="cuda")
+    vec.step(act)
+    still_running = not busy.query()
+    torch.cuda.synchronize()
+    assert still_running, "the first frame with mesh entities waited for the stream"
+    assert 1.0 < float(vec.obs.float().mean()) < 254.0 and float(y.abs().sum()) > 0
+    vec.close()
 
 
 def test_two_engines_are_independent():

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import helpers
-from test_oracle_vs_reference_gl import gl_cases, load_gl
+from test_oracle_vs_reference_gl import gl1_cases, gl_cases, load_gl
 
 pytestmark = pytest.mark.gpu
 
@@ -27,9 +27,16 @@ def _groups(frames):
     return list(groups.values())
 
 
+@pytest.mark.parametrize("path", ["quad", "generic"])
 @pytest.mark.parametrize("case", gl_cases())
-def test_engine_equals_the_reference_on_opengl(case):
+def test_engine_equals_the_reference_on_opengl(case, path, monkeypatch):
+    """path = "quad": the 80x60 frames go through mw_rasterq.hip's 4-sample instantiation — the code of the hot path
+    (mw_rasterq_kernel, 8 samples) with another sample count — wherever the scene holds no mesh entity; "generic":
+    through the generic-resolution kernel (MW_GENERIC_RASTER=1).  The 800x600 views always take the generic kernel."""
     import torch
+    from miniworld_amd import engine as E
+    if path == "generic":
+        monkeypatch.setenv("MW_GENERIC_RASTER", "1")
     frames = load_gl(case)
     off_by_one = 0
     for ks in _groups(frames):
@@ -40,6 +47,9 @@ def test_engine_equals_the_reference_on_opengl(case):
         rgb = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
         depth = torch.zeros((len(scenes), 60, 80, 1), dtype=torch.float32, device="cuda")
         eng.render(rgb, depth)
+        # (scenes with mesh entities and big scenes — a visiting order, max_visible > 64: the Maze — take the generic kernel at 4 samples)
+        quad = path == "quad" and len(eng._test_mesh_map) == 0 and eng.cfg.max_visible <= 64
+        assert eng.raster_path() == (E.PATH_QUAD if quad else E.PATH_GENERIC), (case, path, eng.raster_path())
         top = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
         eng.render_top(top, None, True)
         vis = eng.visible_ents()
@@ -66,3 +76,32 @@ def test_engine_equals_the_reference_on_opengl(case):
                     assert np.count_nonzero(vdiff) <= 2, f"{case} frame {k} {view} view: {np.count_nonzero(vdiff)} values off by one"
         eng.close()
     assert off_by_one == 0, f"{case}: {off_by_one} channel values off by one"
+
+
+@pytest.mark.parametrize("case", gl1_cases())
+def test_engine_equals_the_reference_single_sampled_fallback(case):
+    """msaa = 1 (mw_config): the frames of the reference's non-multisampled FrameBuffer branch (opengl.py:263-284; fixtures
+    gl1_*.npz, tools/gen_gl_fixtures.py --one-spp), through the C ABI: RGB, depth map, top view, visible entities — identical."""
+    import torch
+    frames = load_gl(case, "gl1_")
+    for ks in _groups(frames):
+        scenes = [frames[k][0] for k in ks]
+        s0 = scenes[0]
+        eng = helpers.make_engine_for_scene(s0, len(scenes), agent_radius=float(s0.get("agent_radius", 0.4)), msaa=1)
+        eng.set_state(helpers.scene_state_arrays(scenes))
+        rgb = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
+        depth = torch.zeros((len(scenes), 60, 80, 1), dtype=torch.float32, device="cuda")
+        eng.render(rgb, depth)
+        top = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
+        eng.render_top(top, None, True)
+        vis = eng.visible_ents()
+        eng.check()
+        rgb, depth, top, vis = rgb.cpu().numpy(), depth.cpu().numpy(), top.cpu().numpy(), vis.cpu().numpy()
+        for i, k in enumerate(ks):
+            fr = frames[k][1]
+            assert np.array_equal(depth[i, :, :, 0].view(np.uint32), fr["depth"].reshape(60, 80).view(np.uint32)), f"{case} frame {k}: depth map"
+            assert np.array_equal(rgb[i], fr["rgb"]), f"{case} frame {k}: {np.count_nonzero(rgb[i] != fr['rgb'])} RGB values differ"
+            assert np.array_equal(top[i], fr["top"]), f"{case} frame {k}: top view"
+            n = len(fr["vis"])
+            assert np.array_equal(vis[i, :n].astype(bool), np.asarray(fr["vis"]).astype(bool)), f"{case} frame {k}: visible entities"
+        eng.close()

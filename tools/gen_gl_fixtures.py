@@ -28,6 +28,11 @@ import refshim_gl  # noqa: E402
 
 OUT = os.path.join(HERE, "..", "tests", "golden")
 BIG = {"hallway_s0": [7], "pickup_dr_s1": [100], "sidewalk_s0": [10], "maze_s0": [100]}      # 800x600 render() frames
+# --one-spp: the reference's OTHER fallback (opengl.py:263-284) — a driver whose glTexImage2DMultisample fails gets a plain
+# single-sampled GL_RGBA texture and a 16-bit depth renderbuffer.  tools/refshim_gl.py makes that call raise
+# (MW_REF_FORCE_1SPP), the unmodified FrameBuffer takes its own `except` branch, and these cases are stored as gl1_*.npz.
+ONE_SPP_CASES = ["hallway_s0", "pickup_dr_s1", "maze_s0"]
+NS, PREFIX = 4, "gl_"
 
 
 def cases():
@@ -73,9 +78,9 @@ def capture(env, out, k, stats, big=False):
         out[f"gl/{k}/scene/{key}"] = val
     out[f"gl/{k}/rgb"], out[f"gl/{k}/z16"], out[f"gl/{k}/depth"], out[f"gl/{k}/top"], out[f"gl/{k}/vis"] = rgb, z16, depth, top, vis
     # oracle against the driver, right here
-    r = pyoracle.render(sc, nsamples=4, meshes=meshes)
-    t = pyoracle.render(sc, nsamples=4, meshes=meshes, view="top", render_agent=True)
-    v = pyoracle.visible_ents(sc, nsamples=4)
+    r = pyoracle.render(sc, nsamples=NS, meshes=meshes)
+    t = pyoracle.render(sc, nsamples=NS, meshes=meshes, view="top", render_agent=True)
+    v = pyoracle.visible_ents(sc, nsamples=NS)
     stats["frames"] += 1
     stats["rgb_bad"] += int((r["rgb"] != rgb).any(axis=2).sum())
     stats["rgb_max"] = max(stats["rgb_max"], int(np.abs(r["rgb"].astype(int) - rgb.astype(int)).max()))
@@ -90,7 +95,7 @@ def capture(env, out, k, stats, big=False):
             env.view = view
             img = env.render().copy()
             out[f"gl/{k}/view_{view}"] = img
-            rr = pyoracle.render(sc, width=800, height=600, nsamples=4, meshes=meshes, view=view, render_agent=(view == "top"))
+            rr = pyoracle.render(sc, width=800, height=600, nsamples=NS, meshes=meshes, view=view, render_agent=(view == "top"))
             stats["view_bad"] += int((rr["rgb"] != img).any(axis=2).sum())
         env.view = "agent"
 
@@ -156,7 +161,7 @@ def run_case(name, cls, kwargs, seed, n_actions, steps, frames, totals):
             break
     out["meta/frames"] = np.array(done_frames, np.int32)
     out["meta/env"] = np.array(cls)
-    np.savez_compressed(os.path.join(OUT, "gl_" + name + ".npz"), **out)
+    np.savez_compressed(os.path.join(OUT, PREFIX + name + ".npz"), **out)
     print(f"{name}: {stats}")
     for k, v in stats.items():
         totals[k] = max(totals.get(k, 0), v) if k.endswith("_max") else totals.get(k, 0) + v
@@ -198,7 +203,21 @@ def gl_mip_checksums():
 
 
 def main():
-    only = set(sys.argv[1:])
+    global NS, PREFIX
+    args = sys.argv[1:]
+    if "--one-spp" in args:
+        args.remove("--one-spp")
+        os.environ["MW_REF_FORCE_1SPP"] = "1"
+        NS, PREFIX = 1, "gl1_"
+        BIG.clear()
+        totals = {}
+        for case in cases():
+            if case[0] in (set(args) or set(ONE_SPP_CASES)):
+                name, cls, kwargs, seed, n_actions, steps, frames = case
+                run_case(name, cls, kwargs, seed, n_actions, steps, frames[:3], totals)
+        print("TOTAL (1 sample)", totals)
+        return
+    only = set(args)
     totals = {}
     for case in list(cases()) + EXTRA:
         if not only or case[0] in only:

@@ -154,6 +154,12 @@ class _GLModule(types.ModuleType):
             if not addr:
                 raise RuntimeError("GL entry point missing: " + fn)
             self.__dict__[fn] = ctypes.CFUNCTYPE(res, *args)(addr)
+        if os.environ.get("MW_REF_FORCE_1SPP"):
+            # a driver without multisampled textures: the reference's FrameBuffer takes its own `except` branch and renders
+            # into a plain GL_RGBA texture with a 16-bit depth renderbuffer (opengl.py:263-284) — the "_1spp" fixtures
+            def no_multisample(*a):
+                raise RuntimeError("glTexImage2DMultisample: not supported (MW_REF_FORCE_1SPP)")
+            self.__dict__["glTexImage2DMultisample"] = no_multisample
         self.gl_info = _GLInfo(self)
         self.gluPerspective = self._glu_perspective
         self.gluLookAt = self._glu_look_at
