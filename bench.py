@@ -36,10 +36,10 @@ sys.path.insert(0, ROOT)
 # hallway = configs[1], the configuration the metric is quoted on; the others via --config
 CONFIGS = {
     # obs 14400 + action 4 + agent/episode state r+w 64 + entity 64 + reward/flags 6 (+2 rounding)
-    "hallway": ("MiniWorld-Hallway-v0", "Hallway", 4096, False, False, 3, 1, 14540, "mw_raster_kernel"),
-    "oneroom_rgbd": ("MiniWorld-OneRoom-v0", "OneRoom", 4096, True, False, 3, 1, 33740, "mw_raster_depth_kernel"),
+    "hallway": ("MiniWorld-Hallway-v0", "Hallway", 4096, False, False, 3, 1, 14540, "mw_rasterq_kernel"),
+    "oneroom_rgbd": ("MiniWorld-OneRoom-v0", "OneRoom", 4096, True, False, 3, 1, 33740, "mw_rasterq_kernel"),
     "maze": ("MiniWorld-Maze-v0", "Maze", 1024, False, False, 3, 1, 30860, "mw_raster_big_kernel"),
-    "pickup_dr": ("MiniWorld-PickupObjects-v0", "PickupObjects", 2048, False, True, 5, 2, 14800, "mw_raster_nomesh_kernel"),
+    "pickup_dr": ("MiniWorld-PickupObjects-v0", "PickupObjects", 2048, False, True, 5, 2, 14800, "mw_rasterq_kernel"),
 }
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PREWARM_S = 0.5             # untimed steps before the W warm-up steps: clocks and caches of a cold box (reported)
@@ -108,6 +108,82 @@ def _cpu_worker(seconds, config="hallway"):
     return steps, pyoracle.bench_loop(sc, task, mes, n_act, steps, meshes)
 
 
+def reference_llvmpipe(config):
+    """The REFERENCE ITSELF (/root/reference/miniworld, unmodified, scripts/benchmark.py:22-42's loop) on Mesa llvmpipe: run
+    here when the reference tree and the software GL driver exist (the build container), otherwise the figure recorded
+    there by the same tool (tools/ref_benchmark.py -> profiles/*/ref_llvmpipe.jsonl), labelled as carried over — a GPU
+    box has neither /root/reference nor a GL driver."""
+    import glob
+    env_id = CONFIGS[config][0]
+    name = env_id.split("-")[1]
+    if os.path.isdir("/root/reference") and os.path.exists("/usr/lib/x86_64-linux-gnu/dri/swrast_dri.so"):
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ref_benchmark.py"), "--steps", "300", "--envs", name],
+                               capture_output=True, text=True, timeout=600)
+            j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            return {"value": j["steps_per_s"], "unit": "env-steps/s", "cores": j["host_cores"], "where": "this host, this run",
+                    "sample": f"{j['steps']} steps of 1 {env_id} env, the reference on llvmpipe (4 samples: its GL_MAX_SAMPLES)", "driver": j["driver"]["renderer"]}
+        except Exception as exc:  # noqa: BLE001
+            return {"error": repr(exc)}
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "ref_llvmpipe.jsonl")))
+    for f in reversed(files):
+        for ln in open(f):
+            j = json.loads(ln)
+            if j["env"] == env_id:
+                return {"value": j["steps_per_s"], "unit": "env-steps/s", "cores": j["host_cores"],
+                        "where": "carried over: measured in the build container (no /root/reference, no GL driver on this box)",
+                        "source": os.path.relpath(f, ROOT),
+                        "sample": f"{j['steps']} steps of 1 {env_id} env, the reference on llvmpipe (4 samples: its GL_MAX_SAMPLES)",
+                        "driver": j["driver"]["renderer"]}
+    return None
+
+
+def pmc_live(config, kernel, n):
+    """FETCH_SIZE / WRITE_SIZE of one launch of `kernel`, read during this run: a short child run of this script under
+    rocprofv3 (--pmc with --kernel-trace only, one pass per counter pair) when the profiler is on the box.  Returns a
+    traffic dict like pmc_profiled's, or None."""
+    import csv
+    import shutil
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None or os.environ.get("MW_BENCH_CHILD"):
+        return None
+    import signal
+    out = tempfile.mkdtemp(prefix="mwpmc_", dir="/tmp")
+    env = dict(os.environ, MW_BENCH_CHILD="1", TMPDIR="/tmp")
+    vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+    try:
+        for counter in vals:        # one counter per pass (MI355X_MICROARCH.md: separate --pmc passes), bounded in time
+            p = subprocess.Popen([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "pmc", "--",
+                                  sys.executable, os.path.abspath(__file__), "--config", config, "--envs-per-gpu", str(n), "--steps", "6", "--warmup", "2",
+                                  "--prewarm-steps", "16", "--no-cpu-baseline", "--no-parity-check", "--no-also"], cwd="/tmp", env=env,
+                                 stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=75)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)        # the profiler and the run under it (its own process group)
+                p.wait()
+                return None
+        for root, _, files in os.walk(out):
+            for f in files:
+                if f.endswith("counter_collection.csv"):
+                    for r in csv.DictReader(open(os.path.join(root, f))):
+                        if r["Kernel_Name"].startswith(kernel) and r["Counter_Name"] in vals:
+                            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if not vals["FETCH_SIZE"] or not vals["WRITE_SIZE"]:
+            return None
+        fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024.0      # KiB per launch (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KiB)
+        write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024.0
+        # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests at 64 bytes — doubled here
+        return {"bytes_per_launch": 2.0 * fetch + write, "fetch_bytes": 2.0 * fetch, "fetch_bytes_raw_counter": fetch, "write_bytes": write,
+                "launches": len(vals["FETCH_SIZE"]),
+                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) --kernel-trace, child runs of this command; FETCH_SIZE x 2 (gfx950)"}
+    except Exception:  # noqa: BLE001
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def cpu_baseline(config):
     """The CPU oracle (oracle/, a port of the reference path) on the host: a bounded sample of
     the same workload — one env stepped + rendered in a C loop on one core (`value`), and the same loop
@@ -138,6 +214,9 @@ def cpu_baseline(config):
                 if p.poll() is None:
                     p.kill()
             out["all_cores"] = {"error": repr(exc)}
+    ref = reference_llvmpipe(config)
+    if ref is not None:
+        out["reference_llvmpipe"] = ref
     return out
 
 
@@ -228,6 +307,40 @@ def self_launch(args, argv):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def time_config(config, steps, warmup, device_id=0):
+    """One more BASELINE config timed in this process after the headline (the `also` list of the JSON line): same protocol —
+    pre-generated random actions, W warm-up steps, K timed steps between synchronisations, HIP-event kernel times, the
+    parity spot check after the clock has stopped.  Never touches `value`."""
+    import torch
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    env_id, _, n, want_depth, dr, n_act, _, algo_bytes, dominant = CONFIGS[config]
+    vec = MiniWorldVecEnv(env_id, n, device_id=device_id, seed=0, want_depth=want_depth, domain_rand=dr)
+    vec.reset()
+    g = torch.Generator(device=f"cuda:{device_id}").manual_seed(4321)
+    actions = torch.randint(0, n_act, (steps + warmup, n), generator=g, device=f"cuda:{device_id}", dtype=torch.int32)
+    for t in range(warmup):
+        vec.step(actions[t])
+    vec.engine.kernel_time_ms(2 if steps <= 64 else 8)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for t in range(warmup, warmup + steps):
+        vec.step(actions[t])
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    raster_ms, setup_ms, launches = vec.engine.kernel_time_ms(-1)
+    vec.engine.check()
+    parity = parity_spot_check(vec, actions[warmup + steps - 1], config)
+    vec.close()
+    achieved = algo_bytes * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
+    return {"config": {"workload": f"{env_id}, {n} batched envs, 80x60 RGB{'-D' if want_depth else ''}, 8x MSAA, random actions, "
+                                   f"{'domain_rand, ' if dr else ''}auto-reset", "name": config, "envs_per_gpu": n},
+            "value": n * steps / elapsed, "unit": "env-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
+            "parity_checked": parity,
+            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "algorithmic_bytes_per_launch": algo_bytes * n,
+                         "kernel_ms": raster_ms, "setup_kernel_ms": setup_ms, "launches_timed": launches}}
+
+
 class _DryVec:
     """--dry: stands in for the engine so that the launcher / sharding / reduction path runs on a CPU-only box."""
 
@@ -251,6 +364,7 @@ def main():
     ap.add_argument("--prewarm-steps", type=int, default=0,
                     help="pre-warm with exactly this many steps instead of PREWARM_S seconds (A/B runs: the timed region then "
                          "covers the same episode phases in both)")
+    ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configs timed after the headline (the `also` list)")
     ap.add_argument("--dry", action="store_true", help="CPU dry run of the multi-rank path (gloo, no engine)")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still go through torch.distributed (RCCL, world size 1) — barrier, MAX-reduction, object "
@@ -374,6 +488,10 @@ def main():
         steps_per_s = world * n * args.steps / elapsed_max
         slow = max(per_rank, key=lambda r: r["kernel_ms"])          # the roofline entry is the slowest rank's
         traffic, valu = pmc_profiled(dominant, args.config, n)
+        # counters read during THIS run when the profiler is on the box (a short child run under rocprofv3), else the committed profile's
+        live = pmc_live(args.config, dominant, n) if (world == 1 and not args.dry) else None
+        if live is not None:
+            traffic = live
         out = {
             "metric": "env-steps/s (batched, 80x60 RGB)",
             "value": steps_per_s,
@@ -410,13 +528,21 @@ def main():
                 "launches_timed": slow["launches_timed"],
                 "per_rank": [{k: r[k] for k in ("rank", "kernel_ms", "setup_kernel_ms", "achieved", "frac", "elapsed_s")}
                              for r in sorted(per_rank, key=lambda r: r["rank"])],
+                "traffic_source": "live" if live is not None else ("committed profile" if traffic else None),
                 "note": "per GPU; the path is VALU bound (coverage, depth, texture filtering, resolve), not HBM bound (SURVEY.md "
                         "section 8d): see valu_profiled.  traffic = traffic_profiled.bytes_per_launch = PMC FETCH_SIZE + WRITE_SIZE per "
-                        "launch from the committed profile of the named commit, not a counter read during this run",
+                        "launch: read during this run by a child run under rocprofv3 (traffic_source = live) or, without the profiler, "
+                        "from the committed profile of the named commit",
             },
         }
         if world == 1 and not args.no_cpu_baseline and not args.dry:
             out["cpu_baseline"] = cpu_baseline(args.config)
+        if world == 1 and not args.dry and not args.no_also and args.config == "hallway" and not args.envs_per_gpu:
+            # BASELINE.json configs[2] is a single-GPU config too: timed here so that the driver's one command records it
+            try:
+                out["also"] = [time_config("oneroom_rgbd", args.steps, args.warmup, local)]
+            except Exception as exc:  # noqa: BLE001 — never at the headline's expense
+                out["also"] = [{"config": {"name": "oneroom_rgbd"}, "error": repr(exc)}]
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

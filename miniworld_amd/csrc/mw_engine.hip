@@ -669,7 +669,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     auto launch_k2q = [&](int part_flags) {
         const int S = e->cfg.msaa;
         const int lds = mw_rasterq_lds_bytes(S, a.W, a.H, a.n_tiles, d_depth ? 1 : 0);
-        const int flags = (e->dbg_flags & 0x1C0F) | (e->obs_layout << 8) | part_flags;
+        const int flags = (e->dbg_flags & 0xFC0F) | (e->obs_layout << 8) | part_flags;
         hipLaunchKernelGGL(S == 8 ? mw_rasterq_kernel : mw_rasterq4_kernel, dim3(N), dim3(MW_RASTERQ_THREADS), (size_t)lds, st, a.N, a.W, a.H, a.max_vis,
                            a.tiles_x, a.n_tiles, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.texels, d_obs, d_depth, flags, e->texel_bytes, e->d_k2q_prof);

@@ -79,7 +79,7 @@ __host__ __device__ inline QPlan q_plan(int S, int W, int H, int n_tiles, bool d
     p.frame = take(W * H * 3);
     p.zbuf = depth ? take(W * H * 2) : 0;
     p.qids = take(nquads * 4);
-    p.queue = take((nquads + 16 * QC_NCLS) * 2);
+    p.queue = take((nquads + 16 * QC_NCLS + 48) * 2);
     p.tcnt = take(n_tiles * 4);
     p.tfull = take(n_tiles * 4);                    // triangles that cover the whole tile: count | three ids << 8, 16, 24
     p.tlist = take(n_tiles * MWQ_SLOTS);
@@ -87,7 +87,7 @@ __host__ __device__ inline QPlan q_plan(int S, int W, int H, int n_tiles, bool d
     p.pe = p.frame;                                 // partial (tile, triangle) events, phases A -> B: in the frame (W H 3 >= tiles x 64 bytes), which phase D writes first
     p.xq = take(nquads * 2);                        // the exact list of phase D
     p.misc = take(64 * 4);
-    p.btab = take((nquads / 16 + QC_NCLS) * 2);     // per batch: class | quads << 8
+    p.btab = take((nquads / 16 + QC_NCLS) * 4);     // per batch: first quad of the queue | class << 12 | quads << 16
     p.scratch = p.rec;                              // one record per wavefront (envs with more than MWQ_CAP triangles, 4 samples: no staged records then)
     p.total = o;
     return p;
@@ -305,6 +305,124 @@ __device__ inline void batch_trivial(const QCtx &cx, uint32_t ids, int px, int p
     store_pixel<S>(cx, q, z16, px, py, on);
 }
 
+// TRIV with a whole quad per LANE (64 quads to a batch): what depends on the quad alone — its triangle's record, the lod, the
+// two levels' geometry — is computed once for its four pixels instead of once per pixel-lane, and the lod's corner
+// coordinates are the lane's own values.  Pixel i of the quad: column px0 + (i & 1), image row py0 + (i >> 1).
+template <int S>
+__device__ inline void batch_trivial4(const QCtx &cx, uint32_t ids, int qx, int qy, bool on)
+{
+    const float4 *rec = cx.s_rec + (ids & 63u) * QRec<S>::NQ;
+    const float4 *sr = rec + QRec<S>::SH;
+    const float4 q0 = sr[0], qr = sr[3], qg = sr[4], qb = sr[5];
+    const int px0 = qx * 2, py0 = qy * 2, gy0 = cx.H - 1 - py0;
+    const float fx0 = (float)px0, fy0 = (float)gy0;
+    float wv[4], oow[4];
+    RGB c[4];
+    uint64_t dom = ~0ull;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = fx0 + (0.5f + (float)(i & 1)), y = fy0 + (0.5f - (float)(i >> 1));
+        wv[i] = fmaf(q0.z, y, fmaf(q0.y, x, q0.x));
+        dom &= __builtin_amdgcn_ballot_w64(fabsf(wv[i]) >= MW_RCP_LO) & __builtin_amdgcn_ballot_w64(fabsf(wv[i]) <= MW_RCP_HI);
+    }
+    const bool fast = dom == __builtin_amdgcn_read_exec();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = fx0 + (0.5f + (float)(i & 1)), y = fy0 + (0.5f - (float)(i >> 1));
+        oow[i] = fast ? rcp_exact(wv[i]) : 1.0f / wv[i];
+        c[i].r = fmaf(qr.z, y, fmaf(qr.y, x, qr.x)) * oow[i];
+        c[i].g = fmaf(qg.z, y, fmaf(qg.y, x, qg.x)) * oow[i];
+        c[i].b = fmaf(qb.z, y, fmaf(qb.y, x, qb.x)) * oow[i];
+    }
+    const int tex = __float_as_int(q0.w);
+    if (!cx.te.flat && wave_any(tex >= 0)) {
+        if (tex >= 0) {
+            const float4 q1 = sr[1], q2 = sr[2];
+            float s[4], t[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float x = fx0 + (0.5f + (float)(i & 1)), y = fy0 + (0.5f - (float)(i >> 1));
+                const float qq = wv[i] * oow[i];
+                const float invq = fast ? rcp_exact(qq) : 1.0f / qq;
+                s[i] = (fmaf(q1.z, y, fmaf(q1.y, x, q1.x)) * oow[i]) * invq;
+                t[i] = (fmaf(q2.z, y, fmaf(q2.y, x, q2.x)) * oow[i]) * invq;
+            }
+            const uint32_t info = __float_as_uint(q1.w);
+            const int nlevels = (int)((info >> 10) & 31u);
+            // GL's quad: (qx, qy) is its lower row = the image's odd row: pixel 2; (qx + 1, qy) pixel 3; (qx, qy + 1) pixel 0
+            const float rho2 = mwgl::lod_rho2(s[2], t[2], s[3], t[3], s[0], t[0], q2.w, qr.w);
+            int l0, w8;
+            mwgl::lod_from_rho2_bits(rho2, nlevels, l0, w8);
+            const int l1 = min(l0 + 1, nlevels - 1);
+            const bool two = wave_any(w8 > 0);
+            if (wave_all(((info >> 15) & 1u) != 0u)) {
+                const uint32_t dbase = __float_as_uint(qg.w);
+                const uint32_t off0 = __builtin_amdgcn_raw_buffer_load_b32(cx.te.td, dbase + ((uint32_t)l0 << 5), 0, 0);
+                const uint32_t off1 = __builtin_amdgcn_raw_buffer_load_b32(cx.te.td, dbase + ((uint32_t)l1 << 5), 0, 0);
+                const int lw0 = (int)(info & 31u), lh0 = (int)((info >> 5) & 31u);
+                const uint32_t lwa = (uint32_t)max(lw0 - l0, 0), lha = (uint32_t)max(lh0 - l0, 0), lwb = (uint32_t)max(lw0 - l1, 0), lhb = (uint32_t)max(lh0 - l1, 0);
+                const uint32_t wl = weight_pk8((uint32_t)w8), il = 0x01000100u - wl;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    uint32_t rb, ag;
+                    fetch_pot(cx.te, off0, lwa, lha, s[i], t[i], rb, ag);
+                    if (two) {
+                        uint32_t rb1, ag1;
+                        fetch_pot(cx.te, off1, lwb, lhb, s[i], t[i], rb1, ag1);
+                        rb = lerp8_pk(rb, rb1, wl, il);
+                        ag = lerp8_pk(ag, ag1, wl, il);
+                    }
+                    c[i].r = ((float)(rb & 0xFFu) * (1.0f / 255.0f)) * c[i].r;
+                    c[i].g = ((float)(ag & 0xFFu) * (1.0f / 255.0f)) * c[i].g;
+                    c[i].b = ((float)((rb >> 16) & 0xFFu) * (1.0f / 255.0f)) * c[i].b;
+                }
+            } else {
+                const uint32_t desc = (uint32_t)tex * (uint32_t)(sizeof(MwTexDesc) / 4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int c0[3];
+                    fetch_level(cx.te, desc, l0, s[i], t[i], c0);
+                    if (two) {
+                        int c1[3];
+                        fetch_level(cx.te, desc, l1, s[i], t[i], c1);
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) c0[k] = mwgl::lerp8(c0[k], c1[k], w8);
+                    }
+                    c[i].r = ((float)c0[0] * (1.0f / 255.0f)) * c[i].r;
+                    c[i].g = ((float)c0[1] * (1.0f / 255.0f)) * c[i].g;
+                    c[i].b = ((float)c0[2] * (1.0f / 255.0f)) * c[i].b;
+                }
+            }
+        }
+    }
+    // resolve: the eight samples of a pixel hold the same colour, summed in sample order like any others; bytes of a row's
+    // two pixels leave as three halfwords
+    uint32_t u[4][3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        RGB acc = c[i];
+#pragma unroll
+        for (int k = 1; k < S; ++k) { acc.r = acc.r + c[i].r; acc.g = acc.g + c[i].g; acc.b = acc.b + c[i].b; }
+        u[i][0] = __float_as_uint(acc.r * (255.0f / S)); u[i][1] = __float_as_uint(acc.g * (255.0f / S)); u[i][2] = __float_as_uint(acc.b * (255.0f / S));
+    }
+    if (on) {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int pix = (py0 + r) * cx.W + px0;
+            auto pk = [](uint32_t lo, uint32_t hi) { return __builtin_amdgcn_cvt_pk_u8_f32(__uint_as_float(hi), 1u, __builtin_amdgcn_cvt_pk_u8_f32(__uint_as_float(lo), 0u, 0u)); };
+            uint16_t *dst = reinterpret_cast<uint16_t *>(cx.s_frame + pix * 3);
+            dst[0] = (uint16_t)pk(u[2 * r][0], u[2 * r][1]);
+            dst[1] = (uint16_t)pk(u[2 * r][2], u[2 * r + 1][0]);
+            dst[2] = (uint16_t)pk(u[2 * r + 1][1], u[2 * r + 1][2]);
+            if (cx.depth) {
+                const float4 a2 = rec[2], a3 = rec[3];
+                const uint32_t z0 = depth16_s<S>(a2.z, a2.w, a3.x, fx0, fy0 - (float)r, 0), z1 = depth16_s<S>(a2.z, a2.w, a3.x, fx0 + 1.0f, fy0 - (float)r, 0);
+                *reinterpret_cast<uint32_t *>(cx.s_z + pix) = z0 | (z1 << 16);
+            }
+        }
+    }
+}
+
 // SKY: nothing touches the quad
 template <int S>
 __device__ inline void batch_sky(const QCtx &cx, int px, int py, bool on)
@@ -443,7 +561,7 @@ __device__ inline void rasterq_body(
     uint32_t *s_pe = reinterpret_cast<uint32_t *>(smem + pl.pe);
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + pl.misc);     // [0..8] class counts, [16] partial events, [17] next batch, [18] exact list, [19] next exact batch
     uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_frame);            // phase C only (the partial events are done with, the frame is not written before phase D)
-    uint16_t *s_btab = reinterpret_cast<uint16_t *>(smem + pl.btab);
+    uint32_t *s_btab = reinterpret_cast<uint32_t *>(smem + pl.btab);
     const int QW = W / 2, QH = H / 2, nquads = QW * QH;
     // x / d for x < 2^16 as a multiply (the divisors are launch constants)
     const uint32_t m_qw = 0xFFFFFFFFu / (uint32_t)QW + 1u, m_tx = 0xFFFFFFFFu / (uint32_t)tiles_x + 1u;
@@ -556,6 +674,7 @@ __device__ inline void rasterq_body(
         if (tid < 64) s_misc[tid] = 0u;
         __syncthreads();
         stamp(1);
+        if ((dbg >> 13) == 1) return;       // (bits 13-15: leave after phase 0 / A / B / C1 — instruction counts per phase, frames invalid)
 
         // ---- A: (tile, triangle) pairs -------------------------------------------------------------------------------------
         const bool force_fallback = (dbg & 8) != 0;
@@ -596,6 +715,7 @@ __device__ inline void rasterq_body(
         __syncthreads();
 
         stamp(2);
+        if ((dbg >> 13) == 2) return;
         // ---- B: (quad, triangle) pairs of the tiles a triangle crosses -----------------------------------------------------
         const int npe = __builtin_amdgcn_readfirstlane((int)s_misc[16]);
         for (int i = tid; i < ((npe * 16 + 63) & ~63); i += MWQ_THREADS) {
@@ -624,6 +744,7 @@ __device__ inline void rasterq_body(
         __syncthreads();
 
         stamp(3);
+        if ((dbg >> 13) == 3) return;
         // ---- C1: every quad collects its triangles and takes a class --------------------------------------------------------
         for (int Q = tid; Q < nquads; Q += MWQ_THREADS) {
             const int qy = (int)__umulhi((uint32_t)Q, m_qw), qx = Q - qy * QW;
@@ -632,9 +753,12 @@ __device__ inline void rasterq_body(
             const uint32_t np = (v >> 24) & 127u, nf = tf & 255u, n = np + nf;
             const bool anyfull = (v >> 31) != 0u || nf != 0u;
             uint32_t ids = v & 0xFFFFFFu;
+            if (nf != 0u && np < 4u) ids |= ((tf >> 8) & 63u) << (6u * np);
+            if (wave_any(nf > 1u)) {
 #pragma unroll
-            for (uint32_t j = 0; j < 3u; ++j)
-                if (j < nf && np + j < 4u) ids |= ((tf >> (8u + 8u * j)) & 63u) << (6u * (np + j));
+                for (uint32_t j = 1; j < 3u; ++j)
+                    if (j < nf && np + j < 4u) ids |= ((tf >> (8u + 8u * j)) & 63u) << (6u * (np + j));
+            }
             ids |= (0xFFFFFFu << (6u * min(n, 4u))) & 0xFFFFFFu;          // the places behind the list: MWQ_EMPTY
             int cls;
             if (mesh_env && tile_in_mesh_rect(hdr, tx, ty)) cls = QC_NONE;
@@ -658,49 +782,63 @@ __device__ inline void rasterq_body(
         }
         __syncthreads();
 
-        // ---- C2: class queues, whole batches of 16 quads per class ----------------------------------------------------------
-        uint32_t cnt_c[QC_NCLS], first_b[QC_NCLS + 1];
-        first_b[0] = 0u;
+        if ((dbg >> 13) == 4) return;
+        // ---- C2: class queues in whole slots of 16 quads; a batch is one slot — four for TRIV, whose lanes are whole quads ----
+        uint32_t cnt_c[QC_NCLS], first_b[QC_NCLS + 1], first_bat[QC_NCLS + 1];
+        first_b[0] = 0u; first_bat[0] = 0u;
 #pragma unroll
-        for (int c = 0; c < QC_NCLS; ++c) { cnt_c[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[c]); first_b[c + 1] = first_b[c] + (cnt_c[c] + 15u) / 16u; }
-        for (int Q = tid; Q < nquads; Q += MWQ_THREADS) {
-            const uint32_t cls = s_qids[Q] >> 24;
-            if (cls == QC_NONE) continue;
-            uint32_t base = 0u;
-#pragma unroll
-            for (int c = 0; c < QC_NCLS; ++c) base = cls == (uint32_t)c ? first_b[c] : base;
-            s_queue[base * 16u + s_rank[Q]] = (uint16_t)Q;
+        for (int c = 0; c < QC_NCLS; ++c) {
+            cnt_c[c] = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_misc[c]);
+            first_b[c + 1] = first_b[c] + (cnt_c[c] + 15u) / 16u;
+            first_bat[c + 1] = first_bat[c] + (c == QC_TRIV ? (cnt_c[c] + 63u) / 64u : (cnt_c[c] + 15u) / 16u);
         }
-        for (uint32_t b = tid; b < first_b[QC_NCLS]; b += MWQ_THREADS) {
+        // (the class's first slot: lane c of a register holds first_b[c], a quad fetches its own with one ds_bpermute)
+        uint32_t fb_lane = 0u;
+#pragma unroll
+        for (int c = 0; c < QC_NCLS; ++c) fb_lane = lane == c ? first_b[c] : fb_lane;
+        for (int Q0 = 0; Q0 < nquads; Q0 += MWQ_THREADS) {
+            const int Q = Q0 + tid;
+            const uint32_t cls = Q < nquads ? s_qids[Q] >> 24 : (uint32_t)QC_NONE;
+            const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(cls & 15u) << 2, (int)fb_lane);
+            if (cls != QC_NONE) s_queue[base * 16u + s_rank[Q]] = (uint16_t)Q;
+        }
+        for (uint32_t b = tid; b < first_bat[QC_NCLS]; b += MWQ_THREADS) {
             uint32_t cls = 0u;
 #pragma unroll
-            for (int c = 1; c < QC_NCLS; ++c) cls += b >= first_b[c] ? 1u : 0u;
-            uint32_t cfirst = 0u, ccnt = 0u;
+            for (int c = 1; c < QC_NCLS; ++c) cls += b >= first_bat[c] ? 1u : 0u;
+            uint32_t cfirst = 0u, cslot = 0u, ccnt = 0u;
 #pragma unroll
-            for (int c = 0; c < QC_NCLS; ++c) { cfirst = cls == (uint32_t)c ? first_b[c] : cfirst; ccnt = cls == (uint32_t)c ? cnt_c[c] : ccnt; }
-            s_btab[b] = (uint16_t)(cls | (min(16u, ccnt - (b - cfirst) * 16u) << 8));
+            for (int c = 0; c < QC_NCLS; ++c) { cfirst = cls == (uint32_t)c ? first_bat[c] : cfirst; cslot = cls == (uint32_t)c ? first_b[c] : cslot; ccnt = cls == (uint32_t)c ? cnt_c[c] : ccnt; }
+            const uint32_t size = cls == QC_TRIV ? 64u : 16u, bi = b - cfirst;
+            s_btab[b] = ((cslot + bi * (size / 16u)) * 16u) | (cls << 12) | (min(size, ccnt - bi * size) << 16);      // first quad of the queue | class | quads
         }
         __syncthreads();
 
         stamp(4);
         // ---- D: batches ------------------------------------------------------------------------------------------------------
-        const uint32_t n_batches = (dbg & 0x400) ? 0u : first_b[QC_NCLS];      // (0x400, 0x800, 0x1000: phase timing experiments, frames invalid)
+        const uint32_t n_batches = (dbg & 0x400) ? 0u : first_bat[QC_NCLS];      // (0x400, 0x800, 0x1000: phase timing experiments, frames invalid)
         for (;;) {
             uint32_t b = 0u;
             if (lane == 0) b = atomicAdd(&s_misc[17], 1u);
             b = (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
             if (b >= n_batches) break;
             const uint32_t be = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_btab[b]);
-            const int cls = (int)(be & 255u);
-            const bool on = (uint32_t)(lane >> 2) < (be >> 8);
-            const int Q = on ? (int)s_queue[b * 16u + (uint32_t)(lane >> 2)] : 0;
+            const int cls = (int)((be >> 12) & 15u);
+            if ((dbg & 0x800) && cls != QC_TRIV) continue;
+            if ((dbg & 0x1000) && cls == QC_TRIV) continue;
+            if (cls == QC_TRIV) {
+                const bool on4 = (uint32_t)lane < (be >> 16);
+                const int Q4 = on4 ? (int)s_queue[(be & 0xFFFu) + (uint32_t)lane] : 0;
+                const int qy4 = (int)__umulhi((uint32_t)Q4, m_qw);
+                batch_trivial4<S>(cx, on4 ? s_qids[Q4] : 0u, Q4 - qy4 * QW, qy4, on4);
+                continue;
+            }
+            const bool on = (uint32_t)(lane >> 2) < (be >> 16);
+            const int Q = on ? (int)s_queue[(be & 0xFFFu) + (uint32_t)(lane >> 2)] : 0;
             const int qy = (int)__umulhi((uint32_t)Q, m_qw), qx = Q - qy * QW;
             const int px = qx * 2 + (lane & 1), py = qy * 2 + ((lane >> 1) & 1);
             const uint32_t ids = on ? s_qids[Q] : 0u;
-            if ((dbg & 0x800) && cls != QC_TRIV) continue;
-            if ((dbg & 0x1000) && cls == QC_TRIV) continue;
-            if (cls == QC_TRIV) batch_trivial<S>(cx, ids, px, py, on);
-            else if (cls == QC_SKY) batch_sky<S>(cx, px, py, on);
+            if (cls == QC_SKY) batch_sky<S>(cx, px, py, on);
             else if (cls >= QC_P4) {
                 const bool qc = batch_partial<S>(cx, ids, QC_P1 + 1 - cls, px, py, on);
                 if (qc && on && (lane & 3) == 0) s_xq[atomicAdd(&s_misc[18], 1u)] = (uint16_t)Q;

@@ -3,7 +3,7 @@
 C=${1:-hallway}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-for f in 0 1024 2048 4096; do
+for f in ${FLAGS:-0 1024 2048 4096}; do
   OUT=/tmp/k2qpi_$f; rm -rf $OUT
   MW_DEBUG_FLAGS=$f rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES --kernel-trace --output-format csv -d $OUT -o bench -- python $R/bench.py --config $C --steps 10 --warmup 3 --no-cpu-baseline --no-parity-check > /dev/null 2>&1
   python3 - $OUT $f <<'PY'
