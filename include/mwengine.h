@@ -362,6 +362,10 @@ int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *se
  * Values are those of the state the device holds: with MW_AUTORESET_SAME_STEP an env that just finished reports its new episode. */
 int mw_get_info(mw_engine *e, int32_t *d_health, double *d_ent_pos, int32_t ent_slot, void *stream);
 
+/* Diagnostic (synchronises `stream`): how many triangles the last frame's display list held per env after clipping and culling —
+ * what max_visible has to pay for (6 records per unit), and what decides which raster kernel an env's frame takes. */
+int mw_get_list_lengths(mw_engine *e, int32_t first_env, int32_t count, int32_t *host_out, void *stream);
+
 enum { MW_PATH_TILE = 0, MW_PATH_QUAD = 1, MW_PATH_QUAD_MESH = 2, MW_PATH_GENERIC = 3 };
 int mw_raster_path(const mw_engine *e);
 

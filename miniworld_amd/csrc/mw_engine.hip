@@ -51,10 +51,11 @@ MW_RASTER_DECL(mw_raster_big_mesh_wrap_kernel);
 #define MW_RASTERQ_DECL(name) \
     extern "C" __global__ void name(int N, int W, int H, int max_vis, int tiles_x, int n_tiles, const float *rec_raster, const float *rec_shade, \
                                     const float *rec_cull, const int32_t *nvis, const float *envhdr, const uint32_t *texels, uint8_t *obs, \
-                                    float *depth, int dbg, int texel_bytes, unsigned long long *prof)
+                                    float *depth, int dbg, int texel_bytes, unsigned long long *prof, const uint16_t *rec_order)
 MW_RASTERQ_DECL(mw_rasterq_kernel);
 MW_RASTERQ_DECL(mw_rasterq4_kernel);
 extern "C" int mw_rasterq_lds_bytes(int S, int W, int H, int n_tiles, int depth);
+extern "C" int mw_rasterq_cap(int depth);
 #define MW_RASTERQ_THREADS 512
 extern "C" __global__ void mw_mesh_scatter_kernel(int W, int H, const float *envhdr, const float *mesh_stream, const float *mesh_attr,
                                                   uint32_t *keys, float *plane_cache, int plane_cap, int32_t *slow_count,
@@ -155,6 +156,7 @@ struct mw_engine {
     // A/B switches, read once by mw_create (the launch path never touches the environment)
     bool use_k2q = true;        // MW_K2Q=0: the tile kernels of mw_raster.hip for small scenes too
     bool k2q_ok = false;        // the frame fits the quad kernel's LDS plan
+    bool k2q_big = false;       // MW_K2Q_BIG=1 (experiment; measured slower on the Maze: 350 vs 276 us — without the visiting order's early exit the exact path pays for every hidden wall)
     bool generic_raster = false;    // MW_GENERIC_RASTER=1: msaa = 4 frames through the generic-resolution kernel (tests run both)
     bool geom_any = false;      // MW_GEOM_ANY
     int geom_lanes_override = 0;    // MW_GEOM_LANES
@@ -665,14 +667,18 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // hot path) and 4 (llvmpipe's GL_MAX_SAMPLES: the reference's own frames run through the same code); with mesh entities
     // it draws the tiles no mesh can touch (8 samples only)
     const bool big_scene = e->raster_big >= 0 ? e->raster_big != 0 : a.rec_order != nullptr;
-    const bool k2q = e->use_k2q && e->k2q_ok && !big_scene && !(e->cfg.msaa == 4 && (e->have_meshes || e->generic_raster));
+    // (big scenes — a visiting order exists — keep the tile kernels; MW_K2Q_BIG=1, an experiment: the envs of a big scene whose lists fit
+    // the quad kernel's records take the quad path, the others the tile kernel launched behind it)
+    const bool k2q = e->use_k2q && e->k2q_ok && (!big_scene || (e->k2q_big && e->cfg.msaa == 8 && !e->have_meshes)) &&
+                     !(e->cfg.msaa == 4 && (e->have_meshes || e->generic_raster));
     auto launch_k2q = [&](int part_flags) {
         const int S = e->cfg.msaa;
         const int lds = mw_rasterq_lds_bytes(S, a.W, a.H, a.n_tiles, d_depth ? 1 : 0);
         const int flags = (e->dbg_flags & 0xFC0F) | (e->obs_layout << 8) | part_flags;
         hipLaunchKernelGGL(S == 8 ? mw_rasterq_kernel : mw_rasterq4_kernel, dim3(N), dim3(MW_RASTERQ_THREADS), (size_t)lds, st, a.N, a.W, a.H, a.max_vis,
                            a.tiles_x, a.n_tiles, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
-                           (const int32_t *)a.nvis, (const float *)a.envhdr, a.texels, d_obs, d_depth, flags, e->texel_bytes, e->d_k2q_prof);
+                           (const int32_t *)a.nvis, (const float *)a.envhdr, a.texels, d_obs, d_depth, flags, e->texel_bytes, e->d_k2q_prof,
+                           S == 8 ? (const uint16_t *)a.rec_order : nullptr);
     };
     if (k2q && e->cfg.msaa == 4) {
         launch_k2q(0);
@@ -767,6 +773,10 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
             HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
             launch_k2(2 << 4);
+        } else if (k2q && big_scene) {
+            // the envs whose lists fit the quad kernel's records there, the others in the tile kernel (each skips the other's)
+            launch_k2q(0x40);
+            launch_k2(mw_rasterq_cap(d_depth ? 1 : 0) << 24);
         } else if (k2q) {
             launch_k2q(0);
         } else {
@@ -937,6 +947,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
     if (const char *s = getenv("MW_K2Q")) e->use_k2q = atoi(s) != 0;
     if (const char *s = getenv("MW_GENERIC_RASTER")) e->generic_raster = atoi(s) != 0;
+    if (const char *s = getenv("MW_K2Q_BIG")) e->k2q_big = atoi(s) != 0;
     e->geom_any = getenv("MW_GEOM_ANY") != nullptr;
     if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
     if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;
@@ -1378,6 +1389,16 @@ int mw_check(mw_engine *e, void *stream)
 }
 
 int mw_raster_path(const mw_engine *e) { return e ? e->last_raster_path : MW_E_INVALID; }
+
+int mw_get_list_lengths(mw_engine *e, int32_t first_env, int32_t count, int32_t *host_out, void *stream)
+{
+    if (!e || !host_out) return fail(e, MW_E_INVALID, "null argument");
+    if (first_env < 0 || count <= 0 || first_env + count > e->cfg.num_envs) return fail(e, MW_E_INVALID, "env range out of bounds");
+    ON_DEVICE(e);
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(e, hipMemcpy(host_out, e->args.nvis + first_env, sizeof(int32_t) * (size_t)count, hipMemcpyDeviceToHost));
+    return MW_OK;
+}
 
 int mw_get_info(mw_engine *e, int32_t *d_health, double *d_ent_pos, int32_t ent_slot, void *stream)
 {

@@ -60,6 +60,8 @@ __device__ inline void raster_kernel_body(
         if (!any) return;
     }
     const int nvis = nvis_arr[env];
+    // (big scenes share the batch with the quad kernel, mw_rasterq.hip: bits 24-31 of the flags = the longest list that one drew)
+    if (!MESHAWARE && ((uint32_t)dbg >> 24) != 0u && nvis <= (int)((uint32_t)dbg >> 24)) return;
     const float *__restrict__ rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     const float4 *g_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
     const float4 *g_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
