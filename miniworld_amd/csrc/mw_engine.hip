@@ -26,6 +26,8 @@ extern "C" __global__ void mw_step_setup_dense_kernel(MwArgs a, int do_step, int
 extern "C" __global__ void mw_step_setup_dense_pcg_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
                                                            float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
+extern "C" __global__ void mw_geom_step_kernel(MwArgs a, int L, const int32_t *actions, float *reward, uint8_t *term, uint8_t *trunc);
+extern "C" __global__ void mw_geom_step_pcg_kernel(MwArgs a, int L, const int32_t *actions, float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_geom_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
 extern "C" __global__ void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
 extern "C" __global__ void mw_geom_big_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
@@ -156,6 +158,8 @@ struct mw_engine {
     // A/B switches, read once by mw_create (the launch path never touches the environment)
     bool use_k2q = true;        // MW_K2Q=0: the tile kernels of mw_raster.hip for small scenes too
     bool k2q_ok = false;        // the frame fits the quad kernel's LDS plan
+    bool fuse_step = false;     // MW_FUSE_STEP=1: K1 as the geometry kernel's prologue, one launch (mw_geom_step_kernel) — measured slower: 85 vs 80 us for 4096
+                                // Hallway envs (at one wavefront per SIMD the step's load -> f64 physics -> store chain is fully exposed)
     bool k2q_big = false;       // MW_K2Q_BIG=1 (experiment; measured slower on the Maze: 350 vs 276 us — without the visiting order's early exit the exact path pays for every hidden wall)
     bool generic_raster = false;    // MW_GENERIC_RASTER=1: msaa = 4 frames through the generic-resolution kernel (tests run both)
     bool geom_any = false;      // MW_GEOM_ANY
@@ -634,8 +638,16 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // the worlds from the host (ON_DEVICE_SYNC) — an env that needs its spare earlier follows the refill_mask protocol.
     const bool async_refill = e->spare_mode && do_step && e->cfg.generator == MW_GEN_MAZE;
     const int refill_blocks = (e->spare_mode && do_step && !async_refill) ? (N + 63) / 64 : 0;
+    // small scenes, 8 samples: the step is the geometry kernel's prologue (mw_geom_step_kernel) — one launch for K1 + KG
+    const int gl = geom_lanes(e);
+    const bool fused = do_step && e->fuse_step && view_flags == 0 && k1_dense_lanes(e, 0) != 0 && gl < 64 && e->cfg.msaa == 8 && !e->geom_any;
     if (!do_step) {
         // render only: nothing to step
+    } else if (fused) {
+        const int epw = 64 / gl;
+        const int refill = e->spare_mode ? (N + 63) / 64 : 0;
+        hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_geom_step_pcg_kernel : mw_geom_step_kernel, dim3((N + epw - 1) / epw + refill), dim3(64), 0, st, a, gl,
+                           d_actions, d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch, d_trunc ? d_trunc : e->d_flag_scratch + N);
     } else if (const int lanes = k1_dense_lanes(e, 0)) {
         const int epw = 64 / lanes;
         const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
@@ -651,8 +663,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                            d_trunc ? d_trunc : e->d_flag_scratch + N);
     }
     // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
-    {
-        const int L = geom_lanes(e), epw = 64 / L;
+    if (!fused) {
+        const int L = gl, epw = 64 / L;
         hipLaunchKernelGGL(geom_kernel_of(e, L, e->cfg.msaa), dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
     }
     if (do_step && e->cfg.task == MW_TASK_COLLECT)
@@ -677,7 +689,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     auto launch_k2q = [&](int part_flags) {
         const int S = e->cfg.msaa;
         const int lds = mw_rasterq_lds_bytes(S, a.W, a.H, a.n_tiles, d_depth ? 1 : 0);
-        const int flags = (e->dbg_flags & 0xFC0F) | (e->obs_layout << 8) | part_flags;
+        const int flags = (e->dbg_flags & 0xFC8F) | (e->obs_layout << 8) | part_flags;
         hipLaunchKernelGGL(S == 8 ? mw_rasterq_kernel : mw_rasterq4_kernel, dim3(N), dim3(MW_RASTERQ_THREADS), (size_t)lds, st, a.N, a.W, a.H, a.max_vis,
                            a.tiles_x, a.n_tiles, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.texels, d_obs, d_depth, flags, e->texel_bytes, e->d_k2q_prof,
@@ -951,6 +963,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_K2Q")) e->use_k2q = atoi(s) != 0;
     if (const char *s = getenv("MW_GENERIC_RASTER")) e->generic_raster = atoi(s) != 0;
     if (const char *s = getenv("MW_K2Q_BIG")) e->k2q_big = atoi(s) != 0;
+    if (const char *s = getenv("MW_FUSE_STEP")) e->fuse_step = atoi(s) != 0;
     e->geom_any = getenv("MW_GEOM_ANY") != nullptr;
     if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
     if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;

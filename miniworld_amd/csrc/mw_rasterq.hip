@@ -625,7 +625,8 @@ __device__ inline void rasterq_body(
     };
 
     // ---- envs with more triangles than the LDS records hold ---------------------------------------------------------------
-    if (nvis > q_cap(has_depth)) {
+    // (flag 0x80, tests: as if the records held 8 triangles — every env with more takes the paths below)
+    if (nvis > ((dbg & 0x80) ? 8 : q_cap(has_depth))) {
         if (dbg & 0x40) return;         // the tile kernel's launch behind this one draws these envs (big scenes: mw_engine.hip)
         if constexpr (S == 8 && MWQ_TILE_FALLBACK) {
             // the tile code of mw_raster.hip, records read in place; every wavefront takes every MWQ_WAVES-th tile

@@ -42,6 +42,38 @@ def test_render_matches_golden_and_oracle(case):
     eng.close()
 
 
+@pytest.mark.parametrize("msaa", [8, 4])
+@pytest.mark.parametrize("flags,what", [(4, "every quad through the exact path (packed keys)"), (8, "every quad through the fallback class (all triangles)"),
+                                        (0x80, "records hold 8 triangles: the tile code (8 samples) / the scratch-staged exact path (4)")])
+@pytest.mark.parametrize("case", ["hallway_s0", "oneroom_s0", "putnext_s0", "pickup_s0"])
+def test_quad_kernel_side_paths_equal_the_oracle(case, flags, what, msaa, monkeypatch):
+    """mw_rasterq.hip draws most quads through its trivial and painter classes; the exact, fallback and over-capacity paths
+    are forced here (MW_DEBUG_FLAGS) and must give the same frames: results do not depend on the class a quad is filed under."""
+    import torch
+    import pyoracle
+    from miniworld_amd import engine as E
+    if case not in ALL_CASES:
+        pytest.skip("fixture not present")
+    monkeypatch.setenv("MW_DEBUG_FLAGS", str(flags))
+    s0, tr, meta, obs = helpers.load_case(case)
+    frames = sorted(obs)[:3]
+    scenes = [helpers.frame_scene(s0, obs[f]) for f in frames]
+    eng = helpers.make_engine_for_scene(s0, len(scenes), msaa=msaa)
+    eng.set_state(helpers.scene_state_arrays(scenes))
+    rgb = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
+    depth = torch.zeros((len(scenes), 60, 80, 1), dtype=torch.float32, device="cuda")
+    eng.render(rgb, depth)
+    eng.check()
+    if msaa == 8 or len(eng._test_mesh_map) == 0:
+        assert eng.raster_path() in (E.PATH_QUAD, E.PATH_QUAD_MESH), eng.raster_path()
+    rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
+    for i, f in enumerate(frames):
+        want = pyoracle.render(scenes[i], nsamples=msaa, meshes=helpers.golden_meshes(s0))
+        assert np.array_equal(depth[i], want["depth"]), f"{case} frame {f} ({what}): depth differs"
+        assert np.array_equal(rgb[i], want["rgb"]), f"{case} frame {f} ({what}): {np.count_nonzero(rgb[i] != want['rgb'])} RGB values differ"
+    eng.close()
+
+
 @pytest.mark.parametrize("case", ALL_CASES)
 def test_top_view_matches_oracle(case):
     """render_top_view (miniworld.py:1088-1175): orthographic map + the agent marker lit by GL's
