@@ -621,8 +621,28 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
 
     // one TRIANGLE per lane: lanes 2k and 2k + 1 of a round hold the two triangles of primitive k (both evaluate its vertex
     // stage; each sets up, clips and writes its own triangle)
-    for (int r0 = 0; r0 < 2 * n_items; r0 += L) {
-        const int item = (r0 + sub) >> 1, tsel = (r0 + sub) & 1;
+    // Rounds: the polygons' triangles fill rounds of their own, then every box gets twelve consecutive lanes of ONE round
+    // (L / 12 boxes to a round), the agent marker a last round — a round is either all polygons or all boxes, so its lanes
+    // share one branch of the vertex stage, and a box never straddles two rounds (its clipped-vertex vote below needs all
+    // twelve lanes).  Groups of 8 lanes cannot hold a box: they keep the plain order, two triangles per primitive.
+    const bool aligned = L >= 16;
+    const int bpr = L / 12;
+    const int poly_rounds = (2 * npd + L - 1) / L, box_rounds = aligned ? (total_boxes + bpr - 1) / bpr : 0;
+    const int n_rounds = aligned ? poly_rounds + box_rounds + marker : (2 * n_items + L - 1) / L;
+    for (int rnd = 0; rnd < n_rounds; ++rnd) {
+        int item, tsel;
+        if (!aligned || rnd < poly_rounds) {
+            const int t = rnd * L + sub;
+            item = t >> 1; tsel = t & 1;
+            if (aligned && item >= npd) item = n_items;         // (behind the polygons of the last polygon round: nothing)
+        } else if (rnd < poly_rounds + box_rounds) {
+            const int b = (rnd - poly_rounds) * bpr + sub / 12, tri = sub % 12;
+            item = (sub < 12 * bpr && b < total_boxes) ? npd + 6 * b + (tri >> 1) : n_items;
+            tsel = tri & 1;
+        } else {
+            item = sub == 0 ? n_items - 1 : n_items;            // the marker: one triangle
+            tsel = 0;
+        }
         int box_slot = -1, box_idbase = 0;
         if (__any(item >= npd && item < npd + 6 * total_boxes)) find_box(item >= npd ? (item - npd) / 6 : -1, box_slot, box_idbase);
         if (!(item >= npd && item < npd + 6 * total_boxes)) box_slot = -1;

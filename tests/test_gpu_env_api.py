@@ -915,6 +915,46 @@ def test_first_mesh_frame_does_not_synchronise():
     vec.close()
 
 
+def test_two_engines_on_two_streams_stay_exact():
+    """Multi-GPU readiness on one GPU: two engines in one process, each stepped on a stream of its own (what two ranks of a
+    node do on two devices, here contending for one): frames, rewards and flags equal those of the same batches stepped
+    alone on the default stream.  (Engines share nothing: state, records, textures and scratch are per engine.)"""
+    import torch
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    mk = lambda: (MiniWorldVecEnv("MiniWorld-Hallway-v0", 768, seed=5), MiniWorldVecEnv("MiniWorld-PickupObjects-v0", 256, seed=9))     # noqa: E731
+    g = torch.Generator(device="cuda").manual_seed(2)
+    acts_a = torch.randint(0, 3, (50, 768), generator=g, device="cuda", dtype=torch.int32)
+    acts_b = torch.randint(0, 5, (50, 256), generator=g, device="cuda", dtype=torch.int32)
+    a, b = mk()
+    a.reset(); b.reset()
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    got = []
+    for t in range(50):
+        with torch.cuda.stream(s1):
+            oa, ra, ta, ua = a.step(acts_a[t])
+        with torch.cuda.stream(s2):
+            ob, rb, tb, ub = b.step(acts_b[t])
+        if t % 10 == 9:
+            s1.synchronize(); s2.synchronize()
+            got.append([x.clone() for x in (oa, ra, ta, ua, ob, rb, tb, ub)])
+    torch.cuda.synchronize()
+    a.engine.check(); b.engine.check()
+    a.close(); b.close()
+    a, b = mk()
+    a.reset(); b.reset()
+    k = 0
+    for t in range(50):
+        oa, ra, ta, ua = a.step(acts_a[t])
+        ob, rb, tb, ub = b.step(acts_b[t])
+        if t % 10 == 9:
+            torch.cuda.synchronize()
+            for x, y in zip(got[k], (oa, ra, ta, ua, ob, rb, tb, ub)):
+                assert torch.equal(x, y), (t, k)
+            k += 1
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("env_id,dr", [("MiniWorld-Hallway-v0", False), ("MiniWorld-OneRoom-v0", True)])
 def test_fused_step_and_geometry_kernel_equals_the_two_launches(env_id, dr, monkeypatch):
     """MW_FUSE_STEP=1 (mw_geom_step_kernel: the dense K1's body as the geometry kernel's prologue, one launch) against the

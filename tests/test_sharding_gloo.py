@@ -82,6 +82,19 @@ def test_bench_launcher_dry_run_spawns_the_ranks_it_reports():
     assert res["value"] > 0 and "dry-run" in res["data"]
 
 
+def test_bench_launcher_dry_run_with_eight_ranks():
+    """`bench.py --gpus 8 --dry`: the rank count of BASELINE.json's 8-GPU configs through the launcher, the sharding plan, the
+    barrier / MAX-reduction / object gather (gloo) — everything of an 8-GPU run but the engine and the wire."""
+    out = _bench("--gpus", "8", "--dry", "--steps", "3", "--warmup", "1", "--config", "pickup_dr")
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and res["scaling"] == "weak" and res["config"]["envs_per_gpu"] == 2048
+    assert res["config"]["parallelism"] == "env-shard x8" and [r["rank"] for r in res["roofline"]["per_rank"]] == list(range(8))
+    assert res["value"] > 0 and "cpu_baseline" not in res and "also" not in res
+
+
 def test_bench_refuses_a_rank_count_it_was_not_asked_for():
     # torch.distributed.run gave us one rank, the command line says two: no line, non-zero exit
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
