@@ -423,14 +423,25 @@ __device__ inline void batch_trivial4(const QCtx &cx, uint32_t ids, int qx, int 
     }
 }
 
-// SKY: nothing touches the quad
+// SKY: nothing touches the quad — the clear colour's bytes (the same for every such pixel of the env: resolved once per
+// wavefront, kept in scalar registers)
 template <int S>
-__device__ inline void batch_sky(const QCtx &cx, int px, int py, bool on)
+__device__ inline uint32_t sky_bytes(const QCtx &cx)
 {
-    SmpQ<S> q;
+    RGB acc = {cx.sky_r, cx.sky_g, cx.sky_b};
 #pragma unroll
-    for (int s = 0; s < S; ++s) { q.r[s] = cx.sky_r; q.g[s] = cx.sky_g; q.b[s] = cx.sky_b; }
-    store_pixel<S>(cx, q, 65535u, px, py, on);
+    for (int s = 1; s < S; ++s) { acc.r = acc.r + cx.sky_r; acc.g = acc.g + cx.sky_g; acc.b = acc.b + cx.sky_b; }
+    const uint32_t v = resolve_u8<S>(acc.r) | (resolve_u8<S>(acc.g) << 8) | (resolve_u8<S>(acc.b) << 16);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+__device__ inline void batch_sky(const QCtx &cx, uint32_t bytes, int px, int py, bool on)
+{
+    if (on) {
+        const int pix = py * cx.W + px;
+        uint8_t *dst = cx.s_frame + pix * 3;
+        dst[0] = (uint8_t)bytes; dst[1] = (uint8_t)(bytes >> 8); dst[2] = (uint8_t)(bytes >> 16);
+        if (cx.depth) cx.s_z[pix] = (uint16_t)65535u;
+    }
 }
 
 // P1-P4: "painter without overlap" — while no sample is claimed twice depth is irrelevant and a claimant's colour goes
@@ -822,6 +833,7 @@ __device__ inline void rasterq_body(
 
         stamp(4);
         // ---- D: batches ------------------------------------------------------------------------------------------------------
+        const uint32_t sky_u8 = sky_bytes<S>(cx);
         const uint32_t n_batches = (dbg & 0x400) ? 0u : first_bat[QC_NCLS];      // (0x400, 0x800, 0x1000: phase timing experiments, frames invalid)
         for (;;) {
             uint32_t b = 0u;
@@ -844,7 +856,7 @@ __device__ inline void rasterq_body(
             const int qy = (int)__umulhi((uint32_t)Q, m_qw), qx = Q - qy * QW;
             const int px = qx * 2 + (lane & 1), py = qy * 2 + ((lane >> 1) & 1);
             const uint32_t ids = on ? s_qids[Q] : 0u;
-            if (cls == QC_SKY) batch_sky<S>(cx, px, py, on);
+            if (cls == QC_SKY) batch_sky(cx, sky_u8, px, py, on);
             else if (cls >= QC_P4) {
                 const bool qc = batch_partial<S>(cx, ids, QC_P1 + 1 - cls, px, py, on);
                 if (qc && on && (lane & 3) == 0) s_xq[atomicAdd(&s_misc[18], 1u)] = (uint16_t)Q;
