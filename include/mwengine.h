@@ -94,7 +94,7 @@ typedef struct {
     int32_t max_ents;           /* entity slots per env, agent excluded            */
     int32_t max_polys;          /* room polygons per geometry set                  */
     int32_t max_segs;           /* collision segments per geometry set             */
-    int32_t max_visible;        /* GL primitives (polygons, box faces) that can be in view per env: the triangle list holds 6 x this (two triangles per primitive, up to three pieces each after clipping); more is an error of mw_check */
+    int32_t max_visible;        /* GL primitives (polygons, box faces) that can be in view per env: the triangle list holds 6 x this (two triangles per primitive, three pieces each after clipping — a heuristic: a triangle across the near plane and two side planes clips to four or five pieces, back-face culling halves the list; mw_get_list_lengths reports what a workload needs).  A longer list is an error of mw_check, never a write out of bounds */
     int32_t shared_geometry;    /* 1: one geometry set for all envs, 0: one per env */
     int32_t task;               /* MW_TASK_*                                       */
     int32_t goal_ent;           /* MW_TASK_GOTO: entity slot of the box            */

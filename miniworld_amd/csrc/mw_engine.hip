@@ -971,7 +971,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_SLOW_BX")) { const int v = atoi(s); if (v > 0) e->slow_bx = v; }
     if (const char *s = getenv("MW_RASTER_BIG")) e->raster_big = atoi(s) != 0 ? 1 : 0;
     e->k2_first_full = getenv("MW_K2_FIRST_FULL") != nullptr;
-    if (getenv("MW_K2Q_PROF")) { if (dev_alloc(e, &e->d_k2q_prof, (size_t)N * 64) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
+    if (getenv("MW_K2Q_PROF")) { if (dev_alloc(e, &e->d_k2q_prof, (size_t)N * 80) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
     {
         // the quad kernel (mw_rasterq.hip) keeps an env's frame, quad lists and triangle records in LDS: frames up to 8192 pixels
         const int S = cfg->msaa == 4 ? 4 : 8;
@@ -990,7 +990,7 @@ void mw_destroy(mw_engine *e)
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipDeviceSynchronize();
     if (e->d_k2q_prof) {
-        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 64);
+        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 80);
         if (hipMemcpy(h.data(), e->d_k2q_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(getenv("MW_K2Q_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }

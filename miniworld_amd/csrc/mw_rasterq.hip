@@ -833,6 +833,7 @@ __device__ inline void rasterq_body(
 
         stamp(4);
         // ---- D: batches ------------------------------------------------------------------------------------------------------
+        if (prof && tid < QC_NCLS) prof[(size_t)N * MWQ_WAVES * 8 + (size_t)env * 16 + tid] = cnt_c[0] * 0ull + s_misc[tid];       // (class sizes, beside the stamps)
         const uint32_t sky_u8 = sky_bytes<S>(cx);
         const uint32_t n_batches = (dbg & 0x400) ? 0u : first_bat[QC_NCLS];      // (0x400, 0x800, 0x1000: phase timing experiments, frames invalid)
         for (;;) {

@@ -74,6 +74,30 @@ def test_quad_kernel_side_paths_equal_the_oracle(case, flags, what, msaa, monkey
     eng.close()
 
 
+@pytest.mark.parametrize("offset", [0, 4, 1])
+def test_observation_buffer_of_any_alignment(offset):
+    """The C ABI takes any device pointer for the observations: the quad kernel's frame leaves as 16-byte stores when the
+    buffer allows it, as dwords or bytes otherwise (a view into a larger allocation) — the same frames each way."""
+    import torch
+    import pyoracle
+    s0, tr, meta, obs = helpers.load_case("hallway_s0")
+    frames = sorted(obs)[:3]
+    scenes = [helpers.frame_scene(s0, obs[f]) for f in frames]
+    eng = helpers.make_engine_for_scene(s0, len(scenes))
+    eng.set_state(helpers.scene_state_arrays(scenes))
+    n = len(scenes) * 60 * 80 * 3
+    big = torch.zeros(n + 64, dtype=torch.uint8, device="cuda")
+    rgb = big[offset:offset + n].view(len(scenes), 60, 80, 3)
+    assert rgb.data_ptr() % 16 == offset
+    eng.render(rgb, None)
+    eng.check()
+    out = rgb.cpu().numpy()
+    for i, f in enumerate(frames):
+        assert np.array_equal(out[i], pyoracle.render(scenes[i])["rgb"]), (offset, f)
+    assert int(big[:offset].sum()) == 0 and int(big[offset + n:].sum()) == 0          # nothing written outside the frames
+    eng.close()
+
+
 @pytest.mark.parametrize("case", ALL_CASES)
 def test_top_view_matches_oracle(case):
     """render_top_view (miniworld.py:1088-1175): orthographic map + the agent marker lit by GL's

@@ -8,7 +8,11 @@ dump = "/tmp/k2qprof.bin"
 env = dict(os.environ, MW_K2Q_PROF=dump)
 subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", cfg, "--steps", "12", "--warmup", "4", "--no-cpu-baseline",
                 "--no-parity-check"], env=env, check=True, stdout=subprocess.DEVNULL)
-t = np.fromfile(dump, np.uint64).reshape(-1, 8, 8).astype(np.int64)      # [env][wave][stamp], 100 MHz ticks
+raw = np.fromfile(dump, np.uint64)
+n_env = raw.size // 80
+t = raw[:n_env * 64].reshape(-1, 8, 8).astype(np.int64)      # [env][wave][stamp], shader clock
+cls = raw[n_env * 64:].reshape(n_env, 16)[:, :9].astype(np.int64)
+print('quads per class, mean per env (FALLBACK BIG EXACT P4 P3 P2 P1 TRIV SKY):', np.round(cls.mean(axis=0), 1).tolist())
 names = ["stage", "A tiles", "B quads", "C classes", "D batches", "wait", "D2 exact", "E(rgb)"]
 d = np.diff(t, axis=2)
 print("per-wave phase durations, us (s_memtime ticks / 100): median / mean / p95 over wavefronts")
