@@ -687,17 +687,17 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // the quad kernel's records take the quad path, the others the tile kernel launched behind it)
     const bool k2q = e->use_k2q && e->k2q_ok && (!big_scene || (e->k2q_big && e->cfg.msaa == 8 && !e->have_meshes)) &&
                      !(e->cfg.msaa == 4 && (e->have_meshes || e->generic_raster));
-    auto launch_k2q = [&](int part_flags, hipStream_t qs) {
+    auto launch_k2q = [&](int part_flags) {
         const int S = e->cfg.msaa;
         const int lds = mw_rasterq_lds_bytes(S, a.W, a.H, a.n_tiles, d_depth ? 1 : 0);
-        const int flags = (e->dbg_flags & 0x1FC8F) | (e->obs_layout << 8) | part_flags;
-        hipLaunchKernelGGL(S == 8 ? mw_rasterq_kernel : mw_rasterq4_kernel, dim3(N), dim3(MW_RASTERQ_THREADS), (size_t)lds, qs, a.N, a.W, a.H, a.max_vis,
+        const int flags = (e->dbg_flags & 0xFC8F) | (e->obs_layout << 8) | part_flags;
+        hipLaunchKernelGGL(S == 8 ? mw_rasterq_kernel : mw_rasterq4_kernel, dim3(N), dim3(MW_RASTERQ_THREADS), (size_t)lds, st, a.N, a.W, a.H, a.max_vis,
                            a.tiles_x, a.n_tiles, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                            (const int32_t *)a.nvis, (const float *)a.envhdr, a.texels, d_obs, d_depth, flags, e->texel_bytes, e->d_k2q_prof,
                            S == 8 ? (const uint16_t *)a.rec_order : nullptr);
     };
     if (k2q && e->cfg.msaa == 4) {
-        launch_k2q(0, st);
+        launch_k2q(0);
         e->last_raster_path = MW_PATH_QUAD;
     } else if (e->cfg.msaa != 8 || a.W > 128 || a.H > 128) {
         // FrameBuffer's fallback sample counts (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES gets 4 or 1
@@ -785,22 +785,16 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         };
         e->last_raster_path = k2q ? (mesh ? MW_PATH_QUAD_MESH : MW_PATH_QUAD) : MW_PATH_TILE;
         if (mesh) {
-            if (k2q) launch_k2q(1 << 4, st); else launch_k2(1 << 4);
+            if (k2q) launch_k2q(1 << 4); else launch_k2(1 << 4);
             HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
             HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
             launch_k2(2 << 4);
         } else if (k2q && big_scene) {
             // the envs whose lists fit the quad kernel's records there, the others in the tile kernel (each skips the other's)
-            // — side by side on two streams: both are bound by their slowest workgroups, not by throughput
-            if (!e->mesh_stream) return fail(e, MW_E_INVALID, "second stream missing");
-            HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
-            HIP_TRY(e, hipStreamWaitEvent(e->mesh_stream, e->ev_mesh_fork, 0));
-            launch_k2q(0x40 | 0x10000, e->mesh_stream);
+            launch_k2q(0x40);
             launch_k2(mw_rasterq_cap(d_depth ? 1 : 0) << 24);
-            HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
-            HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
         } else if (k2q) {
-            launch_k2q(0, st);
+            launch_k2q(0);
         } else {
             launch_k2(0);
         }
@@ -971,7 +965,6 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_GENERIC_RASTER")) e->generic_raster = atoi(s) != 0;
     if (const char *s = getenv("MW_K2Q_BIG")) e->k2q_big = atoi(s) != 0;
     if (const char *s = getenv("MW_FUSE_STEP")) e->fuse_step = atoi(s) != 0;
-    if (e->k2q_big && a.rec_order && ensure_mesh_stream(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->geom_any = getenv("MW_GEOM_ANY") != nullptr;
     if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
     if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;

@@ -175,20 +175,6 @@ __device__ inline uint32_t depth16_s(float a0, float dadx, float dady, float fx,
     return __float_as_uint(z * (65535.0f / 65536.0f) + 128.0f) & 0xffffu;
 }
 
-// 16-bit depth bounds of a triangle over the quad whose first pixel is (px0, gylo): [px0, px0 + 2] x [gylo, gylo + 2] holds every
-// sample position of its four pixels, and the plane's float evaluation fma(dady, y, fma(dadx, x, a0)) is monotone in x and in y
-// (rounding is monotone), like the conversion to 16 bits: the corners bound every sample's depth exactly, no epsilon.
-__device__ inline void quad_depth_bounds(const float4 *rec, int px0, int gylo, uint32_t &zmin16, uint32_t &zmax16)
-{
-    const float4 a2 = rec[2], a3 = rec[3];
-    const float a0 = a2.z, dadx = a2.w, dady = a3.x;
-    const float x0 = (float)px0, x1 = x0 + 2.0f, y0 = (float)gylo, y1 = y0 + 2.0f;
-    const float zlo = fmaf(dady, dady > 0.0f ? y0 : y1, fmaf(dadx, dadx > 0.0f ? x0 : x1, a0));
-    const float zhi = fmaf(dady, dady > 0.0f ? y1 : y0, fmaf(dadx, dadx > 0.0f ? x1 : x0, a0));
-    zmin16 = __float_as_uint(__builtin_amdgcn_fmed3f(zlo, 0.0f, 1.0f) * (65535.0f / 65536.0f) + 128.0f) & 0xffffu;
-    zmax16 = __float_as_uint(__builtin_amdgcn_fmed3f(zhi, 0.0f, 1.0f) * (65535.0f / 65536.0f) + 128.0f) & 0xffffu;
-}
-
 // ---- fragment colour of the lane's triangle at the lane's pixel (x, y: pixel centre) ----------------------------------------
 // The four lanes of a quad hold the same triangle, so the quad's corner coordinates are the neighbours' own values.
 
@@ -588,10 +574,6 @@ __device__ inline void rasterq_body(
     uint32_t *s_misc = reinterpret_cast<uint32_t *>(smem + pl.misc);     // [0..8] class counts, [16] partial events, [17] next batch, [18] exact list, [19] next exact batch
     uint16_t *s_rank = reinterpret_cast<uint16_t *>(s_frame);            // phase C only (the partial events are done with, the frame is not written before phase D)
     uint32_t *s_btab = reinterpret_cast<uint32_t *>(smem + pl.btab);
-    // hidden-surface culling per quad (flag 0x10000: big scenes): nearest covering triangle's farthest 16-bit depth; phases B -> C,
-    // in the frame behind the partial events (tiles x 64 bytes each)
-    uint32_t *s_qz = reinterpret_cast<uint32_t *>(s_frame + (size_t)n_tiles * MWQ_SLOTS * 4);
-    const bool hz = (dbg & 0x10000) != 0;
     const int QW = W / 2, QH = H / 2, nquads = QW * QH;
     // x / d for x < 2^16 as a multiply (the divisors are launch constants)
     const uint32_t m_qw = 0xFFFFFFFFu / (uint32_t)QW + 1u, m_tx = 0xFFFFFFFFu / (uint32_t)tiles_x + 1u;
@@ -705,7 +687,7 @@ __device__ inline void rasterq_body(
         // (the texture's level-0 geometry follows during phase A: a dependent load that need not hold the copy up)
         for (int i = tid; i < nvis * R::NQ; i += MWQ_THREADS) { const int p = i / R::NQ, q = i - p * R::NQ; stage_quad(p, q, s_rec + i, false); }
         for (int i = tid; i < n_tiles; i += MWQ_THREADS) { s_tcnt[i] = 0u; s_tfull[i] = 0u; }
-        for (int i = tid; i < nquads; i += MWQ_THREADS) { s_qids[i] = 0u; if (hz) s_qz[i] = 0xFFFFFFFFu; }
+        for (int i = tid; i < nquads; i += MWQ_THREADS) s_qids[i] = 0u;
         if (tid < 64) s_misc[tid] = 0u;
         __syncthreads();
         stamp(1);
@@ -765,17 +747,11 @@ __device__ inline void rasterq_body(
                 const int qx = tx * 8 + (qi & 7), qy = ty * 2 + (qi >> 3);
                 classify_quad<S>(s_rec + p * R::NQ, qx * 2, H - 2 - qy * 2, touch, full);
                 if (touch) {
-                    // the quad's own list: a place by the counter in bits 24-28, the id into it (four 6-bit places), bits 29-31 = places
-                    // 0-2 cover the quad (a covering triangle in a later place goes unnoticed: the quad then takes a slower class)
+                    // the quad's own list: a place by the counter in bits 24-30, the id into it (four 6-bit places), bit 31 = covered by some triangle
                     uint32_t *qd = s_qids + qy * QW + qx;
-                    const uint32_t slot = (atomicAdd(qd, 1u << 24) >> 24) & 31u;
-                    const uint32_t v = ((full && slot < 3u) ? 0x20000000u << slot : 0u) | (slot < 4u ? (uint32_t)p << (6u * slot) : 0u);
+                    const uint32_t slot = (atomicAdd(qd, 1u << 24) >> 24) & 127u;
+                    const uint32_t v = (full ? 0x80000000u : 0u) | (slot < 4u ? (uint32_t)p << (6u * slot) : 0u);
                     if (v) atomicOr(qd, v);
-                    if (hz && full) {
-                        uint32_t zmin16, zmax16;
-                        quad_depth_bounds(s_rec + p * R::NQ, qx * 2, H - 2 - qy * 2, zmin16, zmax16);
-                        atomicMin(s_qz + qy * QW + qx, zmax16);
-                    }
                 }
             }
             const uint64_t tm = __ballot(touch), fm = __ballot(full);
@@ -791,52 +767,21 @@ __device__ inline void rasterq_body(
             const int qy = (int)__umulhi((uint32_t)Q, m_qw), qx = Q - qy * QW;
             const int tx = qx >> 3, ty = qy >> 1, t = ty * tiles_x + tx;
             const uint32_t v = s_qids[Q], tf = s_tfull[t];
-            const uint32_t np = (v >> 24) & 31u, nf = tf & 255u;
-            uint32_t n = np + nf;
-            bool anyfull = (v >> 29) != 0u || nf != 0u;
-            bool first_full = (np == 0u && nf != 0u) || ((v >> 29) & 1u) != 0u;         // the list's first triangle covers the quad
+            const uint32_t np = (v >> 24) & 127u, nf = tf & 255u, n = np + nf;
+            const bool anyfull = (v >> 31) != 0u || nf != 0u;
             uint32_t ids = v & 0xFFFFFFu;
-            if (hz && np <= 4u && nf <= 3u) {
-                // what lies behind the nearest covering triangle everywhere in the quad owns none of its samples: off the list
-                const int px0 = qx * 2, gylo = H - 2 - qy * 2;
-                uint32_t occ = s_qz[Q], fzmin[3] = {0u, 0u, 0u};
+            if (nf != 0u && np < 4u) ids |= ((tf >> 8) & 63u) << (6u * np);
+            if (wave_any(nf > 1u)) {
 #pragma unroll
-                for (uint32_t j = 0; j < 3u; ++j)
-                    if (j < nf) {
-                        uint32_t zmax16;
-                        quad_depth_bounds(s_rec + ((tf >> (8u + 8u * j)) & 63u) * R::NQ, px0, gylo, fzmin[j], zmax16);
-                        occ = min(occ, zmax16);
-                    }
-                uint32_t ids2 = 0u, n2 = 0u, fb2 = 0u;
-#pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k)
-                    if (k < np) {
-                        const uint32_t id = (v >> (6u * k)) & 63u;
-                        uint32_t zmin16, zmax16;
-                        quad_depth_bounds(s_rec + id * R::NQ, px0, gylo, zmin16, zmax16);
-                        if (zmin16 <= occ) { ids2 |= id << (6u * n2); fb2 |= (k < 3u ? (v >> (29u + k)) & 1u : 0u) << n2; ++n2; }
-                    }
-#pragma unroll
-                for (uint32_t j = 0; j < 3u; ++j)
-                    if (j < nf && fzmin[j] <= occ) {
-                        if (n2 < 4u) { ids2 |= ((tf >> (8u + 8u * j)) & 63u) << (6u * n2); fb2 |= 1u << n2; }
-                        ++n2;
-                    }
-                ids = ids2; n = n2; anyfull = fb2 != 0u; first_full = (fb2 & 1u) != 0u;
-            } else {
-                if (nf != 0u && np < 4u) ids |= ((tf >> 8) & 63u) << (6u * np);
-                if (wave_any(nf > 1u)) {
-#pragma unroll
-                    for (uint32_t j = 1; j < 3u; ++j)
-                        if (j < nf && np + j < 4u) ids |= ((tf >> (8u + 8u * j)) & 63u) << (6u * (np + j));
-                }
+                for (uint32_t j = 1; j < 3u; ++j)
+                    if (j < nf && np + j < 4u) ids |= ((tf >> (8u + 8u * j)) & 63u) << (6u * (np + j));
             }
             ids |= (0xFFFFFFu << (6u * min(n, 4u))) & 0xFFFFFFu;          // the places behind the list: MWQ_EMPTY
             int cls;
             if (mesh_env && tile_in_mesh_rect(hdr, tx, ty)) cls = QC_NONE;
             else if (s_tcnt[t] > MWQ_SLOTS || force_fallback) cls = QC_FALLBACK;
             else if (n == 0u) cls = QC_SKY;
-            else if (n == 1u && first_full && !(dbg & 4)) cls = QC_TRIV;
+            else if (n == 1u && anyfull && !(dbg & 4)) cls = QC_TRIV;
             else if (n > 4u || nf > 3u) cls = QC_BIG;
             else if ((n >= 2u && anyfull) || (dbg & 4)) cls = QC_EXACT;
             else cls = QC_P1 + 1 - (int)n;

@@ -44,8 +44,7 @@ def test_render_matches_golden_and_oracle(case):
 
 @pytest.mark.parametrize("msaa", [8, 4])
 @pytest.mark.parametrize("flags,what", [(4, "every quad through the exact path (packed keys)"), (8, "every quad through the fallback class (all triangles)"),
-                                        (0x80, "records hold 8 triangles: the tile code (8 samples) / the scratch-staged exact path (4)"),
-                                        (0x10000, "hidden-surface pruning of the quads' lists (what big scenes run with)")])
+                                        (0x80, "records hold 8 triangles: the tile code (8 samples) / the scratch-staged exact path (4)")])
 @pytest.mark.parametrize("case", ["hallway_s0", "oneroom_s0", "putnext_s0", "pickup_s0"])
 def test_quad_kernel_side_paths_equal_the_oracle(case, flags, what, msaa, monkeypatch):
     """mw_rasterq.hip draws most quads through its trivial and painter classes; the exact, fallback and over-capacity paths
