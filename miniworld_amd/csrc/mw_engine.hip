@@ -160,6 +160,7 @@ struct mw_engine {
     bool k2q_ok = false;        // the frame fits the quad kernel's LDS plan
     bool fuse_step = false;     // MW_FUSE_STEP=1: K1 as the geometry kernel's prologue, one launch (mw_geom_step_kernel) — measured slower: 85 vs 80 us for 4096
                                 // Hallway envs (at one wavefront per SIMD the step's load -> f64 physics -> store chain is fully exposed)
+    bool mesh_tiles_overlap = true; // MW_MESH_TILES_OVERLAP=0: the mesh tiles behind the quad kernel on the caller's stream
     bool k2q_big = false;       // MW_K2Q_BIG=1 (experiment; measured slower on the Maze: 350 vs 276 us — without the visiting order's early exit the exact path pays for every hidden wall)
     bool generic_raster = false;    // MW_GENERIC_RASTER=1: msaa = 4 frames through the generic-resolution kernel (tests run both)
     bool geom_any = false;      // MW_GEOM_ANY
@@ -773,10 +774,10 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         const int flags = e->dbg_flags | (e->obs_layout << 8) | (int)(mesh_stamp << 16);
         // K2's first part of a frame with meshes never enters a mesh tile: the plain tile code with the skip (the small-scene observation path only)
         auto k2_first = (mesh && !big && !general && !e->k2_first_full) ? (d_depth ? mw_raster_nomesh_depth_kernel : mw_raster_nomesh_kernel) : k2;
-        auto launch_k2 = [&](int part_flags) {
+        auto launch_k2 = [&](int part_flags, hipStream_t ks) {
             // the second part (the tiles a mesh can touch: few, slow, clustered) spreads over one wave per tile
             const int wpe2 = (part_flags >> 4) == 2 ? a.n_tiles : wpe, tpw2 = (part_flags >> 4) == 2 ? 1 : tpw;
-            hipLaunchKernelGGL((part_flags >> 4) == 1 ? k2_first : k2, dim3(groups * 8 * wpe2), dim3(64), lds, st, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+            hipLaunchKernelGGL((part_flags >> 4) == 1 ? k2_first : k2, dim3(groups * 8 * wpe2), dim3(64), lds, ks, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                                a.n_tiles, wpe2, tpw2, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                                (const int32_t *)a.nvis,
                                (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, flags | part_flags, e->texel_bytes,
@@ -785,18 +786,27 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         };
         e->last_raster_path = k2q ? (mesh ? MW_PATH_QUAD_MESH : MW_PATH_QUAD) : MW_PATH_TILE;
         if (mesh) {
-            if (k2q) launch_k2q(1 << 4); else launch_k2(1 << 4);
-            HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
-            HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
-            launch_k2(2 << 4);
+            if (k2q && e->mesh_tiles_overlap) {
+                // the mesh tiles depend on the mesh kernels only, and the quad kernel never writes a mesh tile's pixels: they follow
+                // the mesh kernels on THEIR stream, beside the quad kernel (whose frame-wide pass is the longer of the two)
+                launch_k2q(1 << 4);
+                launch_k2(2 << 4, e->mesh_stream);
+                HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
+                HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
+            } else {
+                if (k2q) launch_k2q(1 << 4); else launch_k2(1 << 4, st);
+                HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
+                HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
+                launch_k2(2 << 4, st);
+            }
         } else if (k2q && big_scene) {
             // the envs whose lists fit the quad kernel's records there, the others in the tile kernel (each skips the other's)
             launch_k2q(0x40);
-            launch_k2(mw_rasterq_cap(d_depth ? 1 : 0) << 24);
+            launch_k2(mw_rasterq_cap(d_depth ? 1 : 0) << 24, st);
         } else if (k2q) {
             launch_k2q(0);
         } else {
-            launch_k2(0);
+            launch_k2(0, st);
         }
         if (mesh) e->mesh_keys_dirty = false;
     }
@@ -964,6 +974,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_K2Q")) e->use_k2q = atoi(s) != 0;
     if (const char *s = getenv("MW_GENERIC_RASTER")) e->generic_raster = atoi(s) != 0;
     if (const char *s = getenv("MW_K2Q_BIG")) e->k2q_big = atoi(s) != 0;
+    if (const char *s = getenv("MW_MESH_TILES_OVERLAP")) e->mesh_tiles_overlap = atoi(s) != 0;
     if (const char *s = getenv("MW_FUSE_STEP")) e->fuse_step = atoi(s) != 0;
     e->geom_any = getenv("MW_GEOM_ANY") != nullptr;
     if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
