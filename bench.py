@@ -146,7 +146,8 @@ def pmc_live(config, kernel, n):
     import shutil
     import tempfile
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
-    if prof is None or os.environ.get("MW_BENCH_CHILD"):
+    # (not inside a profiler's child: this script's own child runs, or a run somebody else is profiling)
+    if prof is None or os.environ.get("MW_BENCH_CHILD") or any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
         return None
     import signal
     out = tempfile.mkdtemp(prefix="mwpmc_", dir="/tmp")
