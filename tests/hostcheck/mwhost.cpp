@@ -244,6 +244,25 @@ extern "C" int mwhost_render(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out
 // glibc's sinf / cosf against the restatement the device uses (exhaustive range test in tests/)
 extern "C" void mwhost_sincosf(float x, float *s, float *c) { sincosf_glibc(x, *s, *c); }
 
+// mw_frag.h: the lod from rho^2's bits (the quad kernel's form) against llvmpipe's float arithmetic, on n bit patterns;
+// returns the number of inputs where level or weight differ for some pyramid of 1 .. 12 levels
+extern "C" long mwhost_lod_bits_mismatches(const uint32_t *bits, long n)
+{
+    long bad = 0;
+    for (long i = 0; i < n; ++i) {
+        const float x = mwgl::u2f(bits[i]);
+        bool b = false;
+        for (int nl = 1; nl <= 12; ++nl) {
+            int l0, w8, l0b, w8b;
+            mwgl::lod_from_rho2(x, nl, l0, w8);
+            mwgl::lod_from_rho2_bits(x, nl, l0b, w8b);
+            b |= l0 != l0b || w8 != w8b;
+        }
+        bad += b ? 1 : 0;
+    }
+    return bad;
+}
+
 // The geometry kernel clips flat-shaded triangles on compact work-list vertices (mwgl::ClipVert: no colour, no clip mask);
 // this hook runs both instantiations of the clipper on the same clip-space triangle and reports whether vertex count,
 // clip coordinates, window coordinates and texture coordinates agree bit for bit.

@@ -29,7 +29,24 @@ def host():
     lib = C.CDLL(LIB)
     lib.mwhost_render.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mwhost_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.mwhost_lod_bits_mismatches.argtypes = [C.c_void_p, C.c_long]
+    lib.mwhost_lod_bits_mismatches.restype = C.c_long
     return lib
+
+
+def test_lod_from_the_bits_of_rho2_equals_the_float_arithmetic(host):
+    """mwgl::lod_from_rho2_bits (mw_rasterq.hip's lod: the conversion of exponent.mantissa to float IS the rounding of
+    (float)e + (m - 1)) against mwgl::lod_from_rho2 (llvmpipe's arithmetic as the oracle states it): every exponent with
+    its extreme and tie mantissas, 4 M random bit patterns, zeros, infinities, NaNs.  (The GPU test runs all 2^32.)"""
+    rng = np.random.default_rng(0)
+    mant = np.array([0, 1, 2, 3, 0x3FFFFF, 0x400000, 0x400001, 0x7FFFFE, 0x7FFFFF, 0x0FFFF, 0x10000, 0x7F8000, 0x7FFF80, 0x7FFFC0], np.uint32)
+    edges = (np.arange(256, dtype=np.uint32)[:, None] << np.uint32(23)) | mant[None, :]
+    edges = np.concatenate([edges.ravel(), edges.ravel() | np.uint32(0x80000000)])
+    rand = rng.integers(0, 2 ** 32, 4_000_000, dtype=np.uint64).astype(np.uint32)
+    # the range where the weight's low bits depend on the rounding: rho2 in [1, 2^24)
+    near = (rng.integers(127, 151, 1_000_000, dtype=np.uint64).astype(np.uint32) << np.uint32(23)) | rng.integers(0, 2 ** 23, 1_000_000, dtype=np.uint64).astype(np.uint32)
+    bits = np.ascontiguousarray(np.concatenate([edges, rand, near]))
+    assert host.mwhost_lod_bits_mismatches(bits.ctypes.data, len(bits)) == 0
 
 
 def host_render(lib, scene, nsamples, meshes, view="agent", render_agent=False, width=80, height=60):
