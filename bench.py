@@ -454,9 +454,9 @@ def main():
     for t in range(args.warmup):
         step(t)
     if not args.dry:
-        # HIP-event timing of the kernels on the launch stream: every other launch for short runs, one in 8 otherwise
+        # HIP-event timing of the kernels on the launch stream: one launch in 4 for short runs, one in 8 otherwise
         # (three event records around a launch cost ~7 us, i.e. ~3 % of the step rate on every launch, measured)
-        stride = 2 if args.steps <= 64 else 8
+        stride = 4 if args.steps <= 64 else 8
         vec.engine.kernel_time_ms(stride)
     barrier()
     t0 = time.perf_counter()
