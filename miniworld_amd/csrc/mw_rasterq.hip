@@ -8,7 +8,7 @@
 // completely by ONE triangle: they need no coverage test, no depth, no per-sample select — only that triangle's colour.
 //
 // One workgroup (MWQ_THREADS lanes) per env:
-//   0  the env's triangle records are staged in LDS (at most MWQ_CAP; the texture's level-0 geometry is folded in)
+//   0  the env's triangle records are staged in LDS (at most MWQ_CAP_MAX; the texture's level-0 geometry is folded in)
 //   A  (tile, triangle) pairs, one per lane: touch / full by the edge functions' extremes over the tile
 //   B  (quad, triangle) pairs of the tiles a triangle touches without covering them: 16-bit touch / full masks
 //   C  every quad collects its triangles (at most four 6-bit ids) and is filed under a class:
@@ -88,7 +88,7 @@ __host__ __device__ inline QPlan q_plan(int S, int W, int H, int n_tiles, bool d
     p.xq = take(nquads * 2);                        // the exact list of phase D
     p.misc = take(64 * 4);
     p.btab = take((nquads / 16 + QC_NCLS) * 4);     // per batch: first quad of the queue | class << 12 | quads << 16
-    p.scratch = p.rec;                              // one record per wavefront (envs with more than MWQ_CAP triangles, 4 samples: no staged records then)
+    p.scratch = p.rec;                              // one record per wavefront (envs with more triangles than the records hold, 4 samples: no staged records then)
     p.total = o;
     return p;
 }
@@ -833,7 +833,7 @@ __device__ inline void rasterq_body(
 
         stamp(4);
         // ---- D: batches ------------------------------------------------------------------------------------------------------
-        if (prof && tid < QC_NCLS) prof[(size_t)N * MWQ_WAVES * 8 + (size_t)env * 16 + tid] = cnt_c[0] * 0ull + s_misc[tid];       // (class sizes, beside the stamps)
+        if (prof && tid < QC_NCLS) prof[(size_t)N * MWQ_WAVES * 8 + (size_t)env * 16 + tid] = s_misc[tid];       // (class sizes, beside the stamps)
         const uint32_t sky_u8 = sky_bytes<S>(cx);
         const uint32_t n_batches = (dbg & 0x400) ? 0u : first_bat[QC_NCLS];      // (0x400, 0x800, 0x1000: phase timing experiments, frames invalid)
         for (;;) {
