@@ -685,7 +685,16 @@ __device__ inline void rasterq_body(
     } else {
         // ---- 0: records -> LDS -------------------------------------------------------------------------------------------
         // (the texture's level-0 geometry follows during phase A: a dependent load that need not hold the copy up)
-        for (int i = tid; i < nvis * R::NQ; i += MWQ_THREADS) { const int p = i / R::NQ, q = i - p * R::NQ; stage_quad(p, q, s_rec + i, false); }
+        // (two loops, so that the copied quads and the computed ones do not share a wavefront's instruction stream: plain copies
+        // by source-index arithmetic, then the three threshold quads of every record on their own few lanes)
+        for (int i = tid; i < nvis * R::CT; i += MWQ_THREADS) {
+            const int p = i / R::CT, q = i - p * R::CT;
+            const int kq = q - 4, k = kq / R::TQ, j = kq - k * R::TQ;                    // thresholds: edge k, quad j of it
+            const float4 *rr = reinterpret_cast<const float4 *>(g_rr + (size_t)p * MW_RASTER_REC);
+            const float4 *src = q < R::SH ? rr + (q < 4 ? q : 4 + 4 * k + j) : g_shade + (size_t)p * (MW_SHADE_REC / 4) + (q - R::SH);
+            s_rec[p * R::NQ + q] = *src;
+        }
+        for (int i = tid; i < nvis * 3; i += MWQ_THREADS) { const int p = i / 3, j = i - p * 3; stage_quad(p, R::CT + j, s_rec + p * R::NQ + R::CT + j, false); }
         for (int i = tid; i < n_tiles; i += MWQ_THREADS) { s_tcnt[i] = 0u; s_tfull[i] = 0u; }
         for (int i = tid; i < nquads; i += MWQ_THREADS) s_qids[i] = 0u;
         if (tid < 64) s_misc[tid] = 0u;
