@@ -168,6 +168,7 @@ struct mw_engine {
     bool scatter_overlap = true;    // MW_SCATTER_OVERLAP=0: the mesh scatter kernel alone, before the raster kernel's first part (the tile kernels' order;
                                     // beside the quad kernel the scatter overlaps well: PickupObjects 0.522 -> 0.495 ms per step)
     int slow_bx = 16;           // MW_SLOW_BX
+    int scatter_bx = 4;         // MW_SCATTER_BX: workgroups per env of the mesh scatter kernel
     int raster_big = -1;        // MW_RASTER_BIG
     bool k2_first_full = false; // MW_K2_FIRST_FULL
     unsigned long long *d_k2q_prof = nullptr;   // MW_K2Q_PROF=<file>: s_memtime stamps of the quad kernel's phases, [N][8 waves][8], dumped by mw_destroy
@@ -743,7 +744,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
                 HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
             }
-            hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(4, N), dim3(256), 0, scatter_first ? st : sb, a.W, a.H, (const float *)a.envhdr, (const float *)e->d_mesh_stream, (const float *)e->d_mesh_attr,
+            hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(e->scatter_bx, N), dim3(256), 0, scatter_first ? st : sb, a.W, a.H, (const float *)a.envhdr, (const float *)e->d_mesh_stream, (const float *)e->d_mesh_attr,
                                e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris);
             if (scatter_first) {
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
@@ -980,6 +981,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
     if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;
     if (const char *s = getenv("MW_SLOW_BX")) { const int v = atoi(s); if (v > 0) e->slow_bx = v; }
+    if (const char *s = getenv("MW_SCATTER_BX")) { const int v = atoi(s); if (v > 0 && v <= 64) e->scatter_bx = v; }
     if (const char *s = getenv("MW_RASTER_BIG")) e->raster_big = atoi(s) != 0 ? 1 : 0;
     e->k2_first_full = getenv("MW_K2_FIRST_FULL") != nullptr;
     if (getenv("MW_K2Q_PROF")) { if (dev_alloc(e, &e->d_k2q_prof, (size_t)N * 80) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
