@@ -168,6 +168,7 @@ struct mw_engine {
     bool scatter_overlap = true;    // MW_SCATTER_OVERLAP=0: the mesh scatter kernel alone, before the raster kernel's first part (the tile kernels' order;
                                     // beside the quad kernel the scatter overlaps well: PickupObjects 0.522 -> 0.495 ms per step)
     int slow_bx = 16;           // MW_SLOW_BX
+    int mesh_wpe = 0;           // MW_MESH_WPE: wavefronts per env of the mesh tiles' launch (0: one per tile)
     int scatter_bx = 4;         // MW_SCATTER_BX: workgroups per env of the mesh scatter kernel
     int raster_big = -1;        // MW_RASTER_BIG
     bool k2_first_full = false; // MW_K2_FIRST_FULL
@@ -777,7 +778,8 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         auto k2_first = (mesh && !big && !general && !e->k2_first_full) ? (d_depth ? mw_raster_nomesh_depth_kernel : mw_raster_nomesh_kernel) : k2;
         auto launch_k2 = [&](int part_flags, hipStream_t ks) {
             // the second part (the tiles a mesh can touch: few, slow, clustered) spreads over one wave per tile
-            const int wpe2 = (part_flags >> 4) == 2 ? a.n_tiles : wpe, tpw2 = (part_flags >> 4) == 2 ? 1 : tpw;
+            const int wpe2 = (part_flags >> 4) == 2 ? (e->mesh_wpe > 0 ? std::min(e->mesh_wpe, (int)a.n_tiles) : a.n_tiles) : wpe;
+            const int tpw2 = (part_flags >> 4) == 2 ? (a.n_tiles + wpe2 - 1) / wpe2 : tpw;
             hipLaunchKernelGGL((part_flags >> 4) == 1 ? k2_first : k2, dim3(groups * 8 * wpe2), dim3(64), lds, ks, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                                a.n_tiles, wpe2, tpw2, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                                (const int32_t *)a.nvis,
@@ -981,6 +983,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
     if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;
     if (const char *s = getenv("MW_SLOW_BX")) { const int v = atoi(s); if (v > 0) e->slow_bx = v; }
+    if (const char *s = getenv("MW_MESH_WPE")) e->mesh_wpe = atoi(s);
     if (const char *s = getenv("MW_SCATTER_BX")) { const int v = atoi(s); if (v > 0 && v <= 64) e->scatter_bx = v; }
     if (const char *s = getenv("MW_RASTER_BIG")) e->raster_big = atoi(s) != 0 ? 1 : 0;
     e->k2_first_full = getenv("MW_K2_FIRST_FULL") != nullptr;
