@@ -359,11 +359,14 @@ int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *se
 /* The `info` dict of the envs' step() as device arrays, asynchronous on `stream` (either pointer may be NULL):
  *   d_health  int32[N]     CollectHealth: info["health"] (collecthealth.py:100)
  *   d_ent_pos double[N][3] position of entity slot `ent_slot`: TMaze / YMaze info["goal_pos"] = box.pos (tmaze.py:89, ymaze.py:125)
- * Values are those of the state the device holds: with MW_AUTORESET_SAME_STEP an env that just finished reports its new episode. */
+ * Values are those of the state the device holds: with MW_AUTORESET_SAME_STEP an env that just finished reports its new episode.
+ * d_health on an engine whose task is not MW_TASK_COLLECT is MW_E_INVALID (there is no health array). */
 int mw_get_info(mw_engine *e, int32_t *d_health, double *d_ent_pos, int32_t ent_slot, void *stream);
 
 /* Diagnostic (synchronises `stream`): how many triangles the last frame's display list held per env after clipping and culling —
- * what max_visible has to pay for (6 records per unit), and what decides which raster kernel an env's frame takes. */
+ * what max_visible has to pay for (6 records per unit), and what decides which raster kernel an env's frame takes.
+ * The stored length is clamped to the list's capacity (6 x max_visible): a value EQUAL to the capacity means "at least this
+ * many" — raise max_visible and look again (mw_check reports the overflow itself as MW_E_CAPACITY). */
 int mw_get_list_lengths(mw_engine *e, int32_t first_env, int32_t count, int32_t *host_out, void *stream);
 
 enum { MW_PATH_TILE = 0, MW_PATH_QUAD = 1, MW_PATH_QUAD_MESH = 2, MW_PATH_GENERIC = 3 };

@@ -612,6 +612,8 @@ int ensure_mesh_buffers(mw_engine *e)
         }
         e->d_mesh_keys = (uint32_t *)keys; e->d_slow_count = (int32_t *)cnt; e->d_slow_tris = (uint32_t *)tris;
         e->d_slow_frags = (float4 *)frags; e->d_slow_head = (uint32_t *)head;
+        // (the memsets above ran on the null stream, which a caller's non-blocking stream is not ordered against: finish them here)
+        (void)hipDeviceSynchronize();
         e->mesh_keys_dirty = false;
     }
     return MW_OK;
@@ -1438,6 +1440,8 @@ int mw_get_info(mw_engine *e, int32_t *d_health, double *d_ent_pos, int32_t ent_
     if (!e) return MW_E_INVALID;
     if (!d_health && !d_ent_pos) return fail(e, MW_E_INVALID, "mw_get_info: nothing asked for");
     if (d_ent_pos && (ent_slot < 0 || ent_slot >= e->args.E)) return fail(e, MW_E_INVALID, "mw_get_info: entity slot %d out of range", ent_slot);
+    // (the health array exists for the CollectHealth rule only: collecthealth.py:79-100)
+    if (d_health && !e->args.health) return fail(e, MW_E_INVALID, "mw_get_info: this engine's task keeps no health (MW_TASK_COLLECT only)");
     ON_DEVICE(e);
     const int N = e->cfg.num_envs;
     hipLaunchKernelGGL(mw_info_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, e->args.E, (const int32_t *)e->args.health,

@@ -42,6 +42,11 @@ __device__ inline float div_exact(float a, float y, float b)
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
 #define MW_RSRC_WORD3 0x00020000
+
+// x / d for x < 2^16 as a multiply-high by m = ceil(2^32 / d).  d == 1 has no 32-bit m (it would be 2^32 and the sum wraps
+// to 0 — an env with ONE visible triangle, a 16-pixel-wide frame): m = 0 stands for "divide by one".
+__device__ inline uint32_t mw_magic16(uint32_t d) { return d > 1u ? 0xFFFFFFFFu / d + 1u : 0u; }
+__device__ inline uint32_t mw_div16(uint32_t x, uint32_t m) { return m ? __umulhi(x, m) : x; }
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ inline uint32_t ldw(rsrc_t r, uint32_t dword_index)
@@ -302,7 +307,7 @@ __device__ inline void classify_group(const float4 *s_cull, int cull_stride, int
     uint32_t eo = 0u;
     if (g < G) {
         const uint32_t idx = (uint32_t)(tile0 + g);
-        const uint32_t ty = __umulhi(idx, 0xFFFFFFFFu / (uint32_t)tiles_x + 1u);  // idx / tiles_x, exact for idx < 2^16
+        const uint32_t ty = mw_div16(idx, mw_magic16((uint32_t)tiles_x));        // idx / tiles_x, exact for idx < 2^16
         const uint32_t tx = idx - ty * (uint32_t)tiles_x;
         const int pxlo = (int)(tx * MW_TILE_W), pxhi = pxlo + MW_TILE_W - 1;
         const int gyhi = H - 1 - (int)(ty * MW_TILE_H), gylo = gyhi - (MW_TILE_H - 1);

@@ -576,7 +576,7 @@ __device__ inline void rasterq_body(
     uint32_t *s_btab = reinterpret_cast<uint32_t *>(smem + pl.btab);
     const int QW = W / 2, QH = H / 2, nquads = QW * QH;
     // x / d for x < 2^16 as a multiply (the divisors are launch constants)
-    const uint32_t m_qw = 0xFFFFFFFFu / (uint32_t)QW + 1u, m_tx = 0xFFFFFFFFu / (uint32_t)tiles_x + 1u;
+    const uint32_t m_qw = 0xFFFFFFFFu / (uint32_t)QW + 1u /* QW >= 8 */, m_tx = mw_magic16((uint32_t)tiles_x);
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     const int nvis = nvis_arr[env];
     const int part_mode = (dbg >> 4) & 3;        // 1: every tile but those a mesh entity can touch (the mesh-aware tile kernel draws those)
@@ -710,10 +710,10 @@ __device__ inline void rasterq_body(
             my_tex = __float_as_int(s_rec[tid * R::NQ + R::SH].w);
             if (my_tex >= 0) { my_w = texd[my_tex].w; my_h = texd[my_tex].h; my_nl = texd[my_tex].nlevels; }
         }
-        const uint32_t m_nvis = (uint32_t)__builtin_amdgcn_readfirstlane((int)(0xFFFFFFFFu / (uint32_t)max(nvis, 1) + 1u));
+        const uint32_t m_nvis = (uint32_t)__builtin_amdgcn_readfirstlane((int)mw_magic16((uint32_t)max(nvis, 1)));
         for (int i = tid; i < n_tiles * nvis; i += MWQ_THREADS) {
-            const int t = (int)__umulhi((uint32_t)i, m_nvis), p = i - t * nvis;
-            const int ty = (int)__umulhi((uint32_t)t, m_tx), tx = t - ty * tiles_x;
+            const int t = (int)mw_div16((uint32_t)i, m_nvis), p = i - t * nvis;
+            const int ty = (int)mw_div16((uint32_t)t, m_tx), tx = t - ty * tiles_x;
             bool touch, full;
             classify_tile<S>(s_rec + p * R::NQ, tx * MW_TILE_W, H - MW_TILE_H - ty * MW_TILE_H, touch, full);
             if (touch) {
@@ -752,7 +752,7 @@ __device__ inline void rasterq_body(
                 const uint32_t ep = s_pe[j];
                 e = ep & 0xFFFFu;
                 const int t = (int)(e / MWQ_SLOTS), p = (int)(ep >> 16);
-                const int ty = (int)__umulhi((uint32_t)t, m_tx), tx = t - ty * tiles_x;
+                const int ty = (int)mw_div16((uint32_t)t, m_tx), tx = t - ty * tiles_x;
                 const int qx = tx * 8 + (qi & 7), qy = ty * 2 + (qi >> 3);
                 classify_quad<S>(s_rec + p * R::NQ, qx * 2, H - 2 - qy * 2, touch, full);
                 if (touch) {

@@ -68,7 +68,7 @@ def goals_of(meta):
 # ------------------------------------------------------------------ engine glue (GPU tests)
 
 def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_rand=False, max_visible=None,
-                          goal_ent=0, goal_ent2=-1, agent_radius=0.4, msaa=8):
+                          goal_ent=0, goal_ent2=-1, agent_radius=0.4, msaa=8, width=80, height=60):
     """Engine with the scene's shared geometry / textures uploaded (state not yet set)."""
     from miniworld_amd import engine as eng
     from miniworld_amd import assets
@@ -77,7 +77,7 @@ def make_engine_for_scene(s0, n_envs, task=1, max_episode_steps=None, domain_ran
     P, S = len(s0["polys_nv"]), len(s0["wall_segs"])
     cfg.device_id = 0
     cfg.num_envs = n_envs
-    cfg.obs_width, cfg.obs_height, cfg.msaa = 80, 60, msaa
+    cfg.obs_width, cfg.obs_height, cfg.msaa = width, height, msaa
     cfg.max_ents, cfg.max_polys, cfg.max_segs = E, P, S
     cfg.max_visible = max_visible or -(-(P + 6 * E) // 16) * 16
     cfg.shared_geometry = 1

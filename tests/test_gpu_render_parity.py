@@ -74,6 +74,75 @@ def test_quad_kernel_side_paths_equal_the_oracle(case, flags, what, msaa, monkey
     eng.close()
 
 
+@pytest.mark.parametrize("msaa", [8, 4])
+def test_frame_inside_one_triangle_of_a_wall(msaa):
+    """An agent 10 cm from a Hallway wall sees ONE triangle of the wall's quad: the display list holds a single record
+    (the quad kernel's (tile, triangle) index arithmetic divides by that count: the magic-number division has no 32-bit
+    multiplier for 1).  Every tile of the frame must show the wall, like the oracle's."""
+    import torch
+    import pyoracle
+    from miniworld_amd import engine as E
+    s0, tr, meta, obs = helpers.load_case("hallway_s0")
+    base = helpers.frame_scene(s0, obs[sorted(obs)[0]])
+    segs = np.asarray(s0["wall_segs"], np.float64).reshape(-1, 2, 2)
+    scenes = []
+    for s in segs:                                # face every wall segment from 10 cm, near both of its ends and in the middle
+        a, b = s
+        d = b - a
+        L = float(np.hypot(*d))
+        if L < 1.0:
+            continue
+        n = np.array([-d[1], d[0]]) / L           # one of the two normals; the other side is tried as well
+        for f in (0.1, 0.5, 0.9):
+            for sgn in (1.0, -1.0):
+                p = a + f * d + sgn * 0.1 * n
+                sc = dict(base)
+                sc["agent_pos"] = np.array([p[0], 0.0, p[1]])
+                # dir_vec = (cos d, 0, -sin d): look along -sgn * n
+                sc["agent_dir"] = np.float64(np.arctan2(sgn * n[1], -sgn * n[0]))
+                scenes.append(sc)
+    eng = helpers.make_engine_for_scene(s0, len(scenes), msaa=msaa)
+    eng.set_state(helpers.scene_state_arrays(scenes))
+    rgb = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
+    depth = torch.zeros((len(scenes), 60, 80, 1), dtype=torch.float32, device="cuda")
+    eng.render(rgb, depth)
+    eng.check()
+    assert eng.raster_path() == E.PATH_QUAD
+    nvis = eng.list_lengths()
+    assert (nvis == 1).sum() >= 2, f"no single-triangle frame among {len(scenes)} poses: {sorted(set(nvis.tolist()))}"
+    rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
+    for i in np.flatnonzero(nvis <= 2):
+        want = pyoracle.render(scenes[i], nsamples=msaa)
+        assert np.array_equal(rgb[i], want["rgb"]), f"pose {i} (list of {nvis[i]}): {np.count_nonzero(rgb[i] != want['rgb'])} RGB values differ"
+        assert np.array_equal(depth[i], want["depth"]), f"pose {i}: depth differs"
+    eng.close()
+
+
+@pytest.mark.parametrize("size", [(16, 12), (16, 60), (32, 4), (128, 128)])
+@pytest.mark.parametrize("msaa", [8, 4])
+def test_observation_sizes_at_the_edges_of_the_tile_kernels(size, msaa):
+    """mw_create accepts any multiple of the 16 x 4 tile up to 128 x 128 for the tile / quad kernels: one tile column
+    (16 pixels wide: the tile index arithmetic divides by tiles_x = 1), one tile row, the largest frame."""
+    import torch
+    import pyoracle
+    W, H = size
+    s0, tr, meta, obs = helpers.load_case("hallway_s0")
+    frames = sorted(obs)[:3]
+    scenes = [helpers.frame_scene(s0, obs[f]) for f in frames]
+    eng = helpers.make_engine_for_scene(s0, len(scenes), msaa=msaa, width=W, height=H)
+    eng.set_state(helpers.scene_state_arrays(scenes))
+    rgb = torch.zeros((len(scenes), H, W, 3), dtype=torch.uint8, device="cuda")
+    depth = torch.zeros((len(scenes), H, W, 1), dtype=torch.float32, device="cuda")
+    eng.render(rgb, depth)
+    eng.check()
+    rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
+    for i, f in enumerate(frames):
+        want = pyoracle.render(scenes[i], width=W, height=H, nsamples=msaa)
+        assert np.array_equal(rgb[i], want["rgb"]), f"{W}x{H} frame {f}: {np.count_nonzero(rgb[i] != want['rgb'])} RGB values differ"
+        assert np.array_equal(depth[i], want["depth"]), f"{W}x{H} frame {f}: depth differs"
+    eng.close()
+
+
 @pytest.mark.parametrize("offset", [0, 4, 1])
 def test_observation_buffer_of_any_alignment(offset):
     """The C ABI takes any device pointer for the observations: the quad kernel's frame leaves as 16-byte stores when the
