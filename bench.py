@@ -41,8 +41,31 @@ CONFIGS = {
     "maze": ("MiniWorld-Maze-v0", "Maze", 1024, False, False, 3, 1, 30860, "mw_raster_big_kernel"),
     "pickup_dr": ("MiniWorld-PickupObjects-v0", "PickupObjects", 2048, False, True, 5, 2, 14800, "mw_rasterq_kernel"),
 }
+# The kernels between the engine's second and third timing event (`roofline.kernel_ms`: everything of a frame behind the
+# geometry kernel).  roofline.traffic is the SUM of their PMC bytes, with the per-kernel breakdown beside it: with mesh
+# entities the raster phase is several kernels on two streams, and the dominant one alone would under-report the waste.
+RASTER_PHASE = {
+    "hallway": ("mw_rasterq_kernel",),
+    "oneroom_rgbd": ("mw_rasterq_kernel",),
+    "maze": ("mw_raster_big_kernel",),
+    "pickup_dr": ("mw_rasterq_kernel", "mw_mesh_scatter_kernel", "mw_mesh_slow_kernel", "mw_raster_mesh_kernel"),
+}
+ALSO = ("oneroom_rgbd", "maze", "pickup_dr")      # BASELINE.json configs[2..4], timed after the headline in the default run
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 PREWARM_S = 0.5             # untimed steps before the W warm-up steps: clocks and caches of a cold box (reported)
+
+
+def _traffic_sum(per_kernel, source, extra=None):
+    """per_kernel: {name: (fetch_bytes_raw, write_bytes)} -> the traffic dict of a bench line (FETCH doubled: gfx950)."""
+    if not per_kernel:
+        return None
+    out = {"bytes_per_launch": sum(2.0 * f + w for f, w in per_kernel.values()),
+           "fetch_bytes": sum(2.0 * f for f, w in per_kernel.values()), "write_bytes": sum(w for f, w in per_kernel.values()),
+           "fetch_bytes_raw_counter": sum(f for f, w in per_kernel.values()),
+           "per_kernel": {k: {"bytes": 2.0 * f + w, "fetch_bytes": 2.0 * f, "write_bytes": w} for k, (f, w) in per_kernel.items()},
+           "source": source}
+    out.update(extra or {})
+    return out
 
 
 def pmc_profiled(kernel, config, n):
@@ -60,10 +83,8 @@ def pmc_profiled(kernel, config, n):
     if files:
         try:
             j = json.load(open(files[-1]))
-            d = j.get(kernel)
-            traffic = {"bytes_per_launch": (d["FETCH_SIZE_KiB_mean"] + d["WRITE_SIZE_KiB_mean"]) * 1024.0,
-                       "fetch_bytes": d["FETCH_SIZE_KiB_mean"] * 1024.0, "write_bytes": d["WRITE_SIZE_KiB_mean"] * 1024.0,
-                       "source": os.path.relpath(files[-1], ROOT), "commit": (j.get("_meta") or {}).get("commit")}
+            per = {k: (j[k]["FETCH_SIZE_KiB_mean"] * 1024.0, j[k]["WRITE_SIZE_KiB_mean"] * 1024.0) for k in RASTER_PHASE[config] if k in j}
+            traffic = _traffic_sum(per, os.path.relpath(files[-1], ROOT) + " (FETCH_SIZE x 2: gfx950)", {"commit": (j.get("_meta") or {}).get("commit")})
         except Exception:  # noqa: BLE001
             traffic = None
     name = "pmc_all_summary.json" if config == "hallway" else f"pmc_all_summary_{config}.json"
@@ -138,10 +159,10 @@ def reference_llvmpipe(config):
     return None
 
 
-def pmc_live(config, kernel, n):
-    """FETCH_SIZE / WRITE_SIZE of one launch of `kernel`, read during this run: a short child run of this script under
-    rocprofv3 (--pmc with --kernel-trace only, one pass per counter pair) when the profiler is on the box.  Returns a
-    traffic dict like pmc_profiled's, or None."""
+def pmc_live(config, n):
+    """FETCH_SIZE / WRITE_SIZE per launch of the raster-phase kernels of `config` (RASTER_PHASE), read during this run: a
+    short child run of this script under rocprofv3 (--pmc with --kernel-trace only, one pass per counter) when the profiler
+    is on the box.  Returns a traffic dict like pmc_profiled's (sum + per-kernel breakdown), or None."""
     import csv
     import shutil
     import tempfile
@@ -152,7 +173,8 @@ def pmc_live(config, kernel, n):
     import signal
     out = tempfile.mkdtemp(prefix="mwpmc_", dir="/tmp")
     env = dict(os.environ, MW_BENCH_CHILD="1", TMPDIR="/tmp")
-    vals = {"FETCH_SIZE": [], "WRITE_SIZE": []}
+    kernels = RASTER_PHASE[config]
+    vals = {"FETCH_SIZE": {k: [] for k in kernels}, "WRITE_SIZE": {k: [] for k in kernels}}
     try:
         for counter in vals:        # one counter per pass (MI355X_MICROARCH.md: separate --pmc passes), bounded in time
             p = subprocess.Popen([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "pmc", "--",
@@ -169,16 +191,21 @@ def pmc_live(config, kernel, n):
             for f in files:
                 if f.endswith("counter_collection.csv"):
                     for r in csv.DictReader(open(os.path.join(root, f))):
-                        if r["Kernel_Name"].startswith(kernel) and r["Counter_Name"] in vals:
-                            vals[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        if not vals["FETCH_SIZE"] or not vals["WRITE_SIZE"]:
+                        if r["Counter_Name"] in vals:
+                            for k in kernels:       # (exact name or its signature: mw_rasterq_kernel must not take mw_rasterq4_kernel's rows)
+                                if r["Kernel_Name"] == k or r["Kernel_Name"].startswith(k + "(") or r["Kernel_Name"].startswith(k + " "):
+                                    vals[r["Counter_Name"]][k].append(float(r["Counter_Value"]))
+        per = {}
+        for k in kernels:
+            fv, wv = vals["FETCH_SIZE"][k], vals["WRITE_SIZE"][k]
+            if fv and wv:           # KiB per launch (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KiB)
+                per[k] = (sum(fv) / len(fv) * 1024.0, sum(wv) / len(wv) * 1024.0)
+        if kernels[0] not in per:
             return None
-        fetch = sum(vals["FETCH_SIZE"]) / len(vals["FETCH_SIZE"]) * 1024.0      # KiB per launch (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KiB)
-        write = sum(vals["WRITE_SIZE"]) / len(vals["WRITE_SIZE"]) * 1024.0
-        # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests at 64 bytes — doubled here
-        return {"bytes_per_launch": 2.0 * fetch + write, "fetch_bytes": 2.0 * fetch, "fetch_bytes_raw_counter": fetch, "write_bytes": write,
-                "launches": len(vals["FETCH_SIZE"]),
-                "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) --kernel-trace, child runs of this command; FETCH_SIZE x 2 (gfx950)"}
+        # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests at 64 bytes — doubled in the sum
+        return _traffic_sum(per, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) --kernel-trace, child runs of this command; "
+                                 "FETCH_SIZE x 2 (gfx950); summed over the raster-phase kernels kernel_ms spans",
+                            {"launches": len(vals["FETCH_SIZE"][kernels[0]])})
     except Exception:  # noqa: BLE001
         return None
     finally:
@@ -308,40 +335,6 @@ def self_launch(args, argv):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def time_config(config, steps, warmup, device_id=0):
-    """One more BASELINE config timed in this process after the headline (the `also` list of the JSON line): same protocol —
-    pre-generated random actions, W warm-up steps, K timed steps between synchronisations, HIP-event kernel times, the
-    parity spot check after the clock has stopped.  Never touches `value`."""
-    import torch
-    from miniworld_amd.vec_env import MiniWorldVecEnv
-    env_id, _, n, want_depth, dr, n_act, _, algo_bytes, dominant = CONFIGS[config]
-    vec = MiniWorldVecEnv(env_id, n, device_id=device_id, seed=0, want_depth=want_depth, domain_rand=dr)
-    vec.reset()
-    g = torch.Generator(device=f"cuda:{device_id}").manual_seed(4321)
-    actions = torch.randint(0, n_act, (steps + warmup, n), generator=g, device=f"cuda:{device_id}", dtype=torch.int32)
-    for t in range(warmup):
-        vec.step(actions[t])
-    vec.engine.kernel_time_ms(2 if steps <= 64 else 8)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for t in range(warmup, warmup + steps):
-        vec.step(actions[t])
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    raster_ms, setup_ms, launches = vec.engine.kernel_time_ms(-1)
-    vec.engine.check()
-    parity = parity_spot_check(vec, actions[warmup + steps - 1], config)
-    vec.close()
-    achieved = algo_bytes * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
-    return {"config": {"workload": f"{env_id}, {n} batched envs, 80x60 RGB{'-D' if want_depth else ''}, 8x MSAA, random actions, "
-                                   f"{'domain_rand, ' if dr else ''}auto-reset", "name": config, "envs_per_gpu": n},
-            "value": n * steps / elapsed, "unit": "env-steps/s", "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
-            "parity_checked": parity,
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "algorithmic_bytes_per_launch": algo_bytes * n,
-                         "kernel_ms": raster_ms, "setup_kernel_ms": setup_ms, "launches_timed": launches}}
-
-
 class _DryVec:
     """--dry: stands in for the engine so that the launcher / sharding / reduction path runs on a CPU-only box."""
 
@@ -351,6 +344,147 @@ class _DryVec:
 
     def step(self, _):
         self.x += 1.0
+
+
+def measure(args, ctx, config, n, steps, warmup, headline):
+    """One BASELINE config through the whole protocol: engine of `n` envs per rank, pre-generated random actions, pre-warm,
+    W warm-up steps, K timed steps between barriers (MAX over ranks), HIP-event kernel times (one launch in 4 / 8), the parity
+    spot check after the clock has stopped, PMC traffic of the raster-phase kernels read by child runs (single GPU).
+    Returns the JSON object of the line (the headline's, or an entry of its `also` list) on rank 0, None elsewhere."""
+    import torch
+    from miniworld_amd.sharding import ObsAllGather, gather_objects, max_over_ranks, shard_plan
+    rank, world, local, dist, device = ctx["rank"], ctx["world"], ctx["local"], ctx["dist"], ctx["device"]
+    env_id, _, _, want_depth, dr, n_act, _, algo_bytes, dominant = CONFIGS[config]
+    plan = shard_plan(rank, world, n)
+    if args.dry:
+        vec = _DryVec(n)
+    else:
+        from miniworld_amd.vec_env import MiniWorldVecEnv
+        vec = MiniWorldVecEnv(env_id, n, device_id=local, seed=plan["first_seed"], want_depth=want_depth, domain_rand=dr)
+        vec.reset()
+    total = steps + warmup
+    g = torch.Generator(device=device).manual_seed(1234 + rank)
+    actions = torch.randint(0, n_act, (total, n), generator=g, device=device, dtype=torch.int32)
+
+    gath = None
+    if headline and args.gather_obs and dist is not None:
+        gath = ObsAllGather(dist, torch.zeros((n, 60, 80, 3), dtype=torch.uint8) if args.dry else vec.obs)
+
+    def step(t):
+        vec.step(actions[t])
+        if gath is not None:
+            gath.gather(gath.stage[0] if args.dry else vec.obs)
+
+    def sync():
+        if not args.dry:
+            torch.cuda.synchronize()
+
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+            sync()
+
+    # pre-warm: a cold box (fresh lease, idle clocks, cold L2 / instruction caches) is not what the metric describes;
+    # untimed and reported, separate from the W warm-up steps of the contract
+    t_pre = time.perf_counter()
+    k = 0
+    while not args.dry and (k < args.prewarm_steps if args.prewarm_steps else time.perf_counter() - t_pre < PREWARM_S):
+        for _ in range(16):
+            vec.step(actions[k % total])
+            k += 1
+        sync()
+    prewarm_s = time.perf_counter() - t_pre
+    for t in range(warmup):
+        step(t)
+    if not args.dry:
+        # HIP-event timing of the kernels on the launch stream: one launch in 4 for short runs, one in 8 otherwise
+        # (three event records around a launch cost ~7 us, i.e. ~3 % of the step rate on every launch, measured)
+        vec.engine.kernel_time_ms(4 if steps <= 64 else 8)
+    barrier()
+    t0 = time.perf_counter()
+    for t in range(warmup, total):
+        step(t)
+    if gath is not None:
+        gath.wait()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    raster_ms = setup_ms = 0.0
+    launches = parity = 0
+    if not args.dry:
+        raster_ms, setup_ms, launches = vec.engine.kernel_time_ms(-1)
+        vec.engine.check()
+        # sanity: the frames are real (a static or empty frame would be an invalid measurement)
+        m = float(vec.obs.float().mean())
+        assert 1.0 < m < 254.0, f"degenerate observation tensor (mean {m})"
+        if not args.no_parity_check:
+            parity = parity_spot_check(vec, actions[total - 1], config)
+        vec.close()
+    del vec
+
+    elapsed_max = max_over_ranks(dist, elapsed, device=device) if dist is not None else elapsed
+    achieved = algo_bytes * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
+    mine = {"rank": rank, "device": local, "envs": n, "first_seed": plan["first_seed"], "elapsed_s": elapsed,
+            "kernel_ms": raster_ms, "setup_kernel_ms": setup_ms, "launches_timed": launches, "achieved": achieved,
+            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "parity_checked": parity}
+    per_rank = gather_objects(dist, mine) if dist is not None else [mine]
+    if rank != 0:
+        return None
+    if len(per_rank) != args.gpus or sorted(r["rank"] for r in per_rank) != list(range(args.gpus)):
+        sys.exit(f"bench.py: {len(per_rank)} rank(s) reported, {args.gpus} asked")
+    steps_per_s = world * n * steps / elapsed_max
+    slow = max(per_rank, key=lambda r: r["kernel_ms"])          # the roofline entry is the slowest rank's
+    traffic, valu = pmc_profiled(dominant, config, n)
+    # counters read during THIS run when the profiler is on the box (short child runs under rocprofv3), else the committed profile's
+    live = pmc_live(config, n) if (world == 1 and not args.dry and not args.no_pmc) else None
+    if live is not None:
+        traffic = live
+    out = {
+        "metric": "env-steps/s (batched, 80x60 RGB)",
+        "value": steps_per_s,
+        "unit": "env-steps/s",
+        "n_gpus": world,
+        "steps": steps,
+        "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed_max / steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic" if not args.dry else "dry-run: no GPU work, launcher / sharding path only",
+        "config": {"workload": f"{env_id}, {n} batched envs per GPU, 80x60 RGB{'-D' if want_depth else ''}, 8x MSAA, "
+                               f"random actions, {'domain_rand, ' if dr else ''}auto-reset",
+                   "name": config, "envs_per_gpu": n, "parallelism": f"env-shard x{world}",
+                   "obs_allgather": gath is not None, "torch_distributed": dist is not None},
+        "samples_per_s": steps_per_s * 80 * 60 * 8,
+        "prewarm_s": prewarm_s,
+        "parity_checked": sum(r["parity_checked"] for r in per_rank),
+        "roofline": {
+            "bound": "hbm",
+            "kernel": dominant,
+            "kernels_timed": list(RASTER_PHASE[config]),
+            "achieved": slow["achieved"],
+            "peak": HBM_PEAK_GBPS,
+            "unit": "GB/s",
+            "frac": slow["frac"],
+            "traffic": traffic["bytes_per_launch"] if traffic else None,
+            "traffic_profiled": traffic,
+            "valu_profiled": valu,
+            "algorithmic_bytes_per_launch": algo_bytes * n,
+            "kernel_ms": slow["kernel_ms"],
+            "setup_kernel_ms": slow["setup_kernel_ms"],
+            "launches_timed": slow["launches_timed"],
+            "per_rank": [{k: r[k] for k in ("rank", "kernel_ms", "setup_kernel_ms", "achieved", "frac", "elapsed_s")}
+                         for r in sorted(per_rank, key=lambda r: r["rank"])],
+            "traffic_source": "live" if live is not None else ("committed profile" if traffic else None),
+            "note": "per GPU; kernel_ms = HIP events around the raster phase of a step (kernels_timed; with mesh entities several kernels "
+                    "on two streams), achieved = algorithmic bytes / kernel_ms.  The path is VALU bound (coverage, depth, texture "
+                    "filtering, resolve), not HBM bound (SURVEY.md section 8d): see valu_profiled.  traffic = PMC FETCH_SIZE x 2 + "
+                    "WRITE_SIZE per launch SUMMED over kernels_timed (traffic_profiled.per_kernel): read during this run by child runs "
+                    "under rocprofv3 (traffic_source = live) or, without the profiler, from the committed profile of the named commit",
+        },
+    }
+    return out
 
 
 def main():
@@ -366,6 +500,7 @@ def main():
                     help="pre-warm with exactly this many steps instead of PREWARM_S seconds (A/B runs: the timed region then "
                          "covers the same episode phases in both)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configs timed after the headline (the `also` list)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the child runs under rocprofv3 that read roofline.traffic during the run")
     ap.add_argument("--dry", action="store_true", help="CPU dry run of the multi-rank path (gloo, no engine)")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still go through torch.distributed (RCCL, world size 1) — barrier, MAX-reduction, object "
@@ -378,8 +513,7 @@ def main():
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args, sys.argv[1:])
-    env_id, _, n_default, want_depth, dr, n_act, _, algo_bytes, dominant = CONFIGS[args.config]
-    n = args.envs_per_gpu or n_default
+    n = args.envs_per_gpu or CONFIGS[args.config][2]
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -409,141 +543,27 @@ def main():
         torch.cuda.set_device(0)
         local = 0
     device = "cpu" if args.dry else f"cuda:{local}"
+    ctx = {"rank": rank, "world": world, "local": local, "dist": dist, "device": device}
 
-    from miniworld_amd.sharding import ObsAllGather, gather_objects, max_over_ranks, shard_plan
-    plan = shard_plan(rank, world, n)
-    if args.dry:
-        vec = _DryVec(n)
-    else:
-        from miniworld_amd.vec_env import MiniWorldVecEnv
-        vec = MiniWorldVecEnv(env_id, n, device_id=local, seed=plan["first_seed"], want_depth=want_depth, domain_rand=dr)
-        vec.reset()
-    total = args.steps + args.warmup
-    g = torch.Generator(device=device).manual_seed(1234 + rank)
-    actions = torch.randint(0, n_act, (total, n), generator=g, device=device, dtype=torch.int32)
-
-    gath = None
-    if args.gather_obs and dist is not None:
-        gath = ObsAllGather(dist, torch.zeros((n, 60, 80, 3), dtype=torch.uint8) if args.dry else vec.obs)
-
-    def step(t):
-        vec.step(actions[t])
-        if gath is not None:
-            gath.gather(gath.stage[0] if args.dry else vec.obs)
-
-    def sync():
-        if not args.dry:
-            torch.cuda.synchronize()
-
-    def barrier():
-        sync()
-        if dist is not None:
-            dist.barrier()
-            sync()
-
-    # pre-warm: a cold box (fresh lease, idle clocks, cold L2 / instruction caches) is not what the metric describes;
-    # untimed and reported, separate from the W warm-up steps of the contract
-    t_pre = time.perf_counter()
-    k = 0
-    while not args.dry and (k < args.prewarm_steps if args.prewarm_steps else time.perf_counter() - t_pre < PREWARM_S):
-        for _ in range(16):
-            vec.step(actions[k % total])
-            k += 1
-        sync()
-    prewarm_s = time.perf_counter() - t_pre
-    for t in range(args.warmup):
-        step(t)
-    if not args.dry:
-        # HIP-event timing of the kernels on the launch stream: one launch in 4 for short runs, one in 8 otherwise
-        # (three event records around a launch cost ~7 us, i.e. ~3 % of the step rate on every launch, measured)
-        stride = 4 if args.steps <= 64 else 8
-        vec.engine.kernel_time_ms(stride)
-    barrier()
-    t0 = time.perf_counter()
-    for t in range(args.warmup, total):
-        step(t)
-    if gath is not None:
-        gath.wait()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    raster_ms = setup_ms = 0.0
-    launches = parity = 0
-    if not args.dry:
-        raster_ms, setup_ms, launches = vec.engine.kernel_time_ms(-1)
-        vec.engine.check()
-        # sanity: the frames are real (a static or empty frame would be an invalid measurement)
-        m = float(vec.obs.float().mean())
-        assert 1.0 < m < 254.0, f"degenerate observation tensor (mean {m})"
-        if not args.no_parity_check:
-            parity = parity_spot_check(vec, actions[total - 1], args.config)
-
-    elapsed_max = max_over_ranks(dist, elapsed, device=device) if dist is not None else elapsed
-    achieved = algo_bytes * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
-    mine = {"rank": rank, "device": local, "envs": n, "first_seed": plan["first_seed"], "elapsed_s": elapsed,
-            "kernel_ms": raster_ms, "setup_kernel_ms": setup_ms, "launches_timed": launches, "achieved": achieved,
-            "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "parity_checked": parity}
-    per_rank = gather_objects(dist, mine) if dist is not None else [mine]
+    head = measure(args, ctx, args.config, n, args.steps, args.warmup, headline=True)
+    # BASELINE.json configs[2..4] in the same command (same protocol, same pre-warm, their BASELINE sizes per GPU; under N
+    # ranks every rank runs its shard of each): before the CPU baseline, whose one-process-per-core storm leaves the GPU
+    # idle for ~20 s.  Never touches `value`.
+    also = []
+    if not args.no_also and args.config == "hallway" and not args.envs_per_gpu:
+        for name in ALSO:
+            try:
+                also.append(measure(args, ctx, name, CONFIGS[name][2], args.steps, args.warmup, headline=False))
+            except Exception as exc:  # noqa: BLE001 — never at the headline's expense
+                if dist is not None:
+                    raise                       # (a rank that dropped out of a collective cannot be papered over)
+                also.append({"config": {"name": name}, "error": repr(exc)})
     if rank == 0:
-        if len(per_rank) != args.gpus or sorted(r["rank"] for r in per_rank) != list(range(args.gpus)):
-            sys.exit(f"bench.py: {len(per_rank)} rank(s) reported, {args.gpus} asked")
-        steps_per_s = world * n * args.steps / elapsed_max
-        slow = max(per_rank, key=lambda r: r["kernel_ms"])          # the roofline entry is the slowest rank's
-        traffic, valu = pmc_profiled(dominant, args.config, n)
-        # counters read during THIS run when the profiler is on the box (a short child run under rocprofv3), else the committed profile's
-        live = pmc_live(args.config, dominant, n) if (world == 1 and not args.dry) else None
-        if live is not None:
-            traffic = live
-        out = {
-            "metric": "env-steps/s (batched, 80x60 RGB)",
-            "value": steps_per_s,
-            "unit": "env-steps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_max / args.steps,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic" if not args.dry else "dry-run: no GPU work, launcher / sharding path only",
-            "config": {"workload": f"{env_id}, {n} batched envs per GPU, 80x60 RGB{'-D' if want_depth else ''}, 8x MSAA, "
-                                   f"random actions, {'domain_rand, ' if dr else ''}auto-reset",
-                       "envs_per_gpu": n, "parallelism": f"env-shard x{world}",
-                       "obs_allgather": gath is not None, "torch_distributed": dist is not None},
-            "samples_per_s": steps_per_s * 80 * 60 * 8,
-            "prewarm_s": prewarm_s,
-            "parity_checked": sum(r["parity_checked"] for r in per_rank),
-            "roofline": {
-                "bound": "hbm",
-                "kernel": dominant,
-                "achieved": slow["achieved"],
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": slow["frac"],
-                "traffic": traffic["bytes_per_launch"] if traffic else None,
-                "traffic_profiled": traffic,
-                "valu_profiled": valu,
-                "algorithmic_bytes_per_launch": algo_bytes * n,
-                "kernel_ms": slow["kernel_ms"],
-                "setup_kernel_ms": slow["setup_kernel_ms"],
-                "launches_timed": slow["launches_timed"],
-                "per_rank": [{k: r[k] for k in ("rank", "kernel_ms", "setup_kernel_ms", "achieved", "frac", "elapsed_s")}
-                             for r in sorted(per_rank, key=lambda r: r["rank"])],
-                "traffic_source": "live" if live is not None else ("committed profile" if traffic else None),
-                "note": "per GPU; the path is VALU bound (coverage, depth, texture filtering, resolve), not HBM bound (SURVEY.md "
-                        "section 8d): see valu_profiled.  traffic = traffic_profiled.bytes_per_launch = PMC FETCH_SIZE + WRITE_SIZE per "
-                        "launch: read during this run by a child run under rocprofv3 (traffic_source = live) or, without the profiler, "
-                        "from the committed profile of the named commit",
-            },
-        }
+        out = head
         if world == 1 and not args.no_cpu_baseline and not args.dry:
             out["cpu_baseline"] = cpu_baseline(args.config)
-        if world == 1 and not args.dry and not args.no_also and args.config == "hallway" and not args.envs_per_gpu:
-            # BASELINE.json configs[2] is a single-GPU config too: timed here so that the driver's one command records it
-            try:
-                out["also"] = [time_config("oneroom_rgbd", args.steps, args.warmup, local)]
-            except Exception as exc:  # noqa: BLE001 — never at the headline's expense
-                out["also"] = [{"config": {"name": "oneroom_rgbd"}, "error": repr(exc)}]
+        if also:
+            out["also"] = also
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

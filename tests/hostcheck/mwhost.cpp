@@ -241,6 +241,14 @@ extern "C" int mwhost_render(const mwo_scene *sc, uint8_t *rgb, uint16_t *z16out
     return 0;
 }
 
+// how many triangles the display list of the scene holds after clipping, culling and setup (the engine's nvis)
+extern "C" int mwhost_list_length(const mwo_scene *sc)
+{
+    std::vector<Tri> tris;
+    geometry(sc, sc->nsamples > 1, tris);
+    return (int)tris.size();
+}
+
 // glibc's sinf / cosf against the restatement the device uses (exhaustive range test in tests/)
 extern "C" void mwhost_sincosf(float x, float *s, float *c) { sincosf_glibc(x, *s, *c); }
 
