@@ -30,7 +30,11 @@
 #define MW_OCC_CACHE_HDR 8
 // floats per set: header, 8 per wall, 8 per box of eight polygons; whole 128-byte lines
 #define MW_OCC_CACHE_STRIDE(max_polys) ((MW_OCC_CACHE_HDR + 8 * (size_t)(max_polys) + 8 * (size_t)(((max_polys) + 7) / 8) + 31) / 32 * 32)
-#define MW_HDR_MESH_STRIDE 28 // floats per entry: slot, first draw id, triangles, first triangle, texture, normal scale, light[3], mvp[16]
+#define MW_HDR_MESH_STRIDE 28 // floats per entry: slot, first draw id, triangles, first triangle, texture, normal scale, light[3], mvp[16], mesh triangles drawn before, tile rectangle, mesh id
+#define MW_MESH_VCAP 3584       // distinct positions of a mesh whose vertex stage runs per vertex (mw_mesh_entity_kernel: 16 bytes of LDS each, 56 KB + the winner queue within a workgroup's 64 KB)
+#define MW_ENT_THREADS 512      // lanes of the mesh entity kernel's workgroup
+#define MW_ENT_ROUND 2048       // triangles between two drains of its winner queue
+#define MW_ENT_BIG_PIXELS 48      // a triangle whose bounding box holds more pixels is rasterised by a wavefront, a pixel per lane, instead of by one lane
 
 // status bits written by kernels, read by mw_check()
 #define MW_ST_VIS_OVERFLOW 1u
@@ -56,6 +60,7 @@ struct MwMeshDesc {
     uint32_t bound_bits;           // float bits: max |vertex| (radius of the bounding sphere about the mesh origin)
     float last_n[3];               // vertex normal of the LAST triangle's last vertex in drawing order (GL's current
     uint32_t pad;                  //   normal after the mesh, for the top view's agent marker)
+    uint32_t vfirst, nverts;       // the mesh's table of distinct positions in the vertex pool (nverts = 0: more than MW_MESH_VCAP, no table)
 };
 
 // Mesh pools: per-face-vertex arrays in drawing order (= draw ids, GL's first-drawn-wins on equal depth, the oracle's
@@ -158,5 +163,11 @@ struct MwArgs {
     // frame.  occ_valid[set]: polygon count + 1 of the world the cache belongs to, 0 after anything rewrote the polygons.
     int32_t *occ_valid;     // [sets] or null
     float *occ_cache;       // [sets][MW_OCC_CACHE_STRIDE(max_polys)]
+    // the frame's mesh entities in view, for mw_mesh_entity_kernel (written by the geometry kernel when non-null):
+    // ent_list_n[0 / 1] entries — env | table entry << 24 — at ent_list (meshes of 1024 triangles and more: drawn from
+    // first) and at ent_list + ent_list_cap (the others)
+    uint32_t *ent_list;
+    int32_t *ent_list_n;
+    int32_t ent_list_cap, pad_ent;
     unsigned long long *k1_prof;   // MW_K1_PROF: [N][MW_K1_PROF_SLOTS] cycle counters of the geometry kernel's phases, start and end time of the env's wavefront (tools/perf/kgprof.py; perf experiments only), else null
 };

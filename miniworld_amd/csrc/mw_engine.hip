@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <map>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -59,9 +61,10 @@ MW_RASTERQ_DECL(mw_rasterq4_kernel);
 extern "C" int mw_rasterq_lds_bytes(int S, int W, int H, int n_tiles, int depth);
 extern "C" int mw_rasterq_cap(int depth);
 #define MW_RASTERQ_THREADS 512
-extern "C" __global__ void mw_mesh_scatter_kernel(int W, int H, const float *envhdr, const float *mesh_stream, const float *mesh_attr,
-                                                  uint32_t *keys, float *plane_cache, int plane_cap, int32_t *slow_count,
-                                                  uint32_t *slow_tris);
+extern "C" __global__ void mw_mesh_entity_kernel(int N, int W, int H, const float *envhdr, const MwMeshDesc *meshes, const float4 *mesh_vpos, const uint2 *mesh_idx,
+                                                 const float *mesh_stream, const float *mesh_attr, uint32_t *keys, float *plane_cache, int plane_cap,
+                                                 int32_t *slow_count, uint32_t *slow_tris, const uint32_t *ent_list, int ent_list_cap, int32_t *ent_n, int32_t *ent_n_after,
+                                                 unsigned long long *prof);
 extern "C" __global__ void mw_mesh_slow_kernel(int W, int H, const float *envhdr, const float *mesh_pos, const float *mesh_nrm, const float *mesh_rgb,
                                                const float *mesh_uv, const uint32_t *texels, int texel_bytes, uint32_t *keys, int32_t *counts, int N,
                                                int parity, const uint32_t *slow_tris, float4 *frags, uint32_t *heads, uint32_t stamp, uint32_t *status);
@@ -117,7 +120,12 @@ struct mw_engine {
     std::vector<MwMeshDesc> mesh_desc;
     std::vector<std::vector<float>> mesh_pos, mesh_nrm, mesh_rgb, mesh_uv;   // per mesh id, [ntris][9] ([6] for uv)
     float *d_mesh_pos = nullptr, *d_mesh_nrm = nullptr, *d_mesh_rgb = nullptr, *d_mesh_uv = nullptr;
-    float *d_mesh_stream = nullptr, *d_mesh_attr = nullptr;     // the scatter kernel's triangle streams (rasterisation order): positions, vertex attributes
+    float *d_mesh_stream = nullptr, *d_mesh_attr = nullptr;     // the entity kernel's triangle streams (rasterisation order): positions (meshes without a vertex table), vertex attributes
+    float4 *d_mesh_vpos = nullptr;      // the meshes' distinct positions (MwMeshDesc::vfirst, nverts)
+    uint2 *d_mesh_idx = nullptr;        // per triangle of the rasterisation order: three 16-bit indices into the mesh's table, the triangle's index
+    std::vector<std::vector<float>> mesh_vtab;      // per mesh id: [nverts][4]
+    std::vector<std::vector<uint32_t>> mesh_itab;   // per mesh id: [ntris][2]
+    int max_mesh_verts = 0;
     bool have_meshes = false;
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
     bool visible_attr_set = false;
@@ -128,6 +136,10 @@ struct mw_engine {
     uint32_t *d_mesh_keys = nullptr;    // [N][H][W][8] sample keys of the mesh scatter kernel (all-ones between frames)
     bool mesh_keys_dirty = true;
     int32_t *d_slow_count = nullptr;    // [2 parities][2][N] listed triangles, fragments
+    int32_t *d_ent_counter = nullptr;   // [2][4] the mesh entity kernel's work list: lengths (long / short meshes) and cursor, this frame's and the next frame's
+    uint32_t *d_ent_list = nullptr;     // [2][N * slots] the work list itself (written by the geometry kernel)
+    int ent_list_cap = 0;
+    int ent_blocks = 512;               // its persistent workgroups: two per CU (MW_ENT_BLOCKS; 768 measured slower beside the quad kernel)
     uint32_t mesh_frame_seq = 1;
     uint32_t *d_slow_tris = nullptr;
     float4 *d_slow_frags = nullptr;
@@ -169,9 +181,9 @@ struct mw_engine {
                                     // beside the quad kernel the scatter overlaps well: PickupObjects 0.522 -> 0.495 ms per step)
     int slow_bx = 16;           // MW_SLOW_BX
     int mesh_wpe = 0;           // MW_MESH_WPE: wavefronts per env of the mesh tiles' launch (0: one per tile)
-    int scatter_bx = 4;         // MW_SCATTER_BX: workgroups per env of the mesh scatter kernel
     int raster_big = -1;        // MW_RASTER_BIG
     bool k2_first_full = false; // MW_K2_FIRST_FULL
+    unsigned long long *d_ent_prof = nullptr;   // MW_ENT_PROF=<file>: the mesh entity kernel's per-env times and counts of the last frame, [N][8], dumped by mw_destroy
     unsigned long long *d_k2q_prof = nullptr;   // MW_K2Q_PROF=<file>: s_memtime stamps of the quad kernel's phases, [N][8 waves][8], dumped by mw_destroy
 };
 
@@ -227,6 +239,11 @@ auto geom_kernel_of(const mw_engine *e, int L, int msaa) -> void (*)(MwArgs, int
     return fixed8 ? mw_geom_kernel : mw_geom_any_kernel;
 }
 
+// The tile / quad / mesh-scatter kernels keep edge values in 32 bits: |c_k| = |dcdx X - dcdy Y| <= 2 W H 2^16 has to stay below
+// 2^31, i.e. W H < 16384 — 128 x 96 passes, 128 x 128 does not (a wall across the whole frame lost its triangle there);
+// larger frames take the generic-resolution kernels (64-bit edge values).
+bool tile_kernels_exact(int W, int H) { return W <= 128 && H <= 128 && W * H <= 128 * 96; }
+
 // lanes per env of the geometry kernel: the power of two that holds an env's triangles (two per polygon and box face, the
 // agent marker), 8 .. 64 — except that the smallest scenes get 16 lanes for their up to 32 triangles: an env's lanes go over
 // its triangles in rounds, and four envs per wavefront fill the chip with half the wavefronts of this one-wave-per-SIMD kernel
@@ -237,6 +254,9 @@ int geom_lanes(const mw_engine *e)
     int L = 8;
     while (L < items && L < 64) L <<= 1;
     if (L == 32) L = 16;
+    // mid-sized scenes (PickupObjects: 6 polygons + 5 entity slots = 74 triangles; no visiting order, no sifting): two envs per
+    // wavefront — 2 048 envs are ONE round of this one-wave-per-SIMD kernel instead of two (K1 + KG 103 -> 71 us)
+    if (L == 64 && !e->args.rec_order && e->cfg.max_polys <= 64) L = 32;
     if (e->geom_lanes_override) L = e->geom_lanes_override;
     return L;
 }
@@ -579,7 +599,7 @@ int ensure_mesh_buffers(mw_engine *e)
     const MwArgs &a = e->args;
     const size_t N = (size_t)e->cfg.num_envs;
     if (ensure_mesh_stream(e) != MW_OK) return MW_E_HIP;
-    if (e->cfg.msaa != 8 || a.W > 128 || a.H > 128) {       // the generic-resolution path
+    if (e->cfg.msaa != 8 || !tile_kernels_exact(a.W, a.H)) {       // the generic-resolution path
         const size_t need = N * a.W * a.H * e->cfg.msaa * 4;
         if (need > e->view_keys_bytes) {
             uint32_t *nk = nullptr;
@@ -599,19 +619,24 @@ int ensure_mesh_buffers(mw_engine *e)
         if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
         e->d_plane_cache = np; e->plane_cap = (int)want;
     }
+    if (!e->d_ent_list) {
+        e->ent_list_cap = (int)N * std::min(MW_MAX_MESH_ENTS, std::max(e->cfg.max_ents, 1));
+        if (hipMalloc((void **)&e->d_ent_list, (size_t)e->ent_list_cap * 2 * 4) != hipSuccess) { e->d_ent_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh entity list failed"); }
+    }
     if (!e->d_mesh_keys) {
         const size_t key_bytes = N * a.W * a.H * 8 * 4, head_bytes = N * a.W * a.H * 4;
         void *keys = nullptr, *cnt = nullptr, *tris = nullptr, *frags = nullptr, *head = nullptr;
         // triangles that cross a frustum plane and their fragments (mw_mesh_slow_kernel): counts, 1024 / 2048 entries per env
-        const bool ok = hipMalloc(&keys, key_bytes) == hipSuccess && hipMalloc(&cnt, N * 4 * 4) == hipSuccess && hipMalloc(&tris, N * MW_SLOW_TRIS * 4) == hipSuccess &&
+        const bool ok = hipMalloc(&keys, key_bytes) == hipSuccess && hipMalloc(&cnt, N * 4 * 4 + 32) == hipSuccess && hipMalloc(&tris, N * MW_SLOW_TRIS * 4) == hipSuccess &&
                         hipMalloc(&frags, N * MW_SLOW_STRIDE * 16) == hipSuccess && hipMalloc(&head, head_bytes) == hipSuccess &&
-                        hipMemset(cnt, 0, N * 4 * 4) == hipSuccess && hipMemset(head, 0, head_bytes) == hipSuccess && hipMemset(keys, 0xFF, key_bytes) == hipSuccess;
+                        hipMemset(cnt, 0, N * 4 * 4 + 32) == hipSuccess && hipMemset(head, 0, head_bytes) == hipSuccess && hipMemset(keys, 0xFF, key_bytes) == hipSuccess;
         if (!ok) {
             for (void *p : {keys, cnt, tris, frags, head}) if (p) (void)hipFree(p);
             return fail(e, MW_E_NOMEM, "hipMalloc for the mesh path's buffers failed");
         }
         e->d_mesh_keys = (uint32_t *)keys; e->d_slow_count = (int32_t *)cnt; e->d_slow_tris = (uint32_t *)tris;
         e->d_slow_frags = (float4 *)frags; e->d_slow_head = (uint32_t *)head;
+        e->d_ent_counter = (int32_t *)cnt + N * 4;       // (behind the slow path's counts)
         // (the memsets above ran on the null stream, which a caller's non-blocking stream is not ordered against: finish them here)
         (void)hipDeviceSynchronize();
         e->mesh_keys_dirty = false;
@@ -624,11 +649,16 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
 {
     if (!d_obs) return fail(e, MW_E_INVALID, "d_obs is null");
     // (checked before anything is launched or any timing event is taken)
-    if ((e->cfg.msaa != 8 || e->cfg.obs_width > 128 || e->cfg.obs_height > 128) && e->obs_layout != MW_OBS_HWC_U8)
-        return fail(e, MW_E_INVALID, "wrapper layouts need msaa = 8 and observations up to 128 x 128");
+    if ((e->cfg.msaa != 8 || !tile_kernels_exact(e->cfg.obs_width, e->cfg.obs_height)) && e->obs_layout != MW_OBS_HWC_U8)
+        return fail(e, MW_E_INVALID, "wrapper layouts need msaa = 8 and observations up to 128 x 96");
     MwArgs a = e->args;
     a.step_override = e->use_step_override ? e->d_step_override : nullptr;
     const int N = e->cfg.num_envs;
+    // a frame with mesh entities through the tile / quad kernels: the geometry kernel lists the entities in view for the mesh
+    // entity kernel (lists, slow-path lists and fragment stamps alternate between two sets from frame to frame)
+    const bool mesh_obs = e->have_meshes && e->cfg.msaa == 8 && tile_kernels_exact(a.W, a.H) && e->d_ent_list && e->d_mesh_keys;
+    const uint32_t mesh_seq = mesh_obs ? e->mesh_frame_seq++ : 0u;
+    if (mesh_obs) { a.ent_list = e->d_ent_list; a.ent_list_n = e->d_ent_counter + (mesh_seq & 1u) * 4; a.ent_list_cap = e->ent_list_cap; }
     mw_engine::Ev ev{};
     // kernel durations are sampled: three event records on every launch cost ~4 % of the step rate,
     // on one launch in MW_TIMING_STRIDE they cost nothing measurable
@@ -704,7 +734,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     if (k2q && e->cfg.msaa == 4) {
         launch_k2q(0);
         e->last_raster_path = MW_PATH_QUAD;
-    } else if (e->cfg.msaa != 8 || a.W > 128 || a.H > 128) {
+    } else if (e->cfg.msaa != 8 || !tile_kernels_exact(a.W, a.H)) {
         // FrameBuffer's fallback sample counts (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES gets 4 or 1
         // samples) and observations beyond 128 x 128 (the tile kernels' 24-bit edge arithmetic): not the hot path — the
         // generic-resolution kernels, 64-bit edge values, exact packed-key resolution, the whole batch in one grid
@@ -735,7 +765,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             // The mesh kernels run on the side stream, beside the first part of K2 (every tile no mesh can touch); the
             // tiles inside the meshes' rectangles follow behind both (part 2).
             // frame stamp of the slow-fragment chains (16 bits; the heads are wiped when it wraps) and parity of the lists
-            const uint32_t seq = e->mesh_frame_seq++;
+            const uint32_t seq = mesh_seq;
             mesh_stamp = seq & 0xFFFFu;
             const int parity = (int)(seq & 1u);
             const bool scatter_first = !(e->scatter_overlap && k2q);
@@ -747,8 +777,14 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
                 HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
             }
-            hipLaunchKernelGGL(mw_mesh_scatter_kernel, dim3(e->scatter_bx, N), dim3(256), 0, scatter_first ? st : sb, a.W, a.H, (const float *)a.envhdr, (const float *)e->d_mesh_stream, (const float *)e->d_mesh_attr,
-                               e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris);
+            {
+                // persistent workgroups drawing entities from the geometry kernel's list (two sets of counters swapping places: the
+                // kernel zeroes the next frame's)
+                hipLaunchKernelGGL(mw_mesh_entity_kernel, dim3(std::min(e->ent_list_cap, e->ent_blocks)), dim3(MW_ENT_THREADS), (size_t)e->max_mesh_verts * 16, scatter_first ? st : sb, N, a.W, a.H,
+                                   (const float *)a.envhdr, a.mesh, (const float4 *)e->d_mesh_vpos, (const uint2 *)e->d_mesh_idx, (const float *)e->d_mesh_stream,
+                                   (const float *)e->d_mesh_attr, e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris,
+                                   (const uint32_t *)e->d_ent_list, e->ent_list_cap, e->d_ent_counter + parity * 4, e->d_ent_counter + (parity ^ 1) * 4, e->d_ent_prof);
+            }
             if (scatter_first) {
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
                 HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
@@ -971,6 +1007,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     }
     e->mesh_desc.assign(MW_MAX_MESH, MwMeshDesc{});
     e->mesh_pos.assign(MW_MAX_MESH, {}); e->mesh_nrm.assign(MW_MAX_MESH, {}); e->mesh_rgb.assign(MW_MAX_MESH, {}); e->mesh_uv.assign(MW_MAX_MESH, {});
+    e->mesh_vtab.assign(MW_MAX_MESH, {}); e->mesh_itab.assign(MW_MAX_MESH, {});
     e->tex_desc.assign(MW_MAX_TEX, MwTexDesc{});
     e->tex_data.assign(MW_MAX_TEX, {});
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
@@ -986,9 +1023,10 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;
     if (const char *s = getenv("MW_SLOW_BX")) { const int v = atoi(s); if (v > 0) e->slow_bx = v; }
     if (const char *s = getenv("MW_MESH_WPE")) e->mesh_wpe = atoi(s);
-    if (const char *s = getenv("MW_SCATTER_BX")) { const int v = atoi(s); if (v > 0 && v <= 64) e->scatter_bx = v; }
+    if (const char *s = getenv("MW_ENT_BLOCKS")) { const int v = atoi(s); if (v > 0) e->ent_blocks = v; }
     if (const char *s = getenv("MW_RASTER_BIG")) e->raster_big = atoi(s) != 0 ? 1 : 0;
     e->k2_first_full = getenv("MW_K2_FIRST_FULL") != nullptr;
+    if (getenv("MW_ENT_PROF")) { if (dev_alloc(e, &e->d_ent_prof, (size_t)N * MW_MAX_MESH_ENTS * 8) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
     if (getenv("MW_K2Q_PROF")) { if (dev_alloc(e, &e->d_k2q_prof, (size_t)N * 80) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
     {
         // the quad kernel (mw_rasterq.hip) keeps an env's frame, quad lists and triangle records in LDS: frames up to 8192 pixels
@@ -1012,6 +1050,11 @@ void mw_destroy(mw_engine *e)
         if (hipMemcpy(h.data(), e->d_k2q_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(getenv("MW_K2Q_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
+    if (e->d_ent_prof) {
+        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * MW_MAX_MESH_ENTS * 8);
+        if (hipMemcpy(h.data(), e->d_ent_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
+            if (FILE *f = fopen(getenv("MW_ENT_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
+    }
     if (e->args.k1_prof) {
         std::vector<unsigned long long> h((size_t)e->cfg.num_envs * MW_K1_PROF_SLOTS);
         if (hipMemcpy(h.data(), e->args.k1_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -1028,9 +1071,12 @@ void mw_destroy(mw_engine *e)
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_texels) (void)hipFree(e->d_texels);
     for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb, e->d_mesh_uv, e->d_mesh_stream, e->d_mesh_attr}) if (p) (void)hipFree(p);
+    if (e->d_mesh_vpos) (void)hipFree(e->d_mesh_vpos);
+    if (e->d_mesh_idx) (void)hipFree(e->d_mesh_idx);
     if (e->d_view_keys) (void)hipFree(e->d_view_keys);
     if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
     if (e->d_mesh_keys) (void)hipFree(e->d_mesh_keys);
+    if (e->d_ent_list) (void)hipFree(e->d_ent_list);
     for (void *q : {(void *)e->d_slow_count, (void *)e->d_slow_tris, (void *)e->d_slow_frags, (void *)e->d_slow_head}) if (q) (void)hipFree(q);
     if (e->mesh_stream) { (void)hipStreamDestroy(e->mesh_stream); (void)hipEventDestroy(e->ev_mesh_fork); (void)hipEventDestroy(e->ev_mesh_join); }
     if (e->side_stream) { (void)hipStreamDestroy(e->side_stream); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
@@ -1086,6 +1132,35 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
         memcpy(&P[(size_t)i * MW_MESH_POS_STRIDE], pos + (size_t)i * 9, 36);
         memcpy(&P[(size_t)i * MW_MESH_POS_STRIDE + 9], &order[i], 4);      // the i-th triangle of the rasterisation order
     }
+    {
+        // the table of distinct positions (bit patterns: -0 and 0 stay apart) and the triangles' indices into it, in
+        // rasterisation order; a mesh with more than MW_MESH_VCAP positions keeps none (the entity kernel then takes its
+        // triangles through the vertex stage one by one)
+        std::map<std::array<uint32_t, 3>, uint32_t> seen;
+        auto &VT = e->mesh_vtab[mesh_id]; auto &IT = e->mesh_itab[mesh_id];
+        VT.clear(); IT.assign((size_t)ntris * 2, 0u);
+        bool fits = true;
+        for (int k = 0; k < ntris && fits; ++k) {
+            const uint32_t tri = order[k];
+            uint32_t ix[3];
+            for (int c = 0; c < 3; ++c) {
+                std::array<uint32_t, 3> key;
+                memcpy(key.data(), pos + ((size_t)tri * 3 + c) * 3, 12);
+                auto it = seen.find(key);
+                if (it == seen.end()) {
+                    if (seen.size() >= MW_MESH_VCAP) { fits = false; break; }
+                    it = seen.emplace(key, (uint32_t)seen.size()).first;
+                    const float *pp = pos + ((size_t)tri * 3 + c) * 3;
+                    VT.insert(VT.end(), {pp[0], pp[1], pp[2], 0.0f});
+                }
+                ix[c] = it->second;
+            }
+            IT[(size_t)k * 2] = ix[0] | (ix[1] << 16);
+            IT[(size_t)k * 2 + 1] = ix[2] | (tri << 16);
+        }
+        if (!fits) VT.clear();
+        e->mesh_desc[mesh_id].nverts = (uint32_t)(VT.size() / 4);
+    }
     memcpy(e->mesh_desc[mesh_id].last_n, nrm + ((size_t)(ntris - 1) * 3 + 2) * 3, 12);
     e->mesh_desc[mesh_id].ntris = (uint32_t)ntris;
     e->mesh_desc[mesh_id].tex = tex_id;
@@ -1098,7 +1173,17 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
     }
     // repack all pools (uploads are rare)
     size_t total = 0;
-    for (int i = 0; i < MW_MAX_MESH; ++i) { e->mesh_desc[i].first = (uint32_t)total; total += e->mesh_desc[i].ntris; }
+    size_t total_v = 0;
+    e->max_mesh_verts = 0;
+    for (int i = 0; i < MW_MAX_MESH; ++i) {
+        e->mesh_desc[i].first = (uint32_t)total; total += e->mesh_desc[i].ntris;
+        e->mesh_desc[i].vfirst = (uint32_t)total_v; total_v += e->mesh_desc[i].nverts;
+        e->max_mesh_verts = std::max(e->max_mesh_verts, (int)e->mesh_desc[i].nverts);
+    }
+    if (e->d_mesh_vpos) { (void)hipFree(e->d_mesh_vpos); e->d_mesh_vpos = nullptr; }
+    if (e->d_mesh_idx) { (void)hipFree(e->d_mesh_idx); e->d_mesh_idx = nullptr; }
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_vpos, std::max<size_t>(total_v, 1) * 16));
+    HIP_TRY(e, hipMalloc((void **)&e->d_mesh_idx, total * 8));
     for (float **p : {&e->d_mesh_pos, &e->d_mesh_nrm, &e->d_mesh_rgb, &e->d_mesh_uv, &e->d_mesh_stream, &e->d_mesh_attr})
         if (*p) { (void)hipFree(*p); *p = nullptr; }
     HIP_TRY(e, hipMalloc((void **)&e->d_mesh_pos, total * 4 * MW_MESH_POS_STRIDE));
@@ -1114,6 +1199,9 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
         HIP_TRY(e, hipMemcpy(e->d_mesh_nrm + off, e->mesh_nrm[i].data(), n * 36, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_rgb + off, e->mesh_rgb[i].data(), n * 36, hipMemcpyHostToDevice));
         HIP_TRY(e, hipMemcpy(e->d_mesh_uv + (size_t)e->mesh_desc[i].first * 6, e->mesh_uv[i].data(), n * 24, hipMemcpyHostToDevice));
+        if (e->mesh_desc[i].nverts)
+            HIP_TRY(e, hipMemcpy(e->d_mesh_vpos + e->mesh_desc[i].vfirst, e->mesh_vtab[i].data(), (size_t)e->mesh_desc[i].nverts * 16, hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(e->d_mesh_idx + e->mesh_desc[i].first, e->mesh_itab[i].data(), n * 8, hipMemcpyHostToDevice));
         {
             // the scatter kernel's stream: the triangles in rasterisation order, 48 bytes each (9 coordinates, the triangle's index)
             std::vector<float> st(n * 12, 0.0f);

@@ -322,6 +322,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                         for (int k = 0; k < 16; ++k) m[9 + k] = ex.mvp.m[k];
                         m[25] = __int_as_float(total_mesh_tris);    // mesh triangles drawn before
                         m[26] = __uint_as_float(rect);
+                        m[27] = __int_as_float(mid);
                     }
                     mesh_in_view |= 1ull << s0;
                     total_mesh_tris += md_ntris;      // one draw id per triangle (a mesh out of view takes none)
@@ -629,9 +630,14 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     const int bpr = L / 12;
     const int poly_rounds = (2 * npd + L - 1) / L, box_rounds = aligned ? (total_boxes + bpr - 1) / bpr : 0;
     const int n_rounds = aligned ? poly_rounds + box_rounds + marker : (2 * n_items + L - 1) / L;
-    for (int rnd = 0; rnd < n_rounds; ++rnd) {
+    // (the envs of a wavefront go through the rounds together — the clipper's work lists are served by all 64 lanes, eight to a
+    // list —: an env with fewer rounds than its neighbours idles through the rest)
+    const int n_rounds_wave = L < 64 ? (int)__reduce_max_sync(~0ull, (unsigned)n_rounds) : n_rounds;
+    for (int rnd = 0; rnd < n_rounds_wave; ++rnd) {
         int item, tsel;
-        if (!aligned || rnd < poly_rounds) {
+        if (rnd >= n_rounds) {
+            item = n_items; tsel = 0;
+        } else if (!aligned || rnd < poly_rounds) {
             const int t = rnd * L + sub;
             item = t >> 1; tsel = t & 1;
             if (aligned && item >= npd) item = n_items;         // (behind the polygons of the last polygon round: nothing)
@@ -1045,6 +1051,18 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             m[1] = __int_as_float(p0 + __float_as_int(m[25]));
         }
         if (count + total_mesh_tris >= 0xFFF0) atomicOr(a.status, MW_ST_VIS_OVERFLOW);      // 16-bit draw ids
+        if (a.ent_list && total_meshes > 0) {
+            // the work list of the mesh entity kernel: balls before keys (a workgroup per entity; the long ones start first)
+            int nbig = 0;
+            for (int j = 0; j < total_meshes; ++j) nbig += __float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 2]) >= 1024 ? 1 : 0;
+            int ib = nbig ? atomicAdd(a.ent_list_n, nbig) : 0;
+            int is = total_meshes - nbig ? atomicAdd(a.ent_list_n + 1, total_meshes - nbig) : 0;
+            for (int j = 0; j < total_meshes; ++j) {
+                const uint32_t item = (uint32_t)env | ((uint32_t)j << 24);
+                if (__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 2]) >= 1024) { if (ib < a.ent_list_cap) a.ent_list[ib] = item; ++ib; }
+                else { if (is < a.ent_list_cap) a.ent_list[a.ent_list_cap + is] = item; ++is; }
+            }
+        }
         // the step's pending removal: the picked-up object leaves the entity list after its last frame
         // (pickupobjects.py:86-88); CollectHealth's consumed kit respawns instead, with draws from the env's stream:
         // mw_collect_respawn_kernel, launched behind this one

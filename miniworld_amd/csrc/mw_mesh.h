@@ -10,6 +10,7 @@
 // geometry kernel's mesh table.
 #pragma once
 #include "mw_raster_common.h"
+#include "mw_cover.h"
 
 namespace {
 
@@ -115,48 +116,19 @@ __device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const
 }
 
 // ---- the obs-sized frame's fast path ----------------------------------------------------------------------------------------
-// For frames up to 128 x 128 the 24.8 coordinates stay below 2^15 and every product of the triangle setup fits 32 bits.
+// For frames up to 128 x 96 the 24.8 coordinates stay below 2^15 and every sum of the triangle setup fits 32 bits.
 // A triangle inside the frustum is set up and scattered with 32-bit integers; what crosses a frustum plane is listed for
 // mw_mesh_slow_kernel.  A triangle that covers a sample leaves its attribute planes in the env's plane
 // cache (MW_PLANE_REC floats per mesh triangle in view, indexed like the draw ids), so that the tile phase shades a mesh
 // winner with a 80-byte lookup instead of re-deriving its three vertices.
 
-__device__ inline bool scatter_tri_narrow(const int dcdx[3], const int dcdy[3], const int c[3], const mwgl::Plane &zp, int minx, int maxx,
-                                          int miny, int maxy, int W, int H, uint32_t id, uint32_t *keys)
+// every sample inside the set-up triangle gets min(key, depth16 << 16 | id); true if there was any (mw_cover.h: the sample
+// columns that cross a small triangle's bounding box, the box's pixels otherwise)
+__device__ inline bool scatter_tri_cols(const mwcov::Edges &ed, int W, int H, uint32_t id, uint32_t *keys)
 {
-    int x0 = minx >> 8, x1 = maxx >> 8, y0 = miny >> 8, y1 = maxy >> 8;
-    x0 = x0 < 0 ? 0 : x0; y0 = y0 < 0 ? 0 : y0;
-    x1 = x1 > W - 1 ? W - 1 : x1; y1 = y1 > H - 1 ? H - 1 : y1;
-    if (x0 > x1 || y0 > y1) return false;
-    // sample thresholds: inside <=> E_k(pixel corner) > thr_k[s]
-    int thr[3][8];
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int s = 0; s < 8; ++s)
-            thr[k][s] = __mul24(dcdx[k], (int)mwrec::kPat[2][s][0] * 16) - __mul24(dcdy[k], (int)mwrec::kPat[2][s][1] * 16);
-    bool won = false;
-    for (int gy = y0; gy <= y1; ++gy) {
-        const int e0 = c[0] + __mul24(dcdy[0], gy * 256), e1 = c[1] + __mul24(dcdy[1], gy * 256), e2 = c[2] + __mul24(dcdy[2], gy * 256);
-        for (int px = x0; px <= x1; ++px) {
-            const int E0 = e0 - __mul24(dcdx[0], px * 256), E1 = e1 - __mul24(dcdx[1], px * 256), E2 = e2 - __mul24(dcdx[2], px * 256);
-            uint32_t in = 0u;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) in |= (E0 > thr[0][s] && E1 > thr[1][s] && E2 > thr[2][s]) ? (1u << s) : 0u;
-            if (in == 0u) continue;
-            uint32_t *kp = keys + ((size_t)(H - 1 - gy) * W + px) * 8;
-#pragma unroll
-            for (int s = 0; s < 8; ++s) {
-                if ((in >> s) & 1u) {
-                    const float xs = (float)px + samp_fx<8>(s), ys = (float)gy + samp_fy<8>(s);
-                    const uint32_t key = (mwgl::z_to_unorm16(mwgl::plane_at(zp, xs, ys)) << 16) | id;
-                    atomicMin(kp + s, key);
-                    won = true;
-                }
-            }
-        }
-    }
-    return won;
+    return mwcov::cover(ed, W, H, [&](int px, int gy, int s, float xs, float ys) {
+        atomicMin(keys + ((size_t)(H - 1 - gy) * W + px) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id);
+    });
 }
 
 __device__ inline void store_planes(float *rec, const mwgl::TriSetup &ts, int tex, int state)
@@ -169,59 +141,20 @@ __device__ inline void store_planes(float *rec, const mwgl::TriSetup &ts, int te
     if (tex >= 0) q[4] = make_float4(ts.s.dady, ts.t.a0, ts.t.dadx, ts.t.dady);
 }
 
-// one mesh triangle of an obs-sized 8-sample frame: keys into LDS, planes of a winner into the cache
-__device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys,
-                                      const float4 *attr, float *cache, int j, int32_t *slow_count, uint32_t *slow_tris)
+// a triangle that crosses a frustum plane (rare): left to mw_mesh_slow_kernel, which clips it, scatters its keys and lists its
+// fragments
+__device__ inline void list_slow_tri(int j, int tri, float *rec, int32_t *slow_count, uint32_t *slow_tris)
 {
-    mwgl::Vert v[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
-        mwgl::transform_vertex(f, e.x, p, v[k]);
-    }
-    if (v[0].clipmask & v[1].clipmask & v[2].clipmask) return;
-    const uint32_t id = (uint32_t)(e.start + tri);
-    float *rec = cache + (size_t)tri * MW_PLANE_REC;
-    if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) != 0u) {
-        // crosses a frustum plane (rare): left to mw_mesh_slow_kernel, which clips it, scatters its keys and lists its fragments
-        const int k = atomicAdd(slow_count, 1);
-        if (k < MW_SLOW_TRIS) slow_tris[k] = ((uint32_t)j << 16) | (uint32_t)tri;
-        reinterpret_cast<float4 *>(rec)[1] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(MW_PLANE_SLOW));
-        return;
-    }
-    // setup_triangle_pos in 32 bits
-    int fx[3], fy[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        fx[i] = mwgl::iround_even(v[i].win[0] * 256.0f);
-        fy[i] = mwgl::iround_even(v[i].win[1] * 256.0f);
-    }
-    {
-        const int dx01 = fx[0] - fx[1], dy01 = fy[0] - fy[1], dx20 = fx[2] - fx[0], dy20 = fy[2] - fy[0];
-        if (dx01 * dy20 - dx20 * dy01 >= 0) return;        // back-facing or empty
-    }
-    // front faces are set up in the order (v1, v0, v2)
-    const int X[3] = {fx[1], fx[0], fx[2]}, Y[3] = {fy[1], fy[0], fy[2]};
-    int dcdx[3], dcdy[3], c[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int j = i == 2 ? 0 : i + 1;
-        dcdy[i] = X[i] - X[j];
-        dcdx[i] = Y[i] - Y[j];
-        c[i] = dcdx[i] * X[i] - dcdy[i] * Y[i];
-        c[i] += (dcdx[i] < 0 || (dcdx[i] == 0 && dcdy[i] > 0)) ? 1 : 0;
-    }
-    const int minx = min(min(X[0], X[1]), X[2]), maxx = max(max(X[0], X[1]), X[2]);
-    const int miny = min(min(Y[0], Y[1]), Y[2]), maxy = max(max(Y[0], Y[1]), Y[2]);
-    const float *w0 = v[1].win, *w1 = v[0].win, *w2 = v[2].win;
-    const float fdx01 = w0[0] - w1[0], fdy01 = w0[1] - w1[1], fdx20 = w2[0] - w0[0], fdy20 = w2[1] - w0[1];
-    const float ooa = 1.0f / (fdx01 * fdy20 - fdx20 * fdy01);
-    mwgl::Plane zp;
-    mwgl::plane_coef(zp, w0[2], w1[2], w2[2], fdy20 * ooa, fdy01 * ooa, fdx20 * ooa, fdx01 * ooa, w0[0], w0[1]);
-    // the vertex attributes (normals, colours, texture coordinates: attr[0..5]) are requested before the scatter, whose
-    // atomics they then overlap; a triangle that covers a sample lights its vertices and sets up its attribute planes
+    const int k = atomicAdd(slow_count, 1);
+    if (k < MW_SLOW_TRIS) slow_tris[k] = ((uint32_t)j << 16) | (uint32_t)tri;
+    reinterpret_cast<float4 *>(rec)[1] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(MW_PLANE_SLOW));
+}
+
+// a triangle that covers a sample: its vertices lit (attr: normals, colours, texture coordinates of the three, 96 bytes), its
+// attribute planes set up and stored in the env's plane cache.  v: the vertex stage's window coordinates, drawing order.
+__device__ inline void setup_winner(const mwgl::Frame &f, const MeshEnt &e, mwgl::Vert (&v)[3], const float4 *attr, float *rec)
+{
     const float4 a0 = attr[0], a1 = attr[1], a2 = attr[2], a3 = attr[3], a4 = attr[4], a5 = attr[5];
-    if (!scatter_tri_narrow(dcdx, dcdy, c, zp, minx, maxx, miny, maxy, W, H, id, keys)) return;
     const float at[24] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w,
                           a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z, a4.w, a5.x, a5.y, a5.z, a5.w};
 #pragma unroll
@@ -233,6 +166,92 @@ __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, in
     }
     mwgl::TriSetup ts;
     if (mwgl::setup_triangle(v[0], v[1], v[2], true, e.tex >= 0, ts)) store_planes(rec, ts, e.tex, 1);
+}
+
+// One mesh triangle of an obs-sized 8-sample frame from its own three positions (a mesh without a vertex table): vertex
+// stage, setup, keys; a triangle that covers a sample leaves its attribute planes in the plane cache.
+__device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys,
+                                      const float4 *attr, float *cache, int j, int32_t *slow_count, uint32_t *slow_tris)
+{
+    mwgl::Vert v[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float p[3] = {pos[k * 3], pos[k * 3 + 1], pos[k * 3 + 2]};
+        mwgl::transform_vertex(f, e.x, p, v[k]);
+    }
+    if (v[0].clipmask & v[1].clipmask & v[2].clipmask) return;
+    float *rec = cache + (size_t)tri * MW_PLANE_REC;
+    if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) != 0u) { list_slow_tri(j, tri, rec, slow_count, slow_tris); return; }
+    mwcov::Edges ed;
+    if (!mwcov::setup_edges(v[0].win, v[1].win, v[2].win, ed)) return;        // back-facing or empty
+    if (!scatter_tri_cols(ed, W, H, (uint32_t)(e.start + tri), keys)) return;
+    setup_winner(f, e, v, attr, rec);
+}
+
+// ... from the entity's vertex table in LDS (mw_mesh_entity_kernel): a vertex is (window x, y, z, 1 / w), or, outside the
+// frustum, z = -(its clip mask).  The first pass only ASKS: 1 = the triangle covers a sample (a quarter of a distant ball's front
+// faces do: their keys, lighting and attribute planes are the work of consecutive lanes afterwards, scatter_winner), 2 = its
+// bounding box holds more than MW_ENT_BIG_PIXELS pixels — a lane is no place for a loop over hundreds of pixels, a wavefront
+// takes it pixel per lane (scatter_tri_wave) —, 0 = nothing to do (culled, no sample, or listed for the slow path).
+__device__ inline int classify_tri_table(int tri, const float4 &va, const float4 &vb, const float4 &vc, int W, int H,
+                                         float *cache, int j, int32_t *slow_count, uint32_t *slow_tris)
+{
+    if (va.z < 0.0f || vb.z < 0.0f || vc.z < 0.0f) {
+        const uint32_t ma = va.z < 0.0f ? (uint32_t)(int)(-va.z) : 0u, mb = vb.z < 0.0f ? (uint32_t)(int)(-vb.z) : 0u,
+                       mc = vc.z < 0.0f ? (uint32_t)(int)(-vc.z) : 0u;
+        if (!(ma & mb & mc)) list_slow_tri(j, tri, cache + (size_t)tri * MW_PLANE_REC, slow_count, slow_tris);
+        return 0;
+    }
+    const float wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
+    mwcov::Edges ed;
+    if (!mwcov::setup_edges_xy(wa, wb, wc, ed)) return 0;
+    int x0, x1, y0, y1;
+    if (!mwcov::pixel_box(ed, W, H, x0, x1, y0, y1)) return 0;
+    if ((x1 - x0 + 1) * (y1 - y0 + 1) > MW_ENT_BIG_PIXELS) return 2;
+    return mwcov::covers_any(ed, W, H) ? 1 : 0;
+}
+
+// a triangle that covers a sample (unclipped vertices of the table): its keys — unless a wavefront has scattered them —, its
+// vertices lit, its attribute planes into the plane cache
+__device__ inline void scatter_winner(const mwgl::Frame &f, const MeshEnt &e, int tri, const float4 &va, const float4 &vb, const float4 &vc, int W, int H,
+                                      uint32_t *keys, bool keys_done, const float4 *attr, float *rec)
+{
+    mwgl::Vert v[3];
+    v[0].win[0] = va.x; v[0].win[1] = va.y; v[0].win[2] = va.z; v[0].win[3] = va.w;
+    v[1].win[0] = vb.x; v[1].win[1] = vb.y; v[1].win[2] = vb.z; v[1].win[3] = vb.w;
+    v[2].win[0] = vc.x; v[2].win[1] = vc.y; v[2].win[2] = vc.z; v[2].win[3] = vc.w;
+    if (!keys_done) {
+        mwcov::Edges ed;
+        if (mwcov::setup_edges(v[0].win, v[1].win, v[2].win, ed)) scatter_tri_cols(ed, W, H, (uint32_t)(e.start + tri), keys);
+    }
+    setup_winner(f, e, v, attr, rec);
+}
+
+// A triangle of many pixels, the same for all lanes of the wavefront (vertices of the table, unclipped, front-facing): lane l
+// takes the pixels l, l + 64, ... of its bounding box.  True (in every lane) if it covers a sample.
+__device__ inline bool scatter_tri_wave(const MeshEnt &e, int tri, const float4 &va, const float4 &vb, const float4 &vc, int W, int H, uint32_t *keys, int lane)
+{
+    const float wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
+    mwcov::Edges ed;
+    int x0, x1, y0, y1;
+    if (!mwcov::setup_edges(wa, wb, wc, ed) || !mwcov::pixel_box(ed, W, H, x0, x1, y0, y1)) return false;
+    int thr[3][8];
+    mwcov::make_thresholds(ed, thr);
+    const uint32_t id = (uint32_t)(e.start + tri);
+    const int bw = x1 - x0 + 1, npix = bw * (y1 - y0 + 1);
+    const int q0 = lane / bw, dq = 64 / bw, dr = 64 - dq * bw;
+    int px = x0 + (lane - q0 * bw), gy = y0 + q0;
+    bool any = false;
+    for (int m = lane; m < npix; m += 64) {
+        const uint32_t in = mwcov::pixel_mask(ed, thr, px, gy);
+        mwcov::emit_samples(in, px, gy, [&](int sx, int sy, int s, float xs, float ys) {
+            atomicMin(keys + ((size_t)(H - 1 - sy) * W + sx) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id);
+        });
+        any |= in != 0u;
+        px += dr; gy += dq;
+        if (px > x1) { px -= bw; ++gy; }
+    }
+    return __any(any) != 0;
 }
 
 // Attribute planes of mesh triangle (e, tri) for the pixel (px, gy): the triangle is taken through the vertex stage again

@@ -1,33 +1,157 @@
-// The mesh scatter kernel (mesh triangles -> sample keys + attribute planes of the winners) and the generic-resolution
-// view kernels.  See mw_mesh.h.
+// The mesh entity kernel (mesh triangles -> sample keys + attribute planes of the winners), the kernel of the triangles that
+// cross a frustum plane, and the generic-resolution view kernels.  See mw_mesh.h.
 #include "mw_mesh.h"
 
-// Grid (MW_SCATTER_BLOCKS_X, N): the blocks of row y walk the mesh entities in view of env y, 256 triangles per block and
-// step, one triangle per lane, read from the mesh's stream in the order sorted by face normal (mw_upload_mesh: the 64
-// triangles of a wavefront face the same way, so back-face culling retires whole waves; 48 contiguous bytes per lane).  keys: [N][H][W][8] dwords, all 0xFFFFFFFF on entry inside the
-// entities' tile rectangles (K2 resets what it reads); planes: [N][plane_cap][MW_PLANE_REC].
-extern "C" __global__ __launch_bounds__(256) void mw_mesh_scatter_kernel(int W, int H, const float *__restrict__ envhdr,
-                                                                        const float *__restrict__ mesh_stream, const float *__restrict__ mesh_attr,
-                                                                        uint32_t *__restrict__ keys_all, float *__restrict__ plane_cache, int plane_cap,
-                                                                        int32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_tris)
+namespace {
+// a workgroup barrier that orders LDS only: the global minima and plane records in flight need no other wave's attention,
+// and waiting for them (what __syncthreads' fences do) was most of this kernel's time
+__device__ inline void lds_barrier()
 {
-    const int env = blockIdx.y;
-    const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
-    const int n_mesh = __float_as_int(hdr[3]);
-    if (n_mesh == 0) return;
-    uint32_t *keys = keys_all + (size_t)env * W * H * 8;
-    mwgl::Frame f;
-    frame_lite(hdr, W, H, f);
-    for (int j = 0; j < n_mesh; ++j) {
-        const MeshEnt e = load_ment(hdr + MW_HDR_MESH, j);
-        float *cache_e = plane_cache + ((size_t)env * plane_cap + (size_t)__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 25])) * MW_PLANE_REC;
-        for (int t = (int)blockIdx.x * 256 + (int)threadIdx.x; t < e.ntris; t += (int)gridDim.x * 256) {
-            // record t of the entity's stream: the t-th triangle of the rasterisation order, coalesced
-            const float4 *rec = reinterpret_cast<const float4 *>(mesh_stream) + (size_t)(e.first + t) * 3;
-            const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
-            const float pos[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-            const int tri = __float_as_int(r2.y);
-            raster_tri_obs(f, e, tri, pos, W, H, keys, reinterpret_cast<const float4 *>(mesh_attr) + (size_t)(e.first + t) * 6, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+}  // namespace
+
+// The mesh entity kernel: a workgroup takes a mesh entity in view through the vertex stage ONCE PER VERTEX
+// — ObjMesh draws per-face vertex arrays (objmesh.py:280-292), but a ball's 15 576 face vertices are 2 600 positions, and
+// transform_vertex is a function of the position and the entity's matrix alone — into a table in LDS (16 bytes per vertex:
+// window x, y, z, 1 / w; a vertex outside the frustum keeps its clip mask instead).  Then a triangle per lane, in the order
+// sorted by face normal (mw_upload_mesh: the 64 triangles of a wavefront face the same way, back-face culling retires whole
+// waves): three 16-bit indices, three LDS reads, 32-bit setup, coverage by sample columns (mw_cover.h), atomic minima of the
+// packed keys into the env's key buffer (all 0xFFFFFFFF on entry inside the entities' tile rectangles; K2 resets what it
+// reads).  The first pass only finds the triangles that cover a sample — a quarter of a distant ball's front faces —; they
+// are queued in LDS and consecutive lanes scatter their keys, light them and set them up (vertex attributes are read for those only): their attribute planes go to the env's plane
+// cache [N][plane_cap][MW_PLANE_REC], where K2's mesh tiles shade the winners from.  A mesh with more than MW_MESH_VCAP
+// distinct positions has no table and takes every triangle through the vertex stage by itself (raster_tri_obs).
+// The workgroups (MW_ENT_THREADS lanes; dynamic LDS: 16 bytes x the largest uploaded vertex table — a launch of one workgroup
+// per env would queue 2 048 of them for LDS, most to find no mesh in view) are persistent: each draws envs from a counter and
+// goes through the env's mesh entities in view.
+extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_kernel(
+    int N, int W, int H, const float *__restrict__ envhdr, const MwMeshDesc *__restrict__ meshes, const float4 *__restrict__ mesh_vpos,
+    const uint2 *__restrict__ mesh_idx, const float *__restrict__ mesh_stream, const float *__restrict__ mesh_attr, uint32_t *__restrict__ keys_all,
+    float *__restrict__ plane_cache, int plane_cap, int32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_tris, const uint32_t *__restrict__ ent_list, int ent_list_cap, int32_t *ent_n, int32_t *ent_n_after,
+    unsigned long long *prof)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 s_vert[];
+    __shared__ uint16_t s_queue[MW_ENT_ROUND], s_big[MW_ENT_ROUND];
+    __shared__ int s_qn, s_bn, s_env;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // ent_n: this frame's list lengths (the geometry kernel's) and the cursor into them; ent_n_after: the next frame's, zeroed
+    // here (the two swap places from frame to frame; nothing of the next frame starts before this kernel has ended)
+    if (blockIdx.x == 0 && tid < 4) ent_n_after[tid] = 0;
+    if (tid == 0) { s_qn = 0; s_bn = 0; }
+    const int n_long = min(ent_n[0], ent_list_cap), n_items = n_long + min(ent_n[1], ent_list_cap);
+    for (;;) {
+        lds_barrier();
+        if (tid == 0) s_env = atomicAdd(ent_n + 2, 1);
+        lds_barrier();
+        const int item_i = s_env;
+        if (item_i >= n_items) break;
+        const uint32_t item = item_i < n_long ? ent_list[item_i] : ent_list[ent_list_cap + item_i - n_long];
+        const int env = (int)(item & 0xFFFFFFu), j = (int)(item >> 24);
+        const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
+        uint32_t *keys = keys_all + (size_t)env * W * H * 8;
+        mwgl::Frame f;
+        frame_lite(hdr, W, H, f);
+        // (MW_ENT_PROF, perf experiments: per env start / end time, entities, triangles, wavefront-sized triangles, winners, workgroup)
+        unsigned long long pr_t0 = 0ull, pr_tris = 0ull, pr_big = 0ull, pr_win = 0ull, pr_ph[4] = {0ull, 0ull, 0ull, 0ull}, pr_last = 0ull;
+        if (prof) pr_t0 = pr_last = __builtin_amdgcn_s_memrealtime();
+#define MW_ENT_PHASE(i) if (prof) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); pr_ph[i] += now_ - pr_last; pr_last = now_; }
+        {
+            const MeshEnt e = load_ment(hdr + MW_HDR_MESH, j);
+            float *cache_e = plane_cache + ((size_t)env * plane_cap + (size_t)__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 25])) * MW_PLANE_REC;
+            const MwMeshDesc md = meshes[__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 27])];
+            const int nverts = (int)md.nverts;
+            const float4 *attr_e = reinterpret_cast<const float4 *>(mesh_attr) + (size_t)e.first * 6;
+            if (nverts == 0) {
+                // no vertex table: record t of the entity's stream is the t-th triangle of the rasterisation order (48 bytes)
+                for (int t = tid; t < e.ntris; t += MW_ENT_THREADS) {
+                    const float4 *rec = reinterpret_cast<const float4 *>(mesh_stream) + (size_t)(e.first + t) * 3;
+                    const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
+                    const float pos[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
+                    raster_tri_obs(f, e, __float_as_int(r2.y), pos, W, H, keys, attr_e + (size_t)t * 6, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS);
+                }
+                continue;       // (the next item)
+            }
+            // ---- the vertex stage, a position per lane (the table's last readers are behind a barrier)
+            // (all of a lane's positions requested before the first is used)
+            static_assert(MW_MESH_VCAP == 7 * MW_ENT_THREADS, "seven positions per lane");
+            float4 p4[7];
+#pragma unroll
+            for (int i = 0; i < 7; ++i) { const int v = tid + i * MW_ENT_THREADS; p4[i] = v < nverts ? mesh_vpos[md.vfirst + v] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+#pragma unroll
+            for (int i = 0; i < 7; ++i) {
+                const int v = tid + i * MW_ENT_THREADS;
+                if (v < nverts) {
+                    const float p[3] = {p4[i].x, p4[i].y, p4[i].z};
+                    mwgl::Vert V;
+                    mwgl::transform_vertex(f, e.x, p, V);
+                    s_vert[v] = V.clipmask ? make_float4(0.0f, 0.0f, -(float)V.clipmask, 0.0f) : make_float4(V.win[0], V.win[1], V.win[2], V.win[3]);
+                }
+            }
+            lds_barrier();
+            MW_ENT_PHASE(0)
+            const uint2 *idx_e = mesh_idx + e.first;
+            for (int base = 0; base < e.ntris; base += MW_ENT_ROUND) {
+                // ---- a triangle per lane: keys; what covers a sample is queued (the round's indices are requested up front: a
+                // load behind the first minima would wait for them)
+                static_assert(MW_ENT_ROUND == 4 * MW_ENT_THREADS, "four triangles per lane and round");
+                const int end = min(base + MW_ENT_ROUND, e.ntris);
+                uint2 ixr[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { const int t = base + tid + i * MW_ENT_THREADS; ixr[i] = t < end ? idx_e[t] : make_uint2(0u, 0u); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int t = base + tid + i * MW_ENT_THREADS;
+                    if (t < end) {
+                        const uint2 ix = ixr[i];
+                        const float4 va = s_vert[ix.x & 0xFFFFu], vb = s_vert[ix.x >> 16], vc = s_vert[ix.y & 0xFFFFu];
+                        const int r = classify_tri_table((int)(ix.y >> 16), va, vb, vc, W, H, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS);
+                        if (r == 1) s_queue[atomicAdd(&s_qn, 1)] = (uint16_t)(t - base);
+                        else if (r == 2) s_big[atomicAdd(&s_bn, 1)] = (uint16_t)(t - base);
+                    }
+                }
+                lds_barrier();
+                // ---- the triangles of many pixels, one per wavefront at a time (a key or a medkit at arm's length: one lane would
+                // loop over hundreds of pixels while its wavefront — and the kernel, which ends with its slowest workgroup — waits);
+                // entry k0 + 8 l + w is wavefront w's l-th: its lanes fetch the indices of 64 of them at once
+                const int nb = s_bn;
+                MW_ENT_PHASE(1)
+                if (prof) { pr_big += (unsigned long long)nb; pr_tris += (unsigned long long)(end - base); }
+                for (int k0 = 0; k0 < nb; k0 += MW_ENT_THREADS) {
+                    const int kk = k0 + lane * (MW_ENT_THREADS / 64) + wave;
+                    const int tq = kk < nb ? (int)s_big[kk] : 0;
+                    const uint2 iq = kk < nb ? idx_e[base + tq] : make_uint2(0u, 0u);
+                    const int cnt = (min(nb - k0, MW_ENT_THREADS) - wave + (MW_ENT_THREADS / 64 - 1)) / (MW_ENT_THREADS / 64);
+                    for (int l = 0; l < cnt; ++l) {
+                        const uint32_t ixx = (uint32_t)__builtin_amdgcn_readlane((int)iq.x, l), ixy = (uint32_t)__builtin_amdgcn_readlane((int)iq.y, l);
+                        const int tl = __builtin_amdgcn_readlane(tq, l);
+                        const float4 va = s_vert[ixx & 0xFFFFu], vb = s_vert[ixx >> 16], vc = s_vert[ixy & 0xFFFFu];
+                        if (scatter_tri_wave(e, (int)(ixy >> 16), va, vb, vc, W, H, keys, lane) && lane == 0) s_queue[atomicAdd(&s_qn, 1)] = (uint16_t)(tl | 0x8000);      // (keys done)
+                    }
+                }
+                if (nb) lds_barrier();
+                MW_ENT_PHASE(2)
+                // ---- a queued triangle per lane: keys, lighting, attribute planes
+                const int nq = s_qn;
+                if (prof) pr_win += (unsigned long long)nq;
+                for (int k = tid; k < nq; k += MW_ENT_THREADS) {
+                    const int qe = (int)s_queue[k], tq = base + (qe & 0x7FFF);
+                    const uint2 iq = idx_e[tq];
+                    const float4 va = s_vert[iq.x & 0xFFFFu], vb = s_vert[iq.x >> 16], vc = s_vert[iq.y & 0xFFFFu];
+                    scatter_winner(f, e, (int)(iq.y >> 16), va, vb, vc, W, H, keys, (qe & 0x8000) != 0, attr_e + (size_t)tq * 6, cache_e + (size_t)(iq.y >> 16) * MW_PLANE_REC);
+                }
+                lds_barrier();
+                if (tid == 0) { s_qn = 0; s_bn = 0; }
+                lds_barrier();
+                MW_ENT_PHASE(3)
+            }
+        }
+        if (prof && tid == 0) {
+            unsigned long long *p = prof + (size_t)item_i * 8;
+            p[0] = pr_t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = 1ull | (pr_tris << 8) | (pr_win << 32); p[3] = pr_ph[0]; p[4] = pr_ph[1]; p[5] = pr_ph[2] | (pr_ph[3] << 32);
+            p[6] = (unsigned long long)blockIdx.x; p[7] = (unsigned long long)item;
         }
     }
 }

@@ -4,6 +4,7 @@
 // (tests/test_engine_math_cpu.py).  Never part of the product: the engine has no CPU path.
 // Input: the oracle's scene struct (oracle/mwo.h), so that tests feed both from the same arrays.
 #include "../../miniworld_amd/csrc/mw_frag.h"
+#include "../../miniworld_amd/csrc/mw_cover.h"
 #include "../../oracle/mwo.h"
 #include <vector>
 #include <cstdlib>
@@ -423,3 +424,58 @@ extern "C" int mwhost_box_cull_contradictions(const double eye[3], const double 
     return bad;
 }
 
+
+// mw_cover.h: the mesh entity kernel's coverage of a small triangle by sample columns (setup_edges + cover_columns, 32-bit
+// integers) against the definition — mw_glmath.h's setup_triangle_pos (64-bit edge constants) tested at every sample of every
+// pixel of the frame, and the packed depth keys at the covered samples.  win: [n][3][4] window coordinates; returns the
+// number of triangles whose sample sets, depth keys or culling differ; *covered = samples covered in total.
+extern "C" long mwhost_cover_mismatches(const float *win, long n, int W, int H, long *covered)
+{
+    long bad = 0, cov = 0;
+    std::vector<uint32_t> want((size_t)W * H * 8), got((size_t)W * H * 8);
+    for (long t = 0; t < n; ++t) {
+        const float *wa = win + t * 12, *wb = wa + 4, *wc = wa + 8;
+        TriEdges te;
+        const bool kept = setup_triangle_pos(wa, wb, wc, true, te);
+        mwcov::Edges e;
+        const bool kept2 = mwcov::setup_edges(wa, wb, wc, e);
+        if (kept != kept2) { ++bad; continue; }
+        if (!kept) continue;
+        bool same = e.minx == te.minx && e.maxx == te.maxx && e.miny == te.miny && e.maxy == te.maxy &&
+                    e.z.a0 == te.z.a0 && e.z.dadx == te.z.dadx && e.z.dady == te.z.dady;
+        for (int k = 0; k < 3; ++k) same &= e.dcdx[k] == te.dcdx[k] && e.dcdy[k] == te.dcdy[k] && (int64_t)e.c[k] == te.c[k];
+        std::fill(want.begin(), want.end(), 0xFFFFFFFFu);
+        std::fill(got.begin(), got.end(), 0xFFFFFFFFu);
+        for (int gy = 0; gy < H; ++gy)
+            for (int px = 0; px < W; ++px)
+                for (int s = 0; s < 8; ++s) {
+                    const int64_t fx = (int64_t)px * 256 + PAT8[s][0] * 16, fy = (int64_t)gy * 256 + PAT8[s][1] * 16;
+                    bool in = true;
+                    for (int k = 0; k < 3; ++k) in &= (te.c[k] + (int64_t)te.dcdy[k] * fy - (int64_t)te.dcdx[k] * fx) > 0;
+                    if (!in) continue;
+                    const float xs = (float)px + (float)PAT8[s][0] * 0.0625f, ys = (float)gy + (float)PAT8[s][1] * 0.0625f;
+                    want[((size_t)gy * W + px) * 8 + s] = z_to_unorm16(plane_at(te.z, xs, ys));
+                    ++cov;
+                }
+        int dup = 0;
+        auto sink = [&](int px, int gy, int s, float xs, float ys) {
+            uint32_t &g = got[((size_t)gy * W + px) * 8 + s];
+            if (g != 0xFFFFFFFFu) ++dup;
+            g = z_to_unorm16(plane_at(e.z, xs, ys));
+        };
+        // both forms on every triangle, whichever mwcov::cover would choose
+        mwcov::cover_columns(e, W, H, sink);
+        if (!same || dup || want != got) { ++bad; continue; }
+        std::fill(got.begin(), got.end(), 0xFFFFFFFFu);
+        mwcov::cover_pixels(e, W, H, sink);
+        if (dup || want != got) { ++bad; continue; }
+        std::fill(got.begin(), got.end(), 0xFFFFFFFFu);
+        const bool any = mwcov::cover(e, W, H, sink);
+        if (dup || want != got) { ++bad; continue; }
+        // ... and the question alone (edges and bounds only, no depth plane)
+        mwcov::Edges exy;
+        if (!mwcov::setup_edges_xy(wa, wb, wc, exy) || mwcov::covers_any(exy, W, H) != any) ++bad;
+    }
+    if (covered) *covered = cov;
+    return bad;
+}

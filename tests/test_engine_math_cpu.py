@@ -21,7 +21,7 @@ ROOT = os.path.dirname(HERE)
 
 @pytest.fixture(scope="module")
 def host():
-    deps = [SRC, os.path.join(ROOT, "miniworld_amd", "csrc", "mw_glmath.h"), os.path.join(ROOT, "miniworld_amd", "csrc", "mw_frag.h")]
+    deps = [SRC] + [os.path.join(ROOT, "miniworld_amd", "csrc", h) for h in ("mw_glmath.h", "mw_frag.h", "mw_cover.h")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         fma = ["-mfma"] if " fma " in open("/proc/cpuinfo").read() else []
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", *fma, "-shared", SRC,
@@ -31,7 +31,42 @@ def host():
     lib.mwhost_sincosf.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.mwhost_lod_bits_mismatches.argtypes = [C.c_void_p, C.c_long]
     lib.mwhost_lod_bits_mismatches.restype = C.c_long
+    lib.mwhost_cover_mismatches.argtypes = [C.c_void_p, C.c_long, C.c_int, C.c_int, C.POINTER(C.c_long)]
+    lib.mwhost_cover_mismatches.restype = C.c_long
     return lib
+
+
+@pytest.mark.parametrize("size", [(80, 60), (128, 96), (16, 4)])
+def test_coverage_by_sample_columns_equals_the_per_sample_definition(host, size):
+    """mw_cover.h (the mesh entity kernel's triangle setup in 32 bits and its coverage loop over the sample columns that cross
+    a small triangle's bounding box) against setup_triangle_pos + the inside test at every sample of every pixel: the same
+    culling, edges, bounds and depth plane, the same samples — each once — with the same 16-bit depths.  Sub-pixel triangles
+    (a ball's), triangles of a few pixels, vertices ON sample positions and pixel corners (the fill rule's ties), triangles
+    across the frame's border and larger than the frame."""
+    W, H = size
+    rng = np.random.default_rng(5)
+    tris = []
+
+    def add(centre, radius, n, snap=None):
+        c = centre[:, None, :] + rng.uniform(-1, 1, (n, 3, 2)) * radius[:, None, None]
+        if snap:
+            c = np.round(c * snap) / snap
+        z = rng.uniform(0.05, 0.999, (n, 3, 1))
+        oow = rng.uniform(0.1, 10.0, (n, 3, 1))
+        tris.append(np.concatenate([c, z, oow], axis=2).astype(np.float32))
+
+    frame = np.array([W, H], np.float64)
+    for radius, n in ((0.15, 30000), (0.5, 30000), (1.5, 20000), (6.0, 4000), (60.0, 400)):
+        add(rng.uniform(-0.5, 1.0, (n, 2)) * frame * [1, 1] + rng.uniform(0, 1, (n, 2)) * 0, np.full(n, radius), n)
+        add(rng.uniform(0, 1, (n // 2, 2)) * frame, np.full(n // 2, radius), n // 2, snap=16)        # vertices on the sample lattice
+        add(rng.uniform(0, 1, (n // 4, 2)) * frame, np.full(n // 4, radius), n // 4, snap=1)         # ... on pixel corners
+    win = np.ascontiguousarray(np.concatenate(tris))
+    win[:, :, 0] = np.clip(win[:, :, 0], 0, W)       # unclipped vertices lie inside the viewport
+    win[:, :, 1] = np.clip(win[:, :, 1], 0, H)
+    covered = C.c_long(0)
+    bad = host.mwhost_cover_mismatches(win.ctypes.data, len(win), W, H, C.byref(covered))
+    assert bad == 0, f"{bad} of {len(win)} triangles differ"
+    assert covered.value > 100_000
 
 
 def test_lod_from_the_bits_of_rho2_equals_the_float_arithmetic(host):

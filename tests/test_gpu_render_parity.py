@@ -189,3 +189,42 @@ def test_top_view_matches_oracle(case):
     for i, f in enumerate(frames):
         assert np.array_equal(rgb[i], obs[f]["top_rgb"]), f"{case} frame {f}: {np.count_nonzero(rgb[i] != obs[f]['top_rgb'])} values differ"
     eng.close()
+
+
+def test_mesh_without_a_vertex_table_takes_the_per_triangle_vertex_stage():
+    """The mesh entity kernel runs the vertex stage once per distinct position (a table in LDS, at most MW_MESH_VCAP = 3584
+    positions); a mesh with more keeps no table and every triangle transforms its own three vertices.  Here every ball of
+    the PickupObjects fixture is cracked open — each face vertex moved by an offset of its own, 15 576 distinct positions —
+    and the frames must still be the oracle's of the same arrays."""
+    import torch
+    import pyoracle
+    s0, tr, meta, obs = helpers.load_case("pickup_s0")
+    frames = sorted(obs)[:4]
+    scenes = [helpers.frame_scene(s0, obs[f]) for f in frames]
+    eng = helpers.make_engine_for_scene(s0, len(scenes))
+    meshes = helpers.golden_meshes(s0)
+    rng = np.random.default_rng(11)
+    cracked = 0
+    for i, name in enumerate([str(m) for m in s0["mesh_names"]]):
+        m = meshes[name]
+        if len(m["verts"]) < 2000:
+            continue
+        m["verts"] = (m["verts"] + rng.uniform(-2e-3, 2e-3, m["verts"].shape)).astype(np.float32)
+        assert len(np.unique(m["verts"].reshape(-1, 3), axis=0)) > 3584
+        eng.upload_mesh(eng._test_mesh_map[i], m["verts"], m["norms"], m["texcs"], m["colors"], -1)
+        cracked += 1
+    assert cracked > 0
+    eng.set_state(helpers.scene_state_arrays(scenes))
+    rgb = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
+    depth = torch.zeros((len(scenes), 60, 80, 1), dtype=torch.float32, device="cuda")
+    eng.render(rgb, depth)
+    eng.check()
+    rgb, depth = rgb.cpu().numpy(), depth.cpu().numpy()
+    shown = 0
+    for i, f in enumerate(frames):
+        want = pyoracle.render(scenes[i], meshes=meshes)
+        assert np.array_equal(depth[i], want["depth"]), f"frame {f}: depth differs"
+        assert np.array_equal(rgb[i], want["rgb"]), f"frame {f}: {np.count_nonzero(rgb[i] != want['rgb'])} RGB values differ"
+        shown += int(np.count_nonzero(want["rgb"] != pyoracle.render(scenes[i], meshes=helpers.golden_meshes(s0))["rgb"]))
+    assert shown > 0          # a cracked ball is in view somewhere
+    eng.close()
