@@ -61,6 +61,9 @@ struct MwMeshDesc {
     float last_n[3];               // vertex normal of the LAST triangle's last vertex in drawing order (GL's current
     uint32_t pad;                  //   normal after the mesh, for the top view's agent marker)
     uint32_t vfirst, nverts;       // the mesh's table of distinct positions in the vertex pool (nverts = 0: more than MW_MESH_VCAP, no table)
+    float bmin[3], bmax[3];        // bounding box of the vertices (object space), its centre and the radius of the sphere about the centre
+    float center[3];               //   that holds them: the geometry kernel's view test and tile rectangle (a ball's origin lies at its
+    float radius;                  //   foot: the sphere about the ORIGIN has twice the ball's radius, four times its tiles)
 };
 
 // Mesh pools: per-face-vertex arrays in drawing order (= draw ids, GL's first-drawn-wins on equal depth, the oracle's
@@ -166,8 +169,12 @@ struct MwArgs {
     // the frame's mesh entities in view, for mw_mesh_entity_kernel (written by the geometry kernel when non-null):
     // ent_list_n[0 / 1] entries — env | table entry << 24 — at ent_list (meshes of 1024 triangles and more: drawn from
     // first) and at ent_list + ent_list_cap (the others)
+    // ... and the tiles inside the union of their tile rectangles, for the mesh tiles' launch: ent_list_n[3] entries
+    // env | tile << 24 at tile_list.  (ent_list_n: 8 counters per frame parity — long meshes, short meshes, the entity kernel's
+    // cursor, tiles, 4 spare.)
     uint32_t *ent_list;
     int32_t *ent_list_n;
-    int32_t ent_list_cap, pad_ent;
+    uint32_t *tile_list;
+    int32_t ent_list_cap, tile_list_cap;
     unsigned long long *k1_prof;   // MW_K1_PROF: [N][MW_K1_PROF_SLOTS] cycle counters of the geometry kernel's phases, start and end time of the env's wavefront (tools/perf/kgprof.py; perf experiments only), else null
 };

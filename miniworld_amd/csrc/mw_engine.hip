@@ -39,7 +39,7 @@ extern "C" __global__ void mw_geom_big_any_kernel(MwArgs a, int view_flags, int 
                                     const float *envhdr, const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth, int dbg, \
                                     int texel_bytes, const uint16_t *rec_order, const float *mesh_pos, const float *mesh_nrm, \
                                     const float *mesh_rgb, const float *mesh_uv, uint32_t *mesh_keys, const float *plane_cache, int plane_cap, \
-                                    const float4 *slow_frags, const uint32_t *slow_head)
+                                    const float4 *slow_frags, const uint32_t *slow_head, const uint32_t *tile_list, int32_t *tile_n)
 MW_RASTER_DECL(mw_raster_kernel);
 MW_RASTER_DECL(mw_raster_depth_kernel);
 MW_RASTER_DECL(mw_raster_big_kernel);
@@ -136,7 +136,9 @@ struct mw_engine {
     uint32_t *d_mesh_keys = nullptr;    // [N][H][W][8] sample keys of the mesh scatter kernel (all-ones between frames)
     bool mesh_keys_dirty = true;
     int32_t *d_slow_count = nullptr;    // [2 parities][2][N] listed triangles, fragments
-    int32_t *d_ent_counter = nullptr;   // [2][4] the mesh entity kernel's work list: lengths (long / short meshes) and cursor, this frame's and the next frame's
+    int32_t *d_ent_counter = nullptr;   // [2][8] the work lists' lengths and cursors (mw_device.h: ent_list_n), this frame's and the next frame's
+    uint32_t *d_tile_list = nullptr;    // [N * n_tiles] the mesh tiles' work list (written by the geometry kernel)
+    int mesh_tile_waves = 16384;        // wavefronts of the mesh tiles' launch, wavefront w taking the items w, w + 16384, ... of the list (MW_MESH_TILE_WAVES; 4096: 139 us, 8192: 122, 16384: 112)
     uint32_t *d_ent_list = nullptr;     // [2][N * slots] the work list itself (written by the geometry kernel)
     int ent_list_cap = 0;
     int ent_blocks = 512;               // its persistent workgroups: two per CU (MW_ENT_BLOCKS; 768 measured slower beside the quad kernel)
@@ -180,7 +182,6 @@ struct mw_engine {
     bool scatter_overlap = true;    // MW_SCATTER_OVERLAP=0: the mesh scatter kernel alone, before the raster kernel's first part (the tile kernels' order;
                                     // beside the quad kernel the scatter overlaps well: PickupObjects 0.522 -> 0.495 ms per step)
     int slow_bx = 16;           // MW_SLOW_BX
-    int mesh_wpe = 0;           // MW_MESH_WPE: wavefronts per env of the mesh tiles' launch (0: one per tile)
     int raster_big = -1;        // MW_RASTER_BIG
     bool k2_first_full = false; // MW_K2_FIRST_FULL
     unsigned long long *d_ent_prof = nullptr;   // MW_ENT_PROF=<file>: the mesh entity kernel's per-env times and counts of the last frame, [N][8], dumped by mw_destroy
@@ -622,14 +623,15 @@ int ensure_mesh_buffers(mw_engine *e)
     if (!e->d_ent_list) {
         e->ent_list_cap = (int)N * std::min(MW_MAX_MESH_ENTS, std::max(e->cfg.max_ents, 1));
         if (hipMalloc((void **)&e->d_ent_list, (size_t)e->ent_list_cap * 2 * 4) != hipSuccess) { e->d_ent_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh entity list failed"); }
+        if (hipMalloc((void **)&e->d_tile_list, N * (size_t)a.n_tiles * 4) != hipSuccess) { (void)hipFree(e->d_ent_list); e->d_ent_list = nullptr; e->d_tile_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh tile list failed"); }
     }
     if (!e->d_mesh_keys) {
         const size_t key_bytes = N * a.W * a.H * 8 * 4, head_bytes = N * a.W * a.H * 4;
         void *keys = nullptr, *cnt = nullptr, *tris = nullptr, *frags = nullptr, *head = nullptr;
         // triangles that cross a frustum plane and their fragments (mw_mesh_slow_kernel): counts, 1024 / 2048 entries per env
-        const bool ok = hipMalloc(&keys, key_bytes) == hipSuccess && hipMalloc(&cnt, N * 4 * 4 + 32) == hipSuccess && hipMalloc(&tris, N * MW_SLOW_TRIS * 4) == hipSuccess &&
+        const bool ok = hipMalloc(&keys, key_bytes) == hipSuccess && hipMalloc(&cnt, N * 4 * 4 + 64) == hipSuccess && hipMalloc(&tris, N * MW_SLOW_TRIS * 4) == hipSuccess &&
                         hipMalloc(&frags, N * MW_SLOW_STRIDE * 16) == hipSuccess && hipMalloc(&head, head_bytes) == hipSuccess &&
-                        hipMemset(cnt, 0, N * 4 * 4 + 32) == hipSuccess && hipMemset(head, 0, head_bytes) == hipSuccess && hipMemset(keys, 0xFF, key_bytes) == hipSuccess;
+                        hipMemset(cnt, 0, N * 4 * 4 + 64) == hipSuccess && hipMemset(head, 0, head_bytes) == hipSuccess && hipMemset(keys, 0xFF, key_bytes) == hipSuccess;
         if (!ok) {
             for (void *p : {keys, cnt, tris, frags, head}) if (p) (void)hipFree(p);
             return fail(e, MW_E_NOMEM, "hipMalloc for the mesh path's buffers failed");
@@ -658,7 +660,10 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // entity kernel (lists, slow-path lists and fragment stamps alternate between two sets from frame to frame)
     const bool mesh_obs = e->have_meshes && e->cfg.msaa == 8 && tile_kernels_exact(a.W, a.H) && e->d_ent_list && e->d_mesh_keys;
     const uint32_t mesh_seq = mesh_obs ? e->mesh_frame_seq++ : 0u;
-    if (mesh_obs) { a.ent_list = e->d_ent_list; a.ent_list_n = e->d_ent_counter + (mesh_seq & 1u) * 4; a.ent_list_cap = e->ent_list_cap; }
+    if (mesh_obs) {
+        a.ent_list = e->d_ent_list; a.ent_list_n = e->d_ent_counter + (mesh_seq & 1u) * 8; a.ent_list_cap = e->ent_list_cap;
+        a.tile_list = e->d_tile_list; a.tile_list_cap = N * a.n_tiles;
+    }
     mw_engine::Ev ev{};
     // kernel durations are sampled: three event records on every launch cost ~4 % of the step rate,
     // on one launch in MW_TIMING_STRIDE they cost nothing measurable
@@ -783,7 +788,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                 hipLaunchKernelGGL(mw_mesh_entity_kernel, dim3(std::min(e->ent_list_cap, e->ent_blocks)), dim3(MW_ENT_THREADS), (size_t)e->max_mesh_verts * 16, scatter_first ? st : sb, N, a.W, a.H,
                                    (const float *)a.envhdr, a.mesh, (const float4 *)e->d_mesh_vpos, (const uint2 *)e->d_mesh_idx, (const float *)e->d_mesh_stream,
                                    (const float *)e->d_mesh_attr, e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris,
-                                   (const uint32_t *)e->d_ent_list, e->ent_list_cap, e->d_ent_counter + parity * 4, e->d_ent_counter + (parity ^ 1) * 4, e->d_ent_prof);
+                                   (const uint32_t *)e->d_ent_list, e->ent_list_cap, e->d_ent_counter + parity * 8, e->d_ent_counter + (parity ^ 1) * 8, e->d_ent_prof);
             }
             if (scatter_first) {
                 HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
@@ -815,15 +820,20 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         // K2's first part of a frame with meshes never enters a mesh tile: the plain tile code with the skip (the small-scene observation path only)
         auto k2_first = (mesh && !big && !general && !e->k2_first_full) ? (d_depth ? mw_raster_nomesh_depth_kernel : mw_raster_nomesh_kernel) : k2;
         auto launch_k2 = [&](int part_flags, hipStream_t ks) {
-            // the second part (the tiles a mesh can touch: few, slow, clustered) spreads over one wave per tile
-            const int wpe2 = (part_flags >> 4) == 2 ? (e->mesh_wpe > 0 ? std::min(e->mesh_wpe, (int)a.n_tiles) : a.n_tiles) : wpe;
-            const int tpw2 = (part_flags >> 4) == 2 ? (a.n_tiles + wpe2 - 1) / wpe2 : tpw;
-            hipLaunchKernelGGL((part_flags >> 4) == 1 ? k2_first : k2, dim3(groups * 8 * wpe2), dim3(64), lds, ks, a.N, a.W, a.H, a.max_vis, a.tiles_x,
+            // the second part (the tiles a mesh can touch: few, slow, clustered): persistent wavefronts over the geometry kernel's
+            // tile list (flags 3 << 4)
+            const bool listed = (part_flags >> 4) == 2 && a.tile_list != nullptr;
+            if (listed) part_flags = (part_flags & ~0x30) | (3 << 4);
+            const int wpe2 = (part_flags >> 4) == 2 ? a.n_tiles : wpe;
+            const int tpw2 = (part_flags >> 4) == 2 ? 1 : tpw;
+            const int grid = listed ? std::min(e->mesh_tile_waves, N * (int)a.n_tiles) : groups * 8 * wpe2;
+            hipLaunchKernelGGL((part_flags >> 4) == 1 ? k2_first : k2, dim3(grid), dim3(64), lds, ks, a.N, a.W, a.H, a.max_vis, a.tiles_x,
                                a.n_tiles, wpe2, tpw2, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
                                (const int32_t *)a.nvis,
                                (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, flags | part_flags, e->texel_bytes,
                                (const uint16_t *)a.rec_order, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, e->d_mesh_keys,
-                               (const float *)e->d_plane_cache, e->plane_cap, (const float4 *)e->d_slow_frags, (const uint32_t *)e->d_slow_head);
+                               (const float *)e->d_plane_cache, e->plane_cap, (const float4 *)e->d_slow_frags, (const uint32_t *)e->d_slow_head,
+                               (const uint32_t *)a.tile_list, a.ent_list_n);
         };
         e->last_raster_path = k2q ? (mesh ? MW_PATH_QUAD_MESH : MW_PATH_QUAD) : MW_PATH_TILE;
         if (mesh) {
@@ -1022,7 +1032,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
     if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;
     if (const char *s = getenv("MW_SLOW_BX")) { const int v = atoi(s); if (v > 0) e->slow_bx = v; }
-    if (const char *s = getenv("MW_MESH_WPE")) e->mesh_wpe = atoi(s);
+    if (const char *s = getenv("MW_MESH_TILE_WAVES")) { const int v = atoi(s); if (v > 0) e->mesh_tile_waves = v; }
     if (const char *s = getenv("MW_ENT_BLOCKS")) { const int v = atoi(s); if (v > 0) e->ent_blocks = v; }
     if (const char *s = getenv("MW_RASTER_BIG")) e->raster_big = atoi(s) != 0 ? 1 : 0;
     e->k2_first_full = getenv("MW_K2_FIRST_FULL") != nullptr;
@@ -1066,6 +1076,9 @@ void mw_destroy(mw_engine *e)
             long long tot = 0, nz = 0, mx = 0;
             for (int i = 0; i < e->cfg.num_envs; ++i) { const int v = h[(size_t)e->cfg.num_envs + i] + h[(size_t)e->cfg.num_envs * 3 + i]; tot += v; nz += v > 0; mx = std::max<long long>(mx, v); }
             fprintf(stderr, "slow fragments: total %lld, envs with any %lld of %d, max %lld\n", tot, nz, e->cfg.num_envs, mx);
+            int32_t c[16];
+            if (e->d_ent_counter && hipMemcpy(c, e->d_ent_counter, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
+                fprintf(stderr, "work lists of the last two frames: long meshes %d / %d, short %d / %d, mesh tiles %d / %d\n", c[0], c[8], c[1], c[9], c[3], c[11]);
         }
     }
     for (void *p : e->allocs) (void)hipFree(p);
@@ -1077,6 +1090,7 @@ void mw_destroy(mw_engine *e)
     if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
     if (e->d_mesh_keys) (void)hipFree(e->d_mesh_keys);
     if (e->d_ent_list) (void)hipFree(e->d_ent_list);
+    if (e->d_tile_list) (void)hipFree(e->d_tile_list);
     for (void *q : {(void *)e->d_slow_count, (void *)e->d_slow_tris, (void *)e->d_slow_frags, (void *)e->d_slow_head}) if (q) (void)hipFree(q);
     if (e->mesh_stream) { (void)hipStreamDestroy(e->mesh_stream); (void)hipEventDestroy(e->ev_mesh_fork); (void)hipEventDestroy(e->ev_mesh_join); }
     if (e->side_stream) { (void)hipStreamDestroy(e->side_stream); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
@@ -1170,6 +1184,19 @@ int mw_upload_mesh(mw_engine *e, int32_t mesh_id, const float *pos, const float 
             r2 = std::max(r2, pos[i * 3] * pos[i * 3] + pos[i * 3 + 1] * pos[i * 3 + 1] + pos[i * 3 + 2] * pos[i * 3 + 2]);
         const float r = std::sqrt(r2) * 1.0001f;
         memcpy(&e->mesh_desc[mesh_id].bound_bits, &r, 4);
+        // bounding box, its centre, the sphere about the centre (doubles: the radius rounds up)
+        MwMeshDesc &md = e->mesh_desc[mesh_id];
+        for (int c = 0; c < 3; ++c) { md.bmin[c] = pos[c]; md.bmax[c] = pos[c]; }
+        for (size_t i = 0; i < (size_t)ntris * 3; ++i)
+            for (int c = 0; c < 3; ++c) { md.bmin[c] = std::min(md.bmin[c], pos[i * 3 + c]); md.bmax[c] = std::max(md.bmax[c], pos[i * 3 + c]); }
+        for (int c = 0; c < 3; ++c) md.center[c] = 0.5f * (md.bmin[c] + md.bmax[c]);
+        double rc2 = 0.0;
+        for (size_t i = 0; i < (size_t)ntris * 3; ++i) {
+            double d2 = 0.0;
+            for (int c = 0; c < 3; ++c) { const double d = (double)pos[i * 3 + c] - (double)md.center[c]; d2 += d * d; }
+            rc2 = std::max(rc2, d2);
+        }
+        md.radius = (float)(std::sqrt(rc2) * 1.0001 + 1e-6);
     }
     // repack all pools (uploads are rare)
     size_t total = 0;

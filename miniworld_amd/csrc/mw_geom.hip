@@ -260,6 +260,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     // else the agent marker.
     int total_meshes = 0, total_mesh_tris = 0, total_boxes = 0;
     uint64_t mesh_in_view = 0ull;       // per entity slot: a mesh entity that is drawn
+    uint32_t tile_mask = 0u;            // tile sub + k L lies in a drawn mesh entity's tile rectangle: bit k
     for (int pass = 0; pass < 2; ++pass) {
         for (int s0 = 0; s0 < a.E; ++s0) {
             const int kind = a.ekind[(size_t)s0 * a.N + env];
@@ -279,10 +280,11 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                 bool in_view = true;
                 uint32_t rect;      // the tiles the entity's bounding sphere can touch: tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24 (image rows)
                 {
-                    const float brad = __uint_as_float(mdp->bound_bits) * scale * 1.001f + 1e-3f;
+                    // (the sphere about the bounding box's centre: a ball's origin lies at its foot)
+                    const float brad = mdp->radius * scale * 1.001f + 1e-3f;
                     mwgl::Vert o;
-                    const float zero[3] = {0.0f, 0.0f, 0.0f};
-                    mwgl::transform_vertex(f, ex, zero, o);
+                    const float ctr[3] = {mdp->center[0], mdp->center[1], mdp->center[2]};
+                    mwgl::transform_vertex(f, ex, ctr, o);
                     const float w = o.clip[3];
                     const float p00 = f.proj.m[0], p11 = f.proj.m[5];
                     float xlo = -1.0f, xhi = 1.0f, ylo = -1.0f, yhi = 1.0f;
@@ -303,6 +305,24 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                     const float Wf = (float)a.W, Hf = (float)a.H;
                     int x0 = (int)floorf(fmaxf((xlo * 0.5f + 0.5f) * Wf - 1.5f, 0.0f)), x1 = (int)fminf((xhi * 0.5f + 0.5f) * Wf + 1.5f, Wf - 1.0f);
                     int g0 = (int)floorf(fmaxf((ylo * 0.5f + 0.5f) * Hf - 1.5f, 0.0f)), g1 = (int)fminf((yhi * 0.5f + 0.5f) * Hf + 1.5f, Hf - 1.0f);
+                    // ... cut down to the window bounds of the bounding box's corners when all eight lie in front of the eye (a convex
+                    // combination of the corners then projects to a convex combination of their projections; a key is a thin
+                    // slab inside a sphere of its length)
+                    if (in_view) {
+                        bool front = true;
+                        float cxl = 1e30f, cxh = -1e30f, cyl = 1e30f, cyh = -1e30f;
+                        for (int c = 0; c < 8; ++c) {
+                            const float p[3] = {(c & 1) ? mdp->bmax[0] : mdp->bmin[0], (c & 2) ? mdp->bmax[1] : mdp->bmin[1], (c & 4) ? mdp->bmax[2] : mdp->bmin[2]};
+                            mwgl::Vert q;
+                            mwgl::transform_vertex(f, ex, p, q);
+                            front &= top || q.clip[3] > 0.05f;
+                            cxl = fminf(cxl, q.win[0]); cxh = fmaxf(cxh, q.win[0]); cyl = fminf(cyl, q.win[1]); cyh = fmaxf(cyh, q.win[1]);
+                        }
+                        if (front && cxl <= cxh && cyl <= cyh) {
+                            x0 = max(x0, (int)floorf(fmaxf(cxl - 1.5f, 0.0f))); x1 = min(x1, (int)fminf(cxh + 1.5f, Wf - 1.0f));
+                            g0 = max(g0, (int)floorf(fmaxf(cyl - 1.5f, 0.0f))); g1 = min(g1, (int)fminf(cyh + 1.5f, Hf - 1.0f));
+                        }
+                    }
                     if (x1 < x0 || g1 < g0) in_view = false;
                     const int y0 = a.H - 1 - g1, y1 = a.H - 1 - g0;
                     rect = (uint32_t)(x0 / MW_TILE_W) | ((uint32_t)(x1 / MW_TILE_W) << 8) | ((uint32_t)(y0 / MW_TILE_H) << 16) | ((uint32_t)(y1 / MW_TILE_H) << 24);
@@ -323,6 +343,14 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                         m[25] = __int_as_float(total_mesh_tris);    // mesh triangles drawn before
                         m[26] = __uint_as_float(rect);
                         m[27] = __int_as_float(mid);
+                    }
+                    if (a.tile_list) {
+                        // the tiles this lane answers for — sub, sub + L, ... — inside the entity's tile rectangle
+                        const int tx0 = (int)(rect & 255u), tx1 = (int)((rect >> 8) & 255u), ty0 = (int)((rect >> 16) & 255u), ty1 = (int)(rect >> 24);
+                        for (int k = 0, t = sub; t < a.n_tiles && k < 32; ++k, t += L) {
+                            const int ty = t / a.tiles_x, tx = t - ty * a.tiles_x;
+                            if (tx >= tx0 && tx <= tx1 && ty >= ty0 && ty <= ty1) tile_mask |= 1u << k;
+                        }
                     }
                     mesh_in_view |= 1ull << s0;
                     total_mesh_tris += md_ntris;      // one draw id per triangle (a mesh out of view takes none)
@@ -1071,6 +1099,16 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             a.ekind[(size_t)rs * a.N + env] = MW_ENT_NONE;
             a.pending_remove[env] = -1;
         }
+    }
+    if (a.tile_list) {
+        // the mesh tiles' work list: every tile inside a drawn mesh entity's rectangle once, the group's lanes side by side
+        int total;
+        const int cnt = live ? __popc(tile_mask) : 0, excl = group_excl_scan(cnt, sub, L, total);
+        int o = 0;
+        if (sub == 0 && total > 0) o = atomicAdd(a.ent_list_n + 3, total);
+        o = __shfl(o, 0, L) + excl;
+        for (uint32_t m = live ? tile_mask : 0u; m; m &= m - 1u, ++o)
+            if (o < a.tile_list_cap) a.tile_list[o] = (uint32_t)env | ((uint32_t)(sub + (__ffs((int)m) - 1) * L) << 24);
     }
 }
 

@@ -24,8 +24,8 @@
 // MESHAWARE   : envs may hold mesh entities — the tiles inside a mesh entity's tile rectangle (env header) start from the
 //               sample keys the scatter kernel left (mw_raster_mesh.hip) and give them back cleared.
 template <bool LDS_RECS, int FMT, int HOT = 0, int MESHAWARE = 0>
-__device__ inline void raster_kernel_body(
-    int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave,
+__device__ inline void raster_env_tiles(
+    int env, int t_begin, int t_end, int part_mode, int W, int H, int max_vis, int tiles_x, int n_tiles,
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
     const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes,
@@ -33,30 +33,23 @@ __device__ inline void raster_kernel_body(
     const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint32_t *__restrict__ mesh_keys,
     const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head)
 {
+    // (one wavefront, the tiles t_begin .. t_end - 1 of env; part_mode: below)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lds_recs = LDS_RECS ? (max_vis < MW_LDS_RECS ? max_vis : MW_LDS_RECS) : 0;
     float4 *s_shade = reinterpret_cast<float4 *>(smem);                                       // [max_vis][8]
     float4 *s_cull = reinterpret_cast<float4 *>(smem + (size_t)lds_recs * MW_LDS_SHADE_Q * 16);       // [lds_recs][5]
     uint8_t *s_pack = smem + (size_t)lds_recs * (MW_LDS_SHADE_Q + MW_LDS_CULL_Q) * 16;                 // 192 B
 
-    // XCD-aware block -> (env, part): the parts of one env run on the same XCD (block b is
-    // dispatched to XCD b % 8), adjacent in time, so its records are fetched into one L2 once.
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int env = (slot / waves_per_env) * 8 + xcd;
-    const int part = slot % waves_per_env;
-    if (env >= N) return;
     const int lane = threadIdx.x;
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     const bool mesh_env = MESHAWARE && __float_as_int(hdr[3]) != 0;
     uint32_t *env_keys = MESHAWARE == 1 ? mesh_keys + (size_t)env * W * H * 8 : nullptr;
-    // mesh-aware launches come in two parts (launch flags bits 4-5): 1 = every tile but those a mesh can touch — they need
-    // nothing of the mesh kernels and run beside them —, 2 = those tiles only, behind the mesh kernels; 0 = all tiles
-    const int part_mode = MESHAWARE ? (dbg >> 4) & 3 : 0;
+    // mesh-aware launches come in two parts: 1 = every tile but those a mesh can touch — they need nothing of the mesh kernels and
+    // run beside them —, 2 = those tiles only, behind the mesh kernels; 0 = all tiles
     if (part_mode == 2) {
         if (!mesh_env) return;
         bool any = false;
-        for (int t = part * tiles_per_wave; t < min(part * tiles_per_wave + tiles_per_wave, n_tiles); ++t) any |= tile_in_mesh_rect(hdr, t % tiles_x, t / tiles_x);
+        for (int t = t_begin; t < t_end; ++t) any |= tile_in_mesh_rect(hdr, t % tiles_x, t / tiles_x);
         if (!any) return;
     }
     const int nvis = nvis_arr[env];
@@ -67,6 +60,7 @@ __device__ inline void raster_kernel_body(
     const float4 *g_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
     const bool in_lds = LDS_RECS && nvis <= lds_recs;
     if (in_lds) {
+        __syncthreads();        // (a persistent wavefront: the previous item's readers are done)
         // (the quads K2 reads: 7 of a shade record's 8, 5 of a classification record's 6)
         for (int i = lane; i < nvis * MW_LDS_SHADE_Q; i += 64) { const int r = i / MW_LDS_SHADE_Q, q = i - r * MW_LDS_SHADE_Q; s_shade[i] = g_shade[r * (MW_SHADE_REC / 4) + q]; }
         for (int i = lane; i < nvis * MW_LDS_CULL_Q; i += 64) { const int r = i / MW_LDS_CULL_Q, q = i - r * MW_LDS_CULL_Q; s_cull[i] = g_cull[r * (MW_CULL_REC / 4) + q]; }
@@ -92,8 +86,6 @@ __device__ inline void raster_kernel_body(
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3); cx.te = te;
     cx.sky_r = sky_r; cx.sky_g = sky_g; cx.sky_b = sky_b;
     cx.env = env; cx.nvis = nvis; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane;
-    const int t_begin = part * tiles_per_wave;
-    const int t_end = min(t_begin + tiles_per_wave, n_tiles);
     int tx = t_begin % tiles_x, ty = t_begin / tiles_x;
     // small scenes: classify (tile, primitive) pairs for as many tiles as fit in the 64 lanes at once
     const bool pairs = in_lds && nvis > 0 && nvis <= 32 && (HOT || !(dbg & 2));
@@ -156,6 +148,48 @@ __device__ inline void raster_kernel_body(
     }
 }
 
+
+// One wavefront (= one workgroup) per run of tiles of one env; or, for the tiles a mesh can touch (launch flags bits 4-5 = 3),
+// persistent wavefronts drawing (env, tile) items from the list the geometry kernel left (mw_geom.hip: the union of the
+// entities' tile rectangles; a grid of one wavefront per tile of every env spent most of its time starting wavefronts that
+// found no mesh in their env).
+template <bool LDS_RECS, int FMT, int HOT = 0, int MESHAWARE = 0>
+__device__ inline void raster_kernel_body(
+    int N, int W, int H, int max_vis, int tiles_x, int n_tiles, int waves_per_env, int tiles_per_wave,
+    const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
+    const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
+    const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes,
+    const uint16_t *__restrict__ rec_order, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
+    const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint32_t *__restrict__ mesh_keys,
+    const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head,
+    const uint32_t *__restrict__ tile_list, int32_t *__restrict__ tile_n)
+{
+    // (one call site for both forms: two copies of the tile code in one kernel cost it 150 registers)
+    const int part_mode = MESHAWARE ? (dbg >> 4) & 3 : 0;
+    const bool listed = MESHAWARE == 1 && part_mode == 3;
+    // tile_n[3]: items (mw_mesh_entity_kernel zeroes it for the frame after the next).  Wavefront w takes the items w, w + grid, ...
+    const int n_items = listed ? tile_n[3] : 1;
+    for (int i = listed ? (int)blockIdx.x : 0; i < n_items; i += (int)gridDim.x) {
+        int env, t_begin, t_end;
+        if (listed) {
+            const uint32_t item = tile_list[i];
+            env = (int)(item & 0xFFFFFFu); t_begin = (int)(item >> 24); t_end = t_begin + 1;
+        } else {
+            // XCD-aware block -> (env, part): the parts of one env run on the same XCD (block b is
+            // dispatched to XCD b % 8), adjacent in time, so its records are fetched into one L2 once.
+            const int b = blockIdx.x;
+            const int xcd = b & 7, slot = b >> 3;
+            env = (slot / waves_per_env) * 8 + xcd;
+            if (env >= N) return;
+            t_begin = (slot % waves_per_env) * tiles_per_wave; t_end = min(t_begin + tiles_per_wave, n_tiles);
+        }
+        raster_env_tiles<LDS_RECS, FMT, HOT, MESHAWARE>(env, t_begin, t_end, listed ? 2 : part_mode, W, H, max_vis, tiles_x, n_tiles, rec_raster, rec_shade, rec_cull, nvis_arr,
+                                                        envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order, mesh_pos, mesh_nrm, mesh_rgb, mesh_uv, mesh_keys,
+                                                        plane_cache, plane_cap, slow_frags, slow_head);
+        if (!listed) return;
+    }
+}
+
 // (texd == texels: the descriptor table is the head of the texel block, mw_engine.hip::upload_textures; the kernels
 // use `texels` for both)
 #define MW_RASTER_ARGS \
@@ -165,9 +199,10 @@ __device__ inline void raster_kernel_body(
     const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, \
     const uint16_t *__restrict__ rec_order, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm, \
     const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint32_t *__restrict__ mesh_keys, \
-    const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head
+    const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head, \
+    const uint32_t *__restrict__ tile_list, int32_t *__restrict__ tile_n
 #define MW_RASTER_FWD N, W, H, max_vis, tiles_x, n_tiles, waves_per_env, tiles_per_wave, rec_raster, rec_shade, rec_cull, \
-    nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order, mesh_pos, mesh_nrm, mesh_rgb, mesh_uv, mesh_keys, plane_cache, plane_cap, slow_frags, slow_head
+    nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order, mesh_pos, mesh_nrm, mesh_rgb, mesh_uv, mesh_keys, plane_cache, plane_cap, slow_frags, slow_head, tile_list, tile_n
 
 // the production kernels of small scenes: no debug flags (mw_engine.hip launches the general kernel below when
 // MW_DEBUG_FLAGS asks for any), RGB only / RGB + depth

@@ -39,7 +39,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ent_n: this frame's list lengths (the geometry kernel's) and the cursor into them; ent_n_after: the next frame's, zeroed
     // here (the two swap places from frame to frame; nothing of the next frame starts before this kernel has ended)
-    if (blockIdx.x == 0 && tid < 4) ent_n_after[tid] = 0;
+    if (blockIdx.x == 0 && tid < 8) ent_n_after[tid] = 0;
     if (tid == 0) { s_qn = 0; s_bn = 0; }
     const int n_long = min(ent_n[0], ent_list_cap), n_items = n_long + min(ent_n[1], ent_list_cap);
     for (;;) {
