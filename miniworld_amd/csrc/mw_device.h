@@ -171,7 +171,7 @@ struct MwArgs {
     // first) and at ent_list + ent_list_cap (the others)
     // ... and the tiles inside the union of their tile rectangles, for the mesh tiles' launch: ent_list_n[3] entries
     // env | tile << 24 at tile_list.  (ent_list_n: 8 counters per frame parity — long meshes, short meshes, the entity kernel's
-    // cursor, tiles, 4 spare.)
+    // cursor, tiles, -, envs with slow-path triangles (the entity kernel's list for the slow kernel), 2 spare.)
     uint32_t *ent_list;
     int32_t *ent_list_n;
     uint32_t *tile_list;

@@ -28,8 +28,6 @@ extern "C" __global__ void mw_step_setup_dense_kernel(MwArgs a, int do_step, int
 extern "C" __global__ void mw_step_setup_dense_pcg_kernel(MwArgs a, int do_step, int lanes_per_env, const int32_t *actions,
                                                            float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
-extern "C" __global__ void mw_geom_step_kernel(MwArgs a, int L, const int32_t *actions, float *reward, uint8_t *term, uint8_t *trunc);
-extern "C" __global__ void mw_geom_step_pcg_kernel(MwArgs a, int L, const int32_t *actions, float *reward, uint8_t *term, uint8_t *trunc);
 extern "C" __global__ void mw_geom_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
 extern "C" __global__ void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
 extern "C" __global__ void mw_geom_big_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env);
@@ -55,7 +53,7 @@ MW_RASTER_DECL(mw_raster_big_mesh_wrap_kernel);
 #define MW_RASTERQ_DECL(name) \
     extern "C" __global__ void name(int N, int W, int H, int max_vis, int tiles_x, int n_tiles, const float *rec_raster, const float *rec_shade, \
                                     const float *rec_cull, const int32_t *nvis, const float *envhdr, const uint32_t *texels, uint8_t *obs, \
-                                    float *depth, int dbg, int texel_bytes, unsigned long long *prof, const uint16_t *rec_order)
+                                    float *depth, int dbg, int texel_bytes, unsigned long long *prof)
 MW_RASTERQ_DECL(mw_rasterq_kernel);
 MW_RASTERQ_DECL(mw_rasterq4_kernel);
 extern "C" int mw_rasterq_lds_bytes(int S, int W, int H, int n_tiles, int depth);
@@ -64,10 +62,10 @@ extern "C" int mw_rasterq_cap(int depth);
 extern "C" __global__ void mw_mesh_entity_kernel(int N, int W, int H, const float *envhdr, const MwMeshDesc *meshes, const float4 *mesh_vpos, const uint2 *mesh_idx,
                                                  const float *mesh_stream, const float *mesh_attr, uint32_t *keys, float *plane_cache, int plane_cap,
                                                  int32_t *slow_count, uint32_t *slow_tris, const uint32_t *ent_list, int ent_list_cap, int32_t *ent_n, int32_t *ent_n_after,
-                                                 unsigned long long *prof);
+                                                 uint32_t *slow_envs, unsigned long long *prof);
 extern "C" __global__ void mw_mesh_slow_kernel(int W, int H, const float *envhdr, const float *mesh_pos, const float *mesh_nrm, const float *mesh_rgb,
                                                const float *mesh_uv, const uint32_t *texels, int texel_bytes, uint32_t *keys, int32_t *counts, int N,
-                                               int parity, const uint32_t *slow_tris, float4 *frags, uint32_t *heads, uint32_t stamp, uint32_t *status);
+                                               int parity, const uint32_t *slow_tris, float4 *frags, uint32_t *heads, uint32_t stamp, uint32_t *status, const uint32_t *slow_envs, const int32_t *slow_env_n);
 extern "C" __global__ void mw_reset_kernel(MwArgs a, const uint8_t *mask, int force_all, int mark_refill);
 extern "C" __global__ void mw_refill_kernel(MwArgs a);
 extern "C" __global__ void mw_refill_pcg_kernel(MwArgs a);
@@ -130,18 +128,19 @@ struct mw_engine {
     uint32_t *d_view_keys = nullptr;    // sample keys of the generic-resolution path
     bool visible_attr_set = false;
     hipStream_t side_stream = nullptr;      // low priority: the Maze's spare-world refills beside the steps
-    hipStream_t mesh_stream = nullptr;      // high priority: the mesh kernels beside the first part of K2
+    hipStream_t quad_stream = nullptr;      // low priority: the raster kernel's first part (every tile no mesh can touch) beside the mesh kernels
     hipEvent_t ev_mesh_fork = nullptr, ev_mesh_join = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     uint32_t *d_mesh_keys = nullptr;    // [N][H][W][8] sample keys of the mesh scatter kernel (all-ones between frames)
     bool mesh_keys_dirty = true;
     int32_t *d_slow_count = nullptr;    // [2 parities][2][N] listed triangles, fragments
     int32_t *d_ent_counter = nullptr;   // [2][8] the work lists' lengths and cursors (mw_device.h: ent_list_n), this frame's and the next frame's
+    uint32_t *d_slow_envs = nullptr;    // [2][N] the envs with triangles across a frustum plane (written by the entity kernel: the slow kernel's work list)
     uint32_t *d_tile_list = nullptr;    // [N * n_tiles] the mesh tiles' work list (written by the geometry kernel)
-    int mesh_tile_waves = 16384;        // wavefronts of the mesh tiles' launch, wavefront w taking the items w, w + 16384, ... of the list (MW_MESH_TILE_WAVES; 4096: 139 us, 8192: 122, 16384: 112)
+    static constexpr int mesh_tile_waves = 16384;       // wavefronts of the mesh tiles' launch, wavefront w taking the items w, w + 16384, ... of the list (4096: 139 us, 8192: 122, 16384: 112)
     uint32_t *d_ent_list = nullptr;     // [2][N * slots] the work list itself (written by the geometry kernel)
     int ent_list_cap = 0;
-    int ent_blocks = 512;               // its persistent workgroups: two per CU (MW_ENT_BLOCKS; 768 measured slower beside the quad kernel)
+    static constexpr int ent_blocks = 512;      // its persistent workgroups: two per CU (768 measured slower beside the quad kernel)
     uint32_t mesh_frame_seq = 1;
     uint32_t *d_slow_tris = nullptr;
     float4 *d_slow_frags = nullptr;
@@ -164,26 +163,17 @@ struct mw_engine {
     struct Ev { hipEvent_t a, b, c; };
     std::vector<Ev> ev_used, ev_free;
     int waves_per_env = 0;
-    bool k1_dense = true;    // MW_K1_DENSE=0: always the wave-per-env K1
     MwProgram *d_prog = nullptr;        // placement program (mw_set_gen_program)
     int texel_bytes = 4;
     int dbg_flags = 0;       // MW_DEBUG_FLAGS: perf experiments only (bit0: flat shading)
     int last_raster_path = -1;  // mw_raster_path
-    // A/B switches, read once by mw_create (the launch path never touches the environment)
-    bool use_k2q = true;        // MW_K2Q=0: the tile kernels of mw_raster.hip for small scenes too
+    // switches read once by mw_create (the launch path never touches the environment): the ones tests and A/B baselines use.
+    // (The experiments that lost their A/B — the step fused into the geometry kernel, the quad kernel on big scenes, the stream
+    // arrangements of the mesh kernels — are gone from the library: tools/experiments/ keeps the record and the patches.)
+    bool use_k2q = true;        // MW_K2Q=0: the tile kernels of mw_raster.hip for small scenes too (the A/B baseline of the quad kernel)
     bool k2q_ok = false;        // the frame fits the quad kernel's LDS plan
-    bool fuse_step = false;     // MW_FUSE_STEP=1: K1 as the geometry kernel's prologue, one launch (mw_geom_step_kernel) — measured slower: 85 vs 80 us for 4096
-                                // Hallway envs (at one wavefront per SIMD the step's load -> f64 physics -> store chain is fully exposed)
-    bool mesh_tiles_overlap = true; // MW_MESH_TILES_OVERLAP=0: the mesh tiles behind the quad kernel on the caller's stream
-    bool k2q_big = false;       // MW_K2Q_BIG=1 (experiment; measured slower on the Maze: 350 vs 276 us — without the visiting order's early exit the exact path pays for every hidden wall)
     bool generic_raster = false;    // MW_GENERIC_RASTER=1: msaa = 4 frames through the generic-resolution kernel (tests run both)
-    bool geom_any = false;      // MW_GEOM_ANY
-    int geom_lanes_override = 0;    // MW_GEOM_LANES
-    bool scatter_overlap = true;    // MW_SCATTER_OVERLAP=0: the mesh scatter kernel alone, before the raster kernel's first part (the tile kernels' order;
-                                    // beside the quad kernel the scatter overlaps well: PickupObjects 0.522 -> 0.495 ms per step)
-    int slow_bx = 16;           // MW_SLOW_BX
-    int raster_big = -1;        // MW_RASTER_BIG
-    bool k2_first_full = false; // MW_K2_FIRST_FULL
+    static constexpr int slow_waves = 8192;      // wavefronts of the slow kernel's launch (4096: 59 us, 8192: 55)
     unsigned long long *d_ent_prof = nullptr;   // MW_ENT_PROF=<file>: the mesh entity kernel's per-env times and counts of the last frame, [N][8], dumped by mw_destroy
     unsigned long long *d_k2q_prof = nullptr;   // MW_K2Q_PROF=<file>: s_memtime stamps of the quad kernel's phases, [N][8 waves][8], dumped by mw_destroy
 };
@@ -235,7 +225,7 @@ int k1_threads(const mw_engine *) { return 64; }
 // the geometry kernel: big scenes (one env per wavefront) or small, 8 samples per pixel (compiled in) or any
 auto geom_kernel_of(const mw_engine *e, int L, int msaa) -> void (*)(MwArgs, int, int, int, int)
 {
-    const bool fixed8 = msaa == 8 && !e->geom_any;       // (MW_GEOM_ANY: A/B runs)
+    const bool fixed8 = msaa == 8;
     if (L == 64) return fixed8 ? mw_geom_big_kernel : mw_geom_big_any_kernel;
     return fixed8 ? mw_geom_kernel : mw_geom_any_kernel;
 }
@@ -258,15 +248,14 @@ int geom_lanes(const mw_engine *e)
     // mid-sized scenes (PickupObjects: 6 polygons + 5 entity slots = 74 triangles; no visiting order, no sifting): two envs per
     // wavefront — 2 048 envs are ONE round of this one-wave-per-SIMD kernel instead of two (K1 + KG 103 -> 71 us)
     if (L == 64 && !e->args.rec_order && e->cfg.max_polys <= 64) L = 32;
-    if (e->geom_lanes_override) L = e->geom_lanes_override;
     return L;
 }
 
 // Lanes per env of the dense K1 (mw_setup_dense.hip), or 0 when the step has to go through the wave-per-env kernel: big
-// scenes, CollectHealth, or too many slots to pack two envs into a wavefront.  MW_K1_DENSE=0 switches it off (A/B runs).
+// scenes, CollectHealth, or too many slots to pack two envs into a wavefront.
 int k1_dense_lanes(const mw_engine *e, int view_flags)
 {
-    if (e->args.rec_order || view_flags != 0 || !e->k1_dense || e->cfg.task == MW_TASK_COLLECT) return 0;
+    if (e->args.rec_order || view_flags != 0 || e->cfg.task == MW_TASK_COLLECT) return 0;
     // at least two envs per wavefront: with one, every lane repeats the env's scalar work for nothing and the wave-per-env
     // kernel's lane-cooperative collision tests win (PickupObjects, 35 slots: 62 us dense against 47 us)
     const int lanes = e->cfg.max_polys + 6 * e->cfg.max_ents;
@@ -421,10 +410,6 @@ int upload_textures(mw_engine *e)
 int pick_waves_per_env(const mw_engine *e)
 {
     const int n_tiles = e->args.n_tiles;
-    if (const char *s = getenv("MW_WAVES_PER_ENV")) {
-        const int v = atoi(s);
-        if (v > 0 && v <= n_tiles) return v;
-    }
     // enough wavefronts to fill 256 CUs x 4 SIMDs x 7 resident waves several times over (measured:
     // 15-25 waves per env beat 5 by ~7 % at 4096 envs), in divisors of n_tiles
     int best = n_tiles;
@@ -578,14 +563,14 @@ int ensure_side_stream(mw_engine *e)
     return MW_OK;
 }
 
-// the mesh kernels' stream: HIGH priority — they are latency bound and K2's first part, which runs beside them, would
-// otherwise keep their workgroups waiting for wave slots
+// the stream of the raster kernel's first part in a frame with meshes: LOW priority — the mesh kernels on the caller's stream are the
+// critical path, the quad kernel fills the CUs around them
 int ensure_mesh_stream(mw_engine *e)
 {
-    if (e->mesh_stream) return MW_OK;
+    if (e->quad_stream) return MW_OK;
     int prio_least = 0, prio_greatest = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
-    HIP_TRY(e, hipStreamCreateWithPriority(&e->mesh_stream, hipStreamNonBlocking, prio_greatest));
+    HIP_TRY(e, hipStreamCreateWithPriority(&e->quad_stream, hipStreamNonBlocking, prio_least));
     HIP_TRY(e, hipEventCreateWithFlags(&e->ev_mesh_fork, hipEventDisableTiming));
     HIP_TRY(e, hipEventCreateWithFlags(&e->ev_mesh_join, hipEventDisableTiming));
     return MW_OK;
@@ -623,6 +608,7 @@ int ensure_mesh_buffers(mw_engine *e)
     if (!e->d_ent_list) {
         e->ent_list_cap = (int)N * std::min(MW_MAX_MESH_ENTS, std::max(e->cfg.max_ents, 1));
         if (hipMalloc((void **)&e->d_ent_list, (size_t)e->ent_list_cap * 2 * 4) != hipSuccess) { e->d_ent_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh entity list failed"); }
+        if (hipMalloc((void **)&e->d_slow_envs, N * 2 * 4) != hipSuccess) { (void)hipFree(e->d_ent_list); e->d_ent_list = nullptr; e->d_slow_envs = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the slow path's env list failed"); }
         if (hipMalloc((void **)&e->d_tile_list, N * (size_t)a.n_tiles * 4) != hipSuccess) { (void)hipFree(e->d_ent_list); e->d_ent_list = nullptr; e->d_tile_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh tile list failed"); }
     }
     if (!e->d_mesh_keys) {
@@ -679,16 +665,9 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     // the worlds from the host (ON_DEVICE_SYNC) — an env that needs its spare earlier follows the refill_mask protocol.
     const bool async_refill = e->spare_mode && do_step && e->cfg.generator == MW_GEN_MAZE;
     const int refill_blocks = (e->spare_mode && do_step && !async_refill) ? (N + 63) / 64 : 0;
-    // small scenes, 8 samples: the step is the geometry kernel's prologue (mw_geom_step_kernel) — one launch for K1 + KG
     const int gl = geom_lanes(e);
-    const bool fused = do_step && e->fuse_step && view_flags == 0 && k1_dense_lanes(e, 0) != 0 && gl < 64 && e->cfg.msaa == 8 && !e->geom_any;
     if (!do_step) {
         // render only: nothing to step
-    } else if (fused) {
-        const int epw = 64 / gl;
-        const int refill = e->spare_mode ? (N + 63) / 64 : 0;
-        hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_geom_step_pcg_kernel : mw_geom_step_kernel, dim3((N + epw - 1) / epw + refill), dim3(64), 0, st, a, gl,
-                           d_actions, d_reward ? d_reward : e->d_reward_scratch, d_term ? d_term : e->d_flag_scratch, d_trunc ? d_trunc : e->d_flag_scratch + N);
     } else if (const int lanes = k1_dense_lanes(e, 0)) {
         const int epw = 64 / lanes;
         const bool pcg = e->cfg.rng_mode == MW_RNG_PCG64;
@@ -704,7 +683,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                            d_trunc ? d_trunc : e->d_flag_scratch + N);
     }
     // the frame's vertex half: camera, lighting, transform, clipping, triangle setup (mw_geom.hip)
-    if (!fused) {
+    {
         const int L = gl, epw = 64 / L;
         hipLaunchKernelGGL(geom_kernel_of(e, L, e->cfg.msaa), dim3((N + epw - 1) / epw), dim3(64), 0, st, a, view_flags, e->cfg.msaa, L, N);
     }
@@ -718,26 +697,23 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         hipLaunchKernelGGL(e->cfg.rng_mode == MW_RNG_PCG64 ? mw_refill_pcg_kernel : mw_refill_kernel, dim3(N), dim3(64), 0, e->side_stream, e->args);
         e->side_refill_pending = true;
     }
-    bool forked = false;
     // the quad kernel (mw_rasterq.hip): small scenes without a visiting order, frames that fit its LDS plan — 8 samples (the
     // hot path) and 4 (llvmpipe's GL_MAX_SAMPLES: the reference's own frames run through the same code); with mesh entities
     // it draws the tiles no mesh can touch (8 samples only)
-    const bool big_scene = e->raster_big >= 0 ? e->raster_big != 0 : a.rec_order != nullptr;
-    // (big scenes — a visiting order exists — keep the tile kernels; MW_K2Q_BIG=1, an experiment: the envs of a big scene whose lists fit
-    // the quad kernel's records take the quad path, the others the tile kernel launched behind it)
-    const bool k2q = e->use_k2q && e->k2q_ok && (!big_scene || (e->k2q_big && e->cfg.msaa == 8 && !e->have_meshes)) &&
-                     !(e->cfg.msaa == 4 && (e->have_meshes || e->generic_raster));
-    auto launch_k2q = [&](int part_flags) {
+    const bool big_scene = a.rec_order != nullptr;
+    // (big scenes — a visiting order exists — keep the tile kernels: their near-to-far order with its early exit is the better fit
+    // for deep scenes; the quad kernel on the Maze was measured and lost, tools/experiments/README.md)
+    const bool k2q = e->use_k2q && e->k2q_ok && !big_scene && !(e->cfg.msaa == 4 && (e->have_meshes || e->generic_raster));
+    auto launch_k2q = [&](int part_flags, hipStream_t kq) {
         const int S = e->cfg.msaa;
         const int lds = mw_rasterq_lds_bytes(S, a.W, a.H, a.n_tiles, d_depth ? 1 : 0);
         const int flags = (e->dbg_flags & 0xFC8F) | (e->obs_layout << 8) | part_flags;
-        hipLaunchKernelGGL(S == 8 ? mw_rasterq_kernel : mw_rasterq4_kernel, dim3(N), dim3(MW_RASTERQ_THREADS), (size_t)lds, st, a.N, a.W, a.H, a.max_vis,
+        hipLaunchKernelGGL(S == 8 ? mw_rasterq_kernel : mw_rasterq4_kernel, dim3(N), dim3(MW_RASTERQ_THREADS), (size_t)lds, kq, a.N, a.W, a.H, a.max_vis,
                            a.tiles_x, a.n_tiles, (const float *)a.rec_raster, (const float *)a.rec_shade, (const float *)a.rec_cull,
-                           (const int32_t *)a.nvis, (const float *)a.envhdr, a.texels, d_obs, d_depth, flags, e->texel_bytes, e->d_k2q_prof,
-                           S == 8 ? (const uint16_t *)a.rec_order : nullptr);
+                           (const int32_t *)a.nvis, (const float *)a.envhdr, a.texels, d_obs, d_depth, flags, e->texel_bytes, e->d_k2q_prof);
     };
     if (k2q && e->cfg.msaa == 4) {
-        launch_k2q(0);
+        launch_k2q(0, st);
         e->last_raster_path = MW_PATH_QUAD;
     } else if (e->cfg.msaa != 8 || !tile_kernels_exact(a.W, a.H)) {
         // FrameBuffer's fallback sample counts (opengl.py:229-231: a driver that clamps GL_MAX_SAMPLES gets 4 or 1
@@ -763,48 +739,38 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         if (mesh) {
             // (plane cache, sample keys — all-ones between frames, K2 clears what it reads —, slow-path lists, mesh stream:
             // ensure_mesh_buffers, at upload time)
-            if (!e->d_mesh_keys || !e->d_plane_cache || !e->mesh_stream) return fail(e, MW_E_INVALID, "mesh buffers missing (mw_upload_mesh allocates them)");
+            if (!e->d_mesh_keys || !e->d_plane_cache || !e->quad_stream) return fail(e, MW_E_INVALID, "mesh buffers missing (mw_upload_mesh allocates them)");
             const size_t key_bytes = (size_t)N * a.W * a.H * 8 * 4;
             if (e->mesh_keys_dirty) HIP_TRY(e, hipMemsetAsync(e->d_mesh_keys, 0xFF, key_bytes, st));
             e->mesh_keys_dirty = true;      // until the raster kernel that clears them again has been enqueued
-            // The mesh kernels run on the side stream, beside the first part of K2 (every tile no mesh can touch); the
-            // tiles inside the meshes' rectangles follow behind both (part 2).
             // frame stamp of the slow-fragment chains (16 bits; the heads are wiped when it wraps) and parity of the lists
             const uint32_t seq = mesh_seq;
             mesh_stamp = seq & 0xFFFFu;
             const int parity = (int)(seq & 1u);
-            const bool scatter_first = !(e->scatter_overlap && k2q);
-            if (mesh_stamp == 0u) HIP_TRY(e, hipMemsetAsync(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4, st));
-            // the scatter kernel alone (it is latency bound and would take 2.5x as long beside K2), then the slow path on the
-            // mesh stream beside K2's first part
-            hipStream_t sb = e->mesh_stream;
-            if (!scatter_first) {
-                HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
-                HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
-            }
-            {
-                // persistent workgroups drawing entities from the geometry kernel's list (two sets of counters swapping places: the
-                // kernel zeroes the next frame's)
-                hipLaunchKernelGGL(mw_mesh_entity_kernel, dim3(std::min(e->ent_list_cap, e->ent_blocks)), dim3(MW_ENT_THREADS), (size_t)e->max_mesh_verts * 16, scatter_first ? st : sb, N, a.W, a.H,
-                                   (const float *)a.envhdr, a.mesh, (const float4 *)e->d_mesh_vpos, (const uint2 *)e->d_mesh_idx, (const float *)e->d_mesh_stream,
-                                   (const float *)e->d_mesh_attr, e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris,
-                                   (const uint32_t *)e->d_ent_list, e->ent_list_cap, e->d_ent_counter + parity * 8, e->d_ent_counter + (parity ^ 1) * 8, e->d_ent_prof);
-            }
-            if (scatter_first) {
-                HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
-                HIP_TRY(e, hipStreamWaitEvent(sb, e->ev_mesh_fork, 0));
-            }
-            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(e->slow_bx, N), dim3(64), 0, sb, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
+            // The mesh kernels — the frame's critical path — stay on the caller's stream, right behind the geometry kernel; the quad
+            // kernel, which draws every tile no mesh can touch, goes to the low-priority quad stream beside them.  (The other way
+            // round — mesh kernels on a side stream — the quad kernel started a few microseconds EARLIER, its 2 048 workgroups
+            // took the CUs, and the entity kernel's workgroups waited a quad-kernel workgroup's lifetime for room: 212 instead of
+            // 133 us, PickupObjects 4.55 -> 5.3 M env-steps/s.)
+            HIP_TRY(e, hipEventRecord(e->ev_mesh_fork, st));
+            HIP_TRY(e, hipStreamWaitEvent(e->quad_stream, e->ev_mesh_fork, 0));
+            // persistent workgroups drawing entities from the geometry kernel's list (two sets of counters swapping places: the
+            // kernel zeroes the next frame's)
+            hipLaunchKernelGGL(mw_mesh_entity_kernel, dim3(std::min(e->ent_list_cap, e->ent_blocks)), dim3(MW_ENT_THREADS), (size_t)e->max_mesh_verts * 16, st, N, a.W, a.H,
+                               (const float *)a.envhdr, a.mesh, (const float4 *)e->d_mesh_vpos, (const uint2 *)e->d_mesh_idx, (const float *)e->d_mesh_stream,
+                               (const float *)e->d_mesh_attr, e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris,
+                               (const uint32_t *)e->d_ent_list, e->ent_list_cap, e->d_ent_counter + parity * 8, e->d_ent_counter + (parity ^ 1) * 8, e->d_slow_envs + (size_t)parity * N, e->d_ent_prof);
+            hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(std::min(N * 16, e->slow_waves)), dim3(64), 0, st, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
                                a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, N, parity, (const uint32_t *)e->d_slow_tris,
-                               e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status);
+                               e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status,
+                               (const uint32_t *)(e->d_slow_envs + (size_t)parity * N), (const int32_t *)(e->d_ent_counter + parity * 8 + 5));
         }
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
         const int groups = (N + 7) / 8;
         // big scenes (a visiting order exists): records read in place, near to far; otherwise the env's records are staged
         // in LDS when there are at most MW_LDS_RECS of them (a wave whose env holds more reads them in place).
-        // MW_RASTER_BIG=0 / 1 forces either (A/B runs).
-        const bool big = e->raster_big >= 0 ? e->raster_big != 0 : a.rec_order != nullptr;
+        const bool big = a.rec_order != nullptr;
         const int lds_recs = a.max_vis < MW_LDS_RECS ? a.max_vis : MW_LDS_RECS;
         const size_t lds = big ? 192 : (size_t)lds_recs * (MW_LDS_SHADE_Q + MW_LDS_CULL_Q) * 16 + 192;
         // small scenes: the production kernels carry neither debug flags nor a run-time depth switch (mw_raster.hip);
@@ -818,7 +784,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         }
         const int flags = e->dbg_flags | (e->obs_layout << 8) | (int)(mesh_stamp << 16);
         // K2's first part of a frame with meshes never enters a mesh tile: the plain tile code with the skip (the small-scene observation path only)
-        auto k2_first = (mesh && !big && !general && !e->k2_first_full) ? (d_depth ? mw_raster_nomesh_depth_kernel : mw_raster_nomesh_kernel) : k2;
+        auto k2_first = (mesh && !big && !general) ? (d_depth ? mw_raster_nomesh_depth_kernel : mw_raster_nomesh_kernel) : k2;
         auto launch_k2 = [&](int part_flags, hipStream_t ks) {
             // the second part (the tiles a mesh can touch: few, slow, clustered): persistent wavefronts over the geometry kernel's
             // tile list (flags 3 << 4)
@@ -837,33 +803,18 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
         };
         e->last_raster_path = k2q ? (mesh ? MW_PATH_QUAD_MESH : MW_PATH_QUAD) : MW_PATH_TILE;
         if (mesh) {
-            if (k2q && e->mesh_tiles_overlap) {
-                // the mesh tiles depend on the mesh kernels only, and the quad kernel never writes a mesh tile's pixels: they follow
-                // the mesh kernels on THEIR stream, beside the quad kernel (whose frame-wide pass is the longer of the two)
-                launch_k2q(1 << 4);
-                launch_k2(2 << 4, e->mesh_stream);
-                HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
-                HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
-            } else {
-                if (k2q) launch_k2q(1 << 4); else launch_k2(1 << 4, st);
-                HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->mesh_stream));
-                HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
-                launch_k2(2 << 4, st);
-            }
-        } else if (k2q && big_scene) {
-            // the envs whose lists fit the quad kernel's records there, the others in the tile kernel (each skips the other's)
-            launch_k2q(0x40);
-            launch_k2(mw_rasterq_cap(d_depth ? 1 : 0) << 24, st);
+            // the first part — every tile no mesh can touch: it needs nothing of the mesh kernels — on the quad stream beside them
+            // (forked above, behind the geometry kernel); the mesh tiles end the chain on the caller's stream
+            if (k2q) launch_k2q(1 << 4, e->quad_stream); else launch_k2(1 << 4, e->quad_stream);
+            launch_k2(2 << 4, st);
+            HIP_TRY(e, hipEventRecord(e->ev_mesh_join, e->quad_stream));
+            HIP_TRY(e, hipStreamWaitEvent(st, e->ev_mesh_join, 0));
         } else if (k2q) {
-            launch_k2q(0);
+            launch_k2q(0, st);
         } else {
             launch_k2(0, st);
         }
         if (mesh) e->mesh_keys_dirty = false;
-    }
-    if (forked) {
-        HIP_TRY(e, hipEventRecord(e->ev_join, e->side_stream));
-        HIP_TRY(e, hipStreamWaitEvent(st, e->ev_join, 0));
     }
     if (timed) {
         (void)hipEventRecord(ev.c, st);
@@ -986,7 +937,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.rec_raster, (size_t)N * a.max_vis * MW_RASTER_REC);
     ALLOC(a.rec_shade, (size_t)N * a.max_vis * MW_SHADE_REC);
     ALLOC(a.rec_cull, (size_t)N * a.max_vis * MW_CULL_REC);
-    if (cfg->max_visible > 64 && !(getenv("MW_SORT_VIS") && atoi(getenv("MW_SORT_VIS")) == 0)) {
+    if (cfg->max_visible > 64) {
         // big scenes: the visiting order the geometry kernel leaves for K2 (mw_geom.hip)
         ALLOC(a.rec_order, (size_t)N * (a.max_vis + 1));
         if (rc == MW_OK) (void)hipMemset(a.rec_order, 0, (size_t)N * (a.max_vis + 1) * 2);
@@ -1001,10 +952,12 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.nvis, N); ALLOC(a.envhdr, (size_t)MW_ENVHDR * N); ALLOC(a.status, 1);
     ALLOC(e->d_reward_scratch, N); ALLOC(e->d_flag_scratch, 2 * (size_t)N); ALLOC(e->d_action_scratch, N);
     ALLOC(e->d_mask, N); ALLOC(e->d_step_override, 3 * (size_t)N);
-    if (getenv("MW_K1_PROF")) {     // perf experiments only: per-env cycle stamps of the geometry kernel's phases, dumped by mw_destroy
+#ifdef MW_PERF_HOOKS        // (tools/perf: make EXTRA=-DMW_PERF_HOOKS — kernel phase stamps dumped by mw_destroy; not in the product build)
+    if (getenv("MW_K1_PROF")) {     // per-env cycle stamps of the geometry kernel's phases
         ALLOC(a.k1_prof, MW_K1_PROF_SLOTS * (size_t)N);
         if (rc == MW_OK) (void)hipMemset(a.k1_prof, 0, 8 * MW_K1_PROF_SLOTS * (size_t)N);
     }
+#endif
 #undef ALLOC
     if (rc != MW_OK) { g_create_error = e->err; mw_destroy(e); return rc; }
     // carrying = -1 everywhere; default seeds = env index
@@ -1025,26 +978,16 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
     if (const char *s = getenv("MW_K2Q")) e->use_k2q = atoi(s) != 0;
     if (const char *s = getenv("MW_GENERIC_RASTER")) e->generic_raster = atoi(s) != 0;
-    if (const char *s = getenv("MW_K2Q_BIG")) e->k2q_big = atoi(s) != 0;
-    if (const char *s = getenv("MW_MESH_TILES_OVERLAP")) e->mesh_tiles_overlap = atoi(s) != 0;
-    if (const char *s = getenv("MW_FUSE_STEP")) e->fuse_step = atoi(s) != 0;
-    e->geom_any = getenv("MW_GEOM_ANY") != nullptr;
-    if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if (v == 8 || v == 16 || v == 32 || v == 64) e->geom_lanes_override = v; }
-    if (const char *s = getenv("MW_SCATTER_OVERLAP")) e->scatter_overlap = atoi(s) != 0;
-    if (const char *s = getenv("MW_SLOW_BX")) { const int v = atoi(s); if (v > 0) e->slow_bx = v; }
-    if (const char *s = getenv("MW_MESH_TILE_WAVES")) { const int v = atoi(s); if (v > 0) e->mesh_tile_waves = v; }
-    if (const char *s = getenv("MW_ENT_BLOCKS")) { const int v = atoi(s); if (v > 0) e->ent_blocks = v; }
-    if (const char *s = getenv("MW_RASTER_BIG")) e->raster_big = atoi(s) != 0 ? 1 : 0;
-    e->k2_first_full = getenv("MW_K2_FIRST_FULL") != nullptr;
+#ifdef MW_PERF_HOOKS
     if (getenv("MW_ENT_PROF")) { if (dev_alloc(e, &e->d_ent_prof, (size_t)N * MW_MAX_MESH_ENTS * 8) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
     if (getenv("MW_K2Q_PROF")) { if (dev_alloc(e, &e->d_k2q_prof, (size_t)N * 80) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
+#endif
     {
         // the quad kernel (mw_rasterq.hip) keeps an env's frame, quad lists and triangle records in LDS: frames up to 8192 pixels
         const int S = cfg->msaa == 4 ? 4 : 8;
         const int lds = mw_rasterq_lds_bytes(S, a.W, a.H, a.n_tiles, 1);
         e->k2q_ok = (cfg->msaa == 8 || cfg->msaa == 4) && a.W <= 128 && a.H <= 128 && a.W * a.H <= 8192 && lds <= 64 * 1024;
     }
-    if (const char *s = getenv("MW_K1_DENSE")) e->k1_dense = atoi(s) != 0;
     if (sync_gen_args(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     *out = e;
     return MW_OK;
@@ -1055,6 +998,7 @@ void mw_destroy(mw_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->cfg.device_id);
     (void)hipDeviceSynchronize();
+#ifdef MW_PERF_HOOKS
     if (e->d_k2q_prof) {
         std::vector<unsigned long long> h((size_t)e->cfg.num_envs * 80);
         if (hipMemcpy(h.data(), e->d_k2q_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
@@ -1081,6 +1025,7 @@ void mw_destroy(mw_engine *e)
                 fprintf(stderr, "work lists of the last two frames: long meshes %d / %d, short %d / %d, mesh tiles %d / %d\n", c[0], c[8], c[1], c[9], c[3], c[11]);
         }
     }
+#endif
     for (void *p : e->allocs) (void)hipFree(p);
     if (e->d_texels) (void)hipFree(e->d_texels);
     for (float *p : {e->d_mesh_pos, e->d_mesh_nrm, e->d_mesh_rgb, e->d_mesh_uv, e->d_mesh_stream, e->d_mesh_attr}) if (p) (void)hipFree(p);
@@ -1091,8 +1036,9 @@ void mw_destroy(mw_engine *e)
     if (e->d_mesh_keys) (void)hipFree(e->d_mesh_keys);
     if (e->d_ent_list) (void)hipFree(e->d_ent_list);
     if (e->d_tile_list) (void)hipFree(e->d_tile_list);
+    if (e->d_slow_envs) (void)hipFree(e->d_slow_envs);
     for (void *q : {(void *)e->d_slow_count, (void *)e->d_slow_tris, (void *)e->d_slow_frags, (void *)e->d_slow_head}) if (q) (void)hipFree(q);
-    if (e->mesh_stream) { (void)hipStreamDestroy(e->mesh_stream); (void)hipEventDestroy(e->ev_mesh_fork); (void)hipEventDestroy(e->ev_mesh_join); }
+    if (e->quad_stream) { (void)hipStreamDestroy(e->quad_stream); (void)hipEventDestroy(e->ev_mesh_fork); (void)hipEventDestroy(e->ev_mesh_join); }
     if (e->side_stream) { (void)hipStreamDestroy(e->side_stream); (void)hipEventDestroy(e->ev_fork); (void)hipEventDestroy(e->ev_join); }
     for (auto &ev : e->ev_used) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }
     for (auto &ev : e->ev_free) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); (void)hipEventDestroy(ev.c); }

@@ -24,7 +24,7 @@
 // Big scenes (one env per wavefront): the polygons are sifted first — boxes of eight polygons, then the polygons, against
 // the frustum, full-height walls in front of them and their own facing — from data kept per world (occ_cache).
 #include <cstddef>
-#include "mw_setup_dense_body.h"
+#include "mw_setup_common.h"
 #include "mw_records.h"
 
 namespace {
@@ -1112,32 +1112,6 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     }
 }
 
-// The fused form of small scenes' step (K1 + KG in one launch): an env's lanes first step it — dense_step, the dense K1's body:
-// physics, collision, rules, the same-step auto-reset — and then build its frame's records from the state they just left
-// (same env -> lanes ownership; one launch and one dependent boundary fewer).  Blocks behind the envs' regenerate spare
-// worlds like the dense K1's (mw_setup_dense.hip).  Compiled once per random stream (mw_geom_pcg.hip re-includes this file).
-#ifndef MW_GEOM_STEP_KERNEL_NAME
-#define MW_GEOM_STEP_KERNEL_NAME mw_geom_step_kernel
-#endif
-extern "C" __global__ __launch_bounds__(64) void MW_GEOM_STEP_KERNEL_NAME(MwArgs a, int L, const int32_t *__restrict__ actions, float *__restrict__ reward,
-                                                                          uint8_t *__restrict__ term, uint8_t *__restrict__ trunc)
-{
-    __shared__ unsigned char gen_ws[MW_GEN_WS_BYTES];
-    const int lane = threadIdx.x, epw = 64 / L;
-    const int env_blocks = (a.N + epw - 1) / epw;
-    if ((int)blockIdx.x >= env_blocks) {
-        mw::refill_spares(a, (int)blockIdx.x - env_blocks, lane, gen_ws);
-        return;
-    }
-    const int env = (int)blockIdx.x * epw + lane / L;
-    if (env < a.N) dense_step(a, 1, env, lane, (lane & (L - 1)) == 0, actions, reward, term, trunc, gen_ws);
-    // the leader's stores (state, pending removal, a new world) are read by the env's other lanes below
-    __threadfence();
-    __builtin_amdgcn_wave_barrier();
-    geom_body<false, 8>(a, 0, 8, L, a.N);
-}
-
-#ifndef MW_GEOM_STEP_ONLY
 extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false, 8>(a, view_flags, S, L, n_env); }
 extern "C" __global__ __launch_bounds__(64) void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true, 8>(a, view_flags, S, L, n_env); }
 // ... for frame buffers with 1, 4 or 16 samples per pixel
@@ -1174,4 +1148,3 @@ extern "C" int mw_selftest_sort(const uint32_t *host_keys /*[blocks][512]*/, con
     (void)hipFree(d_keys); (void)hipFree(d_n); (void)hipFree(d_order);
     return rc;
 }
-#endif  // MW_GEOM_STEP_ONLY

@@ -143,9 +143,12 @@ __device__ inline void store_planes(float *rec, const mwgl::TriSetup &ts, int te
 
 // a triangle that crosses a frustum plane (rare): left to mw_mesh_slow_kernel, which clips it, scatters its keys and lists its
 // fragments
-__device__ inline void list_slow_tri(int j, int tri, float *rec, int32_t *slow_count, uint32_t *slow_tris)
+struct SlowEnvs { int32_t *n; uint32_t *envs; int env; };       // the frame's list of envs with such triangles (the slow kernel's work list)
+
+__device__ inline void list_slow_tri(int j, int tri, float *rec, int32_t *slow_count, uint32_t *slow_tris, const SlowEnvs &se)
 {
     const int k = atomicAdd(slow_count, 1);
+    if (k == 0) se.envs[atomicAdd(se.n, 1)] = (uint32_t)se.env;        // the env's first: the env joins the list (at most N entries)
     if (k < MW_SLOW_TRIS) slow_tris[k] = ((uint32_t)j << 16) | (uint32_t)tri;
     reinterpret_cast<float4 *>(rec)[1] = make_float4(0.0f, 0.0f, 0.0f, __int_as_float(MW_PLANE_SLOW));
 }
@@ -171,7 +174,7 @@ __device__ inline void setup_winner(const mwgl::Frame &f, const MeshEnt &e, mwgl
 // One mesh triangle of an obs-sized 8-sample frame from its own three positions (a mesh without a vertex table): vertex
 // stage, setup, keys; a triangle that covers a sample leaves its attribute planes in the plane cache.
 __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys,
-                                      const float4 *attr, float *cache, int j, int32_t *slow_count, uint32_t *slow_tris)
+                                      const float4 *attr, float *cache, int j, int32_t *slow_count, uint32_t *slow_tris, const SlowEnvs &se)
 {
     mwgl::Vert v[3];
 #pragma unroll
@@ -181,7 +184,7 @@ __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, in
     }
     if (v[0].clipmask & v[1].clipmask & v[2].clipmask) return;
     float *rec = cache + (size_t)tri * MW_PLANE_REC;
-    if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) != 0u) { list_slow_tri(j, tri, rec, slow_count, slow_tris); return; }
+    if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) != 0u) { list_slow_tri(j, tri, rec, slow_count, slow_tris, se); return; }
     mwcov::Edges ed;
     if (!mwcov::setup_edges(v[0].win, v[1].win, v[2].win, ed)) return;        // back-facing or empty
     if (!scatter_tri_cols(ed, W, H, (uint32_t)(e.start + tri), keys)) return;
@@ -194,12 +197,12 @@ __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, in
 // bounding box holds more than MW_ENT_BIG_PIXELS pixels — a lane is no place for a loop over hundreds of pixels, a wavefront
 // takes it pixel per lane (scatter_tri_wave) —, 0 = nothing to do (culled, no sample, or listed for the slow path).
 __device__ inline int classify_tri_table(int tri, const float4 &va, const float4 &vb, const float4 &vc, int W, int H,
-                                         float *cache, int j, int32_t *slow_count, uint32_t *slow_tris)
+                                         float *cache, int j, int32_t *slow_count, uint32_t *slow_tris, const SlowEnvs &se)
 {
     if (va.z < 0.0f || vb.z < 0.0f || vc.z < 0.0f) {
         const uint32_t ma = va.z < 0.0f ? (uint32_t)(int)(-va.z) : 0u, mb = vb.z < 0.0f ? (uint32_t)(int)(-vb.z) : 0u,
                        mc = vc.z < 0.0f ? (uint32_t)(int)(-vc.z) : 0u;
-        if (!(ma & mb & mc)) list_slow_tri(j, tri, cache + (size_t)tri * MW_PLANE_REC, slow_count, slow_tris);
+        if (!(ma & mb & mc)) list_slow_tri(j, tri, cache + (size_t)tri * MW_PLANE_REC, slow_count, slow_tris, se);
         return 0;
     }
     const float wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};

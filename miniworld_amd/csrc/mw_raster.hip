@@ -53,8 +53,6 @@ __device__ inline void raster_env_tiles(
         if (!any) return;
     }
     const int nvis = nvis_arr[env];
-    // (big scenes share the batch with the quad kernel, mw_rasterq.hip: bits 24-31 of the flags = the longest list that one drew)
-    if (!MESHAWARE && ((uint32_t)dbg >> 24) != 0u && nvis <= (int)((uint32_t)dbg >> 24)) return;
     const float *__restrict__ rr_env = rec_raster + (size_t)env * max_vis * MW_RASTER_REC;
     const float4 *g_shade = reinterpret_cast<const float4 *>(rec_shade + (size_t)env * max_vis * MW_SHADE_REC);
     const float4 *g_cull = reinterpret_cast<const float4 *>(rec_cull + (size_t)env * max_vis * MW_CULL_REC);
@@ -164,6 +162,7 @@ __device__ inline void raster_kernel_body(
     const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head,
     const uint32_t *__restrict__ tile_list, int32_t *__restrict__ tile_n)
 {
+    if (MESHAWARE == 1) __builtin_amdgcn_s_setprio(3);      // (the mesh tiles end the frame's critical path: ahead of the quad kernel's wavefronts)
     // (one call site for both forms: two copies of the tile code in one kernel cost it 150 registers)
     const int part_mode = MESHAWARE ? (dbg >> 4) & 3 : 0;
     const bool listed = MESHAWARE == 1 && part_mode == 3;

@@ -31,8 +31,10 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_k
     int N, int W, int H, const float *__restrict__ envhdr, const MwMeshDesc *__restrict__ meshes, const float4 *__restrict__ mesh_vpos,
     const uint2 *__restrict__ mesh_idx, const float *__restrict__ mesh_stream, const float *__restrict__ mesh_attr, uint32_t *__restrict__ keys_all,
     float *__restrict__ plane_cache, int plane_cap, int32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_tris, const uint32_t *__restrict__ ent_list, int ent_list_cap, int32_t *ent_n, int32_t *ent_n_after,
-    unsigned long long *prof)
+    uint32_t *__restrict__ slow_envs, unsigned long long *prof)
 {
+    // (the mesh kernels are the frame's critical path: their wavefronts issue ahead of the quad kernel's on a shared SIMD)
+    __builtin_amdgcn_s_setprio(3);
     extern __shared__ __attribute__((aligned(16))) float4 s_vert[];
     __shared__ uint16_t s_queue[MW_ENT_ROUND], s_big[MW_ENT_ROUND];
     __shared__ int s_qn, s_bn, s_env;
@@ -70,7 +72,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_k
                     const float4 *rec = reinterpret_cast<const float4 *>(mesh_stream) + (size_t)(e.first + t) * 3;
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                     const float pos[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-                    raster_tri_obs(f, e, __float_as_int(r2.y), pos, W, H, keys, attr_e + (size_t)t * 6, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS);
+                    raster_tri_obs(f, e, __float_as_int(r2.y), pos, W, H, keys, attr_e + (size_t)t * 6, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS, SlowEnvs{ent_n + 5, slow_envs, env});
                 }
                 continue;       // (the next item)
             }
@@ -107,7 +109,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_k
                     if (t < end) {
                         const uint2 ix = ixr[i];
                         const float4 va = s_vert[ix.x & 0xFFFFu], vb = s_vert[ix.x >> 16], vc = s_vert[ix.y & 0xFFFFu];
-                        const int r = classify_tri_table((int)(ix.y >> 16), va, vb, vc, W, H, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS);
+                        const int r = classify_tri_table((int)(ix.y >> 16), va, vb, vc, W, H, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS, SlowEnvs{ent_n + 5, slow_envs, env});
                         if (r == 1) s_queue[atomicAdd(&s_qn, 1)] = (uint16_t)(t - base);
                         else if (r == 2) s_big[atomicAdd(&s_bn, 1)] = (uint16_t)(t - base);
                     }
@@ -164,6 +166,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_k
 // fan per lane (setup), then a (piece, pixel) pair per lane over all pieces of the eight.  Exits at once for an env without
 // such triangles.
 #define MW_SLOW_GROUPS 8        // triangles per wavefront and turn
+#define MW_SLOW_SHARE 16        // wavefronts that share a listed env's triangles
 
 namespace {
 
@@ -217,25 +220,32 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
                                                                     const float *__restrict__ mesh_uv, const uint32_t *__restrict__ texels, int texel_bytes,
                                                                     uint32_t *__restrict__ keys_all, int32_t *__restrict__ counts, int N, int parity,
                                                                     const uint32_t *__restrict__ slow_tris, float4 *__restrict__ frags_all,
-                                                                    uint32_t *__restrict__ heads_all, uint32_t stamp, uint32_t *__restrict__ status)
+                                                                    uint32_t *__restrict__ heads_all, uint32_t stamp, uint32_t *__restrict__ status,
+                                                                    const uint32_t *__restrict__ slow_envs, const int32_t *__restrict__ slow_env_n)
 {
     // the clipper's work lists, the pieces of one turn, where each piece's pixels start in the turn's pixel list (18 KB: the
     // grid is mostly empty workgroups, which must not queue for LDS)
+    __builtin_amdgcn_s_setprio(3);
     __shared__ mwgl::Vert s_list[MW_SLOW_GROUPS][2][MWGL_MAX_CLIP_VERTS];
     __shared__ SlowPiece s_piece[64];
     __shared__ int s_pref[65];
-    // grid (x, N): the blocks of row y share env y's list, MW_SLOW_GROUPS triangles per block and turn.
-    // counts: [2 parities][2][N] — listed triangles (the scatter kernel's) and fragments of this frame's parity; the other
+    // counts: [2 parities][2][N] — listed triangles (the entity kernel's) and fragments of this frame's parity; the other
     // parity's are zeroed here for the next frame.
-    const int env = blockIdx.y, lane = threadIdx.x;
+    // Work: the envs the entity kernel listed (slow_envs[0 .. *slow_env_n): those with a triangle across a frustum plane, one env in
+    // five), MW_SLOW_SHARE wavefronts to an env, MW_SLOW_GROUPS triangles per wavefront and turn; wavefront w of the launch takes
+    // the items w, w + grid, ...
+    const int lane = threadIdx.x;
+    for (int i = (int)blockIdx.x * 64 + lane; i < 2 * N; i += (int)gridDim.x * 64) counts[(size_t)(parity ^ 1) * 2 * N + i] = 0;
     int32_t *slow_count = counts + ((size_t)parity * 2 + 0) * N, *frag_count = counts + ((size_t)parity * 2 + 1) * N;
-    if (blockIdx.x == 0 && lane == 0) { counts[((size_t)(parity ^ 1) * 2 + 0) * N + env] = 0; counts[((size_t)(parity ^ 1) * 2 + 1) * N + env] = 0; }
+    const int n_items = min(*slow_env_n, N) * MW_SLOW_SHARE;
+    for (int item = (int)blockIdx.x; item < n_items; item += (int)gridDim.x) {
+    const int env = (int)slow_envs[item / MW_SLOW_SHARE], share = item % MW_SLOW_SHARE;
     const int n = slow_count[env];
-    if ((int)blockIdx.x * MW_SLOW_GROUPS >= n) return;
+    if (share * MW_SLOW_GROUPS >= n) continue;
     uint32_t *head = heads_all + (size_t)env * W * H;
     float4 *frags = frags_all + (size_t)env * MW_SLOW_STRIDE;
     float *pieces = reinterpret_cast<float *>(frags + (MW_SLOW_FRAGS + 1));
-    if (n > MW_SLOW_TRIS && lane == 0) atomicOr(status, MW_ST_VIS_OVERFLOW);
+    if (n > MW_SLOW_TRIS && lane == 0 && share == 0) atomicOr(status, MW_ST_VIS_OVERFLOW);
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     uint32_t *keys = keys_all + (size_t)env * W * H * 8;
     (void)texels; (void)texel_bytes;
@@ -244,7 +254,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
     const int nn = min(n, MW_SLOW_TRIS);
     const int g = lane >> 3, e = lane & 7, g0 = lane & ~7;
     mwgl::Vert (&L)[2][MWGL_MAX_CLIP_VERTS] = s_list[g];
-    for (int base = (int)blockIdx.x * MW_SLOW_GROUPS; base < nn; base += (int)gridDim.x * MW_SLOW_GROUPS) {
+    for (int base = share * MW_SLOW_GROUPS; base < nn; base += MW_SLOW_SHARE * MW_SLOW_GROUPS) {
         const int i = base + g;
         const bool valid = i < nn;
         // ---- a vertex per lane (lanes 0 .. 2 of the group)
@@ -354,6 +364,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         __builtin_amdgcn_wave_barrier();
+    }
     }
 }
 

@@ -550,8 +550,7 @@ __device__ inline void rasterq_body(
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles,
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const uint32_t *__restrict__ texels,
-    uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, unsigned long long *__restrict__ prof,
-    const uint16_t *__restrict__ rec_order)
+    uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, unsigned long long *__restrict__ prof)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef QRec<S> R;
@@ -638,7 +637,6 @@ __device__ inline void rasterq_body(
     // ---- envs with more triangles than the LDS records hold ---------------------------------------------------------------
     // (flag 0x80, tests: as if the records held 8 triangles — every env with more takes the paths below)
     if (nvis > ((dbg & 0x80) ? 8 : q_cap(has_depth))) {
-        if (dbg & 0x40) return;         // the tile kernel's launch behind this one draws these envs (big scenes: mw_engine.hip)
         if constexpr (S == 8 && MWQ_TILE_FALLBACK) {
             // the tile code of mw_raster.hip, records read in place; every wavefront takes every MWQ_WAVES-th tile
             TileCtx tc;
@@ -650,13 +648,11 @@ __device__ inline void rasterq_body(
             tc.te = cx.te; tc.sky_r = cx.sky_r; tc.sky_g = cx.sky_g; tc.sky_b = cx.sky_b;
             tc.env = env; tc.nvis = nvis; tc.W = W; tc.H = H; tc.dbg = dbg & ~0xF0; tc.lane = lane;
             tc.pre_touch = tc.pre_full = tc.pre_clip = tc.pre_edges = 0ull; tc.have_pre = 0;
-            // (big scenes: the geometry kernel's near-to-far visiting order, followed until a triangle lies behind all a tile holds)
-            tc.order = rec_order ? rec_order + (size_t)env * (max_vis + 1) : nullptr;
+            tc.order = nullptr;
             for (int tile = wave; tile < n_tiles; tile += MWQ_WAVES) {
                 const int tx = tile % tiles_x, ty = tile / tiles_x;
                 if (mesh_env && tile_in_mesh_rect(hdr, tx, ty)) continue;
-                if (rec_order) raster_tile_fmt<false, -1, true, 0, 0>(tc, tx, ty, nullptr);
-                else raster_tile_fmt<false, -1, false, 0, 0>(tc, tx, ty, nullptr);
+                raster_tile_fmt<false, -1, false, 0, 0>(tc, tx, ty, nullptr);
             }
             return;
         }
@@ -977,9 +973,8 @@ __device__ inline void rasterq_body(
     int N, int W, int H, int max_vis, int tiles_x, int n_tiles, \
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull, \
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const uint32_t *__restrict__ texels, \
-    uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, unsigned long long *__restrict__ prof, \
-    const uint16_t *__restrict__ rec_order
-#define MWQ_FWD N, W, H, max_vis, tiles_x, n_tiles, rec_raster, rec_shade, rec_cull, nvis_arr, envhdr, texels, obs, depth, dbg, texel_bytes, prof, rec_order
+    uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes, unsigned long long *__restrict__ prof
+#define MWQ_FWD N, W, H, max_vis, tiles_x, n_tiles, rec_raster, rec_shade, rec_cull, nvis_arr, envhdr, texels, obs, depth, dbg, texel_bytes, prof
 
 extern "C" __global__ __launch_bounds__(MWQ_THREADS, MWQ_OCC) void mw_rasterq_kernel(MWQ_ARGS) { rasterq_body<8>(MWQ_FWD); }
 extern "C" __global__ __launch_bounds__(MWQ_THREADS) void mw_rasterq4_kernel(MWQ_ARGS) { rasterq_body<4>(MWQ_FWD); }

@@ -955,37 +955,6 @@ def test_two_engines_on_two_streams_stay_exact():
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("env_id,dr", [("MiniWorld-Hallway-v0", False), ("MiniWorld-OneRoom-v0", True)])
-def test_fused_step_and_geometry_kernel_equals_the_two_launches(env_id, dr, monkeypatch):
-    """MW_FUSE_STEP=1 (mw_geom_step_kernel: the dense K1's body as the geometry kernel's prologue, one launch) against the
-    default two launches: observations, rewards, flags and state identical over episodes' ends (auto-reset, spare worlds)."""
-    import torch
-    from miniworld_amd.vec_env import MiniWorldVecEnv
-    runs = []
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("MW_FUSE_STEP", fuse)
-        vec = MiniWorldVecEnv(env_id, 96, seed=11, domain_rand=dr)
-        vec.reset()
-        g = torch.Generator(device="cuda").manual_seed(3)
-        out = []
-        for t in range(130):
-            act = torch.randint(0, 3, (96,), generator=g, device="cuda", dtype=torch.int32)
-            obs, rew, term, trunc = vec.step(act)
-            out.append((obs.clone(), rew.clone(), term.clone(), trunc.clone()))
-        vec.engine.check()
-        st = vec.engine.get_state()
-        runs.append((out, st))
-        vec.close()
-    done = 0
-    for t, (a, b) in enumerate(zip(runs[0][0], runs[1][0])):
-        for x, y in zip(a, b):
-            assert torch.equal(x, y), t
-        done += int((a[2] | a[3]).sum())
-    assert done > 0
-    for k in ("agent_pos", "agent_dir", "ent_pos", "step_count"):
-        assert np.array_equal(runs[0][1][k], runs[1][1][k]), k
-
-
 def test_two_engines_are_independent():
     """Engines do not share state (the reference's display list id 1 and texture cache are process-global,
     miniworld.py:1027, opengl.py:111): two batches of different envs interleave their steps on one device."""
