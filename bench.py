@@ -48,7 +48,7 @@ RASTER_PHASE = {
     "hallway": ("mw_rasterq_kernel",),
     "oneroom_rgbd": ("mw_rasterq_kernel",),
     "maze": ("mw_raster_big_kernel",),
-    "pickup_dr": ("mw_rasterq_kernel", "mw_mesh_scatter_kernel", "mw_mesh_slow_kernel", "mw_raster_mesh_kernel"),
+    "pickup_dr": ("mw_rasterq_kernel", "mw_mesh_entity_kernel", "mw_mesh_slow_kernel", "mw_raster_mesh_kernel"),
 }
 ALSO = ("oneroom_rgbd", "maze", "pickup_dr")      # BASELINE.json configs[2..4], timed after the headline in the default run
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
@@ -487,8 +487,34 @@ def measure(args, ctx, config, n, steps, warmup, headline):
     return out
 
 
+def view800(args):
+    """Not the headline: `render()` / vis_fb of the reference (miniworld.py:518, 1340-1362: one env, 800 x 600, 16 samples, agent
+    view and map view) through mw_render_view — the generic-resolution kernels.  One JSON line of its own."""
+    import torch
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    out = []
+    for env_id in ("MiniWorld-Hallway-v0", "MiniWorld-PickupObjects-v0"):
+        vec = MiniWorldVecEnv(env_id, 16, seed=0)
+        vec.reset()
+        eng = vec.engine
+        for top in (False, True):
+            for _ in range(3):
+                eng.render_view(0, 800, 600, 16, top=top, render_agent=top)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            k = max(5, args.steps // 10)
+            for i in range(k):
+                eng.render_view(i % 16, 800, 600, 16, top=top, render_agent=top)
+            torch.cuda.synchronize()
+            out.append({"env": env_id, "view": "top" if top else "agent", "ms_per_frame": (time.perf_counter() - t0) / k * 1e3, "frames": k})
+        vec.close()
+    print(json.dumps({"metric": "render() ms per 800x600x16spp frame (one env; not the headline)", "unit": "ms", "higher_is_better": False,
+                      "n_gpus": 1, "data": "synthetic", "frames": out}))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--view800", action="store_true", help="time render() at 800 x 600 x 16 samples instead (a line of its own; not the headline)")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
@@ -509,6 +535,8 @@ def main():
                     help="also all-gather every rank's observations onto every rank each step (RCCL over xGMI, overlapped "
                          "with the next step; for a single-process trainer).  Not part of the headline workload")
     args = ap.parse_args()
+    if args.view800:
+        return view800(args)
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

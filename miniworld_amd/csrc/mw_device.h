@@ -32,8 +32,15 @@
 #define MW_OCC_CACHE_STRIDE(max_polys) ((MW_OCC_CACHE_HDR + 8 * (size_t)(max_polys) + 8 * (size_t)(((max_polys) + 7) / 8) + 31) / 32 * 32)
 #define MW_HDR_MESH_STRIDE 28 // floats per entry: slot, first draw id, triangles, first triangle, texture, normal scale, light[3], mvp[16], mesh triangles drawn before, tile rectangle, mesh id
 #define MW_MESH_VCAP 3584       // distinct positions of a mesh whose vertex stage runs per vertex (mw_mesh_entity_kernel: 16 bytes of LDS each, 56 KB + the winner queue within a workgroup's 64 KB)
+#ifndef MW_ENT_THREADS
 #define MW_ENT_THREADS 512      // lanes of the mesh entity kernel's workgroup
+#endif
 #define MW_ENT_ROUND 2048       // triangles between two drains of its winner queue
+#define MW_ENT_VPL ((MW_MESH_VCAP + MW_ENT_THREADS - 1) / MW_ENT_THREADS)     // positions per lane of the vertex stage
+#define MW_ENT_TPL (MW_ENT_ROUND / MW_ENT_THREADS)      // triangles per lane and round
+#ifndef MW_ENT_OCC
+#define MW_ENT_OCC 6            // wavefronts per SIMD the entity kernel is compiled for
+#endif
 #define MW_ENT_BIG_PIXELS 48      // a triangle whose bounding box holds more pixels is rasterised by a wavefront, a pixel per lane, instead of by one lane
 
 // status bits written by kernels, read by mw_check()

@@ -140,7 +140,7 @@ struct mw_engine {
     static constexpr int mesh_tile_waves = 16384;       // wavefronts of the mesh tiles' launch, wavefront w taking the items w, w + 16384, ... of the list (4096: 139 us, 8192: 122, 16384: 112)
     uint32_t *d_ent_list = nullptr;     // [2][N * slots] the work list itself (written by the geometry kernel)
     int ent_list_cap = 0;
-    static constexpr int ent_blocks = 512;      // its persistent workgroups: two per CU (768 measured slower beside the quad kernel)
+    static constexpr int ent_blocks = 512;      // its persistent workgroups: two of 512 lanes per CU (768 of them, or 256 of 1024 lanes: measured slower)
     uint32_t mesh_frame_seq = 1;
     uint32_t *d_slow_tris = nullptr;
     float4 *d_slow_frags = nullptr;

@@ -27,7 +27,7 @@ __device__ inline void lds_barrier()
 // The workgroups (MW_ENT_THREADS lanes; dynamic LDS: 16 bytes x the largest uploaded vertex table — a launch of one workgroup
 // per env would queue 2 048 of them for LDS, most to find no mesh in view) are persistent: each draws envs from a counter and
 // goes through the env's mesh entities in view.
-extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_kernel(
+extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh_entity_kernel(
     int N, int W, int H, const float *__restrict__ envhdr, const MwMeshDesc *__restrict__ meshes, const float4 *__restrict__ mesh_vpos,
     const uint2 *__restrict__ mesh_idx, const float *__restrict__ mesh_stream, const float *__restrict__ mesh_attr, uint32_t *__restrict__ keys_all,
     float *__restrict__ plane_cache, int plane_cap, int32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_tris, const uint32_t *__restrict__ ent_list, int ent_list_cap, int32_t *ent_n, int32_t *ent_n_after,
@@ -78,12 +78,11 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_k
             }
             // ---- the vertex stage, a position per lane (the table's last readers are behind a barrier)
             // (all of a lane's positions requested before the first is used)
-            static_assert(MW_MESH_VCAP == 7 * MW_ENT_THREADS, "seven positions per lane");
-            float4 p4[7];
+            float4 p4[MW_ENT_VPL];
 #pragma unroll
-            for (int i = 0; i < 7; ++i) { const int v = tid + i * MW_ENT_THREADS; p4[i] = v < nverts ? mesh_vpos[md.vfirst + v] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+            for (int i = 0; i < MW_ENT_VPL; ++i) { const int v = tid + i * MW_ENT_THREADS; p4[i] = v < nverts ? mesh_vpos[md.vfirst + v] : make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 #pragma unroll
-            for (int i = 0; i < 7; ++i) {
+            for (int i = 0; i < MW_ENT_VPL; ++i) {
                 const int v = tid + i * MW_ENT_THREADS;
                 if (v < nverts) {
                     const float p[3] = {p4[i].x, p4[i].y, p4[i].z};
@@ -98,13 +97,13 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, 6) void mw_mesh_entity_k
             for (int base = 0; base < e.ntris; base += MW_ENT_ROUND) {
                 // ---- a triangle per lane: keys; what covers a sample is queued (the round's indices are requested up front: a
                 // load behind the first minima would wait for them)
-                static_assert(MW_ENT_ROUND == 4 * MW_ENT_THREADS, "four triangles per lane and round");
+                static_assert(MW_ENT_ROUND == MW_ENT_TPL * MW_ENT_THREADS, "whole triangles per lane and round");
                 const int end = min(base + MW_ENT_ROUND, e.ntris);
-                uint2 ixr[4];
+                uint2 ixr[MW_ENT_TPL];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { const int t = base + tid + i * MW_ENT_THREADS; ixr[i] = t < end ? idx_e[t] : make_uint2(0u, 0u); }
+                for (int i = 0; i < MW_ENT_TPL; ++i) { const int t = base + tid + i * MW_ENT_THREADS; ixr[i] = t < end ? idx_e[t] : make_uint2(0u, 0u); }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int i = 0; i < MW_ENT_TPL; ++i) {
                     const int t = base + tid + i * MW_ENT_THREADS;
                     if (t < end) {
                         const uint2 ix = ixr[i];

@@ -15,8 +15,23 @@ try:  # pragma: no cover - depends on the environment
     from gymnasium import spaces
     from gymnasium.utils import EzPickle
     HAVE_GYMNASIUM = True
+    VectorEnvBase = gym.vector.VectorEnv                # miniworld_amd.vector.MiniWorldVectorEnv is one when gymnasium is there
+    try:                                                # gymnasium >= 1.1: an enum; before: the plain string
+        from gymnasium.vector import AutoresetMode
+        AUTORESET_SAME_STEP = AutoresetMode.SAME_STEP
+    except ImportError:
+        AUTORESET_SAME_STEP = "same-step"
+
+    def batch_action_space(single, n):
+        from gymnasium.vector.utils import batch_space
+        return batch_space(single, n)
 except Exception:  # noqa: BLE001
     HAVE_GYMNASIUM = False
+    VectorEnvBase = object
+    AUTORESET_SAME_STEP = "same-step"
+
+    def batch_action_space(single, n):
+        return Box(single.start, single.start + single.n - 1, (n,), dtype=np.int64)
 
     class _Space:
         def __init__(self, shape=None, dtype=None):

@@ -14,12 +14,13 @@ from __future__ import annotations
 
 import numpy as np
 
-from .gymshim import spaces
+from .gymshim import AUTORESET_SAME_STEP, VectorEnvBase, batch_action_space, spaces
 from .vec_env import MiniWorldVecEnv
 
 
-class MiniWorldVectorEnv:
-    metadata = {"autoreset_mode": "same-step", "render_modes": ["rgb_array"]}
+class MiniWorldVectorEnv(VectorEnvBase):
+    """A gymnasium.vector.VectorEnv when gymnasium is importable (a plain class with the same surface otherwise)."""
+    metadata = {"autoreset_mode": AUTORESET_SAME_STEP, "render_modes": ["rgb_array"]}
 
     def __init__(self, env_id: str, num_envs: int, to_numpy: bool = False, **kwargs):
         self.vec = MiniWorldVecEnv(env_id, num_envs, **kwargs)
@@ -29,7 +30,7 @@ class MiniWorldVectorEnv:
         self.single_observation_space = spaces.Box(0, 255, shape, dtype=dtype)
         self.observation_space = spaces.Box(0, 255, (num_envs,) + shape, dtype=dtype)
         self.single_action_space = spaces.Discrete(self.vec.n_actions)
-        self.action_space = spaces.Box(0, self.vec.n_actions - 1, (num_envs,), dtype=np.int64)
+        self.action_space = batch_action_space(self.single_action_space, num_envs)
         self.render_mode = "rgb_array"
         self.closed = False
 
