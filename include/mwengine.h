@@ -355,7 +355,7 @@ int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *se
  * which code its fixtures exercised: MW_PATH_QUAD the quad kernel (mw_rasterq.hip: small scenes, 8 or 4 samples),
  * MW_PATH_QUAD_MESH the same for every tile no mesh entity can touch + the mesh-aware tile kernel for the others,
  * MW_PATH_TILE the tile kernels (mw_raster.hip: big scenes, MW_K2Q=0), MW_PATH_GENERIC the generic-resolution kernels
- * (other sample counts, frames beyond 128 x 128, MW_GENERIC_RASTER=1); -1 before the first frame. */
+ * (other sample counts, frames beyond 128 x 96 pixels (W H > 12 288: the tile kernels' 32-bit edge sums), MW_GENERIC_RASTER=1); -1 before the first frame. */
 /* The `info` dict of the envs' step() as device arrays, asynchronous on `stream` (either pointer may be NULL):
  *   d_health  int32[N]     CollectHealth: info["health"] (collecthealth.py:100)
  *   d_ent_pos double[N][3] position of entity slot `ent_slot`: TMaze / YMaze info["goal_pos"] = box.pos (tmaze.py:89, ymaze.py:125)

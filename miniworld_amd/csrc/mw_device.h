@@ -41,6 +41,12 @@
 #ifndef MW_ENT_OCC
 #define MW_ENT_OCC 6            // wavefronts per SIMD the entity kernel is compiled for
 #endif
+#define MW_CNT_LONG 0           // counters of the mesh path's work lists (MwArgs::ent_list_n): per XCD long / short meshes in view and the
+#define MW_CNT_SHORT 8          //   entity kernel's cursor into them, the mesh tiles, the envs with slow-path triangles
+#define MW_CNT_CURSOR 16
+#define MW_CNT_TILES 32         // (8: per XCD, like the entities)
+#define MW_CNT_SLOW_ENVS 40
+#define MW_CNT_WORDS 64
 #define MW_ENT_BIG_PIXELS 48      // a triangle whose bounding box holds more pixels is rasterised by a wavefront, a pixel per lane, instead of by one lane
 
 // status bits written by kernels, read by mw_check()
@@ -173,15 +179,18 @@ struct MwArgs {
     // frame.  occ_valid[set]: polygon count + 1 of the world the cache belongs to, 0 after anything rewrote the polygons.
     int32_t *occ_valid;     // [sets] or null
     float *occ_cache;       // [sets][MW_OCC_CACHE_STRIDE(max_polys)]
-    // the frame's mesh entities in view, for mw_mesh_entity_kernel (written by the geometry kernel when non-null):
-    // ent_list_n[0 / 1] entries — env | table entry << 24 — at ent_list (meshes of 1024 triangles and more: drawn from
-    // first) and at ent_list + ent_list_cap (the others)
-    // ... and the tiles inside the union of their tile rectangles, for the mesh tiles' launch: ent_list_n[3] entries
-    // env | tile << 24 at tile_list.  (ent_list_n: 8 counters per frame parity — long meshes, short meshes, the entity kernel's
-    // cursor, tiles, -, envs with slow-path triangles (the entity kernel's list for the slow kernel), 2 spare.)
+    // the frame's mesh entities in view, for mw_mesh_entity_kernel (written by the geometry kernel when non-null): one pair of
+    // lists per XCD — env e's entities go to the lists of XCD e % n_xcc, and the entity kernel's workgroups draw from the lists of
+    // the XCD they run on, so that an env's sample keys are touched from ONE XCD and their atomic minima can stay in its L2 —:
+    // ent_list_n[MW_CNT_LONG + x] entries env | table entry << 24 at ent_list + x * ent_list_cap (meshes of 1024 triangles and more:
+    // drawn from first), ent_list_n[MW_CNT_SHORT + x] at ent_list + (8 + x) * ent_list_cap (the others).
+    // ... and the tiles inside the union of their tile rectangles, for the mesh tiles' launch: ent_list_n[MW_CNT_TILES + x] entries
+    // env | tile << 24 at tile_list + x * tile_list_cap (env e under x = e % n_xcc: the wavefronts b % n_xcc == x of the launch
+    // draw them, so that an env's records and keys are fetched into one XCD's L2).  (ent_list_n: MW_CNT_WORDS counters per frame parity.)
     uint32_t *ent_list;
     int32_t *ent_list_n;
     uint32_t *tile_list;
     int32_t ent_list_cap, tile_list_cap;
+    int32_t n_xcc, pad_xcc;     // XCDs of the device as the engine's probe found them (1, 2, 4 or 8), mw_xcc_probe_kernel
     unsigned long long *k1_prof;   // MW_K1_PROF: [N][MW_K1_PROF_SLOTS] cycle counters of the geometry kernel's phases, start and end time of the env's wavefront (tools/perf/kgprof.py; perf experiments only), else null
 };

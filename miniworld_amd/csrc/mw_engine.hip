@@ -37,7 +37,7 @@ extern "C" __global__ void mw_geom_big_any_kernel(MwArgs a, int view_flags, int 
                                     const float *envhdr, const MwTexDesc *texd, const uint32_t *texels, uint8_t *obs, float *depth, int dbg, \
                                     int texel_bytes, const uint16_t *rec_order, const float *mesh_pos, const float *mesh_nrm, \
                                     const float *mesh_rgb, const float *mesh_uv, uint32_t *mesh_keys, const float *plane_cache, int plane_cap, \
-                                    const float4 *slow_frags, const uint32_t *slow_head, const uint32_t *tile_list, int32_t *tile_n)
+                                    const float4 *slow_frags, const uint32_t *slow_head, const uint32_t *tile_list, int32_t *tile_n, int tile_list_cap, int n_xcc)
 MW_RASTER_DECL(mw_raster_kernel);
 MW_RASTER_DECL(mw_raster_depth_kernel);
 MW_RASTER_DECL(mw_raster_big_kernel);
@@ -59,10 +59,11 @@ MW_RASTERQ_DECL(mw_rasterq4_kernel);
 extern "C" int mw_rasterq_lds_bytes(int S, int W, int H, int n_tiles, int depth);
 extern "C" int mw_rasterq_cap(int depth);
 #define MW_RASTERQ_THREADS 512
+extern "C" __global__ void mw_xcc_probe_kernel(uint32_t *out);
 extern "C" __global__ void mw_mesh_entity_kernel(int N, int W, int H, const float *envhdr, const MwMeshDesc *meshes, const float4 *mesh_vpos, const uint2 *mesh_idx,
                                                  const float *mesh_stream, const float *mesh_attr, uint32_t *keys, float *plane_cache, int plane_cap,
                                                  int32_t *slow_count, uint32_t *slow_tris, const uint32_t *ent_list, int ent_list_cap, int32_t *ent_n, int32_t *ent_n_after,
-                                                 uint32_t *slow_envs, unsigned long long *prof);
+                                                 uint32_t *slow_envs, int n_xcc, unsigned long long *prof);
 extern "C" __global__ void mw_mesh_slow_kernel(int W, int H, const float *envhdr, const float *mesh_pos, const float *mesh_nrm, const float *mesh_rgb,
                                                const float *mesh_uv, const uint32_t *texels, int texel_bytes, uint32_t *keys, int32_t *counts, int N,
                                                int parity, const uint32_t *slow_tris, float4 *frags, uint32_t *heads, uint32_t stamp, uint32_t *status, const uint32_t *slow_envs, const int32_t *slow_env_n);
@@ -134,7 +135,7 @@ struct mw_engine {
     uint32_t *d_mesh_keys = nullptr;    // [N][H][W][8] sample keys of the mesh scatter kernel (all-ones between frames)
     bool mesh_keys_dirty = true;
     int32_t *d_slow_count = nullptr;    // [2 parities][2][N] listed triangles, fragments
-    int32_t *d_ent_counter = nullptr;   // [2][8] the work lists' lengths and cursors (mw_device.h: ent_list_n), this frame's and the next frame's
+    int32_t *d_ent_counter = nullptr;   // [2][MW_CNT_WORDS] the work lists' lengths and cursors (mw_device.h: ent_list_n), this frame's and the next frame's
     uint32_t *d_slow_envs = nullptr;    // [2][N] the envs with triangles across a frustum plane (written by the entity kernel: the slow kernel's work list)
     uint32_t *d_tile_list = nullptr;    // [N * n_tiles] the mesh tiles' work list (written by the geometry kernel)
     static constexpr int mesh_tile_waves = 16384;       // wavefronts of the mesh tiles' launch, wavefront w taking the items w, w + 16384, ... of the list (4096: 139 us, 8192: 122, 16384: 112)
@@ -607,17 +608,17 @@ int ensure_mesh_buffers(mw_engine *e)
     }
     if (!e->d_ent_list) {
         e->ent_list_cap = (int)N * std::min(MW_MAX_MESH_ENTS, std::max(e->cfg.max_ents, 1));
-        if (hipMalloc((void **)&e->d_ent_list, (size_t)e->ent_list_cap * 2 * 4) != hipSuccess) { e->d_ent_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh entity list failed"); }
+        if (hipMalloc((void **)&e->d_ent_list, (size_t)e->ent_list_cap * 16 * 4) != hipSuccess) { e->d_ent_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh entity list failed"); }
         if (hipMalloc((void **)&e->d_slow_envs, N * 2 * 4) != hipSuccess) { (void)hipFree(e->d_ent_list); e->d_ent_list = nullptr; e->d_slow_envs = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the slow path's env list failed"); }
-        if (hipMalloc((void **)&e->d_tile_list, N * (size_t)a.n_tiles * 4) != hipSuccess) { (void)hipFree(e->d_ent_list); e->d_ent_list = nullptr; e->d_tile_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh tile list failed"); }
+        if (hipMalloc((void **)&e->d_tile_list, N * (size_t)a.n_tiles * 8 * 4) != hipSuccess) { (void)hipFree(e->d_ent_list); e->d_ent_list = nullptr; e->d_tile_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh tile list failed"); }
     }
     if (!e->d_mesh_keys) {
         const size_t key_bytes = N * a.W * a.H * 8 * 4, head_bytes = N * a.W * a.H * 4;
         void *keys = nullptr, *cnt = nullptr, *tris = nullptr, *frags = nullptr, *head = nullptr;
         // triangles that cross a frustum plane and their fragments (mw_mesh_slow_kernel): counts, 1024 / 2048 entries per env
-        const bool ok = hipMalloc(&keys, key_bytes) == hipSuccess && hipMalloc(&cnt, N * 4 * 4 + 64) == hipSuccess && hipMalloc(&tris, N * MW_SLOW_TRIS * 4) == hipSuccess &&
+        const bool ok = hipMalloc(&keys, key_bytes) == hipSuccess && hipMalloc(&cnt, N * 4 * 4 + 2 * MW_CNT_WORDS * 4) == hipSuccess && hipMalloc(&tris, N * MW_SLOW_TRIS * 4) == hipSuccess &&
                         hipMalloc(&frags, N * MW_SLOW_STRIDE * 16) == hipSuccess && hipMalloc(&head, head_bytes) == hipSuccess &&
-                        hipMemset(cnt, 0, N * 4 * 4 + 64) == hipSuccess && hipMemset(head, 0, head_bytes) == hipSuccess && hipMemset(keys, 0xFF, key_bytes) == hipSuccess;
+                        hipMemset(cnt, 0, N * 4 * 4 + 2 * MW_CNT_WORDS * 4) == hipSuccess && hipMemset(head, 0, head_bytes) == hipSuccess && hipMemset(keys, 0xFF, key_bytes) == hipSuccess;
         if (!ok) {
             for (void *p : {keys, cnt, tris, frags, head}) if (p) (void)hipFree(p);
             return fail(e, MW_E_NOMEM, "hipMalloc for the mesh path's buffers failed");
@@ -647,7 +648,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
     const bool mesh_obs = e->have_meshes && e->cfg.msaa == 8 && tile_kernels_exact(a.W, a.H) && e->d_ent_list && e->d_mesh_keys;
     const uint32_t mesh_seq = mesh_obs ? e->mesh_frame_seq++ : 0u;
     if (mesh_obs) {
-        a.ent_list = e->d_ent_list; a.ent_list_n = e->d_ent_counter + (mesh_seq & 1u) * 8; a.ent_list_cap = e->ent_list_cap;
+        a.ent_list = e->d_ent_list; a.ent_list_n = e->d_ent_counter + (mesh_seq & 1u) * MW_CNT_WORDS; a.ent_list_cap = e->ent_list_cap;
         a.tile_list = e->d_tile_list; a.tile_list_cap = N * a.n_tiles;
     }
     mw_engine::Ev ev{};
@@ -759,11 +760,11 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             hipLaunchKernelGGL(mw_mesh_entity_kernel, dim3(std::min(e->ent_list_cap, e->ent_blocks)), dim3(MW_ENT_THREADS), (size_t)e->max_mesh_verts * 16, st, N, a.W, a.H,
                                (const float *)a.envhdr, a.mesh, (const float4 *)e->d_mesh_vpos, (const uint2 *)e->d_mesh_idx, (const float *)e->d_mesh_stream,
                                (const float *)e->d_mesh_attr, e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris,
-                               (const uint32_t *)e->d_ent_list, e->ent_list_cap, e->d_ent_counter + parity * 8, e->d_ent_counter + (parity ^ 1) * 8, e->d_slow_envs + (size_t)parity * N, e->d_ent_prof);
+                               (const uint32_t *)e->d_ent_list, e->ent_list_cap, e->d_ent_counter + parity * MW_CNT_WORDS, e->d_ent_counter + (parity ^ 1) * MW_CNT_WORDS, e->d_slow_envs + (size_t)parity * N, e->args.n_xcc, e->d_ent_prof);
             hipLaunchKernelGGL(mw_mesh_slow_kernel, dim3(std::min(N * 16, e->slow_waves)), dim3(64), 0, st, a.W, a.H, (const float *)a.envhdr, a.mesh_pos, a.mesh_nrm, a.mesh_rgb,
                                a.mesh_uv, a.texels, e->texel_bytes, e->d_mesh_keys, e->d_slow_count, N, parity, (const uint32_t *)e->d_slow_tris,
                                e->d_slow_frags, e->d_slow_head, mesh_stamp, a.status,
-                               (const uint32_t *)(e->d_slow_envs + (size_t)parity * N), (const int32_t *)(e->d_ent_counter + parity * 8 + 5));
+                               (const uint32_t *)(e->d_slow_envs + (size_t)parity * N), (const int32_t *)(e->d_ent_counter + parity * MW_CNT_WORDS + MW_CNT_SLOW_ENVS));
         }
         const int wpe = e->waves_per_env;
         const int tpw = (a.n_tiles + wpe - 1) / wpe;
@@ -799,7 +800,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
                                (const float *)a.envhdr, a.tex, a.texels, d_obs, d_depth, flags | part_flags, e->texel_bytes,
                                (const uint16_t *)a.rec_order, a.mesh_pos, a.mesh_nrm, a.mesh_rgb, a.mesh_uv, e->d_mesh_keys,
                                (const float *)e->d_plane_cache, e->plane_cap, (const float4 *)e->d_slow_frags, (const uint32_t *)e->d_slow_head,
-                               (const uint32_t *)a.tile_list, a.ent_list_n);
+                               (const uint32_t *)a.tile_list, a.ent_list_n, a.tile_list_cap, std::max(a.n_xcc, 1));
         };
         e->last_raster_path = k2q ? (mesh ? MW_PATH_QUAD_MESH : MW_PATH_QUAD) : MW_PATH_TILE;
         if (mesh) {
@@ -975,11 +976,30 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     e->tex_data.assign(MW_MAX_TEX, {});
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
+    {
+        // The XCDs of this device as workgroups see them (HW_REG_XCC_ID of 256 workgroups): the mesh path files an env's entities
+        // under XCD env % n_xcc and the entity kernel's workgroups draw from the lists of the XCD they run on, so that an env's
+        // sample keys are touched from one XCD and their minima stay in its L2 (mw_raster_mesh.hip).  MI355X shows 8 (SPX), 4, 2 or
+        // one id per partition mode; one id of any value is one list; any other set of ids is refused rather than guessed at.
+        uint32_t *d_ids = nullptr, ids[256];
+        a.n_xcc = 0;
+        if (hipMalloc((void **)&d_ids, sizeof ids) == hipSuccess) {
+            hipLaunchKernelGGL(mw_xcc_probe_kernel, dim3(256), dim3(64), 0, 0, d_ids);
+            if (hipMemcpy(ids, d_ids, sizeof ids, hipMemcpyDeviceToHost) == hipSuccess) {
+                uint32_t seen = 0u;
+                for (uint32_t v : ids) seen |= 1u << (v & 15u);
+                if ((seen & (seen - 1u)) == 0u) a.n_xcc = 1;
+                for (int n : {8, 4, 2}) if (seen == (1u << n) - 1u) a.n_xcc = n;
+            }
+            (void)hipFree(d_ids);
+        }
+        if (a.n_xcc == 0) { g_create_error = "could not determine the device's XCDs (HW_REG_XCC_ID probe)"; mw_destroy(e); return MW_E_HIP; }
+    }
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
     if (const char *s = getenv("MW_K2Q")) e->use_k2q = atoi(s) != 0;
     if (const char *s = getenv("MW_GENERIC_RASTER")) e->generic_raster = atoi(s) != 0;
 #ifdef MW_PERF_HOOKS
-    if (getenv("MW_ENT_PROF")) { if (dev_alloc(e, &e->d_ent_prof, (size_t)N * MW_MAX_MESH_ENTS * 8) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
+    if (getenv("MW_ENT_PROF")) { if (dev_alloc(e, &e->d_ent_prof, (size_t)N * MW_MAX_MESH_ENTS * 8 * 8) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
     if (getenv("MW_K2Q_PROF")) { if (dev_alloc(e, &e->d_k2q_prof, (size_t)N * 80) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
 #endif
     {
@@ -1005,7 +1025,7 @@ void mw_destroy(mw_engine *e)
             if (FILE *f = fopen(getenv("MW_K2Q_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
     if (e->d_ent_prof) {
-        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * MW_MAX_MESH_ENTS * 8);
+        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * MW_MAX_MESH_ENTS * 8 * 8);
         if (hipMemcpy(h.data(), e->d_ent_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(getenv("MW_ENT_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
@@ -1020,9 +1040,14 @@ void mw_destroy(mw_engine *e)
             long long tot = 0, nz = 0, mx = 0;
             for (int i = 0; i < e->cfg.num_envs; ++i) { const int v = h[(size_t)e->cfg.num_envs + i] + h[(size_t)e->cfg.num_envs * 3 + i]; tot += v; nz += v > 0; mx = std::max<long long>(mx, v); }
             fprintf(stderr, "slow fragments: total %lld, envs with any %lld of %d, max %lld\n", tot, nz, e->cfg.num_envs, mx);
-            int32_t c[16];
+            int32_t c[2 * MW_CNT_WORDS];
             if (e->d_ent_counter && hipMemcpy(c, e->d_ent_counter, sizeof c, hipMemcpyDeviceToHost) == hipSuccess)
-                fprintf(stderr, "work lists of the last two frames: long meshes %d / %d, short %d / %d, mesh tiles %d / %d\n", c[0], c[8], c[1], c[9], c[3], c[11]);
+                for (int p = 0; p < 2; ++p) {
+                    int nl = 0, ns = 0, nt = 0;
+                    for (int x = 0; x < 8; ++x) { nl += c[p * MW_CNT_WORDS + MW_CNT_LONG + x]; ns += c[p * MW_CNT_WORDS + MW_CNT_SHORT + x]; nt += c[p * MW_CNT_WORDS + MW_CNT_TILES + x]; }
+                    fprintf(stderr, "work lists (parity %d): long meshes %d, short %d, mesh tiles %d, envs with slow-path triangles %d\n", p, nl, ns,
+                            nt, c[p * MW_CNT_WORDS + MW_CNT_SLOW_ENVS]);
+                }
         }
     }
 #endif

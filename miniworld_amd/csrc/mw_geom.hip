@@ -1083,12 +1083,14 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             // the work list of the mesh entity kernel: balls before keys (a workgroup per entity; the long ones start first)
             int nbig = 0;
             for (int j = 0; j < total_meshes; ++j) nbig += __float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 2]) >= 1024 ? 1 : 0;
-            int ib = nbig ? atomicAdd(a.ent_list_n, nbig) : 0;
-            int is = total_meshes - nbig ? atomicAdd(a.ent_list_n + 1, total_meshes - nbig) : 0;
+            const int xl = env % a.n_xcc;        // the XCD whose workgroups draw this env's entities
+            int ib = nbig ? atomicAdd(a.ent_list_n + MW_CNT_LONG + xl, nbig) : 0;
+            int is = total_meshes - nbig ? atomicAdd(a.ent_list_n + MW_CNT_SHORT + xl, total_meshes - nbig) : 0;
+            uint32_t *l_long = a.ent_list + (size_t)xl * a.ent_list_cap, *l_short = a.ent_list + (size_t)(8 + xl) * a.ent_list_cap;
             for (int j = 0; j < total_meshes; ++j) {
                 const uint32_t item = (uint32_t)env | ((uint32_t)j << 24);
-                if (__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 2]) >= 1024) { if (ib < a.ent_list_cap) a.ent_list[ib] = item; ++ib; }
-                else { if (is < a.ent_list_cap) a.ent_list[a.ent_list_cap + is] = item; ++is; }
+                if (__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 2]) >= 1024) { if (ib < a.ent_list_cap) l_long[ib] = item; ++ib; }
+                else { if (is < a.ent_list_cap) l_short[is] = item; ++is; }
             }
         }
         // the step's pending removal: the picked-up object leaves the entity list after its last frame
@@ -1105,10 +1107,12 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         int total;
         const int cnt = live ? __popc(tile_mask) : 0, excl = group_excl_scan(cnt, sub, L, total);
         int o = 0;
-        if (sub == 0 && total > 0) o = atomicAdd(a.ent_list_n + 3, total);
+        const int xl = env % a.n_xcc;
+        if (sub == 0 && total > 0) o = atomicAdd(a.ent_list_n + MW_CNT_TILES + xl, total);
         o = __shfl(o, 0, L) + excl;
+        uint32_t *list = a.tile_list + (size_t)xl * a.tile_list_cap;
         for (uint32_t m = live ? tile_mask : 0u; m; m &= m - 1u, ++o)
-            if (o < a.tile_list_cap) a.tile_list[o] = (uint32_t)env | ((uint32_t)(sub + (__ffs((int)m) - 1) * L) << 24);
+            if (o < a.tile_list_cap) list[o] = (uint32_t)env | ((uint32_t)(sub + (__ffs((int)m) - 1) * L) << 24);
     }
 }
 

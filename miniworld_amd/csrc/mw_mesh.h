@@ -126,8 +126,12 @@ __device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const
 // columns that cross a small triangle's bounding box, the box's pixels otherwise)
 __device__ inline bool scatter_tri_cols(const mwcov::Edges &ed, int W, int H, uint32_t id, uint32_t *keys)
 {
+    // (every workgroup that touches this env's keys runs on ONE XCD — the entity kernel's lists are per XCD —: the minima need no
+    // wider scope than that XCD's L2, where they then stay until the kernel's end instead of each going out to memory.  "Workgroup"
+    // is the scope that compiles to an L2 atomic without the system-coherence bits.)
     return mwcov::cover(ed, W, H, [&](int px, int gy, int s, float xs, float ys) {
-        atomicMin(keys + ((size_t)(H - 1 - gy) * W + px) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id);
+        __hip_atomic_fetch_min(keys + ((size_t)(H - 1 - gy) * W + px) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id,
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     });
 }
 
@@ -248,7 +252,8 @@ __device__ inline bool scatter_tri_wave(const MeshEnt &e, int tri, const float4 
     for (int m = lane; m < npix; m += 64) {
         const uint32_t in = mwcov::pixel_mask(ed, thr, px, gy);
         mwcov::emit_samples(in, px, gy, [&](int sx, int sy, int s, float xs, float ys) {
-            atomicMin(keys + ((size_t)(H - 1 - sy) * W + sx) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id);
+            __hip_atomic_fetch_min(keys + ((size_t)(H - 1 - sy) * W + sx) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         });
         any |= in != 0u;
         px += dr; gy += dq;

@@ -160,15 +160,20 @@ __device__ inline void raster_kernel_body(
     const uint16_t *__restrict__ rec_order, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm,
     const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint32_t *__restrict__ mesh_keys,
     const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head,
-    const uint32_t *__restrict__ tile_list, int32_t *__restrict__ tile_n)
+    const uint32_t *__restrict__ tile_list, int32_t *__restrict__ tile_n, int tile_list_cap, int n_xcc)
 {
     if (MESHAWARE == 1) __builtin_amdgcn_s_setprio(3);      // (the mesh tiles end the frame's critical path: ahead of the quad kernel's wavefronts)
     // (one call site for both forms: two copies of the tile code in one kernel cost it 150 registers)
     const int part_mode = MESHAWARE ? (dbg >> 4) & 3 : 0;
     const bool listed = MESHAWARE == 1 && part_mode == 3;
-    // tile_n[3]: items (mw_mesh_entity_kernel zeroes it for the frame after the next).  Wavefront w takes the items w, w + grid, ...
-    const int n_items = listed ? tile_n[3] : 1;
-    for (int i = listed ? (int)blockIdx.x : 0; i < n_items; i += (int)gridDim.x) {
+    // tile_n[MW_CNT_TILES + x]: items of XCD x's list (mw_mesh_entity_kernel zeroes them for the frame after the next).  Workgroup b is
+    // dispatched to XCD b % n_xcc (tools/ubench/xcc_probe.hip: all of 4 096): it takes the items b / n_xcc, + grid / n_xcc, ... of that
+    // XCD's list — the envs e % n_xcc == x, whose records and keys thus meet one L2 only.  (A dispatch that did otherwise would cost
+    // locality, not frames.)
+    const int xl = listed ? (int)blockIdx.x % n_xcc : 0, stride = listed ? ((int)gridDim.x - xl + n_xcc - 1) / n_xcc : 1;      // (the launch's wavefronts b % n_xcc == xl: every item once)
+    const int n_items = listed ? min(tile_n[MW_CNT_TILES + xl], tile_list_cap) : 1;
+    if (listed) tile_list += (size_t)xl * tile_list_cap;
+    for (int i = listed ? (int)blockIdx.x / n_xcc : 0; i < n_items; i += stride) {
         int env, t_begin, t_end;
         if (listed) {
             const uint32_t item = tile_list[i];
@@ -199,9 +204,9 @@ __device__ inline void raster_kernel_body(
     const uint16_t *__restrict__ rec_order, const float *__restrict__ mesh_pos, const float *__restrict__ mesh_nrm, \
     const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, uint32_t *__restrict__ mesh_keys, \
     const float *__restrict__ plane_cache, int plane_cap, const float4 *__restrict__ slow_frags, const uint32_t *__restrict__ slow_head, \
-    const uint32_t *__restrict__ tile_list, int32_t *__restrict__ tile_n
+    const uint32_t *__restrict__ tile_list, int32_t *__restrict__ tile_n, int tile_list_cap, int n_xcc
 #define MW_RASTER_FWD N, W, H, max_vis, tiles_x, n_tiles, waves_per_env, tiles_per_wave, rec_raster, rec_shade, rec_cull, \
-    nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order, mesh_pos, mesh_nrm, mesh_rgb, mesh_uv, mesh_keys, plane_cache, plane_cap, slow_frags, slow_head, tile_list, tile_n
+    nvis_arr, envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order, mesh_pos, mesh_nrm, mesh_rgb, mesh_uv, mesh_keys, plane_cache, plane_cap, slow_frags, slow_head, tile_list, tile_n, tile_list_cap, n_xcc
 
 // the production kernels of small scenes: no debug flags (mw_engine.hip launches the general kernel below when
 // MW_DEBUG_FLAGS asks for any), RGB only / RGB + depth

@@ -2,6 +2,14 @@
 // cross a frustum plane, and the generic-resolution view kernels.  See mw_mesh.h.
 #include "mw_mesh.h"
 
+// HW_REG_XCC_ID of 256 workgroups: which XCDs does this device show (mw_create)
+extern "C" __global__ void mw_xcc_probe_kernel(uint32_t *out)
+{
+    uint32_t x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    if (threadIdx.x == 0) out[blockIdx.x] = x & 15u;
+}
+
 namespace {
 // a workgroup barrier that orders LDS only: the global minima and plane records in flight need no other wave's attention,
 // and waiting for them (what __syncthreads' fences do) was most of this kernel's time
@@ -31,7 +39,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
     int N, int W, int H, const float *__restrict__ envhdr, const MwMeshDesc *__restrict__ meshes, const float4 *__restrict__ mesh_vpos,
     const uint2 *__restrict__ mesh_idx, const float *__restrict__ mesh_stream, const float *__restrict__ mesh_attr, uint32_t *__restrict__ keys_all,
     float *__restrict__ plane_cache, int plane_cap, int32_t *__restrict__ slow_count, uint32_t *__restrict__ slow_tris, const uint32_t *__restrict__ ent_list, int ent_list_cap, int32_t *ent_n, int32_t *ent_n_after,
-    uint32_t *__restrict__ slow_envs, unsigned long long *prof)
+    uint32_t *__restrict__ slow_envs, int n_xcc, unsigned long long *prof)
 {
     // (the mesh kernels are the frame's critical path: their wavefronts issue ahead of the quad kernel's on a shared SIMD)
     __builtin_amdgcn_s_setprio(3);
@@ -41,16 +49,22 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ent_n: this frame's list lengths (the geometry kernel's) and the cursor into them; ent_n_after: the next frame's, zeroed
     // here (the two swap places from frame to frame; nothing of the next frame starts before this kernel has ended)
-    if (blockIdx.x == 0 && tid < 8) ent_n_after[tid] = 0;
+    if (blockIdx.x == 0 && tid < MW_CNT_WORDS) ent_n_after[tid] = 0;
     if (tid == 0) { s_qn = 0; s_bn = 0; }
-    const int n_long = min(ent_n[0], ent_list_cap), n_items = n_long + min(ent_n[1], ent_list_cap);
+    // the lists of the XCD this workgroup runs on (mw_geom.hip files env e under XCD e % n_xcc): an env's keys are touched from one
+    // XCD only, whose L2 holds their minima (mw_mesh.h: scatter_tri_cols)
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc = (xcc & 15u) % (uint32_t)n_xcc;
+    const uint32_t *l_long = ent_list + (size_t)xcc * ent_list_cap, *l_short = ent_list + (size_t)(8u + xcc) * ent_list_cap;
+    const int n_long = min(ent_n[MW_CNT_LONG + xcc], ent_list_cap), n_items = n_long + min(ent_n[MW_CNT_SHORT + xcc], ent_list_cap);
     for (;;) {
         lds_barrier();
-        if (tid == 0) s_env = atomicAdd(ent_n + 2, 1);
+        if (tid == 0) s_env = atomicAdd(ent_n + MW_CNT_CURSOR + xcc, 1);
         lds_barrier();
         const int item_i = s_env;
         if (item_i >= n_items) break;
-        const uint32_t item = item_i < n_long ? ent_list[item_i] : ent_list[ent_list_cap + item_i - n_long];
+        const uint32_t item = item_i < n_long ? l_long[item_i] : l_short[item_i - n_long];
         const int env = (int)(item & 0xFFFFFFu), j = (int)(item >> 24);
         const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
         uint32_t *keys = keys_all + (size_t)env * W * H * 8;
@@ -72,7 +86,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
                     const float4 *rec = reinterpret_cast<const float4 *>(mesh_stream) + (size_t)(e.first + t) * 3;
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                     const float pos[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-                    raster_tri_obs(f, e, __float_as_int(r2.y), pos, W, H, keys, attr_e + (size_t)t * 6, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS, SlowEnvs{ent_n + 5, slow_envs, env});
+                    raster_tri_obs(f, e, __float_as_int(r2.y), pos, W, H, keys, attr_e + (size_t)t * 6, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS, SlowEnvs{ent_n + MW_CNT_SLOW_ENVS, slow_envs, env});
                 }
                 continue;       // (the next item)
             }
@@ -108,7 +122,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
                     if (t < end) {
                         const uint2 ix = ixr[i];
                         const float4 va = s_vert[ix.x & 0xFFFFu], vb = s_vert[ix.x >> 16], vc = s_vert[ix.y & 0xFFFFu];
-                        const int r = classify_tri_table((int)(ix.y >> 16), va, vb, vc, W, H, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS, SlowEnvs{ent_n + 5, slow_envs, env});
+                        const int r = classify_tri_table((int)(ix.y >> 16), va, vb, vc, W, H, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS, SlowEnvs{ent_n + MW_CNT_SLOW_ENVS, slow_envs, env});
                         if (r == 1) s_queue[atomicAdd(&s_qn, 1)] = (uint16_t)(t - base);
                         else if (r == 2) s_big[atomicAdd(&s_bn, 1)] = (uint16_t)(t - base);
                     }
@@ -150,7 +164,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
             }
         }
         if (prof && tid == 0) {
-            unsigned long long *p = prof + (size_t)item_i * 8;
+            unsigned long long *p = prof + ((size_t)xcc * ent_list_cap + (size_t)item_i) * 8;
             p[0] = pr_t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = 1ull | (pr_tris << 8) | (pr_win << 32); p[3] = pr_ph[0]; p[4] = pr_ph[1]; p[5] = pr_ph[2] | (pr_ph[3] << 32);
             p[6] = (unsigned long long)blockIdx.x; p[7] = (unsigned long long)item;
         }

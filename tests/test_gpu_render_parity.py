@@ -126,8 +126,9 @@ def test_display_list_of_one_triangle(msaa):
 @pytest.mark.parametrize("size", [(16, 12), (16, 60), (32, 4), (128, 128)])
 @pytest.mark.parametrize("msaa", [8, 4])
 def test_observation_sizes_at_the_edges_of_the_tile_kernels(size, msaa):
-    """mw_create accepts any multiple of the 16 x 4 tile up to 128 x 128 for the tile / quad kernels: one tile column
-    (16 pixels wide: the tile index arithmetic divides by tiles_x = 1), one tile row, the largest frame."""
+    """mw_create accepts any multiple of the 16 x 4 tile; up to 128 x 96 pixels the tile / quad kernels draw it: one tile column
+    (16 pixels wide: the tile index arithmetic divides by tiles_x = 1), one tile row; 128 x 128 is past their 32-bit edge sums
+    (|c| <= 2 W H 2^16: a wall across the whole frame lost a triangle there) and takes the generic-resolution kernels."""
     import torch
     import pyoracle
     W, H = size
