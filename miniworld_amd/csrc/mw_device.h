@@ -21,12 +21,15 @@
 #define MW_HDR_MESH 32        // first float of the mesh-entity table
 #define MW_K1_PROF_SLOTS 10
 // mesh path (mw_mesh.h, mw_raster_mesh.hip)
-#define MW_PLANE_REC 20         // (w plane, tex) (r plane, state) (g plane, s.a0) (b plane, s.dadx) (s.dady, t plane)
+#define MW_PLANE_REC 16         // plane cache record, one 64-byte sector: (w plane, tex) (r plane, state) (g plane, s.a0) (b plane, s.dadx);
+#define MW_PLANE_XTRA 4         //   a textured mesh's fifth quad (s.dady, t plane) lives in a second array behind the records ([N][cap][4]):
+                                //   at a stride of 80 bytes a record straddled two sectors three times in four (2 x the write traffic)
+#define MW_PIECE_REC 20         // a slow-path piece's record: the five quads in a row
 #define MW_PLANE_SLOW 2         // state: the triangle crosses a frustum plane — its fragments come from the env's slow-fragment list
 #define MW_SLOW_TRIS 1024       // per env: mesh triangles that cross a frustum plane (a mesh at the frame's edge)
 #define MW_SLOW_FRAGS 8191      // per env: their fragments, (draw id << 16 | piece of the fan << 13 | next fragment of the pixel + 1, piece's record), chained per pixel
 #define MW_SLOW_PIECES (MW_SLOW_TRIS * 7)       // per env: the attribute planes of the pieces of their fans (plane-cache records), 7 places per listed triangle
-#define MW_SLOW_STRIDE (MW_SLOW_FRAGS + 1 + MW_SLOW_PIECES * (MW_PLANE_REC / 4))       // float4s per env: fragments, then pieces
+#define MW_SLOW_STRIDE (MW_SLOW_FRAGS + 1 + MW_SLOW_PIECES * (MW_PIECE_REC / 4))       // float4s per env: fragments, then pieces
 #define MW_OCC_CACHE_HDR 8
 // floats per set: header, 8 per wall, 8 per box of eight polygons; whole 128-byte lines
 #define MW_OCC_CACHE_STRIDE(max_polys) ((MW_OCC_CACHE_HDR + 8 * (size_t)(max_polys) + 8 * (size_t)(((max_polys) + 7) / 8) + 31) / 32 * 32)
@@ -39,7 +42,7 @@
 #define MW_ENT_VPL ((MW_MESH_VCAP + MW_ENT_THREADS - 1) / MW_ENT_THREADS)     // positions per lane of the vertex stage
 #define MW_ENT_TPL (MW_ENT_ROUND / MW_ENT_THREADS)      // triangles per lane and round
 #ifndef MW_ENT_OCC
-#define MW_ENT_OCC 6            // wavefronts per SIMD the entity kernel is compiled for
+#define MW_ENT_OCC 6            // wavefronts per SIMD the entity kernel is compiled for: 80 registers (17 spilled: ~30 MB of scratch traffic per step) — at 96 or 105 without spills a quad-kernel workgroup no longer fits beside two of its workgroups on a CU and the frame loses 25 us
 #endif
 #define MW_CNT_LONG 0           // counters of the mesh path's work lists (MwArgs::ent_list_n): per XCD long / short meshes in view and the
 #define MW_CNT_SHORT 8          //   entity kernel's cursor into them, the mesh tiles, the envs with slow-path triangles

@@ -146,7 +146,7 @@ struct mw_engine {
     uint32_t *d_slow_tris = nullptr;
     float4 *d_slow_frags = nullptr;
     uint32_t *d_slow_head = nullptr;
-    float *d_plane_cache = nullptr;     // [N][plane_cap][20] attribute planes of the mesh triangles that win samples (mw_raster_mesh.hip)
+    float *d_plane_cache = nullptr;     // [N][plane_cap][16] + [N][plane_cap][4] attribute planes of the mesh triangles that win samples (mw_raster_mesh.hip)
     int plane_cap = 0, max_mesh_tris = 0;
     int obs_layout = MW_OBS_HWC_U8;
     size_t view_keys_bytes = 0;
@@ -601,7 +601,7 @@ int ensure_mesh_buffers(mw_engine *e)
     const long long want = std::min<long long>(0xC000, (long long)e->cfg.max_ents * e->max_mesh_tris);
     if ((int)want > e->plane_cap) {
         float *np = nullptr;
-        if (hipMalloc((void **)&np, N * (size_t)want * MW_PLANE_REC * 4) != hipSuccess) return fail(e, MW_E_NOMEM, "hipMalloc for the plane cache (%lld records per env) failed", want);
+        if (hipMalloc((void **)&np, N * (size_t)want * (MW_PLANE_REC + MW_PLANE_XTRA) * 4) != hipSuccess) return fail(e, MW_E_NOMEM, "hipMalloc for the plane cache (%lld records per env) failed", want);
         (void)hipDeviceSynchronize();
         if (e->d_plane_cache) (void)hipFree(e->d_plane_cache);
         e->d_plane_cache = np; e->plane_cap = (int)want;

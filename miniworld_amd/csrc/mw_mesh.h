@@ -135,14 +135,14 @@ __device__ inline bool scatter_tri_cols(const mwcov::Edges &ed, int W, int H, ui
     });
 }
 
-__device__ inline void store_planes(float *rec, const mwgl::TriSetup &ts, int tex, int state)
+__device__ inline void store_planes(float *rec, float *xtra, const mwgl::TriSetup &ts, int tex, int state)
 {
     float4 *q = reinterpret_cast<float4 *>(rec);
     q[0] = make_float4(ts.w.a0, ts.w.dadx, ts.w.dady, __int_as_float(tex));
     q[1] = make_float4(ts.col[0].a0, ts.col[0].dadx, ts.col[0].dady, __int_as_float(state));
     q[2] = make_float4(ts.col[1].a0, ts.col[1].dadx, ts.col[1].dady, ts.s.a0);
     q[3] = make_float4(ts.col[2].a0, ts.col[2].dadx, ts.col[2].dady, ts.s.dadx);
-    if (tex >= 0) q[4] = make_float4(ts.s.dady, ts.t.a0, ts.t.dadx, ts.t.dady);
+    if (tex >= 0) *reinterpret_cast<float4 *>(xtra) = make_float4(ts.s.dady, ts.t.a0, ts.t.dadx, ts.t.dady);
 }
 
 // a triangle that crosses a frustum plane (rare): left to mw_mesh_slow_kernel, which clips it, scatters its keys and lists its
@@ -159,7 +159,7 @@ __device__ inline void list_slow_tri(int j, int tri, float *rec, int32_t *slow_c
 
 // a triangle that covers a sample: its vertices lit (attr: normals, colours, texture coordinates of the three, 96 bytes), its
 // attribute planes set up and stored in the env's plane cache.  v: the vertex stage's window coordinates, drawing order.
-__device__ inline void setup_winner(const mwgl::Frame &f, const MeshEnt &e, mwgl::Vert (&v)[3], const float4 *attr, float *rec)
+__device__ inline void setup_winner(const mwgl::Frame &f, const MeshEnt &e, mwgl::Vert (&v)[3], const float4 *attr, float *rec, float *xtra)
 {
     const float4 a0 = attr[0], a1 = attr[1], a2 = attr[2], a3 = attr[3], a4 = attr[4], a5 = attr[5];
     const float at[24] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w,
@@ -172,13 +172,13 @@ __device__ inline void setup_winner(const mwgl::Frame &f, const MeshEnt &e, mwgl
         v[k].st[1] = e.tex >= 0 ? at[18 + k * 2 + 1] : 0.0f;
     }
     mwgl::TriSetup ts;
-    if (mwgl::setup_triangle(v[0], v[1], v[2], true, e.tex >= 0, ts)) store_planes(rec, ts, e.tex, 1);
+    if (mwgl::setup_triangle(v[0], v[1], v[2], true, e.tex >= 0, ts)) store_planes(rec, xtra, ts, e.tex, 1);
 }
 
 // One mesh triangle of an obs-sized 8-sample frame from its own three positions (a mesh without a vertex table): vertex
 // stage, setup, keys; a triangle that covers a sample leaves its attribute planes in the plane cache.
 __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys,
-                                      const float4 *attr, float *cache, int j, int32_t *slow_count, uint32_t *slow_tris, const SlowEnvs &se)
+                                      const float4 *attr, float *cache, float *xcache, int j, int32_t *slow_count, uint32_t *slow_tris, const SlowEnvs &se)
 {
     mwgl::Vert v[3];
 #pragma unroll
@@ -192,7 +192,7 @@ __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, in
     mwcov::Edges ed;
     if (!mwcov::setup_edges(v[0].win, v[1].win, v[2].win, ed)) return;        // back-facing or empty
     if (!scatter_tri_cols(ed, W, H, (uint32_t)(e.start + tri), keys)) return;
-    setup_winner(f, e, v, attr, rec);
+    setup_winner(f, e, v, attr, rec, xcache + (size_t)tri * MW_PLANE_XTRA);
 }
 
 // ... from the entity's vertex table in LDS (mw_mesh_entity_kernel): a vertex is (window x, y, z, 1 / w), or, outside the
@@ -221,7 +221,7 @@ __device__ inline int classify_tri_table(int tri, const float4 &va, const float4
 // a triangle that covers a sample (unclipped vertices of the table): its keys — unless a wavefront has scattered them —, its
 // vertices lit, its attribute planes into the plane cache
 __device__ inline void scatter_winner(const mwgl::Frame &f, const MeshEnt &e, int tri, const float4 &va, const float4 &vb, const float4 &vc, int W, int H,
-                                      uint32_t *keys, bool keys_done, const float4 *attr, float *rec)
+                                      uint32_t *keys, bool keys_done, const float4 *attr, float *rec, float *xtra)
 {
     mwgl::Vert v[3];
     v[0].win[0] = va.x; v[0].win[1] = va.y; v[0].win[2] = va.z; v[0].win[3] = va.w;
@@ -231,7 +231,7 @@ __device__ inline void scatter_winner(const mwgl::Frame &f, const MeshEnt &e, in
         mwcov::Edges ed;
         if (mwcov::setup_edges(v[0].win, v[1].win, v[2].win, ed)) scatter_tri_cols(ed, W, H, (uint32_t)(e.start + tri), keys);
     }
-    setup_winner(f, e, v, attr, rec);
+    setup_winner(f, e, v, attr, rec, xtra);
 }
 
 // A triangle of many pixels, the same for all lanes of the wavefront (vertices of the table, unclipped, front-facing): lane l
@@ -335,7 +335,9 @@ __device__ inline RGB shade_by_draw_id_s(const TileCtx &cx, uint32_t id, int px,
 __device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, int px, int gy)
 {
     const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 1]);
-    const float4 *q = reinterpret_cast<const float4 *>(cx.planes + ((size_t)__float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 25]) + ((int)id - start)) * MW_PLANE_REC);
+    const size_t slot = (size_t)__float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 25]) + (size_t)((int)id - start);
+    const float4 *q = reinterpret_cast<const float4 *>(cx.planes + slot * MW_PLANE_REC);
+    const float4 *q4p = reinterpret_cast<const float4 *>(cx.planes_xtra + slot * MW_PLANE_XTRA);
     if (__float_as_int(q[1].w) == MW_PLANE_SLOW) {
         // a triangle that crosses a frustum plane: mw_mesh_slow_kernel clipped it and left, per pixel, a chain of the pieces
         // of its fan that cover a sample there, and the pieces' planes (of the entries for this id the first piece's counts)
@@ -349,7 +351,8 @@ __device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, 
             k = w & 0x1FFFu;
         }
         if (piece >= (uint32_t)MW_SLOW_PIECES) return RGB{0.0f, 0.0f, 0.0f};
-        q = cx.slow_frags + (MW_SLOW_FRAGS + 1) + (size_t)piece * (MW_PLANE_REC / 4);
+        q = cx.slow_frags + (MW_SLOW_FRAGS + 1) + (size_t)piece * (MW_PIECE_REC / 4);
+        q4p = q + 4;
     }
     const float4 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
     const int tex = cx.te.flat ? -1 : __float_as_int(q0.w);
@@ -359,7 +362,7 @@ __device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, 
         const float oow = rcp_safe(mwgl::plane_at(wp, x, y));
         return RGB{mwgl::plane_at(pr, x, y) * oow, mwgl::plane_at(pg, x, y) * oow, mwgl::plane_at(pb, x, y) * oow};
     }
-    const float4 q4 = q[4];
+    const float4 q4 = *q4p;
     const mwgl::Plane sp = {q2.w, q3.w, q4.x}, tp = {q4.y, q4.z, q4.w};
     return shade_planes(wp, sp, tp, pr, pg, pb, tex, cx.te, px, gy, 0.5f);
 }

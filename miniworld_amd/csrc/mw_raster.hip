@@ -25,7 +25,7 @@
 //               sample keys the scatter kernel left (mw_raster_mesh.hip) and give them back cleared.
 template <bool LDS_RECS, int FMT, int HOT = 0, int MESHAWARE = 0>
 __device__ inline void raster_env_tiles(
-    int env, int t_begin, int t_end, int part_mode, int W, int H, int max_vis, int tiles_x, int n_tiles,
+    int N, int env, int t_begin, int t_end, int part_mode, int W, int H, int max_vis, int tiles_x, int n_tiles,
     const float *__restrict__ rec_raster, const float *__restrict__ rec_shade, const float *__restrict__ rec_cull,
     const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr, const MwTexDesc *__restrict__ texd,
     const uint32_t *__restrict__ texels, uint8_t *__restrict__ obs, float *__restrict__ depth, int dbg, int texel_bytes,
@@ -77,6 +77,7 @@ __device__ inline void raster_env_tiles(
     cx.shade_stride = in_lds ? MW_LDS_SHADE_Q : MW_SHADE_REC / 4; cx.cull_stride = in_lds ? MW_LDS_CULL_Q : MW_CULL_REC / 4; cx.rr_env = rr_env; cx.s_pack = s_pack; cx.hdr = hdr; cx.ment = hdr + MW_HDR_MESH;
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.planes = MESHAWARE == 1 ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
+    cx.planes_xtra = MESHAWARE == 1 ? plane_cache + (size_t)N * plane_cap * MW_PLANE_REC + (size_t)env * plane_cap * MW_PLANE_XTRA : nullptr;
     cx.slow_frags = MESHAWARE == 1 ? slow_frags + (size_t)env * MW_SLOW_STRIDE : nullptr;
     cx.slow_head = MESHAWARE == 1 ? slow_head + (size_t)env * W * H : nullptr;
     cx.slow_stamp = (uint32_t)dbg >> 16;
@@ -187,7 +188,7 @@ __device__ inline void raster_kernel_body(
             if (env >= N) return;
             t_begin = (slot % waves_per_env) * tiles_per_wave; t_end = min(t_begin + tiles_per_wave, n_tiles);
         }
-        raster_env_tiles<LDS_RECS, FMT, HOT, MESHAWARE>(env, t_begin, t_end, listed ? 2 : part_mode, W, H, max_vis, tiles_x, n_tiles, rec_raster, rec_shade, rec_cull, nvis_arr,
+        raster_env_tiles<LDS_RECS, FMT, HOT, MESHAWARE>(N, env, t_begin, t_end, listed ? 2 : part_mode, W, H, max_vis, tiles_x, n_tiles, rec_raster, rec_shade, rec_cull, nvis_arr,
                                                         envhdr, texd, texels, obs, depth, dbg, texel_bytes, rec_order, mesh_pos, mesh_nrm, mesh_rgb, mesh_uv, mesh_keys,
                                                         plane_cache, plane_cap, slow_frags, slow_head);
         if (!listed) return;

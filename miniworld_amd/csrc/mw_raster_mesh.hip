@@ -76,7 +76,8 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
 #define MW_ENT_PHASE(i) if (prof) { const unsigned long long now_ = __builtin_amdgcn_s_memrealtime(); pr_ph[i] += now_ - pr_last; pr_last = now_; }
         {
             const MeshEnt e = load_ment(hdr + MW_HDR_MESH, j);
-            float *cache_e = plane_cache + ((size_t)env * plane_cap + (size_t)__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 25])) * MW_PLANE_REC;
+            const size_t slot0 = (size_t)env * plane_cap + (size_t)__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 25]);
+            float *cache_e = plane_cache + slot0 * MW_PLANE_REC, *xcache_e = plane_cache + (size_t)N * plane_cap * MW_PLANE_REC + slot0 * MW_PLANE_XTRA;
             const MwMeshDesc md = meshes[__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 27])];
             const int nverts = (int)md.nverts;
             const float4 *attr_e = reinterpret_cast<const float4 *>(mesh_attr) + (size_t)e.first * 6;
@@ -86,7 +87,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
                     const float4 *rec = reinterpret_cast<const float4 *>(mesh_stream) + (size_t)(e.first + t) * 3;
                     const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2];
                     const float pos[9] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w, r2.x};
-                    raster_tri_obs(f, e, __float_as_int(r2.y), pos, W, H, keys, attr_e + (size_t)t * 6, cache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS, SlowEnvs{ent_n + MW_CNT_SLOW_ENVS, slow_envs, env});
+                    raster_tri_obs(f, e, __float_as_int(r2.y), pos, W, H, keys, attr_e + (size_t)t * 6, cache_e, xcache_e, j, slow_count + env, slow_tris + (size_t)env * MW_SLOW_TRIS, SlowEnvs{ent_n + MW_CNT_SLOW_ENVS, slow_envs, env});
                 }
                 continue;       // (the next item)
             }
@@ -155,7 +156,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
                     const int qe = (int)s_queue[k], tq = base + (qe & 0x7FFF);
                     const uint2 iq = idx_e[tq];
                     const float4 va = s_vert[iq.x & 0xFFFFu], vb = s_vert[iq.x >> 16], vc = s_vert[iq.y & 0xFFFFu];
-                    scatter_winner(f, e, (int)(iq.y >> 16), va, vb, vc, W, H, keys, (qe & 0x8000) != 0, attr_e + (size_t)tq * 6, cache_e + (size_t)(iq.y >> 16) * MW_PLANE_REC);
+                    scatter_winner(f, e, (int)(iq.y >> 16), va, vb, vc, W, H, keys, (qe & 0x8000) != 0, attr_e + (size_t)tq * 6, cache_e + (size_t)(iq.y >> 16) * MW_PLANE_REC, xcache_e + (size_t)(iq.y >> 16) * MW_PLANE_XTRA);
                 }
                 lds_barrier();
                 if (tid == 0) { s_qn = 0; s_bn = 0; }
@@ -353,7 +354,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
                 p.id = (id << 16) | ((uint32_t)(q - 2) << 13);
                 p.rec = (uint32_t)(i * 7 + (q - 2));
                 have = p.x0 <= p.x1 && p.y0 <= p.y1;
-                if (have) store_planes(pieces + (size_t)p.rec * MW_PLANE_REC, ts, tex, 1);
+                if (have) store_planes(pieces + (size_t)p.rec * MW_PIECE_REC, pieces + (size_t)p.rec * MW_PIECE_REC + 16, ts, tex, 1);
             }
         }
         // ---- a (piece, pixel) pair per lane and turn over all pieces
@@ -511,7 +512,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.te.flat = 0;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
     cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr;
-    cx.planes = nullptr; cx.slow_frags = nullptr; cx.slow_head = nullptr; cx.slow_stamp = 0u;
+    cx.planes = nullptr; cx.planes_xtra = nullptr; cx.slow_frags = nullptr; cx.slow_head = nullptr; cx.slow_stamp = 0u;
     cx.pre_touch = cx.pre_full = cx.pre_clip = cx.pre_edges = 0ull;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
     else if (S == 4) view_tile_body<4>(cx, tiles_x, mesh_keys);
