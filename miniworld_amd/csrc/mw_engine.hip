@@ -757,7 +757,7 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             HIP_TRY(e, hipStreamWaitEvent(e->quad_stream, e->ev_mesh_fork, 0));
             // persistent workgroups drawing entities from the geometry kernel's list (two sets of counters swapping places: the
             // kernel zeroes the next frame's)
-            hipLaunchKernelGGL(mw_mesh_entity_kernel, dim3(std::min(e->ent_list_cap, e->ent_blocks)), dim3(MW_ENT_THREADS), (size_t)e->max_mesh_verts * 16, st, N, a.W, a.H,
+            hipLaunchKernelGGL(mw_mesh_entity_kernel, dim3(std::max(a.n_xcc, std::min(e->ent_list_cap, e->ent_blocks))), dim3(MW_ENT_THREADS), (size_t)e->max_mesh_verts * 16, st, N, a.W, a.H,
                                (const float *)a.envhdr, a.mesh, (const float4 *)e->d_mesh_vpos, (const uint2 *)e->d_mesh_idx, (const float *)e->d_mesh_stream,
                                (const float *)e->d_mesh_attr, e->d_mesh_keys, e->d_plane_cache, e->plane_cap, e->d_slow_count + (size_t)parity * 2 * N, e->d_slow_tris,
                                (const uint32_t *)e->d_ent_list, e->ent_list_cap, e->d_ent_counter + parity * MW_CNT_WORDS, e->d_ent_counter + (parity ^ 1) * MW_CNT_WORDS, e->d_slow_envs + (size_t)parity * N, e->args.n_xcc, e->d_ent_prof);
@@ -977,10 +977,11 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (upload_textures(e) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_HIP; }
     e->waves_per_env = pick_waves_per_env(e);
     {
-        // The XCDs of this device as workgroups see them (HW_REG_XCC_ID of 256 workgroups): the mesh path files an env's entities
-        // under XCD env % n_xcc and the entity kernel's workgroups draw from the lists of the XCD they run on, so that an env's
-        // sample keys are touched from one XCD and their minima stay in its L2 (mw_raster_mesh.hip).  MI355X shows 8 (SPX), 4, 2 or
-        // one id per partition mode; one id of any value is one list; any other set of ids is refused rather than guessed at.
+        // The XCDs of this device as workgroups see them (HW_REG_XCC_ID of 256 workgroups: 8, 4, 2 or one id per partition mode).
+        // The mesh path files an env's entities and mesh tiles under class env % n_xcc and workgroup b of the entity / tile launches
+        // draws from class b % n_xcc: where workgroup b runs on XCD b % n_xcc — every launch of a fresh process — an env's records,
+        // keys and planes meet one L2 (the mesh tiles' fetch 50 -> 37 MB).  Locality only: nothing is wrong when the dispatcher's
+        // round-robin starts elsewhere.
         uint32_t *d_ids = nullptr, ids[256];
         a.n_xcc = 0;
         if (hipMalloc((void **)&d_ids, sizeof ids) == hipSuccess) {
@@ -988,12 +989,11 @@ int mw_create(const mw_config *cfg, mw_engine **out)
             if (hipMemcpy(ids, d_ids, sizeof ids, hipMemcpyDeviceToHost) == hipSuccess) {
                 uint32_t seen = 0u;
                 for (uint32_t v : ids) seen |= 1u << (v & 15u);
-                if ((seen & (seen - 1u)) == 0u) a.n_xcc = 1;
                 for (int n : {8, 4, 2}) if (seen == (1u << n) - 1u) a.n_xcc = n;
             }
             (void)hipFree(d_ids);
         }
-        if (a.n_xcc == 0) { g_create_error = "could not determine the device's XCDs (HW_REG_XCC_ID probe)"; mw_destroy(e); return MW_E_HIP; }
+        if (a.n_xcc == 0) a.n_xcc = 1;      // (one id, or a set this code does not know: one class — the lists are about locality only)
     }
     if (const char *s = getenv("MW_DEBUG_FLAGS")) e->dbg_flags = atoi(s);
     if (const char *s = getenv("MW_K2Q")) e->use_k2q = atoi(s) != 0;

@@ -88,9 +88,19 @@ __device__ inline void scatter_tri(const mwgl::TriEdges &t, int W, int H, uint32
         }
 }
 
+// the view kernels' clipper: lanes take turns with work lists in LDS, MW_CLIP_TURN lanes at a time
+#define MW_CLIP_TURN 8
+template <int K> __device__ inline uint64_t drop_lowest(uint64_t m)
+{
+#pragma unroll
+    for (int k = 0; k < K; ++k) m &= m - 1ull;
+    return m;
+}
+
 // rasterise one mesh triangle into the key buffer (one lane per triangle)
 template <int S>
-__device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys)
+__device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys,
+                                                      mwgl::Vert *clipbuf)
 {
     mwgl::Vert v[3];
 #pragma unroll
@@ -106,13 +116,20 @@ __device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const
         if (mwgl::setup_triangle_pos(v[0].win, v[1].win, v[2].win, S > 1, te)) scatter_tri<S>(te, W, H, id, keys);
         return;
     }
-    // a triangle that crosses a frustum plane (rare: a mesh at the screen's edge or the near plane): clipped in private memory
+    // a triangle that crosses a frustum plane (rare: a mesh at the screen's edge or the near plane): the wavefront's lanes that
+    // hold one take turns, MW_CLIP_TURN at a time, with a pair of work lists each in LDS (clipbuf: MW_CLIP_TURN x 2 x
+    // MWGL_MAX_CLIP_VERTS vertices) — as private arrays they were 1.1 KB of scratch in every lane of the kernel
 #pragma unroll
     for (int k = 0; k < 3; ++k) { v[k].st[0] = v[k].st[1] = 0.0f; v[k].col[0] = v[k].col[1] = v[k].col[2] = 0.0f; }
-    mwgl::Vert buf0[MWGL_MAX_CLIP_VERTS], buf1[MWGL_MAX_CLIP_VERTS], *r;
-    const int n = mwgl::clip_triangle<false>(f, v[0], v[1], v[2], buf0, buf1, &r);
-    for (int i = 2; i < n; ++i)
-        if (mwgl::setup_triangle_pos(r[i - 1].win, r[i].win, r[0].win, S > 1, te)) scatter_tri<S>(te, W, H, id, keys);
+    const int lane = (int)(threadIdx.x & 63u);
+    for (uint64_t pend = __ballot(true); pend; pend = drop_lowest<MW_CLIP_TURN>(pend)) {
+        const int rank = __popcll((unsigned long long)(pend & ((1ull << lane) - 1ull)));
+        if (!((pend >> lane) & 1ull) || rank >= MW_CLIP_TURN) continue;
+        mwgl::Vert *buf = clipbuf + rank * 2 * MWGL_MAX_CLIP_VERTS, *r;
+        const int n = mwgl::clip_triangle<false>(f, v[0], v[1], v[2], buf, buf + MWGL_MAX_CLIP_VERTS, &r);
+        for (int i = 2; i < n; ++i)
+            if (mwgl::setup_triangle_pos(r[i - 1].win, r[i].win, r[0].win, S > 1, te)) scatter_tri<S>(te, W, H, id, keys);
+    }
 }
 
 // ---- the obs-sized frame's fast path ----------------------------------------------------------------------------------------
@@ -126,12 +143,11 @@ __device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const
 // columns that cross a small triangle's bounding box, the box's pixels otherwise)
 __device__ inline bool scatter_tri_cols(const mwcov::Edges &ed, int W, int H, uint32_t id, uint32_t *keys)
 {
-    // (every workgroup that touches this env's keys runs on ONE XCD — the entity kernel's lists are per XCD —: the minima need no
-    // wider scope than that XCD's L2, where they then stay until the kernel's end instead of each going out to memory.  "Workgroup"
-    // is the scope that compiles to an L2 atomic without the system-coherence bits.)
+    // (device-scope minima.  XCD-local ones — minima without the system-coherence bits, for keys that only one XCD's workgroups
+    // touch — were tried in round 5: no faster, the same HBM write bytes, and only as safe as the claim "these workgroups run on
+    // that XCD", which a long-lived process does not keep: tools/experiments/README.md)
     return mwcov::cover(ed, W, H, [&](int px, int gy, int s, float xs, float ys) {
-        __hip_atomic_fetch_min(keys + ((size_t)(H - 1 - gy) * W + px) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id,
-                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        atomicMin(keys + ((size_t)(H - 1 - gy) * W + px) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id);
     });
 }
 
@@ -252,8 +268,7 @@ __device__ inline bool scatter_tri_wave(const MeshEnt &e, int tri, const float4 
     for (int m = lane; m < npix; m += 64) {
         const uint32_t in = mwcov::pixel_mask(ed, thr, px, gy);
         mwcov::emit_samples(in, px, gy, [&](int sx, int sy, int s, float xs, float ys) {
-            __hip_atomic_fetch_min(keys + ((size_t)(H - 1 - sy) * W + sx) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            atomicMin(keys + ((size_t)(H - 1 - sy) * W + sx) * 8 + s, (mwgl::z_to_unorm16(mwgl::plane_at(ed.z, xs, ys)) << 16) | id);
         });
         any |= in != 0u;
         px += dr; gy += dq;
@@ -288,9 +303,13 @@ __device__ __attribute__((noinline)) RGB shade_mesh_tri(const TileCtx &cx, const
     bool have = false;
     if ((v[0].clipmask | v[1].clipmask | v[2].clipmask) == 0u) {
         have = mwgl::setup_triangle(v[0], v[1], v[2], S > 1, e.tex >= 0, ts);
-    } else {
-        mwgl::Vert buf0[MWGL_MAX_CLIP_VERTS], buf1[MWGL_MAX_CLIP_VERTS], *r;
-        const int n = mwgl::clip_triangle<true>(f, v[0], v[1], v[2], buf0, buf1, &r);
+    } else for (uint64_t pend = __ballot(true); pend; pend = drop_lowest<MW_CLIP_TURN>(pend)) {
+        // (the lanes whose triangle crosses a frustum plane take turns, MW_CLIP_TURN at a time, with the wavefront's work lists in
+        // LDS, cx.clipbuf)
+        const int rank = __popcll((unsigned long long)(pend & ((1ull << cx.lane) - 1ull)));
+        if (!((pend >> cx.lane) & 1ull) || rank >= MW_CLIP_TURN) continue;
+        mwgl::Vert *buf = cx.clipbuf + rank * 2 * MWGL_MAX_CLIP_VERTS, *r;
+        const int n = mwgl::clip_triangle<true>(f, v[0], v[1], v[2], buf, buf + MWGL_MAX_CLIP_VERTS, &r);
         // the first triangle of the fan with a sample of this pixel inside
         for (int i = 2; i < n && !have; ++i) {
             mwgl::TriSetup t2;

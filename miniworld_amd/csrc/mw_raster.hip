@@ -78,6 +78,7 @@ __device__ inline void raster_env_tiles(
     cx.mesh_pos = mesh_pos; cx.mesh_nrm = mesh_nrm; cx.mesh_rgb = mesh_rgb; cx.mesh_uv = mesh_uv;
     cx.planes = MESHAWARE == 1 ? plane_cache + (size_t)env * plane_cap * MW_PLANE_REC : nullptr;
     cx.planes_xtra = MESHAWARE == 1 ? plane_cache + (size_t)N * plane_cap * MW_PLANE_REC + (size_t)env * plane_cap * MW_PLANE_XTRA : nullptr;
+    cx.clipbuf = nullptr;
     cx.slow_frags = MESHAWARE == 1 ? slow_frags + (size_t)env * MW_SLOW_STRIDE : nullptr;
     cx.slow_head = MESHAWARE == 1 ? slow_head + (size_t)env * W * H : nullptr;
     cx.slow_stamp = (uint32_t)dbg >> 16;

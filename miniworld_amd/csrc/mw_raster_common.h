@@ -257,6 +257,7 @@ struct TileCtx {
     const float *mesh_pos, *mesh_nrm, *mesh_rgb, *mesh_uv;
     const float *planes;            // the env's plane cache (mesh-aware K2; null elsewhere)
     const float *planes_xtra;       // ... and the textured meshes' fifth quads
+    mwgl::Vert *clipbuf;            // view kernels: the wavefront's two clipper work lists in LDS (shade_mesh_tri)
     const float4 *slow_frags;       // the env's slow-fragment list and its length (mw_mesh_slow_kernel)
     const uint32_t *slow_head;      // [H][W] (frame stamp << 16) | newest fragment of the pixel + 1
     uint32_t slow_stamp;            // this frame's stamp (bits 16-31 of the launch flags)

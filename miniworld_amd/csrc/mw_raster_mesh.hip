@@ -51,11 +51,11 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
     // here (the two swap places from frame to frame; nothing of the next frame starts before this kernel has ended)
     if (blockIdx.x == 0 && tid < MW_CNT_WORDS) ent_n_after[tid] = 0;
     if (tid == 0) { s_qn = 0; s_bn = 0; }
-    // the lists of the XCD this workgroup runs on (mw_geom.hip files env e under XCD e % n_xcc): an env's keys are touched from one
-    // XCD only, whose L2 holds their minima (mw_mesh.h: scatter_tri_cols)
-    uint32_t xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc = (xcc & 15u) % (uint32_t)n_xcc;
+    // the lists of class b % n_xcc (mw_geom.hip files env e under e % n_xcc; the launch has at least n_xcc workgroups).  A fresh
+    // process dispatches workgroup b to XCD b % 8 (tools/ubench/xcc_probe.hip), so an env's entities, its mesh tiles and their
+    // records then meet one L2; nothing depends on it — later launches of a long-lived process start their round-robin elsewhere
+    // (a version that picked the lists by HW_REG_XCC_ID left whole lists undrawn when a small launch missed an XCD).
+    const uint32_t xcc = blockIdx.x % (uint32_t)n_xcc;
     const uint32_t *l_long = ent_list + (size_t)xcc * ent_list_cap, *l_short = ent_list + (size_t)(8u + xcc) * ent_list_cap;
     const int n_long = min(ent_n[MW_CNT_LONG + xcc], ent_list_cap), n_items = n_long + min(ent_n[MW_CNT_SHORT + xcc], ent_list_cap);
     for (;;) {
@@ -388,7 +388,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
 // resolution only; the mesh keys go through a global buffer; 64-bit edge values (the frame may be large).  Not the hot path.
 // ======================================================================================
 template <int S>
-__device__ inline void view_mesh_body(int W, int H, const float *hdr, const float *mesh_pos, uint32_t *keys)
+__device__ inline void view_mesh_body(int W, int H, const float *hdr, const float *mesh_pos, uint32_t *keys, mwgl::Vert *clipbuf)
 {
     mwgl::Frame f;
     frame_lite(hdr, W, H, f);
@@ -400,7 +400,7 @@ __device__ inline void view_mesh_body(int W, int H, const float *hdr, const floa
             const int tri = tri_sorted(mesh_pos, e, t);
             float pos[9];
             tri_load(mesh_pos, e, tri, pos);
-            raster_tri<S>(f, e, tri, pos, W, H, keys);
+            raster_tri<S>(f, e, tri, pos, W, H, keys, clipbuf);
         }
     }
 }
@@ -409,12 +409,14 @@ __device__ inline void view_mesh_body(int W, int H, const float *hdr, const floa
 extern "C" __global__ __launch_bounds__(256) void mw_view_mesh_kernel(int W, int H, int S, int first_env, const float *__restrict__ envhdr,
                                                                      const float *__restrict__ mesh_pos, uint32_t *keys)
 {
+    __shared__ mwgl::Vert s_clip[4][MW_CLIP_TURN * 2 * MWGL_MAX_CLIP_VERTS];       // the clipper's work lists, MW_CLIP_TURN pairs per wavefront
+    mwgl::Vert *clipbuf = s_clip[threadIdx.x >> 6];
     const float *hdr = envhdr + (size_t)(first_env + (int)blockIdx.y) * MW_ENVHDR;
     keys += (size_t)blockIdx.y * W * H * S;
-    if (S == 16) view_mesh_body<16>(W, H, hdr, mesh_pos, keys);
-    else if (S == 4) view_mesh_body<4>(W, H, hdr, mesh_pos, keys);
-    else if (S == 1) view_mesh_body<1>(W, H, hdr, mesh_pos, keys);
-    else view_mesh_body<8>(W, H, hdr, mesh_pos, keys);
+    if (S == 16) view_mesh_body<16>(W, H, hdr, mesh_pos, keys, clipbuf);
+    else if (S == 4) view_mesh_body<4>(W, H, hdr, mesh_pos, keys, clipbuf);
+    else if (S == 1) view_mesh_body<1>(W, H, hdr, mesh_pos, keys, clipbuf);
+    else view_mesh_body<8>(W, H, hdr, mesh_pos, keys, clipbuf);
 }
 
 template <int S>
@@ -492,6 +494,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     const float *__restrict__ mesh_nrm, const float *__restrict__ mesh_rgb, const float *__restrict__ mesh_uv, const uint32_t *mesh_keys,
     uint8_t *__restrict__ out, float *__restrict__ depth, int texel_bytes)
 {
+    __shared__ mwgl::Vert s_clip[MW_CLIP_TURN * 2 * MWGL_MAX_CLIP_VERTS];
     const int env = first_env + (int)blockIdx.y;
     out += (size_t)blockIdx.y * H * W * 3;
     if (depth) depth += (size_t)blockIdx.y * H * W;
@@ -512,7 +515,7 @@ extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
     cx.te.flat = 0;
     cx.sky_r = hdr[0]; cx.sky_g = hdr[1]; cx.sky_b = hdr[2];
     cx.env = 0; cx.nvis = nvis_arr[env]; cx.W = W; cx.H = H; cx.dbg = 0; cx.lane = threadIdx.x; cx.have_pre = 0; cx.order = nullptr;
-    cx.planes = nullptr; cx.planes_xtra = nullptr; cx.slow_frags = nullptr; cx.slow_head = nullptr; cx.slow_stamp = 0u;
+    cx.planes = nullptr; cx.planes_xtra = nullptr; cx.clipbuf = s_clip; cx.slow_frags = nullptr; cx.slow_head = nullptr; cx.slow_stamp = 0u;
     cx.pre_touch = cx.pre_full = cx.pre_clip = cx.pre_edges = 0ull;
     if (S == 16) view_tile_body<16>(cx, tiles_x, mesh_keys);
     else if (S == 4) view_tile_body<4>(cx, tiles_x, mesh_keys);

@@ -642,7 +642,7 @@ __device__ inline void rasterq_body(
             TileCtx tc;
             tc.s_shade = g_shade; tc.s_cull = g_cull; tc.shade_stride = MW_SHADE_REC / 4; tc.cull_stride = MW_CULL_REC / 4;
             tc.rr_env = g_rr; tc.s_pack = smem + wave * 192; tc.hdr = hdr; tc.ment = hdr + MW_HDR_MESH;
-            tc.mesh_pos = tc.mesh_nrm = tc.mesh_rgb = tc.mesh_uv = nullptr; tc.planes = nullptr; tc.planes_xtra = nullptr; tc.slow_frags = nullptr; tc.slow_head = nullptr;
+            tc.mesh_pos = tc.mesh_nrm = tc.mesh_rgb = tc.mesh_uv = nullptr; tc.planes = nullptr; tc.planes_xtra = nullptr; tc.clipbuf = nullptr; tc.slow_frags = nullptr; tc.slow_head = nullptr;
             tc.slow_stamp = 0u; tc.obs = obs; tc.depth = depth;
             tc.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3);
             tc.te = cx.te; tc.sky_r = cx.sky_r; tc.sky_g = cx.sky_g; tc.sky_b = cx.sky_b;
