@@ -243,12 +243,15 @@ extern "C" __global__ __launch_bounds__(64) void mw_raster_big_wrap_kernel(MW_RA
     raster_kernel_body<false, -1>(MW_RASTER_FWD);
 }
 
+#ifndef MW_MESH_TILE_OCC
+#define MW_MESH_TILE_OCC 4
+#endif
 // the same for envs that may hold mesh entities (PickupObjects, Sign, CollectHealth, ...)
 // ... the tiles no mesh can touch, of envs that hold mesh entities (K2's first part, beside the mesh kernels): the plain tile code,
 // at the plain kernels' register count
 extern "C" __global__ __launch_bounds__(64) void mw_raster_nomesh_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 1, 2>(MW_RASTER_FWD); }
 extern "C" __global__ __launch_bounds__(64) void mw_raster_nomesh_depth_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 2, 2>(MW_RASTER_FWD); }
-extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 1, 1>(MW_RASTER_FWD); }
-extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_depth_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 2, 1>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64, MW_MESH_TILE_OCC) void mw_raster_mesh_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 1, 1>(MW_RASTER_FWD); }
+extern "C" __global__ __launch_bounds__(64, MW_MESH_TILE_OCC) void mw_raster_mesh_depth_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 2, 1>(MW_RASTER_FWD); }
 extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, -1, 0, 1>(MW_RASTER_FWD); }
 extern "C" __global__ __launch_bounds__(64) void mw_raster_big_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<false, -1, 0, 1>(MW_RASTER_FWD); }
