@@ -174,21 +174,49 @@ __device__ inline void list_slow_tri(int j, int tri, float *rec, int32_t *slow_c
 }
 
 // a triangle that covers a sample: its vertices lit (attr: normals, colours, texture coordinates of the three, 96 bytes), its
-// attribute planes set up and stored in the env's plane cache.  v: the vertex stage's window coordinates, drawing order.
-__device__ inline void setup_winner(const mwgl::Frame &f, const MeshEnt &e, mwgl::Vert (&v)[3], const float4 *attr, float *rec, float *xtra)
+// attribute planes set up and stored in the env's plane cache.  v: the vertex stage's window coordinates (x, y, z, 1 / w), drawing
+// order; the triangle is front-facing (it went through setup_edges).  mw_glmath.h::setup_triangle's plane arithmetic for a
+// multisampled target — (v1, v0, v2), calc_coef on the unsnapped floats, attributes times 1 / w — without the edges it also builds:
+// a plane leaves for its record as soon as it is known (the whole TriSetup alive cost this kernel its place at 80 registers).
+__device__ inline void setup_winner(const mwgl::Frame &f, const MeshEnt &e, const float4 &va, const float4 &vb, const float4 &vc, const float4 *attr,
+                                    float *rec, float *xtra)
 {
     const float4 a0 = attr[0], a1 = attr[1], a2 = attr[2], a3 = attr[3], a4 = attr[4], a5 = attr[5];
-    const float at[24] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w, a2.x, a2.y, a2.z, a2.w,
-                          a3.x, a3.y, a3.z, a3.w, a4.x, a4.y, a4.z, a4.w, a5.x, a5.y, a5.z, a5.w};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const float n[3] = {at[k * 3], at[k * 3 + 1], at[k * 3 + 2]}, cl[3] = {at[9 + k * 3], at[9 + k * 3 + 1], at[9 + k * 3 + 2]};
-        mwgl::light_vertex(f, e.x, n, cl, v[k].col);
-        v[k].st[0] = e.tex >= 0 ? at[18 + k * 2] : 0.0f;
-        v[k].st[1] = e.tex >= 0 ? at[18 + k * 2 + 1] : 0.0f;
+    // front faces are set up in the order (v1, v0, v2)
+    const float4 &p0 = vb, &p1 = va, &p2 = vc;
+    const float fdx01 = p0.x - p1.x, fdy01 = p0.y - p1.y, fdx20 = p2.x - p0.x, fdy20 = p2.y - p0.y;
+    const float ooa = 1.0f / (fdx01 * fdy20 - fdx20 * fdy01);
+    const float dy20_ooa = fdy20 * ooa, dy01_ooa = fdy01 * ooa, dx20_ooa = fdx20 * ooa, dx01_ooa = fdx01 * ooa;
+    const float x0c = p0.x, y0c = p0.y;
+    float4 *q = reinterpret_cast<float4 *>(rec);
+    mwgl::Plane pl;
+#define MW_COEF(q0, q1, q2) mwgl::plane_coef(pl, q0, q1, q2, dy20_ooa, dy01_ooa, dx20_ooa, dx01_ooa, x0c, y0c)
+    // vertex colours (drawing order a, b, c -> setup order b, a, c)
+    float ca[3], cb[3], cc[3];
+    {
+        const float na[3] = {a0.x, a0.y, a0.z}, nb[3] = {a0.w, a1.x, a1.y}, nc[3] = {a1.z, a1.w, a2.x};
+        const float ka[3] = {a2.y, a2.z, a2.w}, kb[3] = {a3.x, a3.y, a3.z}, kc[3] = {a3.w, a4.x, a4.y};
+        mwgl::light_vertex(f, e.x, na, ka, ca);
+        mwgl::light_vertex(f, e.x, nb, kb, cb);
+        mwgl::light_vertex(f, e.x, nc, kc, cc);
     }
-    mwgl::TriSetup ts;
-    if (mwgl::setup_triangle(v[0], v[1], v[2], true, e.tex >= 0, ts)) store_planes(rec, xtra, ts, e.tex, 1);
+    const bool textured = e.tex >= 0;
+    mwgl::Plane sp = {0.0f, 0.0f, 0.0f}, tp = {0.0f, 0.0f, 0.0f};
+    if (textured) {
+        // (s, t) of a, b, c: a4.zw, a5.xy, a5.zw
+        MW_COEF(a5.x * p0.w, a4.z * p1.w, a5.z * p2.w); sp = pl;
+        MW_COEF(a5.y * p0.w, a4.w * p1.w, a5.w * p2.w); tp = pl;
+    }
+    MW_COEF(p0.w, p1.w, p2.w);
+    q[0] = make_float4(pl.a0, pl.dadx, pl.dady, __int_as_float(e.tex));
+    MW_COEF(cb[0] * p0.w, ca[0] * p1.w, cc[0] * p2.w);
+    q[1] = make_float4(pl.a0, pl.dadx, pl.dady, __int_as_float(1));
+    MW_COEF(cb[1] * p0.w, ca[1] * p1.w, cc[1] * p2.w);
+    q[2] = make_float4(pl.a0, pl.dadx, pl.dady, sp.a0);
+    MW_COEF(cb[2] * p0.w, ca[2] * p1.w, cc[2] * p2.w);
+    q[3] = make_float4(pl.a0, pl.dadx, pl.dady, sp.dadx);
+    if (textured) *reinterpret_cast<float4 *>(xtra) = make_float4(sp.dady, tp.a0, tp.dadx, tp.dady);
+#undef MW_COEF
 }
 
 // One mesh triangle of an obs-sized 8-sample frame from its own three positions (a mesh without a vertex table): vertex
@@ -208,7 +236,8 @@ __device__ inline void raster_tri_obs(const mwgl::Frame &f, const MeshEnt &e, in
     mwcov::Edges ed;
     if (!mwcov::setup_edges(v[0].win, v[1].win, v[2].win, ed)) return;        // back-facing or empty
     if (!scatter_tri_cols(ed, W, H, (uint32_t)(e.start + tri), keys)) return;
-    setup_winner(f, e, v, attr, rec, xcache + (size_t)tri * MW_PLANE_XTRA);
+    setup_winner(f, e, make_float4(v[0].win[0], v[0].win[1], v[0].win[2], v[0].win[3]), make_float4(v[1].win[0], v[1].win[1], v[1].win[2], v[1].win[3]),
+                 make_float4(v[2].win[0], v[2].win[1], v[2].win[2], v[2].win[3]), attr, rec, xcache + (size_t)tri * MW_PLANE_XTRA);
 }
 
 // ... from the entity's vertex table in LDS (mw_mesh_entity_kernel): a vertex is (window x, y, z, 1 / w), or, outside the
@@ -239,15 +268,12 @@ __device__ inline int classify_tri_table(int tri, const float4 &va, const float4
 __device__ inline void scatter_winner(const mwgl::Frame &f, const MeshEnt &e, int tri, const float4 &va, const float4 &vb, const float4 &vc, int W, int H,
                                       uint32_t *keys, bool keys_done, const float4 *attr, float *rec, float *xtra)
 {
-    mwgl::Vert v[3];
-    v[0].win[0] = va.x; v[0].win[1] = va.y; v[0].win[2] = va.z; v[0].win[3] = va.w;
-    v[1].win[0] = vb.x; v[1].win[1] = vb.y; v[1].win[2] = vb.z; v[1].win[3] = vb.w;
-    v[2].win[0] = vc.x; v[2].win[1] = vc.y; v[2].win[2] = vc.z; v[2].win[3] = vc.w;
     if (!keys_done) {
+        const float wa[4] = {va.x, va.y, va.z, va.w}, wb[4] = {vb.x, vb.y, vb.z, vb.w}, wc[4] = {vc.x, vc.y, vc.z, vc.w};
         mwcov::Edges ed;
-        if (mwcov::setup_edges(v[0].win, v[1].win, v[2].win, ed)) scatter_tri_cols(ed, W, H, (uint32_t)(e.start + tri), keys);
+        if (mwcov::setup_edges(wa, wb, wc, ed)) scatter_tri_cols(ed, W, H, (uint32_t)(e.start + tri), keys);
     }
-    setup_winner(f, e, v, attr, rec, xtra);
+    setup_winner(f, e, va, vb, vc, attr, rec, xtra);
 }
 
 // A triangle of many pixels, the same for all lanes of the wavefront (vertices of the table, unclipped, front-facing): lane l
