@@ -167,7 +167,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
         if (prof && tid == 0) {
             unsigned long long *p = prof + ((size_t)xcc * ent_list_cap + (size_t)item_i) * 8;
             p[0] = pr_t0; p[1] = __builtin_amdgcn_s_memrealtime(); p[2] = 1ull | (pr_tris << 8) | (pr_win << 32); p[3] = pr_ph[0]; p[4] = pr_ph[1]; p[5] = pr_ph[2] | (pr_ph[3] << 32);
-            p[6] = (unsigned long long)blockIdx.x; p[7] = (unsigned long long)item;
+            p[6] = (unsigned long long)blockIdx.x; p[7] = (unsigned long long)item | (pr_big << 32);
         }
     }
 }

@@ -5,7 +5,7 @@ import numpy as np
 a = np.fromfile(sys.argv[1], np.uint64).reshape(-1, 8)
 t0, t1, nm, pv, p1, p23, blk, item = [a[:, i].astype(np.int64) for i in range(8)]
 tris, win, nm = (nm >> 8) & 0xFFFFFF, nm >> 32, nm & 0xFF
-big = np.zeros_like(nm)
+big, item = item >> 32, item & 0xFFFFFFFF
 p2, p3 = p23 & 0xFFFFFFFF, p23 >> 32
 live = nm > 0
 print("entities", int(live.sum()), "in", len(np.unique(item[live] & 0xFFFFFF)), "envs,", "triangles", int(tris.sum()), "wave-sized", int(big.sum()), "winners", int(win.sum()))
