@@ -362,6 +362,11 @@ int mw_kernel_time_ms(mw_engine *e, int32_t reset, double *raster_ms, double *se
  * Values are those of the state the device holds: with MW_AUTORESET_SAME_STEP an env that just finished reports its new episode.
  * d_health on an engine whose task is not MW_TASK_COLLECT is MW_E_INVALID (there is no health array). */
 int mw_get_info(mw_engine *e, int32_t *d_health, double *d_ent_pos, int32_t ent_slot, void *stream);
+/* The same two values as they stood when each env's LAST FINISHED episode ended (collecthealth.py:100: the health that ended it;
+ * tmaze.py:89 / ymaze.py:125: that episode's goal_pos = position of entity slot mw_config.goal_ent) — with MW_AUTORESET_SAME_STEP the step
+ * kernel keeps them before it installs the next world (Gymnasium's `final_info` of a same-step vector env).  Undefined for an env that
+ * has not finished an episode yet; either pointer may be NULL; d_health needs MW_TASK_COLLECT. */
+int mw_get_final_info(mw_engine *e, int32_t *d_health, double *d_goal_pos, void *stream);
 
 /* Diagnostic (synchronises `stream`): how many triangles the last frame's display list held per env after clipping and culling —
  * what max_visible has to pay for (6 records per unit), and what decides which raster kernel an env's frame takes.

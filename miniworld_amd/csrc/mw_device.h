@@ -145,6 +145,11 @@ struct MwArgs {
     double *light;      // [12][N]
     int32_t *carry, *step, *picked;
     int32_t *health;    // [N] MW_TASK_COLLECT (collecthealth.py:77, 83)
+    // what `info` held when an env's last episode ended — the same-step auto-reset installs the next world in the same kernel, so
+    // K1 keeps the finished episode's values here: health (MW_TASK_COLLECT) and the position of entity slot goal_ent (TMaze / YMaze:
+    // info["goal_pos"])
+    int32_t *final_health;  // [N]
+    double *final_goal;     // [3][N]
     int32_t *ekind, *emesh, *estatic;   // [E][N]
     double *epos;       // [3][E][N]
     double *edir;       // [E][N]

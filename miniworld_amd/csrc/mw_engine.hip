@@ -889,7 +889,8 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     ALLOC(a.ax, N); ALLOC(a.ay, N); ALLOC(a.az, N); ALLOC(a.adir, N);
     ALLOC(a.cam, 4 * (size_t)N); ALLOC(a.light, 12 * (size_t)N);
     ALLOC(a.carry, N); ALLOC(a.step, N); ALLOC(a.picked, N);
-    if (cfg->task == MW_TASK_COLLECT) ALLOC(a.health, N);
+    if (cfg->task == MW_TASK_COLLECT) { ALLOC(a.health, N); ALLOC(a.final_health, N); }
+    ALLOC(a.final_goal, 3 * (size_t)N);
     ALLOC(a.ekind, (size_t)E * N); ALLOC(a.emesh, (size_t)E * N); ALLOC(a.estatic, (size_t)E * N);
     ALLOC(a.epos, 3 * (size_t)E * N); ALLOC(a.edir, (size_t)E * N); ALLOC(a.egeom, 9 * (size_t)E * N);
     ALLOC(a.rng, 5 * (size_t)N); ALLOC(a.extent, 4 * (size_t)N);
@@ -1532,6 +1533,20 @@ int mw_get_info(mw_engine *e, int32_t *d_health, double *d_ent_pos, int32_t ent_
     const int N = e->cfg.num_envs;
     hipLaunchKernelGGL(mw_info_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, e->args.E, (const int32_t *)e->args.health,
                        (const double *)e->args.epos, d_ent_pos ? ent_slot : 0, d_health, d_ent_pos);
+    HIP_TRY(e, hipGetLastError());
+    return MW_OK;
+}
+
+int mw_get_final_info(mw_engine *e, int32_t *d_health, double *d_goal_pos, void *stream)
+{
+    if (!e) return MW_E_INVALID;
+    if (!d_health && !d_goal_pos) return fail(e, MW_E_INVALID, "mw_get_final_info: nothing asked for");
+    if (d_health && !e->args.final_health) return fail(e, MW_E_INVALID, "mw_get_final_info: this engine's task keeps no health (MW_TASK_COLLECT only)");
+    ON_DEVICE(e);
+    const int N = e->cfg.num_envs;
+    // (the arrays are component-major like the state: the gather kernel of mw_get_info with slot 0 of a one-slot table)
+    hipLaunchKernelGGL(mw_info_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, N, 1, (const int32_t *)e->args.final_health,
+                       (const double *)e->args.final_goal, 0, d_health, d_goal_pos);
     HIP_TRY(e, hipGetLastError());
     return MW_OK;
 }

@@ -728,6 +728,15 @@ __device__ inline void generate_world(const MwArgs &a, int env, unsigned char *w
     rng_store(a.rng, a.N, env, r);
 }
 
+// What `info` holds when an episode ends (collecthealth.py:100 health; tmaze.py:89 / ymaze.py:125 goal_pos = the box's position): kept
+// before the same-step auto-reset installs the next world (mw_get_final_info; one lane of the env).
+__device__ inline void keep_final_info(const MwArgs &a, int env)
+{
+    if (a.final_health && a.health) a.final_health[env] = a.health[env];
+    if (a.final_goal && a.goal_ent >= 0 && a.goal_ent < a.E)
+        for (int c = 0; c < 3; ++c) a.final_goal[(size_t)c * a.N + env] = a.epos[((size_t)c * a.E + a.goal_ent) * a.N + env];
+}
+
 // An episode ends in spare mode: the env's pre-generated world becomes the live one (64 lanes of one wavefront).
 __device__ inline void take_spare(const MwArgs &a, int env, int lane)
 {

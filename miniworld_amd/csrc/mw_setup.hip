@@ -171,6 +171,7 @@ extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_
         // next episode (the reference leaves the reset to the caller, scripts/benchmark.py:36-37)
         regenerated = (tm | tr) != 0;
         if (regenerated) {
+            if (writer) mw::keep_final_info(a, env);
             if (a.spare) {
                 // the next world was generated ahead (by a refill block of an earlier launch): claim it
                 if (writer) s_cnt[0][0] = (int)atomicCAS(a.refill_mask + env, 1u, 3u);

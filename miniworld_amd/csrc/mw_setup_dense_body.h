@@ -132,6 +132,7 @@ __device__ inline void dense_step(const MwArgs &a, int do_step, int env, int lan
             // The env's leading lane installs the next world (several envs of the wave may do so side by side); the
             // env's other lanes then read it like the leader does.
             if (leader) {
+                mw::keep_final_info(a, env);
                 if (a.spare) {
                     // spare mode: the next world was generated ahead by a refill block of an earlier launch (the
                     // blocks behind the env blocks of this grid): claim it.  States of refill_mask: mw_device.h.

@@ -33,7 +33,7 @@ PATH_TILE, PATH_QUAD, PATH_QUAD_MESH, PATH_GENERIC = 0, 1, 2, 3
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms", "mw_raster_path", "mw_get_info", "mw_get_list_lengths",
+    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms", "mw_raster_path", "mw_get_info", "mw_get_final_info", "mw_get_list_lengths",
     "mw_set_gen_program", "mw_selftest_rcp", "mw_selftest_div", "mw_selftest_sort", "mw_selftest_q",
 ]
 
@@ -187,6 +187,7 @@ def load_library():
     L.mw_kernel_time_ms.argtypes = [vp, i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int64)]
     L.mw_raster_path.argtypes = [vp]
     L.mw_get_info.argtypes = [vp, vp, vp, i32, vp]
+    L.mw_get_final_info.argtypes = [vp, vp, vp, vp]
     L.mw_get_list_lengths.argtypes = [vp, i32, i32, vp, vp]
     _lib = L
     return L
@@ -395,6 +396,16 @@ class Engine:
                 assert t.is_cuda and t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous()
         self._check(self.lib.mw_get_info(self.h, health.data_ptr() if health is not None else None,
                                          ent_pos.data_ptr() if ent_pos is not None else None, int(ent_slot), _stream_ptr(self.device)), "mw_get_info")
+
+    def get_final_info(self, health=None, goal_pos=None):
+        """The `info` values of each env's last FINISHED episode (kept by the step kernel before the same-step auto-reset): health
+        int32[N] (CollectHealth) and / or goal_pos float64[N, 3] (TMaze / YMaze)."""
+        import torch
+        for t, dt, shape in ((health, torch.int32, (self.N,)), (goal_pos, torch.float64, (self.N, 3))):
+            if t is not None:
+                assert t.is_cuda and t.dtype == dt and tuple(t.shape) == shape and t.is_contiguous()
+        self._check(self.lib.mw_get_final_info(self.h, health.data_ptr() if health is not None else None,
+                                               goal_pos.data_ptr() if goal_pos is not None else None, _stream_ptr(self.device)), "mw_get_final_info")
 
     def list_lengths(self):
         """int32[N]: triangles in each env's display list of the last frame (after clipping and culling)."""

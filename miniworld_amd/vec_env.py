@@ -121,6 +121,7 @@ class MiniWorldVecEnv:
         cfg.domain_rand = int(domain_rand)
         cfg.generator = generator
         cfg.autoreset = eng.AUTORESET_SAME_STEP if autoreset else eng.AUTORESET_OFF
+        self.autoreset = bool(autoreset)
         cfg.agent_radius = float(self.template.agent.radius)
         if generator in (eng.GEN_HALLWAY, eng.GEN_ONEROOM):
             room = self.template.rooms[0]
@@ -215,6 +216,7 @@ class MiniWorldVecEnv:
                            "YMaze": "goal_pos", "YMazeLeft": "goal_pos", "YMazeRight": "goal_pos"}.get(cls_name)
         self._info_slot = int(cfg.goal_ent)
         self._info_buf = None
+        self._final_info_buf = None
 
     # ------------------------------------------------------------------ assets / worlds
     def _upload_assets(self, sc):
@@ -281,7 +283,8 @@ class MiniWorldVecEnv:
         """The batched `info` of the last step as device tensors: {"health": int32[N]} for CollectHealth (collecthealth.py:100),
         {"goal_pos": float64[N, 3]} for TMaze / YMaze (the box's position, tmaze.py:89, ymaze.py:125), {} for the other envs
         (miniworld.py:730 returns an empty dict).  One small gather kernel on the engine's stream; the values are those of the
-        state the device holds (with the same-step auto-reset an env that just finished reports its new episode)."""
+        state the device holds (with the same-step auto-reset an env that just finished reports its new episode; the finished
+        episode's own values: final_infos)."""
         if self._info_kind is None:
             return {}
         torch = self.torch
@@ -294,6 +297,23 @@ class MiniWorldVecEnv:
         else:
             self.engine.get_info(ent_pos=self._info_buf, ent_slot=self._info_slot)
         return {self._info_kind: self._info_buf}
+
+    def final_infos(self):
+        """The `info` each env's last FINISHED episode ended with ({"health": …} / {"goal_pos": …} / {}), as the step kernel kept it
+        before the same-step auto-reset installed the next world (mw_get_final_info); rows of envs that have not finished an episode yet
+        are undefined (mask them with terminated | truncated of the step)."""
+        if self._info_kind is None:
+            return {}
+        torch = self.torch
+        if self._final_info_buf is None:
+            dev = self.engine.device
+            self._final_info_buf = (torch.zeros(self.num_envs, dtype=torch.int32, device=dev) if self._info_kind == "health"
+                                    else torch.zeros((self.num_envs, 3), dtype=torch.float64, device=dev))
+        if self._info_kind == "health":
+            self.engine.get_final_info(health=self._final_info_buf)
+        else:
+            self.engine.get_final_info(goal_pos=self._final_info_buf)
+        return {self._info_kind: self._final_info_buf}
 
     def render_top_view(self, render_agent=True):
         """uint8[N,H,W,3] map views (render_top_view, miniworld.py:1088-1175) of every env."""

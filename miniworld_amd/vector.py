@@ -52,7 +52,15 @@ class MiniWorldVectorEnv(VectorEnvBase):
             actions = torch.as_tensor(np.asarray(actions), device=self.vec.engine.device)
         actions = actions.to(device=self.vec.engine.device, dtype=torch.int32)
         obs, rew, term, trunc = self.vec.step(actions)
-        return self._out(obs), self._out(rew), self._out(term.bool()), self._out(trunc.bool()), self._infos()
+        info = self._infos()
+        if info and self.vec.autoreset:
+            # gymnasium's same-step convention: the finished episodes' own info under "final_info", "_final_info" masks the envs it is
+            # valid for (no "final_obs": the engine renders the new episode's first frame only)
+            done = self._out((term | trunc).bool())
+            final = {k: self._out(v) for k, v in self.vec.final_infos().items()}
+            final.update({"_" + k: done for k in list(final)})
+            info["final_info"], info["_final_info"] = final, done
+        return self._out(obs), self._out(rew), self._out(term.bool()), self._out(trunc.bool()), info
 
     def render(self):
         """Tuple-free batched render: the map view of every env (uint8[N, H, W, 3])."""

@@ -636,6 +636,65 @@ def test_batched_info_matches_the_host_classes():
     envs.close()
 
 
+def test_final_info_is_the_finished_episodes_info_under_same_step_autoreset():
+    """With the same-step auto-reset an env that just finished reports its NEW episode in `info`; the finished episode's own info
+    (what a gymnasium same-step vector env returns as info["final_info"], masked by info["_final_info"]) is kept by the step kernel
+    before it installs the next world: CollectHealth's terminal health (collecthealth.py:100; the wave-per-env K1) and TMaze's
+    goal_pos of the episode that was truncated (tmaze.py:89; the dense K1), against the env classes' own episodes."""
+    from miniworld_amd import envs as host_envs
+    from miniworld_amd.vector import MiniWorldVectorEnv
+    n = 4
+    envs = MiniWorldVectorEnv("MiniWorld-CollectHealth-v0", n, to_numpy=True, seed=21)
+    envs.reset(seed=21)
+    hosts = []
+    for i in range(n):
+        h = host_envs.CollectHealth()
+        h.reset(seed=21 + i)
+        hosts.append(h)
+    ended = np.zeros(n, bool)
+    for t in range(60):
+        a = np.full(n, t % 2, np.int64)          # turning on the spot: the health runs out after 50 steps
+        _, _, term, trunc, infos = envs.step(a)
+        assert set(infos) == {"health", "final_info", "_final_info"} and set(infos["final_info"]) == {"health", "_health"}
+        assert np.array_equal(infos["_final_info"], term | trunc) and np.array_equal(infos["final_info"]["_health"], term | trunc)
+        for i, h in enumerate(hosts):
+            if ended[i]:
+                continue
+            _, _, hterm, htrunc, hi = h.step(int(a[i]))
+            assert bool(term[i]) == bool(hterm) and bool(trunc[i]) == bool(htrunc), (t, i)
+            if hterm or htrunc:
+                ended[i] = True
+                assert int(infos["final_info"]["health"][i]) == int(hi["health"]) <= 0, (t, i)
+                assert int(infos["health"][i]) == 100, (t, i)                  # the new episode's (collecthealth.py:60)
+            else:
+                assert int(infos["health"][i]) == int(hi["health"]), (t, i)
+    assert ended.all()
+    envs.close()
+    for h in hosts:
+        h.close()
+
+    envs = MiniWorldVectorEnv("MiniWorld-TMaze-v0", n, to_numpy=True, seed=33)
+    envs.reset(seed=33)
+    first = None
+    for t in range(280):                         # max_episode_steps = 280 (tmaze.py:28): every env is truncated on the last one
+        _, _, term, trunc, infos = envs.step(np.zeros(n, np.int64))
+        first = infos["goal_pos"].copy() if first is None else first
+        assert not (term | trunc).any() or t == 279
+    assert trunc.all() and infos["_final_info"].all()
+    assert np.array_equal(infos["final_info"]["goal_pos"], first)
+    for i in range(n):
+        h = host_envs.TMaze()
+        h.reset(seed=33 + i)
+        _, _, _, _, hi = h.step(0)
+        h.close()
+        assert np.array_equal(infos["final_info"]["goal_pos"][i], np.asarray(hi["goal_pos"], np.float64)), i
+    # the running `info` has moved on to the new episodes' boxes (left or right arm at random: not all four can have stayed)
+    nxt = envs.step(np.zeros(n, np.int64))[4]
+    assert np.array_equal(nxt["goal_pos"], infos["goal_pos"]) and not nxt["_final_info"].any()
+    assert np.array_equal(nxt["final_info"]["goal_pos"], first)                # kept until the next episode ends
+    envs.close()
+
+
 def _assert_same_world(vec, st, i, h, tag):
     """Device state of env i == host env h (same seed, same episode): poses, entity table, per-episode parameters."""
     from miniworld_amd.entity import Box, MeshEnt
