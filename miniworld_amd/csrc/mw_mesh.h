@@ -43,10 +43,11 @@ __device__ inline void frame_lite(const float *hdr, int W, int H, mwgl::Frame &f
 }
 
 // the i-th triangle of the rasterisation order (sorted by face-normal direction; mw_device.h: MW_MESH_POS_STRIDE)
-__device__ inline int tri_sorted(const float *mesh_pos, const MeshEnt &e, int i)
+__device__ inline int tri_sorted(const float *mesh_pos, int first, int i)
 {
-    return (int)__float_as_uint(mesh_pos[(size_t)(e.first + i) * MW_MESH_POS_STRIDE + 9]);
+    return (int)__float_as_uint(mesh_pos[(size_t)(first + i) * MW_MESH_POS_STRIDE + 9]);
 }
+__device__ inline int tri_sorted(const float *mesh_pos, const MeshEnt &e, int i) { return tri_sorted(mesh_pos, e.first, i); }
 
 __device__ inline void tri_load(const float *mesh_pos, const MeshEnt &e, int tri, float (&p)[9])
 {
@@ -97,11 +98,17 @@ template <int K> __device__ inline uint64_t drop_lowest(uint64_t m)
     return m;
 }
 
-// rasterise one mesh triangle into the key buffer (one lane per triangle)
+// rasterise one mesh triangle (triangle tri of entry j of the env's mesh table) into the key buffer, one lane per triangle.
+// Out of line, and every argument a scalar: structures by reference live in the caller's frame, i.e. in scratch memory — the
+// frame, the table entry and the positions were 352 B of it in every lane of mw_view_mesh_kernel; the callee reads them itself.
 template <int S>
-__device__ __attribute__((noinline)) void raster_tri(const mwgl::Frame &f, const MeshEnt &e, int tri, const float (&pos)[9], int W, int H, uint32_t *keys,
-                                                      mwgl::Vert *clipbuf)
+__device__ __attribute__((noinline)) void raster_tri(const float *hdr, int j, int tri, const float *mesh_pos, int W, int H, uint32_t *keys, mwgl::Vert *clipbuf)
 {
+    mwgl::Frame f;
+    frame_lite(hdr, W, H, f);
+    const MeshEnt e = load_ment(hdr + MW_HDR_MESH, j);
+    float pos[9];
+    tri_load(mesh_pos, e, tri, pos);
     mwgl::Vert v[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -305,15 +312,20 @@ __device__ inline bool scatter_tri_wave(const MeshEnt &e, int tri, const float4 
 
 // Attribute planes of mesh triangle (e, tri) for the pixel (px, gy): the triangle is taken through the vertex stage again
 // (lighting per vertex: Gouraud), clipped if it has to be — then the part of the fan that covers the pixel — and set up.
+// (out of line with scalar arguments, like raster_tri: the tile context and the table entry by reference were 500 B of scratch)
 template <int S>
-__device__ __attribute__((noinline)) RGB shade_mesh_tri(const TileCtx &cx, const MeshEnt &e, int tri, int px, int gy)
+__device__ __attribute__((noinline)) RGB shade_mesh_tri(const float *hdr, int W, int H, int j, int tri, int px, int gy, const float *mesh_pos,
+                                                        const float *mesh_nrm, const float *mesh_rgb, const float *mesh_uv, rsrc_t tex_rsrc,
+                                                        int flat, mwgl::Vert *clipbuf)
 {
     mwgl::Frame f;
-    frame_lite(cx.hdr, cx.W, cx.H, f);
+    frame_lite(hdr, W, H, f);
+    const MeshEnt e = load_ment(hdr + MW_HDR_MESH, j);
+    const int lane = (int)(threadIdx.x & 63u);
     float pos[9];
-    tri_load(cx.mesh_pos, e, tri, pos);
-    const float *nrm = cx.mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = cx.mesh_rgb + (size_t)(e.first + tri) * 9;
-    const float *uv = cx.mesh_uv + (size_t)(e.first + tri) * 6;
+    tri_load(mesh_pos, e, tri, pos);
+    const float *nrm = mesh_nrm + (size_t)(e.first + tri) * 9, *rgb = mesh_rgb + (size_t)(e.first + tri) * 9;
+    const float *uv = mesh_uv + (size_t)(e.first + tri) * 6;
     mwgl::Vert v[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
@@ -332,9 +344,9 @@ __device__ __attribute__((noinline)) RGB shade_mesh_tri(const TileCtx &cx, const
     } else for (uint64_t pend = __ballot(true); pend; pend = drop_lowest<MW_CLIP_TURN>(pend)) {
         // (the lanes whose triangle crosses a frustum plane take turns, MW_CLIP_TURN at a time, with the wavefront's work lists in
         // LDS, cx.clipbuf)
-        const int rank = __popcll((unsigned long long)(pend & ((1ull << cx.lane) - 1ull)));
-        if (!((pend >> cx.lane) & 1ull) || rank >= MW_CLIP_TURN) continue;
-        mwgl::Vert *buf = cx.clipbuf + rank * 2 * MWGL_MAX_CLIP_VERTS, *r;
+        const int rank = __popcll((unsigned long long)(pend & ((1ull << lane) - 1ull)));
+        if (!((pend >> lane) & 1ull) || rank >= MW_CLIP_TURN) continue;
+        mwgl::Vert *buf = clipbuf + rank * 2 * MWGL_MAX_CLIP_VERTS, *r;
         const int n = mwgl::clip_triangle<true>(f, v[0], v[1], v[2], buf, buf + MWGL_MAX_CLIP_VERTS, &r);
         // the first triangle of the fan with a sample of this pixel inside
         for (int i = 2; i < n && !have; ++i) {
@@ -353,7 +365,20 @@ __device__ __attribute__((noinline)) RGB shade_mesh_tri(const TileCtx &cx, const
         }
     }
     if (!have) return RGB{0.0f, 0.0f, 0.0f};
-    return shade_planes(ts.w, ts.s, ts.t, ts.col[0], ts.col[1], ts.col[2], cx.te.flat ? -1 : e.tex, cx.te, px, gy, eo);
+    TexEnv te;
+    te.td = te.tx = tex_rsrc; te.texd = nullptr; te.flat = flat;
+    return shade_planes_body(ts.w, ts.s, ts.t, ts.col[0], ts.col[1], ts.col[2], flat ? -1 : e.tex, te, px, gy, eo);
+}
+
+// the view kernels' shade_frag: out of line with the record's address as the argument (shade_planes takes its planes by reference)
+__device__ __attribute__((noinline)) RGB shade_frag_view(const float4 *sr, rsrc_t tex_rsrc, int flat, int px, int gy, float eo)
+{
+    TexEnv te;
+    te.td = te.tx = tex_rsrc; te.texd = nullptr; te.flat = flat;
+    const float4 q0 = sr[0], q1 = sr[1], q2 = sr[2], qr = sr[3], qg = sr[4], qb = sr[5];
+    const mwgl::Plane wp = {q0.x, q0.y, q0.z}, sp = {q1.x, q1.y, q1.z}, tp = {q2.x, q2.y, q2.z};
+    const mwgl::Plane pr = {qr.x, qr.y, qr.z}, pg = {qg.x, qg.y, qg.z}, pb = {qb.x, qb.y, qb.z};
+    return shade_planes_body(wp, sp, tp, pr, pg, pb, flat ? -1 : __float_as_int(q0.w), te, px, gy, eo);
 }
 
 // draw id -> fragment colour: ids inside a mesh entity's range are triangles, the others index the record list once the
@@ -369,11 +394,11 @@ __device__ inline RGB shade_by_draw_id_s(const TileCtx &cx, uint32_t id, int px,
         if ((int)id >= start + nt) {
             vis -= nt;
         } else if ((int)id >= start) {
-            const MeshEnt e = load_ment(cx.ment, j);
-            return shade_mesh_tri<S>(cx, e, (int)id - start, px, gy);
+            return shade_mesh_tri<S>(cx.hdr, cx.W, cx.H, j, (int)id - start, px, gy, cx.mesh_pos, cx.mesh_nrm, cx.mesh_rgb, cx.mesh_uv, cx.te.tx,
+                                     cx.te.flat, cx.clipbuf);
         }
     }
-    return shade_frag(cx.s_shade + vis * (MW_SHADE_REC / 4), cx.te, px, gy, S > 1 ? 0.5f : 0.0f);
+    return shade_frag_view(cx.s_shade + vis * (MW_SHADE_REC / 4), cx.te.tx, cx.te.flat, px, gy, S > 1 ? 0.5f : 0.0f);
 }
 
 // the tile kernels (obs path): mesh triangle `id` of table entry mj from the plane cache (raster_tri_obs)

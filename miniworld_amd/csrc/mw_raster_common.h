@@ -110,8 +110,9 @@ __device__ inline void fetch_level(const TexEnv &te, uint32_t desc, int l, float
 
 // fragment colour from a triangle's attribute planes at GL pixel (px, gy); eo: where the pixel centre sits in the planes'
 // coordinates (0.5 for a multisampled target, 0 for a single-sampled one)
-__device__ __attribute__((noinline)) RGB shade_planes(const mwgl::Plane &wp, const mwgl::Plane &sp, const mwgl::Plane &tp, const mwgl::Plane &pr,
-                                   const mwgl::Plane &pg, const mwgl::Plane &pb, int tex, const TexEnv &te, int px, int gy, float eo)
+__device__ inline __attribute__((always_inline)) RGB shade_planes_body(const mwgl::Plane &wp, const mwgl::Plane &sp, const mwgl::Plane &tp,
+                                                                       const mwgl::Plane &pr, const mwgl::Plane &pg, const mwgl::Plane &pb, int tex,
+                                                                       const TexEnv &te, int px, int gy, float eo)
 {
     const float x = (float)px + eo, y = (float)gy + eo;
     const float wv = mwgl::plane_at(wp, x, y);
@@ -153,6 +154,12 @@ __device__ __attribute__((noinline)) RGB shade_planes(const mwgl::Plane &wp, con
         }
     }
     return c;
+}
+// (out of line: the tile kernels call it from several places; arguments by reference, i.e. through the caller's frame)
+__device__ __attribute__((noinline)) RGB shade_planes(const mwgl::Plane &wp, const mwgl::Plane &sp, const mwgl::Plane &tp, const mwgl::Plane &pr,
+                                   const mwgl::Plane &pg, const mwgl::Plane &pb, int tex, const TexEnv &te, int px, int gy, float eo)
+{
+    return shade_planes_body(wp, sp, tp, pr, pg, pb, tex, te, px, gy, eo);
 }
 
 // ... of the triangle with shade record sr (per lane)

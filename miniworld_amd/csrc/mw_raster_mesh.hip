@@ -387,26 +387,25 @@ extern "C" __global__ __launch_bounds__(64) void mw_mesh_slow_kernel(int W, int 
 // FrameBuffer (opengl.py:229-231: 4 on the reference's CI driver) and any other frame buffer size.  Exact packed-key
 // resolution only; the mesh keys go through a global buffer; 64-bit edge values (the frame may be large).  Not the hot path.
 // ======================================================================================
+// (The out-of-line functions of this path take scalars only, so LLVM would mark their calls `tail` — they touch nothing of the caller's
+// frame — and a function with such a call site saves every callee-saved register it uses, 178 of them around each triangle of
+// raster_tri<16>: without the marks the calls' clobbers are known to the callers instead and nothing is saved.)
+#define MW_NO_TAIL_MARKS __attribute__((disable_tail_calls))
 template <int S>
 __device__ inline void view_mesh_body(int W, int H, const float *hdr, const float *mesh_pos, uint32_t *keys, mwgl::Vert *clipbuf)
 {
-    mwgl::Frame f;
-    frame_lite(hdr, W, H, f);
     const int n_mesh = __float_as_int(hdr[3]);
     const int stride = gridDim.x * blockDim.x;
     for (int j = 0; j < n_mesh; ++j) {
-        const MeshEnt e = load_ment(hdr + MW_HDR_MESH, j);
-        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < e.ntris; t += stride) {
-            const int tri = tri_sorted(mesh_pos, e, t);
-            float pos[9];
-            tri_load(mesh_pos, e, tri, pos);
-            raster_tri<S>(f, e, tri, pos, W, H, keys, clipbuf);
-        }
+        const float *m = hdr + MW_HDR_MESH + MW_HDR_MESH_STRIDE * j;         // load_ment's layout: [2] ntris, [3] first
+        const int ntris = __float_as_int(m[2]), first = __float_as_int(m[3]);
+        for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < ntris; t += stride)
+            raster_tri<S>(hdr, j, tri_sorted(mesh_pos, first, t), mesh_pos, W, H, keys, clipbuf);
     }
 }
 
 // grid (x, count): blockIdx.y = env first_env + y of the batch, its keys at keys + y * W * H * S
-extern "C" __global__ __launch_bounds__(256) void mw_view_mesh_kernel(int W, int H, int S, int first_env, const float *__restrict__ envhdr,
+extern "C" __global__ __launch_bounds__(256) MW_NO_TAIL_MARKS void mw_view_mesh_kernel(int W, int H, int S, int first_env, const float *__restrict__ envhdr,
                                                                      const float *__restrict__ mesh_pos, uint32_t *keys)
 {
     __shared__ mwgl::Vert s_clip[4][MW_CLIP_TURN * 2 * MWGL_MAX_CLIP_VERTS];       // the clipper's work lists, MW_CLIP_TURN pairs per wavefront
@@ -487,7 +486,7 @@ __device__ inline void view_tile_body(TileCtx &cx, int tiles_x, const uint32_t *
 
 // grid (n_tiles, count): blockIdx.y = env first_env + y of the batch; its frame at out + y * H * W * 3, its mesh keys
 // at mesh_keys + y * W * H * S
-extern "C" __global__ __launch_bounds__(64) void mw_view_raster_kernel(
+extern "C" __global__ __launch_bounds__(64) MW_NO_TAIL_MARKS void mw_view_raster_kernel(
     int first_env, int W, int H, int S, int max_vis, int tiles_x, const float *__restrict__ rec_raster,
     const float *__restrict__ rec_shade, const float *__restrict__ rec_cull, const int32_t *__restrict__ nvis_arr, const float *__restrict__ envhdr,
     const MwTexDesc *__restrict__ texd, const uint32_t *__restrict__ texels, const float *__restrict__ mesh_pos,
