@@ -374,6 +374,14 @@ int mw_get_final_info(mw_engine *e, int32_t *d_health, double *d_goal_pos, void 
  * many" — raise max_visible and look again (mw_check reports the overflow itself as MW_E_CAPACITY). */
 int mw_get_list_lengths(mw_engine *e, int32_t first_env, int32_t count, int32_t *host_out, void *stream);
 
+/* Test hook: the sequence number of the next frame with mesh entities.  Its low 16 bits stamp the per-pixel chains of the
+ * fragments of mesh triangles that cross a frustum plane (a head of another stamp reads as empty; the heads are wiped on the
+ * frame whose stamp is 0); a test moves it to the wrap instead of rendering 65 536 frames.  The parity must stay (the frame's
+ * work lists alternate with it). */
+int mw_debug_set_mesh_frame_seq(mw_engine *e, uint32_t seq);
+/* ... and the chain heads themselves, uint32[N][H][W] = stamp << 16 | newest fragment of the pixel + 1 (synchronises `stream`). */
+int mw_debug_get_slow_heads(mw_engine *e, uint32_t *host_out, void *stream);
+
 enum { MW_PATH_TILE = 0, MW_PATH_QUAD = 1, MW_PATH_QUAD_MESH = 2, MW_PATH_GENERIC = 3 };
 int mw_raster_path(const mw_engine *e);
 

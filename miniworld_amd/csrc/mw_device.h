@@ -34,7 +34,7 @@
 // floats per set: header, 8 per wall, 8 per box of eight polygons; whole 128-byte lines
 #define MW_OCC_CACHE_STRIDE(max_polys) ((MW_OCC_CACHE_HDR + 8 * (size_t)(max_polys) + 8 * (size_t)(((max_polys) + 7) / 8) + 31) / 32 * 32)
 #define MW_HDR_MESH_STRIDE 28 // floats per entry: slot, first draw id, triangles, first triangle, texture, normal scale, light[3], mvp[16], mesh triangles drawn before, tile rectangle, mesh id
-#define MW_MESH_VCAP 3584       // distinct positions of a mesh whose vertex stage runs per vertex (mw_mesh_entity_kernel: 16 bytes of LDS each, 56 KB + the winner queue within a workgroup's 64 KB)
+#define MW_MESH_VCAP 3568       // distinct positions of a mesh whose vertex stage runs per vertex (mw_mesh_entity_kernel: 16 bytes of LDS each, 57 088 B + the kernel's 8 204 B of queues = 65 292 B, within a workgroup's 64 KB; static_assert in mw_raster_mesh.hip)
 #ifndef MW_ENT_THREADS
 #define MW_ENT_THREADS 512      // lanes of the mesh entity kernel's workgroup
 #endif

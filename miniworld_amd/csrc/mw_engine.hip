@@ -607,10 +607,17 @@ int ensure_mesh_buffers(mw_engine *e)
         e->d_plane_cache = np; e->plane_cap = (int)want;
     }
     if (!e->d_ent_list) {
-        e->ent_list_cap = (int)N * std::min(MW_MAX_MESH_ENTS, std::max(e->cfg.max_ents, 1));
-        if (hipMalloc((void **)&e->d_ent_list, (size_t)e->ent_list_cap * 16 * 4) != hipSuccess) { e->d_ent_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh entity list failed"); }
-        if (hipMalloc((void **)&e->d_slow_envs, N * 2 * 4) != hipSuccess) { (void)hipFree(e->d_ent_list); e->d_ent_list = nullptr; e->d_slow_envs = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the slow path's env list failed"); }
-        if (hipMalloc((void **)&e->d_tile_list, N * (size_t)a.n_tiles * 8 * 4) != hipSuccess) { (void)hipFree(e->d_ent_list); e->d_ent_list = nullptr; e->d_tile_list = nullptr; return fail(e, MW_E_NOMEM, "hipMalloc for the mesh tile list failed"); }
+        // (all three work lists or none: a failed allocation leaves no pointer behind)
+        const int cap = (int)N * std::min(MW_MAX_MESH_ENTS, std::max(e->cfg.max_ents, 1));
+        void *ents = nullptr, *slow = nullptr, *tiles = nullptr;
+        const bool ok = hipMalloc(&ents, (size_t)cap * 16 * 4) == hipSuccess && hipMalloc(&slow, N * 2 * 4) == hipSuccess &&
+                        hipMalloc(&tiles, N * (size_t)a.n_tiles * 8 * 4) == hipSuccess;
+        if (!ok) {
+            for (void *p : {ents, slow, tiles}) if (p) (void)hipFree(p);
+            return fail(e, MW_E_NOMEM, "hipMalloc for the mesh path's work lists failed");
+        }
+        e->ent_list_cap = cap;
+        e->d_ent_list = (uint32_t *)ents; e->d_slow_envs = (uint32_t *)slow; e->d_tile_list = (uint32_t *)tiles;
     }
     if (!e->d_mesh_keys) {
         const size_t key_bytes = N * a.W * a.H * 8 * 4, head_bytes = N * a.W * a.H * 4;
@@ -744,9 +751,13 @@ int launch_frame(mw_engine *e, bool do_step, int view_flags, const int32_t *d_ac
             const size_t key_bytes = (size_t)N * a.W * a.H * 8 * 4;
             if (e->mesh_keys_dirty) HIP_TRY(e, hipMemsetAsync(e->d_mesh_keys, 0xFF, key_bytes, st));
             e->mesh_keys_dirty = true;      // until the raster kernel that clears them again has been enqueued
-            // frame stamp of the slow-fragment chains (16 bits; the heads are wiped when it wraps) and parity of the lists
+            // frame stamp of the slow-fragment chains and parity of the lists.  The stamp has 16 bits: a head that no frame has
+            // overwritten since frame F would read as valid again at frame F + 65536 (24 s of PickupObjects), so the heads are
+            // wiped on the frame whose stamp is 0 — behind the previous frame's readers, before this frame's slow-path kernel, in
+            // stream order (tests/test_gpu_env_api.py::test_slow_fragment_heads_survive_the_stamp_wrap)
             const uint32_t seq = mesh_seq;
             mesh_stamp = seq & 0xFFFFu;
+            if (mesh_stamp == 0u) HIP_TRY(e, hipMemsetAsync(e->d_slow_head, 0, (size_t)N * a.W * a.H * 4, st));
             const int parity = (int)(seq & 1u);
             // The mesh kernels — the frame's critical path — stay on the caller's stream, right behind the geometry kernel; the quad
             // kernel, which draws every tile no mesh can touch, goes to the low-priority quad stream beside them.  (The other way
@@ -1511,6 +1522,25 @@ int mw_check(mw_engine *e, void *stream)
 }
 
 int mw_raster_path(const mw_engine *e) { return e ? e->last_raster_path : MW_E_INVALID; }
+
+int mw_debug_set_mesh_frame_seq(mw_engine *e, uint32_t seq)
+{
+    if (!e) return MW_E_INVALID;
+    // (the work lists and the slow-path counters alternate with the sequence number's parity: keep it)
+    if ((seq & 1u) != (e->mesh_frame_seq & 1u)) return fail(e, MW_E_INVALID, "mw_debug_set_mesh_frame_seq: the parity of the sequence number must stay");
+    e->mesh_frame_seq = seq;
+    return MW_OK;
+}
+
+int mw_debug_get_slow_heads(mw_engine *e, uint32_t *host_out, void *stream)
+{
+    if (!e || !host_out) return fail(e, MW_E_INVALID, "null argument");
+    if (!e->d_slow_head) return fail(e, MW_E_INVALID, "mw_debug_get_slow_heads: this engine has no mesh path buffers");
+    ON_DEVICE(e);
+    HIP_TRY(e, hipStreamSynchronize((hipStream_t)stream));
+    HIP_TRY(e, hipMemcpy(host_out, e->d_slow_head, sizeof(uint32_t) * (size_t)e->cfg.num_envs * e->args.W * e->args.H, hipMemcpyDeviceToHost));
+    return MW_OK;
+}
 
 int mw_get_list_lengths(mw_engine *e, int32_t first_env, int32_t count, int32_t *host_out, void *stream)
 {

@@ -16,6 +16,7 @@
 //   output   : RGB bytes staged through 192 B of LDS so the tile leaves as dword stores.
 // HBM traffic per env-step is the observation (14 400 B, + 19 200 B with depth) plus the geometry kernel's records; textures
 // and records are L2-resident.
+#include <cstring>
 #include "mw_mesh.h"
 
 // LDS_RECS = true : the env's shade / classification records are staged in LDS (small scenes);
@@ -255,3 +256,16 @@ extern "C" __global__ __launch_bounds__(64, MW_MESH_TILE_OCC) void mw_raster_mes
 extern "C" __global__ __launch_bounds__(64, MW_MESH_TILE_OCC) void mw_raster_mesh_depth_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, 0, 2, 1>(MW_RASTER_FWD); }
 extern "C" __global__ __launch_bounds__(64) void mw_raster_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<true, -1, 0, 1>(MW_RASTER_FWD); }
 extern "C" __global__ __launch_bounds__(64) void mw_raster_big_mesh_wrap_kernel(MW_RASTER_ARGS) { raster_kernel_body<false, -1, 0, 1>(MW_RASTER_FWD); }
+
+#ifdef MW_PERF_HOOKS
+// tools/perf/k2prof.py: read (and zero) this translation unit's phase counters
+extern "C" int mw_debug_k2prof(unsigned long long *out16)
+{
+    static unsigned long long h[K2P_SLOTS][16];
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_k2prof), sizeof h) != hipSuccess) return -2;
+    for (int i = 0; i < 16; ++i) { out16[i] = 0; for (int k = 0; k < K2P_SLOTS; ++k) out16[i] += h[k][i]; }
+    memset(h, 0, sizeof h);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_k2prof), h, sizeof h) == hipSuccess ? 0 : -3;
+}
+#endif

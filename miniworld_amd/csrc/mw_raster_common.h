@@ -248,6 +248,20 @@ __device__ inline RGB shade_uniform(const float4 *sr, const TexEnv &te, int px, 
     return c;
 }
 
+#ifdef MW_PERF_HOOKS
+// tools/perf/k2prof.py (perf build only): cycles and event counts of the tile code's phases, summed over every tile of the launches
+// [0] tiles [1] classification cycles [2] coverage / depth loop cycles [3] shading loop cycles [4] resolve / pack / store cycles
+// [5] (tile, triangle) events visited [6] ... that covered a sample [7] winners shaded [8] classified chunks [9] tiles left early
+// (one line of counters per 8 192 workgroups: 800 000 atomics per step on ONE line slowed the kernel tenfold)
+#define K2P_SLOTS 8192
+__device__ unsigned long long g_k2prof[K2P_SLOTS][16];
+#define K2P_NOW() __builtin_readcyclecounter()
+#define K2P_ADD(i, v) do { if (cx.lane == 0) atomicAdd(&g_k2prof[blockIdx.x % K2P_SLOTS][i], (unsigned long long)(v)); } while (0)
+#else
+#define K2P_NOW() 0ull
+#define K2P_ADD(i, v) do { } while (0)
+#endif
+
 struct TileCtx;
 // colour of mesh triangle `id` (entry mj of the env's mesh table) at the lane's pixel: defined by the kernels that see meshes
 __device__ inline RGB shade_mesh_winner(const TileCtx &cx, int mj, uint32_t id, int px, int gy);
@@ -503,6 +517,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     }
 
     // ============ pass B: exact packed-key resolution =================================
+    [[maybe_unused]] unsigned long long kp_t0 = K2P_NOW(), kp_cls = 0, kp_ev = 0, kp_hit = 0, kp_win = 0, kp_chunks = 0, kp_early = 0;
     if (exact) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) { smp.r[s] = sky.r; smp.g[s] = sky.g; smp.b[s] = sky.b; }
@@ -515,6 +530,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             pmask_t todo;
             int pidx = chunk + lane;
             uint32_t zlo = 0u;
+            [[maybe_unused]] const unsigned long long kp_c0 = K2P_NOW();
             if (have_pre) {
                 todo = (pmask_t)cx.pre_touch;
             } else {
@@ -527,13 +543,17 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 }
                 todo = (pmask_t)__ballot(touch);
             }
+#ifdef MW_PERF_HOOKS
+            kp_cls += K2P_NOW() - kp_c0; ++kp_chunks;
+#endif
             while (todo) {
                 const int bit = ffs_mask(todo) - 1;
                 const int p = (SORTED && sorted) ? __builtin_amdgcn_readlane(pidx, bit) : chunk + bit;
                 todo &= todo - 1;
                 if (SORTED && sorted) {
-                    if ((uint32_t)__builtin_amdgcn_readlane((int)zlo, bit) > far16) { done = true; break; }
+                    if ((uint32_t)__builtin_amdgcn_readlane((int)zlo, bit) > far16) { done = true; ++kp_early; break; }
                 }
+                ++kp_ev;
                 const int *__restrict__ rr = reinterpret_cast<const int *>(rr_env + (size_t)p * MW_RASTER_REC);
                 // (coverage as wave masks in scalar registers, like pass A: one compare per sample and open edge, one select
                 // per sample — no per-lane flags, no branches around the samples)
@@ -552,6 +572,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
 #pragma unroll
                 for (int s = 0; s < 8; ++s) any_m |= in_m[s];
                 if (!any_m) continue;
+                ++kp_hit;
                 const float za0 = __int_as_float(rr[10]), zdx = __int_as_float(rr[11]), zdy = __int_as_float(rr[12]);
                 const uint32_t id = MESH ? (uint32_t)rr[9] : (uint32_t)p;           // the mesh kernel's keys carry draw ids
 #pragma unroll
@@ -566,6 +587,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             }
         }
         z16 = key[0] >> 16;
+        [[maybe_unused]] const unsigned long long kp_t1 = K2P_NOW();
         // deferred shading: every distinct winner once per pixel (GL multisampling shades a pixel once per triangle).  The
         // tile's distinct winners are visited in ascending draw id, each shaded for the whole wavefront at once
         // (shade_uniform); mesh triangles, which differ from pixel to pixel, per lane, every lane its own next one.  A
@@ -579,6 +601,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             for (int s = 0; s < 8; ++s) mine = min(mine, pid[s]);
             const uint32_t id = __reduce_min_sync(~0ull, mine);
             if (id == 0x10000u) break;
+            ++kp_win;
             int rec = (int)id;
             const int mj = MESH ? mesh_entry_of(cx, id, rec) : -1;
             uint32_t sel = id;
@@ -599,7 +622,12 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 pid[s] = eq ? 0x10000u : pid[s];
             }
         }
+#ifdef MW_PERF_HOOKS
+        K2P_ADD(1, kp_cls); K2P_ADD(2, kp_t1 - kp_t0 - kp_cls); K2P_ADD(3, K2P_NOW() - kp_t1);
+        K2P_ADD(5, kp_ev); K2P_ADD(6, kp_hit); K2P_ADD(7, kp_win); K2P_ADD(8, kp_chunks); K2P_ADD(9, kp_early);
+#endif
     }
+    [[maybe_unused]] const unsigned long long kp_t2 = K2P_NOW();
     out = resolve_samples(smp);
     const uint32_t R = to_u8(out.r), G = to_u8(out.g), B = to_u8(out.b);
 
@@ -647,6 +675,9 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         const float den = clip * (float)(100.0 - 0.04) - (float)(100.0 + 0.04);
         depth[((size_t)env * H + py) * W + px] = (float)(-2.0 * 100.0 * 0.04) / den;
     }
+#ifdef MW_PERF_HOOKS
+    K2P_ADD(0, 1); K2P_ADD(4, K2P_NOW() - kp_t2);
+#endif
 }
 
 }  // namespace

@@ -46,6 +46,7 @@ extern "C" __global__ __launch_bounds__(MW_ENT_THREADS, MW_ENT_OCC) void mw_mesh
     extern __shared__ __attribute__((aligned(16))) float4 s_vert[];
     __shared__ uint16_t s_queue[MW_ENT_ROUND], s_big[MW_ENT_ROUND];
     __shared__ int s_qn, s_bn, s_env;
+    static_assert(MW_MESH_VCAP * 16 + sizeof(uint16_t) * 2 * MW_ENT_ROUND + 3 * sizeof(int) <= 65536, "the vertex table and the queues share a workgroup's 64 KB of LDS");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // ent_n: this frame's list lengths (the geometry kernel's) and the cursor into them; ent_n_after: the next frame's, zeroed
     // here (the two swap places from frame to frame; nothing of the next frame starts before this kernel has ended)

@@ -14,7 +14,8 @@ import subprocess
 import numpy as np
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "libmwengine.so")
+# (MW_ENGINE_LIB: a variant build of the library for A/B measurements — tools/perf; the product is csrc/libmwengine.so)
+LIB_PATH = os.environ.get("MW_ENGINE_LIB") or os.path.join(_CSRC, "libmwengine.so")
 
 ABI_VERSION = 4
 ENT_NONE, ENT_BOX, ENT_MESH, ENT_FRAME = 0, 1, 2, 3
@@ -33,7 +34,7 @@ PATH_TILE, PATH_QUAD, PATH_QUAD_MESH, PATH_GENERIC = 0, 1, 2, 3
 EXPORTS = [
     "mw_create", "mw_destroy", "mw_last_error", "mw_upload_texture", "mw_upload_mesh",
     "mw_set_geometry", "mw_get_geometry", "mw_set_state", "mw_get_state", "mw_set_step_params", "mw_reset",
-    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms", "mw_raster_path", "mw_get_info", "mw_get_final_info", "mw_get_list_lengths",
+    "mw_step", "mw_render", "mw_render_top", "mw_render_view", "mw_visible_ents", "mw_set_obs_layout", "mw_pcg64_draws", "mw_check", "mw_kernel_time_ms", "mw_raster_path", "mw_get_info", "mw_get_final_info", "mw_get_list_lengths", "mw_debug_set_mesh_frame_seq", "mw_debug_get_slow_heads",
     "mw_set_gen_program", "mw_selftest_rcp", "mw_selftest_div", "mw_selftest_sort", "mw_selftest_q",
 ]
 
@@ -189,6 +190,8 @@ def load_library():
     L.mw_get_info.argtypes = [vp, vp, vp, i32, vp]
     L.mw_get_final_info.argtypes = [vp, vp, vp, vp]
     L.mw_get_list_lengths.argtypes = [vp, i32, i32, vp, vp]
+    L.mw_debug_set_mesh_frame_seq.argtypes = [vp, C.c_uint32]
+    L.mw_debug_get_slow_heads.argtypes = [vp, vp, vp]
     _lib = L
     return L
 

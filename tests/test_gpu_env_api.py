@@ -974,6 +974,58 @@ def test_first_mesh_frame_does_not_synchronise():
     vec.close()
 
 
+def test_slow_fragment_heads_survive_the_stamp_wrap():
+    """The per-pixel chains of the fragments of mesh triangles that cross a frustum plane are tagged with a 16-bit frame
+    stamp instead of being cleared every frame (mw_raster_mesh.hip: slow_pixel): a head that nothing has overwritten since frame F
+    would read as valid again at frame F + 65 536, so the engine wipes the heads on the frame whose stamp is 0.  Here a batch
+    looks at a view (stamp a), turns away for k frames, the sequence number is moved to 65 536 + a - k (test hook), and k
+    turns back bring the first view back exactly on stamp a — through the wrap.  The frames must equal those of the same
+    batch stepped without the jump."""
+    import torch
+    from miniworld_amd.vec_env import MiniWorldVecEnv
+    n, k = 512, 6
+
+    def run(jump):
+        vec = MiniWorldVecEnv("MiniWorld-PickupObjects-v0", n, seed=31)
+        vec.reset()                                         # frame 1
+        left = torch.zeros(n, dtype=torch.int32, device="cuda")
+        right = torch.ones(n, dtype=torch.int32, device="cuda")
+        frames = []
+        for _ in range(3):                                  # frames 2 .. 4: the view at stamp a = 4 (right, left, right: back and forth)
+            vec.step(right if len(frames) % 2 == 0 else left)
+            frames.append(vec.obs.clone())
+        for _ in range(k):
+            vec.step(left)
+            frames.append(vec.obs.clone())
+        if jump:
+            # next frame would be 5 + k; move it to 65 536 + 5 - k: the k frames turning back carry the stamps 5 - k .. 4 (mod 2^16)
+            rc = vec.engine.lib.mw_debug_set_mesh_frame_seq(vec.engine.h, 65536 + 5 - k)
+            assert rc == 0, vec.engine.lib.mw_last_error(vec.engine.h)
+        def stamps():
+            from miniworld_amd.engine import _stream_ptr
+            h = np.zeros((n, 60, 80), np.uint32)
+            assert vec.engine.lib.mw_debug_get_slow_heads(vec.engine.h, h.ctypes.data, _stream_ptr(vec.engine.device)) == 0
+            return h >> 16
+
+        if jump:
+            assert (stamps() != 0).sum() > 100, "no mesh triangle crossed a frustum plane: the test sees nothing"
+        for i in range(k):
+            vec.step(right)
+            frames.append(vec.obs.clone())
+            if jump and i == 1:
+                # the frame whose stamp is 0 has been drawn: nothing of the frames before it is left in the heads
+                assert (stamps() == 0).all(), "chain heads of earlier frames survived the frame with stamp 0"
+        vec.engine.check()
+        out = torch.stack(frames).cpu().numpy()
+        vec.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert a.shape == b.shape and 1.0 < a.mean() < 254.0
+    bad = np.argwhere((a != b).reshape(a.shape[0], -1).any(axis=1)).ravel()
+    assert bad.size == 0, f"frames {bad.tolist()} differ after the stamp wrapped"
+
+
 def test_two_engines_on_two_streams_stay_exact():
     """Multi-GPU readiness on one GPU: two engines in one process, each stepped on a stream of its own (what two ranks of a
     node do on two devices, here contending for one): frames, rewards and flags equal those of the same batches stepped
