@@ -249,6 +249,9 @@ int geom_lanes(const mw_engine *e)
     // mid-sized scenes (PickupObjects: 6 polygons + 5 entity slots = 74 triangles; no visiting order, no sifting): two envs per
     // wavefront — 2 048 envs are ONE round of this one-wave-per-SIMD kernel instead of two (K1 + KG 103 -> 71 us)
     if (L == 64 && !e->args.rec_order && e->cfg.max_polys <= 64) L = 32;
+#ifdef MW_PERF_HOOKS
+    if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if ((v == 8 || v == 16 || v == 32 || v == 64) && v >= L) L = v; }
+#endif
     return L;
 }
 

@@ -31,6 +31,16 @@ namespace {
 
 constexpr int kClipSlots = 24;      // work lists of the clipper in LDS: 2 x 10 vertices of 48 bytes each (23 KB)
 
+// The lanes of ONE wavefront (= the workgroup) exchange data through LDS: the LDS pipeline serves a wavefront's accesses in program order, so
+// an exchange needs the compiler to keep that order and the data to have arrived (lgkmcnt) — not the vmcnt(0) of a full
+// workgroup fence, which also waits for every record store in flight (one to two microseconds each time at one wavefront per SIMD).
+__device__ inline void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // exclusive scan inside the env's L-lane group; total: the group's sum
 __device__ inline int group_excl_scan(int v, int sub, int L, int &total)
 {
@@ -166,6 +176,32 @@ __device__ inline bool occluded(const float *occ_z, const mwgl::Vert v[4], float
     return ok && occluded_span(occ_z, xmn - 0.1f, xmx + 0.1f, zq, bins_per_px);
 }
 
+// The same question answered from a sparse table over the bins (rmq[k * BINS + b] = the largest value of bins b .. b + 2^k - 1):
+// two reads instead of a walk over up to 46 bins and group maxima whose length differs from lane to lane (the wavefront
+// waited for its widest polygon at every call).
+__device__ inline bool occluded_span_rmq(const float *rmq, float xlo, float xhi, float zq, float bins_per_px)
+{
+    const float fb0 = floorf(fmaxf(xlo, 0.0f) * bins_per_px), fb1 = floorf(fmaxf(xhi, 0.0f) * bins_per_px);
+    const int b0 = (int)fminf(fb0, (float)(MW_OCC_BINS - 1)), b1 = (int)fminf(fb1, (float)(MW_OCC_BINS - 1));
+    const float thr = zq * __builtin_amdgcn_rcpf(fmaf(1.2e-3f, zq, 1.0f)) * 0.9999f;
+    if (b1 < b0) return true;       // (an empty span, like the walk's)
+    const int k = 31 - __builtin_clz((unsigned)(b1 - b0 + 1));
+    const float m = fmaxf(rmq[k * MW_OCC_BINS + b0], rmq[k * MW_OCC_BINS + b1 - (1 << k) + 1]);
+    return m < thr;
+}
+
+__device__ inline bool occluded_rmq(const float *rmq, const mwgl::Vert v[4], float bins_per_px)
+{
+    float zq = 1e30f, xmn = 1e30f, xmx = -1e30f;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ok &= v[k].clip[3] >= 0.1f;
+        xmn = fminf(xmn, v[k].win[0]); xmx = fmaxf(xmx, v[k].win[0]); zq = fminf(zq, v[k].clip[3]);
+    }
+    return ok && occluded_span_rmq(rmq, xmn - 0.1f, xmx + 0.1f, zq, bins_per_px);
+}
+
 }  // namespace
 
 // view_flags: bit 0 top view, bit 1 draw the agent marker, bit 2 get_visible_ents' proxy pass (rooms untextured + one
@@ -187,10 +223,19 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     __shared__ float s_occ_z[BIG ? MW_OCC_BINS + MW_OCC_BINS / 16 : 1];      // occlusion culling: farthest depth of the nearest wall per column bin, group maxima
     __shared__ float s_occ_wall[BIG ? MW_OCC_CAP * 5 : 1];
     __shared__ int s_occ_n;
+    float *s_rmq = reinterpret_cast<float *>(&s_clip[0]);      // big scenes, during the sift: range maxima of the column bins (9 levels x 256)
     __shared__ uint16_t s_list[BIG ? 4096 : 1];
     __shared__ uint32_t s_key[BIG ? MW_ORDER_CAP : 1];        // big scenes: (depth bound << 16 | list index) of every record, for the visiting order      // big scenes: the polygons that pass the cheap tests (frustum, occlusion), in drawing order
-    const unsigned long long tstart = __builtin_readcyclecounter();
-    const unsigned long long rt_start = a.k1_prof ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz, the same clock on every CU
+#ifdef MW_PERF_HOOKS      // (tools/perf/kgprof.py; the product build carries no time stamps)
+#define KGP_ON (a.k1_prof != nullptr)
+#else
+#define KGP_ON false
+#endif
+    const unsigned long long tstart = KGP_ON ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long rt_start = KGP_ON ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz, the same clock on every CU
+    [[maybe_unused]] unsigned long long ts[4] = {0, 0, 0, 0};     // inside the sift: occluder walls, column bins, boxes, polygons
+    [[maybe_unused]] int kp_nocc = 0, kp_nkept = 0, kp_nclip = 0;
+    [[maybe_unused]] unsigned long long kp_clip = 0, kp_emit = 0;
     const int lane = threadIdx.x;
     const int epw = 64 / L, sub = lane & (L - 1), grp = lane / L;
     const int rel = (int)blockIdx.x * epw + grp;
@@ -198,6 +243,32 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     const int env = a.env_base + (live ? rel : n_env - 1);      // a padding group recomputes the last env and writes nothing
     const int set = a.shared_geom ? 0 : env;
     const bool top = (view_flags & 1) != 0, proxy = (view_flags & 4) != 0, ms = S > 1;
+    // big scenes: the per-world culling data (occ_cache: full-height walls, boxes of eight polygons) lives in HBM, one to two
+    // microseconds away at one wavefront per SIMD — requested here, ahead of the camera's double-precision prologue, instead of
+    // one round trip per 64 walls inside the sift (29 k of the kernel's 150 k cycles)
+    constexpr int kWallPf = BIG ? 4 : 1;
+    float4 pf_wall[kWallPf], pf_box0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f), pf_box1 = pf_box0;
+    float pf_sgn[kWallPf], pf_hdr[3] = {0.0f, 0.0f, 0.0f};
+    auto prefetch_occ = [&]() {
+        if (!BIG || L != 64 || a.occ_cache == nullptr) return;
+        const float *pc = a.occ_cache + (size_t)set * MW_OCC_CACHE_STRIDE(a.max_polys);
+#pragma unroll
+        for (int q = 0; q < kWallPf; ++q) {
+            const int i = lane + 64 * q;
+            if (i < a.max_polys) {
+                pf_wall[q] = reinterpret_cast<const float4 *>(pc + MW_OCC_CACHE_HDR + 8 * (size_t)i)[0];
+                pf_sgn[q] = pc[MW_OCC_CACHE_HDR + 8 * (size_t)i + 4];
+            }
+        }
+        if (lane < (a.max_polys + 7) / 8) {
+            const float4 *b4 = reinterpret_cast<const float4 *>(pc + MW_OCC_CACHE_HDR + 8 * (size_t)a.max_polys + 8 * (size_t)lane);
+            pf_box0 = b4[0]; pf_box1 = b4[1];
+        }
+        pf_hdr[0] = pc[0]; pf_hdr[1] = pc[1]; pf_hdr[2] = pc[2];
+    };
+#pragma unroll
+    for (int q = 0; q < kWallPf; ++q) { pf_wall[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); pf_sgn[q] = 0.0f; }
+    prefetch_occ();
     // ---- the frame's GL state (every lane of the group evaluates it: same instruction stream)
     mwgl::Frame f;
     const double px = a.ax[env], py = a.ay[env], pz = a.az[env], dir = a.adir[env];
@@ -243,11 +314,12 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         }
         mwgl::frame_finish(f, a.W, a.H, lpos, lcol, lamb);
     }
-    const unsigned long long tp0 = a.k1_prof ? __builtin_readcyclecounter() : 0ull;
     mwgl::Xform cam;
     mwgl::make_xform(f, f.view, f.view_flags, cam);
     unsigned long long tp[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a.k1_prof) tp[0] = __builtin_readcyclecounter();
+    [[maybe_unused]] unsigned long long racc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = 0, rstart = 0, rtot[2] = {0, 0}, rvert[2] = {0, 0};      // per-round phases, summed over the rounds
+#define KGP_R(k) do { if (KGP_ON) { const unsigned long long n_ = __builtin_readcyclecounter(); racc[k] += n_ - tprev; tprev = n_; } } while (0)
+    if (KGP_ON) tp[0] = __builtin_readcyclecounter();
 
     const mw_poly *polys = a.polys + (size_t)set * a.max_polys;
     const int np = a.npolys[set];
@@ -471,64 +543,88 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         __threadfence();
         __syncthreads();
         if (lane == 0) a.occ_valid[set] = np + 1;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        prefetch_occ();         // (what was requested at the top was the cache before this world)
+    } else if (cached && a.shared_geom) {
+        // (a shared set may have been filled by another wavefront of this launch after this one asked for it)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        prefetch_occ();
     }
-    // (acquire: the cache is read behind the flag — a shared set may have been filled by another wavefront of this launch)
-    if (cached) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 
     // ---- occlusion culling: the walls that hide what lies behind them
     const float bins_per_px = (float)MW_OCC_BINS / (float)a.W;
     if (occ_on) {
-        const float lo = oc[1], hi = oc[2];
-        const int n_walls = __float_as_int(oc[0]);
-        if (lane == 0) s_occ_n = 0;
-        __syncthreads();
+        const float lo = pf_hdr[1], hi = pf_hdr[2];
+        const int n_walls = __float_as_int(pf_hdr[0]);
         occ_on = eye_y > lo + 1e-3f && eye_y < hi - 1e-3f;
+        if (!occ_on && lane == 0) s_occ_n = 0;
         if (occ_on) {
             const float wc = 0.1f;
             const float *V = f.view.m;          // column major: eye x = V[0] x + V[8] z + V[12], depth = -(V[2] x + V[10] z + V[14])
             const float p00 = f.proj.m[0], halfw = (float)a.W * 0.5f;
             const float inv_p00 = 1.0f / p00, inv_hp = 1.0f / (halfw * p00), px_per_bin = 1.0f / bins_per_px;
-            for (int i = lane; i < n_walls; i += 64) {
-                const float4 w0 = reinterpret_cast<const float4 *>(oc_wall + 8 * (size_t)i)[0];
-                const float sgn = oc_wall[8 * (size_t)i + 4];
+            // (walls 0 .. 255 were requested at the top of the kernel; the occluders are numbered by ballots: a place per wall in
+            // the order of the world's list, no atomics)
+            int n_found = 0;
+            for (int it = 0, i = lane; it * 64 < n_walls; ++it, i += 64) {
+                float4 w0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                float sgn = 0.0f;
+                if (it < kWallPf) {
+#pragma unroll
+                    for (int q = 0; q < kWallPf; ++q) if (q == it) { w0 = pf_wall[q]; sgn = pf_sgn[q]; }
+                } else if (i < n_walls) {
+                    w0 = reinterpret_cast<const float4 *>(oc_wall + 8 * (size_t)i)[0];
+                    sgn = oc_wall[8 * (size_t)i + 4];
+                }
+                bool found = false;
+                float o_xl = 0.0f, o_xr = 0.0f, o_a2 = 0.0f, o_b2 = 0.0f, o_d = 0.0f;
+                do {
+                if (i >= n_walls) break;
                 const float vx0 = w0.x, vz0 = w0.y, bx = w0.z, bz = w0.w;
                 // drawn at all?  GL_CCW front faces (miniworld.py:512): the winding normal, s * (tz, 0, -tx) for a vertical
                 // rectangle over the foot line B0 -> B1 = (tx, tz), points at the eye — by a centimetre at least
                 const float tx = bx - vx0, tz = bz - vz0;
                 const float side = tz * (eye_x - vx0) - tx * (eye_z - vz0);
                 const float facing = sgn > 0.0f ? side : -side;
-                if (!(facing > 0.0f && facing * facing > 1e-4f * (tx * tx + tz * tz))) continue;
+                if (!(facing > 0.0f && facing * facing > 1e-4f * (tx * tx + tz * tz))) break;
                 // its foot line in eye space: (x, depth) of the two vertical edges, cut at depth wc
                 float ea = fmaf(V[0], vx0, fmaf(V[8], vz0, V[12]));
                 float wa = -fmaf(V[2], vx0, fmaf(V[10], vz0, V[14]));
                 float eb = fmaf(V[0], bx, fmaf(V[8], bz, V[12]));
                 float wb = -fmaf(V[2], bx, fmaf(V[10], bz, V[14]));
-                if (!(wa >= wc) && !(wb >= wc)) continue;
+                if (!(wa >= wc) && !(wb >= wc)) break;
                 // (hardware reciprocals: their last-bit error moves a column by 1e-5 px, the margins are 0.05)
                 if (!(wa >= wc)) { const float t = (wc - wa) * __builtin_amdgcn_rcpf(wb - wa); ea = fmaf(t, eb - ea, ea); wa = wc; }
                 else if (!(wb >= wc)) { const float t = (wc - wb) * __builtin_amdgcn_rcpf(wa - wb); eb = fmaf(t, ea - eb, eb); wb = wc; }
-                if (!(fmaxf(wa, wb) < 95.0f)) continue;         // the far plane is at 100
+                if (!(fmaxf(wa, wb) < 95.0f)) break;         // the far plane is at 100
                 const float xa = halfw * fmaf(p00, ea * __builtin_amdgcn_rcpf(wa), 1.0f);
                 const float xb = halfw * fmaf(p00, eb * __builtin_amdgcn_rcpf(wb), 1.0f);
                 const float xl = fminf(xa, xb) + 0.05f, xr = fmaxf(xa, xb) - 0.05f;
-                if (!(xr > 0.0f && xl < (float)a.W && xr - xl >= px_per_bin)) continue;
+                if (!(xr > 0.0f && xl < (float)a.W && xr - xl >= px_per_bin)) break;
                 // depth along the wall as a function of the pixel column: A ex + B w = D with ex / w = (x / halfw - 1) / p00
                 float A = wb - wa, B = -(eb - ea), D = A * ea + B * wa;
                 if (D < 0.0f) { A = -A; B = -B; D = -D; }
-                if (!(D > 1e-4f)) continue;
+                if (!(D > 1e-4f)) break;
                 const float A2 = A * inv_hp, B2 = B - A * inv_p00;
                 const float dl = fmaf(A2, xl, B2), dr = fmaf(A2, xr, B2);
-                if (!(dl * 100.0f > D && dr * 100.0f > D)) continue;       // depths below 100 at both ends (and positive denominators)
-                const int j = atomicAdd(&s_occ_n, 1);
-                if (j < MW_OCC_CAP) {
+                if (!(dl * 100.0f > D && dr * 100.0f > D)) break;       // depths below 100 at both ends (and positive denominators)
+                found = true; o_xl = xl; o_xr = xr; o_a2 = A2; o_b2 = B2; o_d = D;
+                } while (false);
+                const uint64_t fm = __ballot(found);
+                const int j = n_found + (int)__popcll((unsigned long long)(fm & ((1ull << lane) - 1ull)));
+                if (found && j < MW_OCC_CAP) {
                     float *ow = s_occ_wall + 5 * j;
-                    ow[0] = xl; ow[1] = xr; ow[2] = A2; ow[3] = B2; ow[4] = D;
+                    ow[0] = o_xl; ow[1] = o_xr; ow[2] = o_a2; ow[3] = o_b2; ow[4] = o_d;
                 }
+                n_found += (int)__popcll((unsigned long long)fm);
             }
+            if (lane == 0) s_occ_n = n_found;
         }
-        __syncthreads();
+        wave_lds_sync();
+        if (KGP_ON) ts[0] = __builtin_readcyclecounter();
         if (occ_on) {
             const int n_occ = s_occ_n < MW_OCC_CAP ? s_occ_n : MW_OCC_CAP;
+            kp_nocc = n_occ;
             // (four bins per lane in registers, the walls in the outer loop: one broadcast read of a wall serves them all)
             static_assert(MW_OCC_BINS == 256, "four column bins per lane");
             float zb[4] = {1e30f, 1e30f, 1e30f, 1e30f}, xa[4], xb[4];
@@ -553,9 +649,21 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
 #pragma unroll
                 for (int o = 8; o > 0; o >>= 1) gz = fmaxf(gz, __shfl_xor(gz, o));
                 if ((lane & 15) == 0) s_occ_z[MW_OCC_BINS + (b >> 4)] = gz;
+                s_rmq[b] = z;
+            }
+            // the sparse table of the sift's range queries, level by level (in the clipper's work lists: idle until the rounds)
+            static_assert(sizeof(ClipSlot) * kClipSlots >= 9 * MW_OCC_BINS * sizeof(float), "the range-maximum table borrows the clipper's LDS");
+            for (int k = 1; k <= 8; ++k) {
+                wave_lds_sync();
+                const int half = 1 << (k - 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int b = lane + 64 * q;
+                    if (b + 2 * half <= MW_OCC_BINS) s_rmq[k * MW_OCC_BINS + b] = fmaxf(s_rmq[(k - 1) * MW_OCC_BINS + b], s_rmq[(k - 1) * MW_OCC_BINS + b + half]);
+                }
             }
         }
-        __syncthreads();
+        wave_lds_sync();
     }
 
     // ---- big scenes: most polygons lie outside the frustum or behind walls — sift them with the cheap tests first, so that
@@ -563,6 +671,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     // that fails a test takes its polygons along unseen.  A box fails only where each of its polygons would (its margins
     // are the wider ones), so the list is the one the polygons' own tests leave.
     int n_polys_drawn = np;
+    if (KGP_ON) ts[1] = ts[2] = ts[3] = __builtin_readcyclecounter();
     if (sifted) {
         uint16_t *s_box = reinterpret_cast<uint16_t *>(s_key);      // the boxes that stay, ascending (s_key is not in use yet)
         const int nbox = (np + 7) >> 3;
@@ -571,7 +680,9 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             const int c = base + lane;
             bool keep = c < nbox;
             if (keep && cached) {
-                const float4 b0 = reinterpret_cast<const float4 *>(oc_box + 8 * (size_t)c)[0], b1 = reinterpret_cast<const float4 *>(oc_box + 8 * (size_t)c)[1];
+                // (boxes 0 .. 63 were requested at the top of the kernel)
+                const float4 b0 = base == 0 ? pf_box0 : reinterpret_cast<const float4 *>(oc_box + 8 * (size_t)c)[0];
+                const float4 b1 = base == 0 ? pf_box1 : reinterpret_cast<const float4 *>(oc_box + 8 * (size_t)c)[1];
                 const int fl = __float_as_int(b1.z);
                 if (fl & 1) {
                     const float mn[3] = {b0.x, b0.y, b0.z}, mx[3] = {b0.w, b1.x, b1.y};
@@ -580,14 +691,16 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                     const bool front = bv.front;
                     const float xmn = bv.xmn, xmx = bv.xmx, zq = bv.zq;
                     keep = all == 0u;
-                    if (keep && occ_on && (fl & 2) && front && occluded_span(s_occ_z, xmn - 0.15f, xmx + 0.15f, zq * 0.9999f, bins_per_px)) keep = false;
+                    if (keep && occ_on && (fl & 2) && front && occluded_span_rmq(s_rmq, xmn - 0.15f, xmx + 0.15f, zq * 0.9999f, bins_per_px)) keep = false;
                 }
             }
             const uint64_t m = __ballot(keep);
             if (keep) s_box[nkept + __popcll((unsigned long long)(m & ((1ull << lane) - 1ull)))] = (uint16_t)c;
             nkept += __popcll((unsigned long long)m);
         }
-        __syncthreads();
+        wave_lds_sync();
+        kp_nkept = nkept;
+        if (KGP_ON) ts[2] = __builtin_readcyclecounter();
         int ns = 0;
         // (the next turn's polygon is in flight while this turn's is tested)
         auto cand = [&](int k) { return k < 8 * nkept ? 8 * (int)s_box[k >> 3] + (k & 7) : np; };
@@ -613,7 +726,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                         all &= v[k2].clipmask;
                     }
                     keep = all == 0u;       // no frustum plane has every vertex outside
-                    if (keep && occ_on && nv == 4 && occluded(s_occ_z, v, bins_per_px)) keep = false;
+                    if (keep && occ_on && nv == 4 && occluded_rmq(s_rmq, v, bins_per_px)) keep = false;
                     // seen from behind — the other side of most walls of other rooms: with no vertex clipped its two
                     // triangles are the ones the rounds would set up, and when both are back-facing by more than snapping
                     // the vertices can change (clearly_back), setup would drop both: no record either way
@@ -631,10 +744,11 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             ns += __popcll((unsigned long long)m);
         }
         n_polys_drawn = ns;
-        __syncthreads();
+        wave_lds_sync();
+        if (KGP_ON) ts[3] = __builtin_readcyclecounter();
     }
 
-    if (a.k1_prof) tp[1] = __builtin_readcyclecounter();
+    if (KGP_ON) tp[1] = tprev = __builtin_readcyclecounter();
     int count = 0;          // the env's list length so far (uniform in the group)
     float stale_n[3] = {0.0f, 1.0f, 0.0f};
     const int marker = (view_flags & 2) ? 1 : 0;
@@ -662,6 +776,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     // list —: an env with fewer rounds than its neighbours idles through the rest)
     const int n_rounds_wave = L < 64 ? (int)__reduce_max_sync(~0ull, (unsigned)n_rounds) : n_rounds;
     for (int rnd = 0; rnd < n_rounds_wave; ++rnd) {
+        if (KGP_ON) rstart = tprev;
         int item, tsel;
         if (rnd >= n_rounds) {
             item = n_items; tsel = 0;
@@ -719,7 +834,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                     v[k].col[0] = col[0]; v[k].col[1] = col[1]; v[k].col[2] = col[2];
                 }
                 nt = nv == 3 ? 1 : 2;
-                if (occ_on && nv == 4 && !own && occluded(s_occ_z, v, bins_per_px)) nt = 0;      // hidden behind a full-height wall
+                if (occ_on && !sifted && nv == 4 && !own && occluded(s_occ_z, v, bins_per_px)) nt = 0;      // hidden behind a full-height wall (a sifted list has passed this very test)
             }
         } else if (box_slot >= 0) {
             const int slot = box_slot, fc = (item - npd) % 6;
@@ -836,7 +951,8 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             }
         }
 
-        if (a.k1_prof) tp[2] = __builtin_readcyclecounter();
+        KGP_R(2);
+        if (KGP_ON) { if (rnd == 0) rvert[0] = tprev - rstart; rvert[1] = tprev - rstart; }
         // this lane's triangle of v[]: (0,1,3) / (1,2,3), or (0,1,2) / (0,2,3) for a direct quad
         const mwgl::Vert va = tsel ? (direct ? v[0] : v[1]) : v[0], vb = tsel ? v[2] : v[1], vc = tsel ? v[3] : (direct ? v[2] : v[3]);
         // ---- pass 1: does it survive, and as how many triangles
@@ -847,7 +963,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             if ((va.clipmask | vb.clipmask | vc.clipmask) == 0u) cnt = tri_front(va.win, vb.win, vc.win, ms) ? 1 : 0;
             else clipped = true;
         }
-        if (a.k1_prof) tp[3] = __builtin_readcyclecounter();
+        KGP_R(3);
         // A triangle that crosses a frustum plane goes through a work list in LDS: kClipSlots of the wave's clipped
         // triangles at a time are clipped, counted, placed in the env's list and written (the serial form, for a triangle
         // across all six planes: clipped in pass 1, and again in pass 2 when the wave has more of them than lists).
@@ -872,8 +988,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                 ClipSlot &cs = s_clip[my_v - v0];
                 mwgl::clip_copy_in(cs.l[0][0], va); mwgl::clip_copy_in(cs.l[0][1], vb); mwgl::clip_copy_in(cs.l[0][2], vc);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
             const int nb = n_clip - v0 < kClipSlots ? n_clip - v0 : kClipSlots;
             for (int b0 = 0; b0 < nb; b0 += 8) {
                 const int slot = b0 + (lane >> 3);
@@ -908,8 +1023,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                         mwgl::clip_interp<false>(f, out[pos + (emit ? 1 : 0)], t, from_cur ? Vn : V, from_cur ? V : Vn);
                     }
                     if (act) { n = bg ? 0 : __popc(eg) + __popc(xg); cur ^= 1; }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
+                    wave_lds_sync();
                 }
                 if (n < 3) n = 0;
                 // the fan (r[e-1], r[e], r[0]), e = 2 .. n-1: which of its triangles leave setup
@@ -919,8 +1033,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                 const uint32_t fm = (uint32_t)(__ballot(front) >> cg0) & 0xFFu;
                 if (valid && ce == 0) s_res[v0 + slot] = (uint32_t)n | ((uint32_t)cur << 4) | (fm << 8);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
         };
         // the records of the fans in lists 0 .. of triangles v0 ..: every triangle of every fan on a lane of its own — list
         // position from the owner's (base_now), setup, record
@@ -946,8 +1059,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            __builtin_amdgcn_wave_barrier();
+            wave_lds_sync();
         };
         int total = 0, base = 0;
         bool scanned = false;
@@ -956,10 +1068,13 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             // to come: they lie behind these in the list), written — then the lists serve the next ones
             if (clipped) s_meta[my_v] = (uint32_t)lane | (cm_union << 8);
             for (int v0 = 0; v0 < n_clip; v0 += kClipSlots) {
+                [[maybe_unused]] const unsigned long long c0 = KGP_ON ? __builtin_readcyclecounter() : 0ull;
                 clip_lists(v0);
+                [[maybe_unused]] const unsigned long long c1 = KGP_ON ? __builtin_readcyclecounter() : 0ull;
                 if (clipped && my_v >= v0 && my_v < v0 + kClipSlots) cnt = __popc(s_res[my_v] >> 8);
                 base = count + group_excl_scan(cnt, sub, L, total);
                 emit_fans(v0, base);
+                if (KGP_ON) { kp_clip += c1 - c0; kp_emit += __builtin_readcyclecounter() - c1; kp_nclip += n_clip > v0 + kClipSlots ? kClipSlots : n_clip - v0; }
             }
             scanned = true;     // the last scan saw every count
         } else {
@@ -981,12 +1096,12 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                 pend = rest;
             }
         }
-        if (a.k1_prof) tp[4] = __builtin_readcyclecounter();
+        KGP_R(4);
         // ---- list positions
         if (!scanned) base = count + group_excl_scan(cnt, sub, L, total);
         count += total;
         if (base + cnt > a.max_vis && cnt) atomicOr(a.status, MW_ST_VIS_OVERFLOW);
-        if (a.k1_prof) tp[5] = __builtin_readcyclecounter();
+        KGP_R(5);
         // ---- pass 2: the records
         if (cnt == 1 && !clipped && live && base < a.max_vis) {
             mwgl::TriSetup ts;
@@ -1029,13 +1144,13 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                 pend = rest;
             }
         }
-        if (a.k1_prof) tp[6] = __builtin_readcyclecounter();
+        KGP_R(6);
+        if (KGP_ON && rnd < 2) rtot[rnd] = tprev - rstart;
         // list positions the meshes' draw ids need
         if (is_box && tsel == 0 && (item - npd) % 6 == 0 && (item - npd) / 6 < 64) pos[(item - npd) / 6] = base;
         if (marker && tsel == 0 && item == n_items - 1) pos[total_boxes < 64 ? total_boxes : 64] = base;
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    wave_lds_sync();
     if (BIG && a.rec_order && L < 64) {
         if (sub == 0 && live) a.rec_order[(size_t)env * (a.max_vis + 1)] = 0;      // no order
     } else if (BIG && a.rec_order) {
@@ -1048,7 +1163,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         if (n > MW_ORDER_CAP || n > a.max_vis || !live) {
             if (lane == 0 && live) order[0] = 0;
         } else {
-            __syncthreads();
+            wave_lds_sync();
             // (64 R keys in R registers per lane, key i = 64 r + lane: the network's exchanges are lane shuffles and
             // register swaps — no LDS round trip per stage)
             if (n <= 64) sort_store_keys<1>(s_key, n, lane, order);
@@ -1058,11 +1173,16 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             if (lane == 0) order[0] = 1;
         }
     }
-    if (a.k1_prof && sub == 0 && live) {
+    if (KGP_ON && sub == 0 && live) {
         unsigned long long *pp = a.k1_prof + (size_t)env * MW_K1_PROF_SLOTS;
-        pp[0] = tp[0] - tstart; (void)tp0; for (int i = 1; i < 7; ++i) pp[i] = tp[i] - tp[i - 1];
-        pp[7] = __builtin_readcyclecounter() - tp[6];
+        pp[0] = tp[0] - tstart; pp[1] = tp[1] - tp[0]; for (int i = 2; i < 7; ++i) pp[i] = racc[i];
+        pp[7] = __builtin_readcyclecounter() - tprev;
+        pp[20] = rtot[0]; pp[21] = rtot[1]; pp[22] = rvert[0]; pp[23] = rvert[1];
+        pp[24] = kp_clip; pp[25] = kp_emit; pp[26] = (unsigned long long)kp_nclip; pp[27] = 0;
         pp[8] = rt_start; pp[9] = __builtin_amdgcn_s_memrealtime();
+        pp[10] = (unsigned long long)np; pp[11] = (unsigned long long)npd; pp[12] = (unsigned long long)count; pp[13] = (unsigned long long)n_rounds;
+        pp[14] = (unsigned long long)kp_nocc; pp[15] = (unsigned long long)kp_nkept;
+        pp[16] = ts[0] - tp[0]; pp[17] = ts[1] - ts[0]; pp[18] = ts[2] - ts[1]; pp[19] = ts[3] - ts[2];
     }
     if (sub == 0 && live) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
@@ -1116,8 +1236,11 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     }
 }
 
-extern "C" __global__ __launch_bounds__(64) void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false, 8>(a, view_flags, S, L, n_env); }
-extern "C" __global__ __launch_bounds__(64) void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true, 8>(a, view_flags, S, L, n_env); }
+#ifndef MW_GEOM_OCC
+#define MW_GEOM_OCC
+#endif
+extern "C" __global__ __launch_bounds__(64) MW_GEOM_OCC void mw_geom_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false, 8>(a, view_flags, S, L, n_env); }
+extern "C" __global__ __launch_bounds__(64) MW_GEOM_OCC void mw_geom_big_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true, 8>(a, view_flags, S, L, n_env); }
 // ... for frame buffers with 1, 4 or 16 samples per pixel
 extern "C" __global__ __launch_bounds__(64) void mw_geom_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<false, 0>(a, view_flags, S, L, n_env); }
 extern "C" __global__ __launch_bounds__(64) void mw_geom_big_any_kernel(MwArgs a, int view_flags, int S, int L, int n_env) { geom_body<true, 0>(a, view_flags, S, L, n_env); }
