@@ -221,9 +221,10 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     __shared__ int s_pos[BIG ? 1 : 8][66];       // (the big scenes' kernel serves one env per wavefront: its LDS must stay within a quarter of a CU's)
     __shared__ uint32_t s_meta[64], s_res[64];      // per work list: owner lane | clip planes << 8; vertices | list << 4 | front-facing fan triangles << 8
     __shared__ float s_occ_z[BIG ? MW_OCC_BINS + MW_OCC_BINS / 16 : 1];      // occlusion culling: farthest depth of the nearest wall per column bin, group maxima
-    __shared__ float s_occ_wall[BIG ? MW_OCC_CAP * 5 : 1];
     __shared__ int s_occ_n;
     float *s_rmq = reinterpret_cast<float *>(&s_clip[0]);      // big scenes, during the sift: range maxima of the column bins (9 levels x 256)
+    float4 *s_occ_wall = reinterpret_cast<float4 *>(s_rmq + 9 * MW_OCC_BINS);       // ... and the occluders, two quads each (xl, xr, A2, B2), (D, -, -, -)
+    static_assert(!BIG || sizeof(ClipSlot) * kClipSlots >= (9 * MW_OCC_BINS + 8 * MW_OCC_CAP) * sizeof(float), "the sift borrows the clipper's LDS");
     __shared__ uint16_t s_list[BIG ? 4096 : 1];
     __shared__ uint32_t s_key[BIG ? MW_ORDER_CAP : 1];        // big scenes: (depth bound << 16 | list index) of every record, for the visiting order      // big scenes: the polygons that pass the cheap tests (frustum, occlusion), in drawing order
 #ifdef MW_PERF_HOOKS      // (tools/perf/kgprof.py; the product build carries no time stamps)
@@ -269,6 +270,17 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
 #pragma unroll
     for (int q = 0; q < kWallPf; ++q) { pf_wall[q] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); pf_sgn[q] = 0.0f; }
     prefetch_occ();
+    // the env's entity table, one slot per lane of its group (the walks below ask for slot after slot: a chain of dependent
+    // global loads otherwise — with five slots and two passes, a quarter of PickupObjects' kernel)
+    const bool ent_pre = a.E <= L;
+    const int my_ekind = (ent_pre && sub < a.E) ? a.ekind[(size_t)sub * a.N + env] : 0;
+    const int my_estatic = (ent_pre && sub < a.E) ? a.estatic[(size_t)sub * a.N + env] : 0;
+    const int my_emesh = (ent_pre && sub < a.E && my_ekind == MW_ENT_MESH) ? a.emesh[(size_t)sub * a.N + env] : 0;
+    const int my_mesh_ntris = (ent_pre && sub < a.E && my_ekind == MW_ENT_MESH) ? (int)a.mesh[my_emesh].ntris : 0;
+    auto ent_kind = [&](int s0) { return ent_pre ? __shfl(my_ekind, s0, L) : a.ekind[(size_t)s0 * a.N + env]; };
+    auto ent_static = [&](int s0) { return ent_pre ? __shfl(my_estatic, s0, L) : a.estatic[(size_t)s0 * a.N + env]; };
+    auto ent_mesh = [&](int s0) { return ent_pre ? __shfl(my_emesh, s0, L) : a.emesh[(size_t)s0 * a.N + env]; };
+    auto ent_mesh_ntris = [&](int s0) { return ent_pre ? __shfl(my_mesh_ntris, s0, L) : (int)a.mesh[a.emesh[(size_t)s0 * a.N + env]].ntris; };
     // ---- the frame's GL state (every lane of the group evaluates it: same instruction stream)
     mwgl::Frame f;
     const double px = a.ax[env], py = a.ay[env], pz = a.az[env], dir = a.adir[env];
@@ -335,12 +347,12 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     uint32_t tile_mask = 0u;            // tile sub + k L lies in a drawn mesh entity's tile rectangle: bit k
     for (int pass = 0; pass < 2; ++pass) {
         for (int s0 = 0; s0 < a.E; ++s0) {
-            const int kind = a.ekind[(size_t)s0 * a.N + env];
+            const int kind = ent_kind(s0);
             if (kind == MW_ENT_NONE) continue;
-            const bool stat = proxy ? true : a.estatic[(size_t)s0 * a.N + env] != 0;
+            const bool stat = proxy ? true : ent_static(s0) != 0;
             if (stat != (pass == 0)) continue;
             if (kind == MW_ENT_MESH && !proxy) {
-                const int mid = a.emesh[(size_t)s0 * a.N + env];
+                const int mid = ent_mesh(s0);
                 const MwMeshDesc *mdp = a.mesh + mid;
                 const int md_ntris = (int)mdp->ntris;
                 const float pos[3] = {(float)a.epos[((size_t)0 * a.E + s0) * a.N + env], (float)a.epos[((size_t)1 * a.E + s0) * a.N + env],
@@ -441,12 +453,12 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         slot_out = -1; idbase_out = 0;
         for (int pass = 0; pass < 2; ++pass) {
             for (int s0 = 0; s0 < a.E; ++s0) {
-                const int kind = a.ekind[(size_t)s0 * a.N + env];
+                const int kind = ent_kind(s0);
                 if (kind == MW_ENT_NONE) continue;
-                const bool stat = proxy ? true : a.estatic[(size_t)s0 * a.N + env] != 0;
+                const bool stat = proxy ? true : ent_static(s0) != 0;
                 if (stat != (pass == 0)) continue;
                 if (kind == MW_ENT_MESH && !proxy) {
-                    if (s0 < 64 && ((mesh_in_view >> s0) & 1ull)) mt += (int)a.mesh[a.emesh[(size_t)s0 * a.N + env]].ntris;
+                    if (s0 < 64 && ((mesh_in_view >> s0) & 1ull)) mt += ent_mesh_ntris(s0);
                 } else if (kind == MW_ENT_BOX || proxy) {
                     if (nb == want) { slot_out = s0; idbase_out = mt; }
                     ++nb;
@@ -613,8 +625,8 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                 const uint64_t fm = __ballot(found);
                 const int j = n_found + (int)__popcll((unsigned long long)(fm & ((1ull << lane) - 1ull)));
                 if (found && j < MW_OCC_CAP) {
-                    float *ow = s_occ_wall + 5 * j;
-                    ow[0] = o_xl; ow[1] = o_xr; ow[2] = o_a2; ow[3] = o_b2; ow[4] = o_d;
+                    s_occ_wall[2 * j] = make_float4(o_xl, o_xr, o_a2, o_b2);
+                    s_occ_wall[2 * j + 1] = make_float4(o_d, 0.0f, 0.0f, 0.0f);
                 }
                 n_found += (int)__popcll((unsigned long long)fm);
             }
@@ -630,13 +642,17 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             float zb[4] = {1e30f, 1e30f, 1e30f, 1e30f}, xa[4], xb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) { const int b = lane + 64 * q; xa[q] = (float)b / bins_per_px; xb[q] = (float)(b + 1) / bins_per_px; }
+            // (a bin inside the wall's span has positive denominators at both ends — the wall was listed with positive ones at its own ends and
+            // they are linear in x —: the farther end is the smaller one, one reciprocal.  Its last-bit error is 1e-7 of the depth; the
+            // margin below is 1e-4.)
+#pragma unroll 2
             for (int j = 0; j < n_occ; ++j) {
-                const float *ow = s_occ_wall + 5 * j;
-                const float o0 = ow[0], o1 = ow[1], o2 = ow[2], o3 = ow[3], o4 = ow[4];
+                const float4 w = s_occ_wall[2 * j];
+                const float o4 = s_occ_wall[2 * j + 1].x;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float far = o4 * fmaxf(__builtin_amdgcn_rcpf(fmaf(o2, xa[q], o3)), __builtin_amdgcn_rcpf(fmaf(o2, xb[q], o3)));
-                    zb[q] = (xa[q] >= o0 && xb[q] <= o1) ? fminf(zb[q], far) : zb[q];
+                    const float far = o4 * __builtin_amdgcn_rcpf(fminf(fmaf(w.z, xa[q], w.w), fmaf(w.z, xb[q], w.w)));
+                    zb[q] = (xa[q] >= w.x && xb[q] <= w.y) ? fminf(zb[q], far) : zb[q];
                 }
             }
 #pragma unroll
