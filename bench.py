@@ -159,34 +159,45 @@ def reference_llvmpipe(config):
     return None
 
 
-def pmc_live(config, n):
-    """FETCH_SIZE / WRITE_SIZE per launch of the raster-phase kernels of `config` (RASTER_PHASE), read during this run: a
-    short child run of this script under rocprofv3 (--pmc with --kernel-trace only, one pass per counter) when the profiler
-    is on the box.  Returns a traffic dict like pmc_profiled's (sum + per-kernel breakdown), or None."""
+# counter passes of the live child runs: HBM bytes (one counter per pass, as MI355X_MICROARCH.md prescribes), then the SQ counters of the
+# VALU picture (separate passes too; --pmc with --kernel-trace only)
+PMC_PASSES = (("FETCH_SIZE",), ("WRITE_SIZE",),
+              ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES"),
+              ("SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_TRANS_F32"),
+              ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_CVT", "SQ_INSTS_SALU", "SQ_WAIT_INST_ANY"))
+N_SIMD = 256 * 4            # MI355X: 256 CUs x 4 SIMDs
+
+
+def pmc_live(config, n, dominant=None, kernel_ms=None):
+    """Counters of the raster-phase kernels of `config` (RASTER_PHASE), read during this run: short child runs of this script
+    under rocprofv3 (--pmc with --kernel-trace only, one pass per counter group: PMC_PASSES) when the profiler is on the box.
+    Returns (traffic dict like pmc_profiled's — sum + per-kernel breakdown —, valu dict of the dominant kernel), either may be None."""
     import csv
     import shutil
     import tempfile
     prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     # (not inside a profiler's child: this script's own child runs, or a run somebody else is profiling)
     if prof is None or os.environ.get("MW_BENCH_CHILD") or any(k.startswith(("ROCPROF", "ROCP_", "ROCTRACER")) for k in os.environ):
-        return None
+        return None, None
     import signal
     out = tempfile.mkdtemp(prefix="mwpmc_", dir="/tmp")
     env = dict(os.environ, MW_BENCH_CHILD="1", TMPDIR="/tmp")
     kernels = RASTER_PHASE[config]
-    vals = {"FETCH_SIZE": {k: [] for k in kernels}, "WRITE_SIZE": {k: [] for k in kernels}}
+    vals = {c: {k: [] for k in kernels} for grp in PMC_PASSES for c in grp}
     try:
-        for counter in vals:        # one counter per pass (MI355X_MICROARCH.md: separate --pmc passes), bounded in time
-            p = subprocess.Popen([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, counter), "-o", "pmc", "--",
+        for gi, grp in enumerate(PMC_PASSES):        # bounded in time
+            p = subprocess.Popen([prof, "--pmc", *grp, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(out, f"pass{gi}"), "-o", "pmc", "--",
                                   sys.executable, os.path.abspath(__file__), "--config", config, "--envs-per-gpu", str(n), "--steps", "6", "--warmup", "2",
-                                  "--prewarm-steps", "16", "--no-cpu-baseline", "--no-parity-check", "--no-also"], cwd="/tmp", env=env,
+                                  "--prewarm-steps", "64", "--windows", "1", "--no-cpu-baseline", "--no-parity-check", "--no-also"], cwd="/tmp", env=env,
                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 p.wait(timeout=75)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)        # the profiler and the run under it (its own process group)
                 p.wait()
-                return None
+                if gi < 2:
+                    return None, None
+                break                                   # (the traffic passes are in: report what there is)
         for root, _, files in os.walk(out):
             for f in files:
                 if f.endswith("counter_collection.csv"):
@@ -195,19 +206,52 @@ def pmc_live(config, n):
                             for k in kernels:       # (exact name or its signature: mw_rasterq_kernel must not take mw_rasterq4_kernel's rows)
                                 if r["Kernel_Name"] == k or r["Kernel_Name"].startswith(k + "(") or r["Kernel_Name"].startswith(k + " "):
                                     vals[r["Counter_Name"]][k].append(float(r["Counter_Value"]))
+        mean = lambda c, k: (sum(vals[c][k]) / len(vals[c][k])) if vals[c][k] else None       # noqa: E731
         per = {}
         for k in kernels:
-            fv, wv = vals["FETCH_SIZE"][k], vals["WRITE_SIZE"][k]
-            if fv and wv:           # KiB per launch (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KiB)
-                per[k] = (sum(fv) / len(fv) * 1024.0, sum(wv) / len(wv) * 1024.0)
+            fv, wv = mean("FETCH_SIZE", k), mean("WRITE_SIZE", k)
+            if fv is not None and wv is not None:           # KiB per launch (MI355X_MICROARCH.md: FETCH_SIZE / WRITE_SIZE count KiB)
+                per[k] = (fv * 1024.0, wv * 1024.0)
         if kernels[0] not in per:
-            return None
+            return None, None
         # gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE tallies 128-byte requests at 64 bytes — doubled in the sum
-        return _traffic_sum(per, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) --kernel-trace, child runs of this command; "
-                                 "FETCH_SIZE x 2 (gfx950); summed over the raster-phase kernels kernel_ms spans",
-                            {"launches": len(vals["FETCH_SIZE"][kernels[0]])})
+        traffic = _traffic_sum(per, "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each) --kernel-trace, child runs of this command; "
+                                    "FETCH_SIZE x 2 (gfx950); summed over the raster-phase kernels kernel_ms spans",
+                               {"launches": len(vals["FETCH_SIZE"][kernels[0]])})
+        valu = None
+        k = dominant or kernels[0]
+        iv = mean("SQ_INSTS_VALU", k) if k in kernels else None
+        if iv:
+            g = lambda c: mean(c, k)        # noqa: E731
+            fp = [g("SQ_INSTS_VALU_FMA_F32"), g("SQ_INSTS_VALU_MUL_F32"), g("SQ_INSTS_VALU_ADD_F32")]
+            trans, i32, cvt = g("SQ_INSTS_VALU_TRANS_F32"), g("SQ_INSTS_VALU_INT32"), g("SQ_INSTS_VALU_CVT")
+            act, wav = g("SQ_ACTIVE_INST_VALU"), g("SQ_WAVE_CYCLES")
+            valu = {"kernel": k, "insts_per_launch": iv, "insts_per_env": iv / n, "insts_per_64px_tile": iv / (n * 75),
+                    # SQ_ACTIVE_INST_VALU counts quad-cycles in which a SIMD's VALU works on an instruction (1.009 per instruction in
+                    # every kernel here, whatever its class); over the kernel's duration at the probe's clock that is the share of
+                    # SIMD time the VALU is busy
+                    "active_quadcycles_per_launch": act, "wave_quadcycles_per_launch": wav,
+                    "active_over_wave_cycles": (act / wav) if act and wav else None,
+                    # the classes of tools/ubench/clock_probe.hip: fp32 fma / mul / add issue in 2.4 cycles per wave64 instruction per SIMD,
+                    # transcendentals in 8.2, conversions and the integer / compare / select / packed / DPP group in 4.2 (part of the INT32
+                    # group — mov, and, add, arithmetic shifts — is full rate too: full_rate_share is a lower bound)
+                    "full_rate_share": (sum(fp) / iv) if all(x is not None for x in fp) else None,
+                    "trans_share": (trans / iv) if trans is not None else None,
+                    "int32_share": (i32 / iv) if i32 is not None else None,
+                    "cvt_share": (cvt / iv) if cvt is not None else None,
+                    "salu_insts_per_launch": g("SQ_INSTS_SALU"),
+                    "source": "rocprofv3 --pmc (SQ counters, one group per pass) --kernel-trace, child runs of this command"}
+            if valu["full_rate_share"] is not None and trans is not None and kernel_ms:
+                full = sum(fp)
+                cyc = (full * 2.4 + trans * 8.2 + (iv - full - trans) * 4.2) / N_SIMD        # cycles per SIMD if the VALU never idled
+                valu["model"] = {"cycles_per_simd": cyc, "kernel_ms": kernel_ms, "clock_ghz_for_100pct_valu": cyc / (kernel_ms * 1e-3) / 1e9,
+                                 "valu_issue_share_at_2p2_ghz": cyc / (kernel_ms * 1e-3) / 2.2e9,
+                                 "note": "issue cycles per SIMD from the class mix (2.4 / 4.2 / 8.2 cycles per wave64 instruction: profiles/r06/clock_probe.txt) "
+                                         "/ the kernel's HIP-event duration = the shader clock at which the kernel would be 100 % VALU-issue bound; "
+                                         "the probe measures 1.8-2.4 GHz under VALU load"}
+        return traffic, valu
     except Exception:  # noqa: BLE001
-        return None
+        return None, None
     finally:
         shutil.rmtree(out, ignore_errors=True)
 
@@ -409,6 +453,18 @@ def measure(args, ctx, config, n, steps, warmup, headline):
         gath.wait()
     barrier()
     elapsed = time.perf_counter() - t0
+    # more windows of the same K steps behind the contract's one (each between barriers): `value` stays the first window's; the
+    # list shows how far a region of a few milliseconds scatters
+    window_s = [elapsed]
+    for _ in range(max(0, args.windows - 1)):
+        barrier()
+        tw = time.perf_counter()
+        for t in range(warmup, total):
+            step(t)
+        if gath is not None:
+            gath.wait()
+        barrier()
+        window_s.append(time.perf_counter() - tw)
     raster_ms = setup_ms = 0.0
     launches = parity = 0
     if not args.dry:
@@ -423,6 +479,7 @@ def measure(args, ctx, config, n, steps, warmup, headline):
     del vec
 
     elapsed_max = max_over_ranks(dist, elapsed, device=device) if dist is not None else elapsed
+    window_max = [elapsed_max] + [max_over_ranks(dist, w, device=device) if dist is not None else w for w in window_s[1:]]       # (every rank: a collective)
     achieved = algo_bytes * n / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else None
     mine = {"rank": rank, "device": local, "envs": n, "first_seed": plan["first_seed"], "elapsed_s": elapsed,
             "kernel_ms": raster_ms, "setup_kernel_ms": setup_ms, "launches_timed": launches, "achieved": achieved,
@@ -436,7 +493,7 @@ def measure(args, ctx, config, n, steps, warmup, headline):
     slow = max(per_rank, key=lambda r: r["kernel_ms"])          # the roofline entry is the slowest rank's
     traffic, valu = pmc_profiled(dominant, config, n)
     # counters read during THIS run when the profiler is on the box (short child runs under rocprofv3), else the committed profile's
-    live = pmc_live(config, n) if (world == 1 and not args.dry and not args.no_pmc) else None
+    live, valu_live = pmc_live(config, n, dominant, slow["kernel_ms"]) if (world == 1 and not args.dry and not args.no_pmc) else (None, None)
     if live is not None:
         traffic = live
     out = {
@@ -457,6 +514,9 @@ def measure(args, ctx, config, n, steps, warmup, headline):
                    "name": config, "envs_per_gpu": n, "parallelism": f"env-shard x{world}",
                    "obs_allgather": gath is not None, "torch_distributed": dist is not None},
         "samples_per_s": steps_per_s * 80 * 60 * 8,
+        "windows": (lambda v: {"n": len(v), "steps_each": steps, "values": v, "median": sorted(v)[len(v) // 2], "min": min(v), "max": max(v),
+                               "note": "env-steps/s of consecutive timed windows of K steps each (rank 0's clock); `value` is the first — the contract's — window"})(
+            [world * n * steps / w for w in window_max]),
         "prewarm_s": prewarm_s,
         "parity_checked": sum(r["parity_checked"] for r in per_rank),
         "roofline": {
@@ -469,6 +529,7 @@ def measure(args, ctx, config, n, steps, warmup, headline):
             "frac": slow["frac"],
             "traffic": traffic["bytes_per_launch"] if traffic else None,
             "traffic_profiled": traffic,
+            "valu": valu_live,
             "valu_profiled": valu,
             "algorithmic_bytes_per_launch": algo_bytes * n,
             "kernel_ms": slow["kernel_ms"],
@@ -526,6 +587,7 @@ def main():
                     help="pre-warm with exactly this many steps instead of PREWARM_S seconds (A/B runs: the timed region then "
                          "covers the same episode phases in both)")
     ap.add_argument("--no-also", action="store_true", help="skip the extra single-GPU configs timed after the headline (the `also` list)")
+    ap.add_argument("--windows", type=int, default=5, help="timed windows of K steps each; `value` is the first one's (the contract's), the others show the spread")
     ap.add_argument("--no-pmc", action="store_true", help="skip the child runs under rocprofv3 that read roofline.traffic during the run")
     ap.add_argument("--dry", action="store_true", help="CPU dry run of the multi-rank path (gloo, no engine)")
     ap.add_argument("--force-dist", action="store_true",

@@ -9,6 +9,14 @@ reset -> (obs, infos), step -> 5-tuple, autoreset mode "same-step": the observat
 a finished episode is the first one of the next episode).  Observations, rewards and flags stay
 torch tensors on the engine's GPU by default (`to_numpy=True` copies them to the host like a
 classic VectorEnv); actions may be a torch tensor, a numpy array or a list.
+
+**What a same-step consumer does NOT get: `final_obs`.**  Gymnasium's SAME_STEP mode promises the finished episode's last
+observation under info["final_obs"]; the engine never draws it (the step's only frame is the next episode's first one —
+the reference leaves resets to the caller and renders once per step, miniworld.py:670-730).  Code that bootstraps a value
+from final_obs on truncation must take the returned observation's predecessor instead.  What IS there: info["_final_info"]
+(bool[N], for every env family, also those without info keys) and — for the families that have info keys
+(CollectHealth's health, TMaze / YMaze's goal_pos) — info["final_info"], the finished episodes' own values.  The arrays
+under final_info are copies: they stay valid after the next step.
 """
 from __future__ import annotations
 
@@ -53,13 +61,16 @@ class MiniWorldVectorEnv(VectorEnvBase):
         actions = actions.to(device=self.vec.engine.device, dtype=torch.int32)
         obs, rew, term, trunc = self.vec.step(actions)
         info = self._infos()
-        if info and self.vec.autoreset:
-            # gymnasium's same-step convention: the finished episodes' own info under "final_info", "_final_info" masks the envs it is
-            # valid for (no "final_obs": the engine renders the new episode's first frame only)
+        if self.vec.autoreset:
+            # gymnasium's same-step convention: "_final_info" masks the envs whose episode ended with this step (every family); the
+            # finished episodes' own info under "final_info" where the family has info keys — clones, the engine's buffers are
+            # rewritten by the next step.  (No "final_obs": see the module's docstring.)
             done = self._out((term | trunc).bool())
-            final = {k: self._out(v) for k, v in self.vec.final_infos().items()}
-            final.update({"_" + k: done for k in list(final)})
-            info["final_info"], info["_final_info"] = final, done
+            info["_final_info"] = done
+            if info.keys() - {"_final_info"}:
+                final = {k: (self._out(v) if self.to_numpy else v.clone()) for k, v in self.vec.final_infos().items()}
+                final.update({"_" + k: done for k in list(final)})
+                info["final_info"] = final
         return self._out(obs), self._out(rew), self._out(term.bool()), self._out(trunc.bool()), info
 
     def render(self):

@@ -695,6 +695,34 @@ def test_final_info_is_the_finished_episodes_info_under_same_step_autoreset():
     envs.close()
 
 
+def test_final_info_mask_exists_for_every_family_and_final_values_are_copies():
+    """A family without info keys (Hallway) still reports which envs finished ("_final_info"); and with tensors left on the
+    device the values under final_info are copies — a consumer may hold on to them across the next step."""
+    import torch
+    from miniworld_amd.vector import MiniWorldVectorEnv
+    envs = MiniWorldVectorEnv("MiniWorld-Hallway-v0", 64, seed=3)
+    envs.reset(seed=3)
+    seen = 0
+    for t in range(260):                          # max_episode_steps = 250 (hallway.py:31): every env finishes in here
+        _, _, term, trunc, infos = envs.step(torch.full((64,), 2 if t % 3 else 0, dtype=torch.int32, device="cuda"))
+        assert set(infos) == {"_final_info"}
+        assert torch.equal(infos["_final_info"], (term | trunc))
+        seen += int(infos["_final_info"].sum())
+    assert seen >= 64
+    envs.close()
+    envs = MiniWorldVectorEnv("MiniWorld-TMaze-v0", 8, seed=5)
+    envs.reset(seed=5)
+    for t in range(280):
+        infos = envs.step(torch.zeros(8, dtype=torch.int32, device="cuda"))[4]
+    held = infos["final_info"]["goal_pos"]
+    snapshot = held.clone()
+    for t in range(280):                          # the next episodes end too: the engine's buffer is rewritten
+        infos = envs.step(torch.ones(8, dtype=torch.int32, device="cuda"))[4]
+    assert torch.equal(held, snapshot)
+    assert held.data_ptr() != infos["final_info"]["goal_pos"].data_ptr()
+    envs.close()
+
+
 def _assert_same_world(vec, st, i, h, tag):
     """Device state of env i == host env h (same seed, same episode): poses, entity table, per-episode parameters."""
     from miniworld_amd.entity import Box, MeshEnt
