@@ -19,7 +19,7 @@
 #define MW_ENVHDR 640         // floats per env: sky, light colours, mesh-entity table (geometry kernel -> raster kernels)
 #define MW_MAX_MESH_ENTS 21   // mesh entities drawn per env
 #define MW_HDR_MESH 32        // first float of the mesh-entity table
-#define MW_K1_PROF_SLOTS 28
+#define MW_K1_PROF_SLOTS 32
 // mesh path (mw_mesh.h, mw_raster_mesh.hip)
 #define MW_PLANE_REC 16         // plane cache record, one 64-byte sector: (w plane, tex) (r plane, state) (g plane, s.a0) (b plane, s.dadx);
 #define MW_PLANE_XTRA 4         //   a textured mesh's fifth quad (s.dady, t plane) lives in a second array behind the records ([N][cap][4]):

@@ -417,6 +417,9 @@ int pick_waves_per_env(const mw_engine *e)
     // enough wavefronts to fill 256 CUs x 4 SIMDs x 7 resident waves several times over (measured:
     // 15-25 waves per env beat 5 by ~7 % at 4096 envs), in divisors of n_tiles
     int best = n_tiles;
+#ifdef MW_PERF_HOOKS
+    if (const char *s = getenv("MW_WAVES_PER_ENV")) { const int v = atoi(s); if (v > 0 && n_tiles % v == 0) return v; }
+#endif
     for (int w = 1; w <= n_tiles; ++w) {
         if (n_tiles % w) continue;
         if ((long long)e->cfg.num_envs * w >= 49152) { best = w; break; }

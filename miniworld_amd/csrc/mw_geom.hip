@@ -236,7 +236,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     const unsigned long long rt_start = KGP_ON ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz, the same clock on every CU
     [[maybe_unused]] unsigned long long ts[4] = {0, 0, 0, 0};     // inside the sift: occluder walls, column bins, boxes, polygons
     [[maybe_unused]] int kp_nocc = 0, kp_nkept = 0, kp_nclip = 0;
-    [[maybe_unused]] unsigned long long kp_clip = 0, kp_emit = 0;
+    [[maybe_unused]] unsigned long long kp_clip = 0, kp_emit = 0, kp_e_shfl = 0, kp_e_setup = 0, kp_e_write = 0;
     const int lane = threadIdx.x;
     const int epw = 64 / L, sub = lane & (L - 1), grp = lane / L;
     const int rel = (int)blockIdx.x * epw + grp;
@@ -279,7 +279,6 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     const int my_mesh_ntris = (ent_pre && sub < a.E && my_ekind == MW_ENT_MESH) ? (int)a.mesh[my_emesh].ntris : 0;
     auto ent_kind = [&](int s0) { return ent_pre ? __shfl(my_ekind, s0, L) : a.ekind[(size_t)s0 * a.N + env]; };
     auto ent_static = [&](int s0) { return ent_pre ? __shfl(my_estatic, s0, L) : a.estatic[(size_t)s0 * a.N + env]; };
-    auto ent_mesh = [&](int s0) { return ent_pre ? __shfl(my_emesh, s0, L) : a.emesh[(size_t)s0 * a.N + env]; };
     auto ent_mesh_ntris = [&](int s0) { return ent_pre ? __shfl(my_mesh_ntris, s0, L) : (int)a.mesh[a.emesh[(size_t)s0 * a.N + env]].ntris; };
     // ---- the frame's GL state (every lane of the group evaluates it: same instruction stream)
     mwgl::Frame f;
@@ -345,6 +344,78 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
     int total_meshes = 0, total_mesh_tris = 0, total_boxes = 0;
     uint64_t mesh_in_view = 0ull;       // per entity slot: a mesh entity that is drawn
     uint32_t tile_mask = 0u;            // tile sub + k L lies in a drawn mesh entity's tile rectangle: bit k
+    // What a mesh entity's place in the frame takes — its transform, the view test on its bounding sphere, the tile rectangle —
+    // depends on the entity alone: lane s of the group works it out for slot s, all slots side by side (a serial walk with every
+    // lane repeating every entity was 26 k of PickupObjects' 95 k cycles); the walk behind it only counts and writes.
+    struct MeshView { bool in_view; uint32_t rect; int ntris, mid, first, tex; mwgl::Xform ex; };
+    auto mesh_view = [&](int s0, MeshView &mv) {
+        const int mid = a.emesh[(size_t)s0 * a.N + env];
+        const MwMeshDesc *mdp = a.mesh + mid;
+        mv.mid = mid; mv.ntris = (int)mdp->ntris; mv.first = (int)mdp->first; mv.tex = (int)mdp->tex;
+        const float pos[3] = {(float)a.epos[((size_t)0 * a.E + s0) * a.N + env], (float)a.epos[((size_t)1 * a.E + s0) * a.N + env],
+                              (float)a.epos[((size_t)2 * a.E + s0) * a.N + env]};
+        const float scale = (float)a.egeom[((size_t)6 * a.E + s0) * a.N + env];
+        mwgl::entity_xform(f, pos, (float)(a.edir[(size_t)s0 * a.N + env] * 180 / kPi), scale, true, mv.ex);
+        // whole-entity frustum test on the bounding sphere (conservative): clip-space distance to the five planes
+        bool in_view = true;
+        uint32_t rect;      // the tiles the entity's bounding sphere can touch: tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24 (image rows)
+        {
+            // (the sphere about the bounding box's centre: a ball's origin lies at its foot)
+            const float brad = mdp->radius * scale * 1.001f + 1e-3f;
+            mwgl::Vert o;
+            const float ctr[3] = {mdp->center[0], mdp->center[1], mdp->center[2]};
+            mwgl::transform_vertex(f, mv.ex, ctr, o);
+            const float w = o.clip[3];
+            const float p00 = f.proj.m[0], p11 = f.proj.m[5];
+            float xlo = -1.0f, xhi = 1.0f, ylo = -1.0f, yhi = 1.0f;
+            if (!top) {
+                const float lx = sqrtf(fmaf(p00, p00, 1.0f)), ly = sqrtf(fmaf(p11, p11, 1.0f));
+                in_view = !(w + brad < 0.04f) && !(w - fabsf(o.clip[0]) < -(brad * lx)) && !(w - fabsf(o.clip[1]) < -(brad * ly));
+                if (w - brad > 0.04f) {
+                    // eye-space box around the sphere, projected: x / d with d in [w - r, w + r]
+                    const float dn = 1.0f / (w - brad), df = 1.0f / (w + brad);
+                    const float nxl = o.clip[0] - brad * p00, nxh = o.clip[0] + brad * p00, nyl = o.clip[1] - brad * p11, nyh = o.clip[1] + brad * p11;
+                    xlo = fminf(nxl * dn, nxl * df); xhi = fmaxf(nxh * dn, nxh * df);
+                    ylo = fminf(nyl * dn, nyl * df); yhi = fmaxf(nyh * dn, nyh * df);
+                }
+            } else {
+                xlo = o.clip[0] - brad * fabsf(p00); xhi = o.clip[0] + brad * fabsf(p00);
+                ylo = o.clip[1] - brad * fabsf(p11); yhi = o.clip[1] + brad * fabsf(p11);
+            }
+            const float Wf = (float)a.W, Hf = (float)a.H;
+            int x0 = (int)floorf(fmaxf((xlo * 0.5f + 0.5f) * Wf - 1.5f, 0.0f)), x1 = (int)fminf((xhi * 0.5f + 0.5f) * Wf + 1.5f, Wf - 1.0f);
+            int g0 = (int)floorf(fmaxf((ylo * 0.5f + 0.5f) * Hf - 1.5f, 0.0f)), g1 = (int)fminf((yhi * 0.5f + 0.5f) * Hf + 1.5f, Hf - 1.0f);
+            // ... cut down to the window bounds of the bounding box's corners when all eight lie in front of the eye (a convex
+            // combination of the corners then projects to a convex combination of their projections; a key is a thin
+            // slab inside a sphere of its length)
+            if (in_view) {
+                bool front = true;
+                float cxl = 1e30f, cxh = -1e30f, cyl = 1e30f, cyh = -1e30f;
+                for (int c = 0; c < 8; ++c) {
+                    const float p[3] = {(c & 1) ? mdp->bmax[0] : mdp->bmin[0], (c & 2) ? mdp->bmax[1] : mdp->bmin[1], (c & 4) ? mdp->bmax[2] : mdp->bmin[2]};
+                    mwgl::Vert q;
+                    mwgl::transform_vertex(f, mv.ex, p, q);
+                    front &= top || q.clip[3] > 0.05f;
+                    cxl = fminf(cxl, q.win[0]); cxh = fmaxf(cxh, q.win[0]); cyl = fminf(cyl, q.win[1]); cyh = fmaxf(cyh, q.win[1]);
+                }
+                if (front && cxl <= cxh && cyl <= cyh) {
+                    x0 = max(x0, (int)floorf(fmaxf(cxl - 1.5f, 0.0f))); x1 = min(x1, (int)fminf(cxh + 1.5f, Wf - 1.0f));
+                    g0 = max(g0, (int)floorf(fmaxf(cyl - 1.5f, 0.0f))); g1 = min(g1, (int)fminf(cyh + 1.5f, Hf - 1.0f));
+                }
+            }
+            if (x1 < x0 || g1 < g0) in_view = false;
+            const int y0 = a.H - 1 - g1, y1 = a.H - 1 - g0;
+            rect = (uint32_t)(x0 / MW_TILE_W) | ((uint32_t)(x1 / MW_TILE_W) << 8) | ((uint32_t)(y0 / MW_TILE_H) << 16) | ((uint32_t)(y1 / MW_TILE_H) << 24);
+        }
+        mv.in_view = in_view; mv.rect = rect;
+    };
+    // (a slot's lane keeps what its header entry still needs at the end of the kernel — nothing written by one lane is read back by another)
+    int my_mesh_j = -1, my_boxes_before = 0, my_tris_before = 0;
+    uint32_t big_mask = 0u;             // the drawn meshes of 1 024 triangles and more (entry numbers): first in the entity kernel's list
+    static_assert(MW_MAX_MESH_ENTS <= 32, "one bit per drawn mesh");
+    MeshView my_mv;
+    my_mv.in_view = false; my_mv.rect = 0u; my_mv.ntris = 0; my_mv.mid = 0; my_mv.first = 0; my_mv.tex = -1;
+    if (ent_pre && !proxy && sub < a.E && my_ekind == MW_ENT_MESH) mesh_view(sub, my_mv);
     for (int pass = 0; pass < 2; ++pass) {
         for (int s0 = 0; s0 < a.E; ++s0) {
             const int kind = ent_kind(s0);
@@ -352,81 +423,31 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
             const bool stat = proxy ? true : ent_static(s0) != 0;
             if (stat != (pass == 0)) continue;
             if (kind == MW_ENT_MESH && !proxy) {
-                const int mid = ent_mesh(s0);
-                const MwMeshDesc *mdp = a.mesh + mid;
-                const int md_ntris = (int)mdp->ntris;
-                const float pos[3] = {(float)a.epos[((size_t)0 * a.E + s0) * a.N + env], (float)a.epos[((size_t)1 * a.E + s0) * a.N + env],
-                                      (float)a.epos[((size_t)2 * a.E + s0) * a.N + env]};
-                const float scale = (float)a.egeom[((size_t)6 * a.E + s0) * a.N + env];
-                mwgl::Xform ex;
-                mwgl::entity_xform(f, pos, (float)(a.edir[(size_t)s0 * a.N + env] * 180 / kPi), scale, true, ex);
-                // whole-entity frustum test on the bounding sphere (conservative): clip-space distance to the five planes
-                bool in_view = true;
-                uint32_t rect;      // the tiles the entity's bounding sphere can touch: tx0 | tx1 << 8 | ty0 << 16 | ty1 << 24 (image rows)
-                {
-                    // (the sphere about the bounding box's centre: a ball's origin lies at its foot)
-                    const float brad = mdp->radius * scale * 1.001f + 1e-3f;
-                    mwgl::Vert o;
-                    const float ctr[3] = {mdp->center[0], mdp->center[1], mdp->center[2]};
-                    mwgl::transform_vertex(f, ex, ctr, o);
-                    const float w = o.clip[3];
-                    const float p00 = f.proj.m[0], p11 = f.proj.m[5];
-                    float xlo = -1.0f, xhi = 1.0f, ylo = -1.0f, yhi = 1.0f;
-                    if (!top) {
-                        const float lx = sqrtf(fmaf(p00, p00, 1.0f)), ly = sqrtf(fmaf(p11, p11, 1.0f));
-                        in_view = !(w + brad < 0.04f) && !(w - fabsf(o.clip[0]) < -(brad * lx)) && !(w - fabsf(o.clip[1]) < -(brad * ly));
-                        if (w - brad > 0.04f) {
-                            // eye-space box around the sphere, projected: x / d with d in [w - r, w + r]
-                            const float dn = 1.0f / (w - brad), df = 1.0f / (w + brad);
-                            const float nxl = o.clip[0] - brad * p00, nxh = o.clip[0] + brad * p00, nyl = o.clip[1] - brad * p11, nyh = o.clip[1] + brad * p11;
-                            xlo = fminf(nxl * dn, nxl * df); xhi = fmaxf(nxh * dn, nxh * df);
-                            ylo = fminf(nyl * dn, nyl * df); yhi = fmaxf(nyh * dn, nyh * df);
-                        }
-                    } else {
-                        xlo = o.clip[0] - brad * fabsf(p00); xhi = o.clip[0] + brad * fabsf(p00);
-                        ylo = o.clip[1] - brad * fabsf(p11); yhi = o.clip[1] + brad * fabsf(p11);
-                    }
-                    const float Wf = (float)a.W, Hf = (float)a.H;
-                    int x0 = (int)floorf(fmaxf((xlo * 0.5f + 0.5f) * Wf - 1.5f, 0.0f)), x1 = (int)fminf((xhi * 0.5f + 0.5f) * Wf + 1.5f, Wf - 1.0f);
-                    int g0 = (int)floorf(fmaxf((ylo * 0.5f + 0.5f) * Hf - 1.5f, 0.0f)), g1 = (int)fminf((yhi * 0.5f + 0.5f) * Hf + 1.5f, Hf - 1.0f);
-                    // ... cut down to the window bounds of the bounding box's corners when all eight lie in front of the eye (a convex
-                    // combination of the corners then projects to a convex combination of their projections; a key is a thin
-                    // slab inside a sphere of its length)
-                    if (in_view) {
-                        bool front = true;
-                        float cxl = 1e30f, cxh = -1e30f, cyl = 1e30f, cyh = -1e30f;
-                        for (int c = 0; c < 8; ++c) {
-                            const float p[3] = {(c & 1) ? mdp->bmax[0] : mdp->bmin[0], (c & 2) ? mdp->bmax[1] : mdp->bmin[1], (c & 4) ? mdp->bmax[2] : mdp->bmin[2]};
-                            mwgl::Vert q;
-                            mwgl::transform_vertex(f, ex, p, q);
-                            front &= top || q.clip[3] > 0.05f;
-                            cxl = fminf(cxl, q.win[0]); cxh = fmaxf(cxh, q.win[0]); cyl = fminf(cyl, q.win[1]); cyh = fmaxf(cyh, q.win[1]);
-                        }
-                        if (front && cxl <= cxh && cyl <= cyh) {
-                            x0 = max(x0, (int)floorf(fmaxf(cxl - 1.5f, 0.0f))); x1 = min(x1, (int)fminf(cxh + 1.5f, Wf - 1.0f));
-                            g0 = max(g0, (int)floorf(fmaxf(cyl - 1.5f, 0.0f))); g1 = min(g1, (int)fminf(cyh + 1.5f, Hf - 1.0f));
-                        }
-                    }
-                    if (x1 < x0 || g1 < g0) in_view = false;
-                    const int y0 = a.H - 1 - g1, y1 = a.H - 1 - g0;
-                    rect = (uint32_t)(x0 / MW_TILE_W) | ((uint32_t)(x1 / MW_TILE_W) << 8) | ((uint32_t)(y0 / MW_TILE_H) << 16) | ((uint32_t)(y1 / MW_TILE_H) << 24);
-                }
+                // (with the slots' views on their lanes: the slot's lane holds everything, the others ask for what they need)
+                MeshView walk_mv;
+                if (!ent_pre) mesh_view(s0, walk_mv);
+                const bool in_view = ent_pre ? __shfl((int)my_mv.in_view, s0, L) != 0 : walk_mv.in_view;
                 if (!in_view) continue;
+                const uint32_t rect = ent_pre ? (uint32_t)__shfl((int)my_mv.rect, s0, L) : walk_mv.rect;
+                const int md_ntris = ent_pre ? __shfl(my_mv.ntris, s0, L) : walk_mv.ntris;
                 if (total_meshes < MW_MAX_MESH_ENTS && total_mesh_tris + md_ntris < 0xC000 && s0 < 64) {
-                    if (sub == 0 && live) {
+                    if (md_ntris >= 1024) big_mask |= 1u << total_meshes;
+                    if (ent_pre && sub == s0) { my_mesh_j = total_meshes; my_boxes_before = total_boxes; my_tris_before = total_mesh_tris; }
+                    if ((ent_pre ? sub == s0 : sub == 0) && live) {
+                        const MeshView &mv = ent_pre ? my_mv : walk_mv;
                         float *m = hdr + MW_HDR_MESH + MW_HDR_MESH_STRIDE * total_meshes;
                         m[0] = __int_as_float(s0);
                         m[1] = __int_as_float(total_boxes);         // boxes drawn before: turned into the first draw id at the end
                         m[2] = __int_as_float(md_ntris);
-                        m[3] = __int_as_float((int)mdp->first);
-                        m[4] = __int_as_float((int)mdp->tex);
-                        m[5] = ex.nscale;
-                        m[6] = ex.light[0]; m[7] = ex.light[1]; m[8] = ex.light[2];
+                        m[3] = __int_as_float(mv.first);
+                        m[4] = __int_as_float(mv.tex);
+                        m[5] = mv.ex.nscale;
+                        m[6] = mv.ex.light[0]; m[7] = mv.ex.light[1]; m[8] = mv.ex.light[2];
 #pragma unroll
-                        for (int k = 0; k < 16; ++k) m[9 + k] = ex.mvp.m[k];
+                        for (int k = 0; k < 16; ++k) m[9 + k] = mv.ex.mvp.m[k];
                         m[25] = __int_as_float(total_mesh_tris);    // mesh triangles drawn before
                         m[26] = __uint_as_float(rect);
-                        m[27] = __int_as_float(mid);
+                        m[27] = __int_as_float(mv.mid);
                     }
                     if (a.tile_list) {
                         // the tiles this lane answers for — sub, sub + L, ... — inside the entity's tile rectangle
@@ -1055,6 +1076,7 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         // position from the owner's (base_now), setup, record
         auto emit_fans = [&](int v0, int base_now) {
             const int nb = n_clip - v0 < kClipSlots ? n_clip - v0 : kClipSlots;
+            [[maybe_unused]] unsigned long long e_prev = KGP_ON ? __builtin_readcyclecounter() : 0ull;
             for (int b0 = 0; b0 < nb; b0 += 8) {
                 const int slot = b0 + (lane >> 3);
                 const bool valid = slot < nb;
@@ -1065,15 +1087,25 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
                 const int o_base = __shfl(base_now, owner), o_tex = __shfl(tex, owner), o_env = __shfl(env, owner), o_live = __shfl((int)live, owner);
                 const uint32_t o_tag = (uint32_t)__shfl((int)tag, owner), o_idb = (uint32_t)__shfl((int)id_base, owner);
                 const float o_col[3] = {__shfl(va.col[0], owner), __shfl(va.col[1], owner), __shfl(va.col[2], owner)};
+                [[maybe_unused]] const unsigned long long e0 = KGP_ON ? __builtin_readcyclecounter() : 0ull;
+                if (KGP_ON) kp_e_shfl += e0 - e_prev;
+                bool e_ok = false;
+                mwgl::TriSetup t2;
+                int idx = 0;
+                const mwgl::ClipVert *r = s_clip[slot].l[cur];
                 if (ce >= 2 && ce < n && ((fm >> ce) & 1u)) {
-                    const mwgl::ClipVert *r = s_clip[slot].l[cur];
-                    const int idx = o_base + __popc(fm & ((1u << ce) - 1u));
-                    mwgl::TriSetup t2;
-                    if (mwgl::setup_triangle(to_vert(r[ce - 1], o_col), to_vert(r[ce], o_col), to_vert(r[0], o_col), ms, o_tex >= 0, t2) && o_live && idx < a.max_vis) {
+                    idx = o_base + __popc(fm & ((1u << ce) - 1u));
+                    e_ok = mwgl::setup_triangle(to_vert(r[ce - 1], o_col), to_vert(r[ce], o_col), to_vert(r[0], o_col), ms, o_tex >= 0, t2) && o_live && idx < a.max_vis;
+                }
+                [[maybe_unused]] const unsigned long long e1 = KGP_ON ? __builtin_readcyclecounter() : 0ull;
+                if (KGP_ON) kp_e_setup += e1 - e0;
+                if (e_ok) {
+                    {
                         const uint32_t zlo = (SFIX == 8 ? mwrec::write_tri_s<8>(a, o_env, idx, o_tag ? o_tag : (uint32_t)idx + o_idb, t2, o_tex) : mwrec::write_tri(a, o_env, idx, o_tag ? o_tag : (uint32_t)idx + o_idb, t2, o_tex, S));
                         if (BIG && idx < MW_ORDER_CAP) s_key[idx] = (zlo << 16) | (uint32_t)idx;
                     }
                 }
+                if (KGP_ON) { e_prev = __builtin_readcyclecounter(); kp_e_write += e_prev - e1; }
             }
             wave_lds_sync();
         };
@@ -1194,11 +1226,18 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         pp[0] = tp[0] - tstart; pp[1] = tp[1] - tp[0]; for (int i = 2; i < 7; ++i) pp[i] = racc[i];
         pp[7] = __builtin_readcyclecounter() - tprev;
         pp[20] = rtot[0]; pp[21] = rtot[1]; pp[22] = rvert[0]; pp[23] = rvert[1];
-        pp[24] = kp_clip; pp[25] = kp_emit; pp[26] = (unsigned long long)kp_nclip; pp[27] = 0;
+        pp[24] = kp_clip; pp[25] = kp_emit; pp[26] = (unsigned long long)kp_nclip; pp[27] = 0; pp[28] = kp_e_shfl; pp[29] = kp_e_setup; pp[30] = kp_e_write;
         pp[8] = rt_start; pp[9] = __builtin_amdgcn_s_memrealtime();
         pp[10] = (unsigned long long)np; pp[11] = (unsigned long long)npd; pp[12] = (unsigned long long)count; pp[13] = (unsigned long long)n_rounds;
         pp[14] = (unsigned long long)kp_nocc; pp[15] = (unsigned long long)kp_nkept;
         pp[16] = ts[0] - tp[0]; pp[17] = ts[1] - ts[0]; pp[18] = ts[2] - ts[1]; pp[19] = ts[3] - ts[2];
+    }
+    if (ent_pre && my_mesh_j >= 0 && live) {
+        // the mesh's first draw id: the records drawn before it plus the mesh triangles drawn before it
+        const int nb = total_boxes < 64 ? total_boxes : 64;
+        const int end_pos = marker ? pos[nb] : count;
+        const int p0 = my_boxes_before < nb ? pos[my_boxes_before] : end_pos;
+        hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * my_mesh_j + 1] = __int_as_float(p0 + my_tris_before);
     }
     if (sub == 0 && live) {
         a.nvis[env] = count < a.max_vis ? count : a.max_vis;
@@ -1208,24 +1247,25 @@ __device__ inline void geom_body(const MwArgs &a, int view_flags, int S_, int L,
         for (int i = 0; i < 3; ++i) { hdr[4 + i] = f.l_amb[i]; hdr[8 + i] = f.l_dif[i]; }
         const int nb = total_boxes < 64 ? total_boxes : 64;
         const int end_pos = marker ? pos[nb] : count;
-        for (int j = 0; j < total_meshes; ++j) {
-            float *m = hdr + MW_HDR_MESH + MW_HDR_MESH_STRIDE * j;
-            const int before = __float_as_int(m[1]);
-            const int p0 = before < nb ? pos[before] : end_pos;
-            m[1] = __int_as_float(p0 + __float_as_int(m[25]));
+        if (!ent_pre) {
+            for (int j = 0; j < total_meshes; ++j) {
+                float *m = hdr + MW_HDR_MESH + MW_HDR_MESH_STRIDE * j;
+                const int before = __float_as_int(m[1]);
+                const int p0 = before < nb ? pos[before] : end_pos;
+                m[1] = __int_as_float(p0 + __float_as_int(m[25]));
+            }
         }
         if (count + total_mesh_tris >= 0xFFF0) atomicOr(a.status, MW_ST_VIS_OVERFLOW);      // 16-bit draw ids
         if (a.ent_list && total_meshes > 0) {
             // the work list of the mesh entity kernel: balls before keys (a workgroup per entity; the long ones start first)
-            int nbig = 0;
-            for (int j = 0; j < total_meshes; ++j) nbig += __float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 2]) >= 1024 ? 1 : 0;
+            const int nbig = __popc(big_mask);
             const int xl = env % a.n_xcc;        // the XCD whose workgroups draw this env's entities
             int ib = nbig ? atomicAdd(a.ent_list_n + MW_CNT_LONG + xl, nbig) : 0;
             int is = total_meshes - nbig ? atomicAdd(a.ent_list_n + MW_CNT_SHORT + xl, total_meshes - nbig) : 0;
             uint32_t *l_long = a.ent_list + (size_t)xl * a.ent_list_cap, *l_short = a.ent_list + (size_t)(8 + xl) * a.ent_list_cap;
             for (int j = 0; j < total_meshes; ++j) {
                 const uint32_t item = (uint32_t)env | ((uint32_t)j << 24);
-                if (__float_as_int(hdr[MW_HDR_MESH + MW_HDR_MESH_STRIDE * j + 2]) >= 1024) { if (ib < a.ent_list_cap) l_long[ib] = item; ++ib; }
+                if ((big_mask >> j) & 1u) { if (ib < a.ent_list_cap) l_long[ib] = item; ++ib; }
                 else { if (is < a.ent_list_cap) l_short[is] = item; ++is; }
             }
         }

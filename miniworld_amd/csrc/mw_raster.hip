@@ -42,6 +42,7 @@ __device__ inline void raster_env_tiles(
     uint8_t *s_pack = smem + (size_t)lds_recs * (MW_LDS_SHADE_Q + MW_LDS_CULL_Q) * 16;                 // 192 B
 
     const int lane = threadIdx.x;
+    [[maybe_unused]] const unsigned long long kp_e0 = K2P_NOW();
     const float *hdr = envhdr + (size_t)env * MW_ENVHDR;
     const bool mesh_env = MESHAWARE && __float_as_int(hdr[3]) != 0;
     uint32_t *env_keys = MESHAWARE == 1 ? mesh_keys + (size_t)env * W * H * 8 : nullptr;
@@ -87,6 +88,9 @@ __device__ inline void raster_env_tiles(
     cx.obs_rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)(obs + (size_t)env * H * W * 3), 0, H * W * 3, MW_RSRC_WORD3); cx.te = te;
     cx.sky_r = sky_r; cx.sky_g = sky_g; cx.sky_b = sky_b;
     cx.env = env; cx.nvis = nvis; cx.W = W; cx.H = H; cx.dbg = dbg; cx.lane = lane;
+#ifdef MW_PERF_HOOKS
+    K2P_ADD(10, K2P_NOW() - kp_e0); K2P_ADD(14, 1);
+#endif
     int tx = t_begin % tiles_x, ty = t_begin / tiles_x;
     // small scenes: classify (tile, primitive) pairs for as many tiles as fit in the 64 lanes at once
     const bool pairs = in_lds && nvis > 0 && nvis <= 32 && (HOT || !(dbg & 2));
@@ -126,7 +130,11 @@ __device__ inline void raster_env_tiles(
             if (MESHAWARE && part_mode != 0 && mesh_tile != (part_mode == 2)) continue;
             if (MESHAWARE == 1 && mesh_tile) {
                 uint32_t mk[8];
+                [[maybe_unused]] const unsigned long long kk0 = K2P_NOW();
                 take_mesh_keys(env_keys, W, tx, ty, lane, mk);
+#ifdef MW_PERF_HOOKS
+                { uint32_t o = 0; for (int q = 0; q < 8; ++q) o |= mk[q]; if (o == 0x12345u) K2P_ADD(15, 1); K2P_ADD(11, K2P_NOW() - kk0); }
+#endif
                 raster_tile_fmt<true, FMT, false, HOT, 1>(cx, tx, ty, mk);
                 continue;
             }
@@ -140,7 +148,11 @@ __device__ inline void raster_env_tiles(
         if (MESHAWARE && part_mode != 0 && mesh_tile != (part_mode == 2)) continue;
         if (MESHAWARE == 1 && mesh_tile) {
             uint32_t mk[8];
+            [[maybe_unused]] const unsigned long long kk0 = K2P_NOW();
             take_mesh_keys(env_keys, W, tx, ty, lane, mk);
+#ifdef MW_PERF_HOOKS
+            { uint32_t o = 0; for (int q = 0; q < 8; ++q) o |= mk[q]; if (o == 0x12345u) K2P_ADD(15, 1); K2P_ADD(11, K2P_NOW() - kk0); }
+#endif
             raster_tile_fmt<true, FMT, false, HOT, 0>(cx, tx, ty, mk);
             continue;
         }

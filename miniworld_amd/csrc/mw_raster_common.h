@@ -252,6 +252,7 @@ __device__ inline RGB shade_uniform(const float4 *sr, const TexEnv &te, int px, 
 // tools/perf/k2prof.py (perf build only): cycles and event counts of the tile code's phases, summed over every tile of the launches
 // [0] tiles [1] classification cycles [2] coverage / depth loop cycles [3] shading loop cycles [4] resolve / pack / store cycles
 // [5] (tile, triangle) events visited [6] ... that covered a sample [7] winners shaded [8] classified chunks [9] tiles left early
+// [10] cycles before a wavefront's first tile (records staged) [11] mesh key fetch cycles [12] per-lane mesh winner turns [13] their cycles [14] wavefront items
 // (one line of counters per 8 192 workgroups: 800 000 atomics per step on ONE line slowed the kernel tenfold)
 #define K2P_SLOTS 8192
 __device__ unsigned long long g_k2prof[K2P_SLOTS][16];
@@ -517,7 +518,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     }
 
     // ============ pass B: exact packed-key resolution =================================
-    [[maybe_unused]] unsigned long long kp_t0 = K2P_NOW(), kp_cls = 0, kp_ev = 0, kp_hit = 0, kp_win = 0, kp_chunks = 0, kp_early = 0;
+    [[maybe_unused]] unsigned long long kp_t0 = K2P_NOW(), kp_cls = 0, kp_ev = 0, kp_hit = 0, kp_win = 0, kp_chunks = 0, kp_early = 0, kp_mesh_cyc = 0, kp_mesh_n = 0;
     if (exact) {
 #pragma unroll
         for (int s = 0; s < 8; ++s) { smp.r[s] = sky.r; smp.g[s] = sky.g; smp.b[s] = sky.b; }
@@ -611,7 +612,11 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 const int start = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 1]), nt = __float_as_int(cx.ment[MW_HDR_MESH_STRIDE * mj + 2]);
                 const bool on = (int)mine < start + nt;      // mine >= id >= start
                 sel = on ? mine : 0x20000u;
+                [[maybe_unused]] const unsigned long long km0 = K2P_NOW();
                 c = shade_mesh_winner(cx, mj, on ? mine : id, px, gy);
+#ifdef MW_PERF_HOOKS
+                kp_mesh_cyc += K2P_NOW() - km0; ++kp_mesh_n;
+#endif
             } else {
                 c = shade_uniform(s_shade + rec * cx.shade_stride, te, px, gy);
             }
@@ -624,7 +629,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         }
 #ifdef MW_PERF_HOOKS
         K2P_ADD(1, kp_cls); K2P_ADD(2, kp_t1 - kp_t0 - kp_cls); K2P_ADD(3, K2P_NOW() - kp_t1);
-        K2P_ADD(5, kp_ev); K2P_ADD(6, kp_hit); K2P_ADD(7, kp_win); K2P_ADD(8, kp_chunks); K2P_ADD(9, kp_early);
+        K2P_ADD(5, kp_ev); K2P_ADD(6, kp_hit); K2P_ADD(7, kp_win); K2P_ADD(8, kp_chunks); K2P_ADD(9, kp_early); K2P_ADD(12, kp_mesh_n); K2P_ADD(13, kp_mesh_cyc);
 #endif
     }
     [[maybe_unused]] const unsigned long long kp_t2 = K2P_NOW();

@@ -629,8 +629,13 @@ def test_batched_info_matches_the_host_classes():
     envs.close()
     for h in hosts:
         h.close()
-    # every other env: an empty dict, like miniworld.py:730
+    # every other env: no info keys, like miniworld.py:730 — only the same-step vector env's mask of the envs that just finished
     envs = MiniWorldVectorEnv("MiniWorld-Hallway-v0", 2, seed=0)
+    envs.reset(seed=0)
+    info = envs.step(np.zeros(2, np.int64))[4]
+    assert set(info) == {"_final_info"} and not bool(info["_final_info"].any())
+    envs.close()
+    envs = MiniWorldVectorEnv("MiniWorld-Hallway-v0", 2, seed=0, autoreset=False)
     envs.reset(seed=0)
     assert envs.step(np.zeros(2, np.int64))[4] == {}
     envs.close()

@@ -34,3 +34,6 @@ print("  events visited %.2f, covering %.2f, winners shaded %.2f, chunks classif
       (v[5] / tiles, v[6] / tiles, v[7] / tiles, v[8] / tiles, v[9] / tiles))
 print("  cycles per event %.0f, per winner %.0f, per chunk %.0f" % (v[2] / max(v[5], 1), v[3] / max(v[7], 1), v[1] / max(v[8], 1)))
 print("  list lengths: median %d p90 %d max %d" % (np.median(nv), np.percentile(nv, 90), nv.max()))
+if v[14]:
+    print("  per wavefront item: %.0f cycles before the first tile (records staged); mesh tiles: key fetch %.0f cycles, %.2f per-lane mesh winner turns of %.0f cycles each" %
+          (v[10] / v[14], v[11] / tiles, v[12] / tiles, v[13] / max(v[12], 1)))

@@ -15,7 +15,7 @@ for t in range(40):
     vec.step(torch.randint(0, n_act, (n,), generator=g, device="cuda", dtype=torch.int32))
 torch.cuda.synchronize()
 vec.close()
-raw = np.fromfile(out, np.uint64).reshape(n, 28)
+raw = np.fromfile(out, np.uint64).reshape(n, 32)
 d = raw[:, :8].astype(np.float64)
 names = ["xform", "walk/occ/sift", "vertex stage", "pass1 setups", "pass1 clip", "scan", "pass2", "tail"]
 print(cfg, "cycles per phase (mean over envs, the rounds' phases summed over the rounds, last frame):")
@@ -46,3 +46,6 @@ print("  rounds (cycles, mean / slowest 3 %%): first round %.0f / %.0f (its vert
 cl = raw[:, 24:28].astype(np.float64)
 print("  clipper (per wavefront, mean / slowest 3 %%): clipping %.0f / %.0f cycles, fans' setup + records %.0f / %.0f cycles; clipped triangles %.1f / %.1f, fan triangles %.1f / %.1f" %
       (cl[:, 0].mean(), cl[slow, 0].mean(), cl[:, 1].mean(), cl[slow, 1].mean(), cl[:, 2].mean(), cl[slow, 2].mean(), cl[:, 3].mean(), cl[slow, 3].mean()))
+
+ee = raw[:, 28:31].astype(np.float64)
+print("  inside the fans' pass (cycles per wavefront, mean): owner shuffles %.0f, setup %.0f, record stores %.0f" % (ee[:, 0].mean(), ee[:, 1].mean(), ee[:, 2].mean()))
