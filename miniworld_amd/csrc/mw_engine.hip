@@ -249,7 +249,7 @@ int geom_lanes(const mw_engine *e)
     // mid-sized scenes (PickupObjects: 6 polygons + 5 entity slots = 74 triangles; no visiting order, no sifting): two envs per
     // wavefront — 2 048 envs are ONE round of this one-wave-per-SIMD kernel instead of two (K1 + KG 103 -> 71 us)
     if (L == 64 && !e->args.rec_order && e->cfg.max_polys <= 64) L = 32;
-#ifdef MW_PERF_HOOKS
+#if defined(MW_PERF_HOOKS) || defined(MW_TUNE_HOOKS)
     if (const char *s = getenv("MW_GEOM_LANES")) { const int v = atoi(s); if ((v == 8 || v == 16 || v == 32 || v == 64) && v >= L) L = v; }
 #endif
     return L;
@@ -417,7 +417,7 @@ int pick_waves_per_env(const mw_engine *e)
     // enough wavefronts to fill 256 CUs x 4 SIMDs x 7 resident waves several times over (measured:
     // 15-25 waves per env beat 5 by ~7 % at 4096 envs), in divisors of n_tiles
     int best = n_tiles;
-#ifdef MW_PERF_HOOKS
+#if defined(MW_PERF_HOOKS) || defined(MW_TUNE_HOOKS)      // (MW_TUNE_HOOKS: the launch-shape overrides alone, without the perf build's counters)
     if (const char *s = getenv("MW_WAVES_PER_ENV")) { const int v = atoi(s); if (v > 0 && n_tiles % v == 0) return v; }
 #endif
     for (int w = 1; w <= n_tiles; ++w) {

@@ -133,7 +133,7 @@ __device__ inline void raster_env_tiles(
                 [[maybe_unused]] const unsigned long long kk0 = K2P_NOW();
                 take_mesh_keys(env_keys, W, tx, ty, lane, mk);
 #ifdef MW_PERF_HOOKS
-                { uint32_t o = 0; for (int q = 0; q < 8; ++q) o |= mk[q]; if (o == 0x12345u) K2P_ADD(15, 1); K2P_ADD(11, K2P_NOW() - kk0); }
+                { uint32_t o = 0; for (int q = 0; q < 8; ++q) o |= mk[q]; if (o == 0x12345u) K2P_ADD(14, 0); K2P_ADD(11, K2P_NOW() - kk0); }
 #endif
                 raster_tile_fmt<true, FMT, false, HOT, 1>(cx, tx, ty, mk);
                 continue;
@@ -151,7 +151,7 @@ __device__ inline void raster_env_tiles(
             [[maybe_unused]] const unsigned long long kk0 = K2P_NOW();
             take_mesh_keys(env_keys, W, tx, ty, lane, mk);
 #ifdef MW_PERF_HOOKS
-            { uint32_t o = 0; for (int q = 0; q < 8; ++q) o |= mk[q]; if (o == 0x12345u) K2P_ADD(15, 1); K2P_ADD(11, K2P_NOW() - kk0); }
+            { uint32_t o = 0; for (int q = 0; q < 8; ++q) o |= mk[q]; if (o == 0x12345u) K2P_ADD(14, 0); K2P_ADD(11, K2P_NOW() - kk0); }
 #endif
             raster_tile_fmt<true, FMT, false, HOT, 0>(cx, tx, ty, mk);
             continue;
@@ -235,7 +235,10 @@ extern "C" __global__ __launch_bounds__(64) void mw_raster_depth_kernel(MW_RASTE
     raster_kernel_body<true, 0, 2>(MW_RASTER_FWD);
 }
 
-extern "C" __global__ __launch_bounds__(64) void mw_raster_big_kernel(MW_RASTER_ARGS)
+#ifndef MW_K2BIG_OCC
+#define MW_K2BIG_OCC
+#endif
+extern "C" __global__ __launch_bounds__(64) MW_K2BIG_OCC void mw_raster_big_kernel(MW_RASTER_ARGS)
 {
     raster_kernel_body<false, 0, 1>(MW_RASTER_FWD);
 }

@@ -518,10 +518,11 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
     }
 
     // ============ pass B: exact packed-key resolution =================================
+#ifdef MW_PERF_HOOKS
+    const unsigned long long kp_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     [[maybe_unused]] unsigned long long kp_t0 = K2P_NOW(), kp_cls = 0, kp_ev = 0, kp_hit = 0, kp_win = 0, kp_chunks = 0, kp_early = 0, kp_mesh_cyc = 0, kp_mesh_n = 0;
     if (exact) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) { smp.r[s] = sky.r; smp.g[s] = sky.g; smp.b[s] = sky.b; }
         uint32_t key[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) key[s] = MESH ? mesh_key[s] : 0xFFFFFFFFu;
@@ -593,6 +594,9 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         // tile's distinct winners are visited in ascending draw id, each shaded for the whole wavefront at once
         // (shade_uniform); mesh triangles, which differ from pixel to pixel, per lane, every lane its own next one.  A
         // winner's colour goes to the samples it owns.
+        // (the samples' colours start from the sky HERE, behind the coverage / depth loop: 24 registers that loop does not have to carry)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { smp.r[s] = sky.r; smp.g[s] = sky.g; smp.b[s] = sky.b; }
         uint32_t pid[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) { pid[s] = key[s] & 0xFFFFu; pid[s] = pid[s] == MW_SKY_PID ? 0x10000u : pid[s]; }
@@ -628,7 +632,7 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
             }
         }
 #ifdef MW_PERF_HOOKS
-        K2P_ADD(1, kp_cls); K2P_ADD(2, kp_t1 - kp_t0 - kp_cls); K2P_ADD(3, K2P_NOW() - kp_t1);
+        K2P_ADD(1, kp_cls); K2P_ADD(2, kp_t1 - kp_t0 - kp_cls); K2P_ADD(3, K2P_NOW() - kp_t1); K2P_ADD(15, __builtin_amdgcn_s_memrealtime() - kp_r0);
         K2P_ADD(5, kp_ev); K2P_ADD(6, kp_hit); K2P_ADD(7, kp_win); K2P_ADD(8, kp_chunks); K2P_ADD(9, kp_early); K2P_ADD(12, kp_mesh_n); K2P_ADD(13, kp_mesh_cyc);
 #endif
     }

@@ -37,3 +37,5 @@ print("  list lengths: median %d p90 %d max %d" % (np.median(nv), np.percentile(
 if v[14]:
     print("  per wavefront item: %.0f cycles before the first tile (records staged); mesh tiles: key fetch %.0f cycles, %.2f per-lane mesh winner turns of %.0f cycles each" %
           (v[10] / v[14], v[11] / tiles, v[12] / tiles, v[13] / max(v[12], 1)))
+if v[15]:
+    print("  shader clock over the tiles' coverage + shading phases: %.0f MHz (s_memtime cycles / s_memrealtime ticks x 100 MHz)" % ((v[1] + v[2] + v[3]) / v[15] * 100.0))
