@@ -1017,7 +1017,7 @@ int mw_create(const mw_config *cfg, mw_engine **out)
     if (const char *s = getenv("MW_K2Q")) e->use_k2q = atoi(s) != 0;
     if (const char *s = getenv("MW_GENERIC_RASTER")) e->generic_raster = atoi(s) != 0;
 #ifdef MW_PERF_HOOKS
-    if (getenv("MW_ENT_PROF")) { if (dev_alloc(e, &e->d_ent_prof, (size_t)N * MW_MAX_MESH_ENTS * 8 * 8) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
+    if (getenv("MW_ENT_PROF")) { if (dev_alloc(e, &e->d_ent_prof, (size_t)16 * 2 * N * MW_MAX_MESH_ENTS * 8) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
     if (getenv("MW_K2Q_PROF")) { if (dev_alloc(e, &e->d_k2q_prof, (size_t)N * 80) != MW_OK) { g_create_error = e->err; mw_destroy(e); return MW_E_NOMEM; } }
 #endif
     {
@@ -1043,7 +1043,7 @@ void mw_destroy(mw_engine *e)
             if (FILE *f = fopen(getenv("MW_K2Q_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
     if (e->d_ent_prof) {
-        std::vector<unsigned long long> h((size_t)e->cfg.num_envs * MW_MAX_MESH_ENTS * 8 * 8);
+        std::vector<unsigned long long> h((size_t)16 * 2 * e->cfg.num_envs * MW_MAX_MESH_ENTS * 8);
         if (hipMemcpy(h.data(), e->d_ent_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess)
             if (FILE *f = fopen(getenv("MW_ENT_PROF"), "wb")) { fwrite(h.data(), 8, h.size(), f); fclose(f); }
     }
