@@ -16,7 +16,9 @@
 #define MW_SETUP_KERNEL_NAME mw_step_setup_kernel
 #endif
 #define MW_K1_WAVES 1
+#ifndef MW_K1_OCC
 #define MW_K1_OCC 3      // waves per SIMD the register allocation aims at
+#endif
 
 extern "C" __global__ __launch_bounds__(64 * MW_K1_WAVES) __attribute__((amdgpu_waves_per_eu(MW_K1_OCC, 4))) void MW_SETUP_KERNEL_NAME(
     MwArgs a, int do_step, int view_flags, const int32_t *__restrict__ actions, float *__restrict__ reward,
