@@ -74,6 +74,38 @@ def test_quad_kernel_side_paths_equal_the_oracle(case, flags, what, msaa, monkey
     eng.close()
 
 
+@pytest.mark.parametrize("case", ["hallway_s0", "oneroom_s0", "putnext_s0", "pickup_dr_s1", "fourrooms_s0"])
+def test_tile_kernels_on_small_scenes_equal_the_oracle(case, monkeypatch):
+    """MW_K2Q=0: small scenes through the tile kernels (mw_raster.hip: the painter pass, the pairs classification of up to 32 triangles,
+    records staged in LDS) instead of the quad kernel — the quad kernel's A/B baseline, and the code its over-capacity envs and the mesh
+    tiles run.  Same frames, with and without a depth channel (two instantiations)."""
+    import torch
+    import pyoracle
+    from miniworld_amd import engine as E
+    if case not in ALL_CASES:
+        pytest.skip("fixture not present")
+    monkeypatch.setenv("MW_K2Q", "0")
+    s0, tr, meta, obs = helpers.load_case(case)
+    frames = sorted(obs)[:3]
+    scenes = [helpers.frame_scene(s0, obs[f]) for f in frames]
+    meshes = helpers.golden_meshes(s0)
+    want = [pyoracle.render(sc, meshes=meshes) for sc in scenes]
+    for with_depth in (True, False):
+        eng = helpers.make_engine_for_scene(s0, len(scenes))
+        eng.set_state(helpers.scene_state_arrays(scenes))
+        rgb = torch.zeros((len(scenes), 60, 80, 3), dtype=torch.uint8, device="cuda")
+        depth = torch.zeros((len(scenes), 60, 80, 1), dtype=torch.float32, device="cuda") if with_depth else None
+        eng.render(rgb, depth)
+        eng.check()
+        assert eng.raster_path() == E.PATH_TILE, eng.raster_path()
+        got = rgb.cpu().numpy()
+        for i, f in enumerate(frames):
+            assert np.array_equal(got[i], want[i]["rgb"]), f"{case} frame {f} (depth {with_depth}): {np.count_nonzero(got[i] != want[i]['rgb'])} RGB values differ"
+            if with_depth:
+                assert np.array_equal(depth[i].cpu().numpy(), want[i]["depth"]), f"{case} frame {f}: depth differs"
+        eng.close()
+
+
 # (agent_pos, agent_dir, cam_height, cam_pitch): the Hallway seen from outside and above, with just the tip of one wall
 # triangle inside the frustum — display lists of ONE triangle (found with tests/hostcheck's mwhost_list_length)
 ONE_TRIANGLE_POSES = [

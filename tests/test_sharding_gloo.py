@@ -80,6 +80,10 @@ def test_bench_launcher_dry_run_spawns_the_ranks_it_reports():
     assert res["config"]["obs_allgather"] is True
     assert [r["rank"] for r in res["roofline"]["per_rank"]] == [0, 1]
     assert res["value"] > 0 and "dry-run" in res["data"]
+    # five timed windows of K steps each by default, `value` the first one's (MAX over the ranks of each)
+    w = res["windows"]
+    assert w["n"] == 5 and w["steps_each"] == 5 and len(w["values"]) == 5 and w["values"][0] == res["value"]
+    assert w["min"] <= w["median"] <= w["max"] and min(w["values"]) > 0
 
 
 def test_bench_launcher_dry_run_with_eight_ranks():
