@@ -604,6 +604,11 @@ int ensure_mesh_buffers(mw_engine *e)
         return MW_OK;
     }
     if (a.W > 255 * MW_TILE_W || a.H > 255 * MW_TILE_H) return fail(e, MW_E_CAPACITY, "frame too large for the mesh tile rectangles");
+    // the mesh tiles' work list (mw_geom.hip): a tile index in the 8 bits above the env, and one bit of a lane's 32-bit mask per tile
+    // sub + k L.  tile_kernels_exact caps these frames at 192 tiles and the geometry kernel has at least 8 lanes per env, so this holds
+    // today; a larger frame limit or fewer lanes must not leave mesh tiles undrawn (and their sample keys uncleared) in silence
+    if (a.n_tiles > 255 || a.n_tiles > 32 * geom_lanes(e))
+        return fail(e, MW_E_CAPACITY, "%d tiles per frame: the mesh tiles' work list holds 255 (8-bit tile index) and 32 per lane of the geometry kernel (%d lanes)", a.n_tiles, geom_lanes(e));
     const long long want = std::min<long long>(0xC000, (long long)e->cfg.max_ents * e->max_mesh_tris);
     if ((int)want > e->plane_cap) {
         float *np = nullptr;
