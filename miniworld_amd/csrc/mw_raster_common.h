@@ -600,6 +600,27 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         uint32_t pid[8];
 #pragma unroll
         for (int s = 0; s < 8; ++s) { pid[s] = key[s] & 0xFFFFu; pid[s] = pid[s] == MW_SKY_PID ? 0x10000u : pid[s]; }
+#ifdef MW_PERF_HOOKS
+        if (MESH) {
+            // (k2prof: the turns a per-lane winner loop would take — the most distinct winners any lane of the tile holds)
+            uint32_t q[8];
+            int cnt = 0;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) q[s] = pid[s];
+            for (;;) {
+                uint32_t m = 0x10000u;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) m = min(m, q[s]);
+                if (m == 0x10000u) break;
+                ++cnt;
+#pragma unroll
+                for (int s = 0; s < 8; ++s) q[s] = q[s] == m ? 0x10000u : q[s];
+            }
+            K2P_ADD(14, 0);
+            const int mx = (int)__reduce_max_sync(~0ull, (unsigned)cnt);
+            if (cx.lane == 0) atomicAdd(&g_k2prof[blockIdx.x % K2P_SLOTS][9], (unsigned long long)mx);
+        }
+#endif
         for (;;) {
             uint32_t mine = 0x10000u;
 #pragma unroll

@@ -39,3 +39,5 @@ if v[14]:
           (v[10] / v[14], v[11] / tiles, v[12] / tiles, v[13] / max(v[12], 1)))
 if v[15]:
     print("  shader clock over the tiles' coverage + shading phases: %.0f MHz (s_memtime cycles / s_memrealtime ticks x 100 MHz)" % ((v[1] + v[2] + v[3]) / v[15] * 100.0))
+if cfg != "maze":
+    print("  (mesh tiles: slot 9 counts the most distinct winners any lane holds: %.2f per tile — the turns of a per-lane winner loop)" % (v[9] / tiles))
