@@ -528,6 +528,11 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
         for (int s = 0; s < 8; ++s) key[s] = MESH ? mesh_key[s] : 0xFFFFFFFFu;
         bool done = false;
         uint32_t far16 = 0xFFFFu;
+        // (the visiting order's early exit needs the tile's farthest key, and that is 0xFFFF for as long as any sample is uncovered: the samples
+        // covered so far are kept as wave masks, and the maximum over keys and lanes is only taken once they are all ones)
+        uint64_t cov_m[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) cov_m[s] = 0ull;
         for (int chunk = 0; chunk < (PRE == 1 ? 1 : nvis) && !done; chunk += 64) {
             pmask_t todo;
             int pidx = chunk + lane;
@@ -583,8 +588,13 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                     key[s] = sel_mask(in_m[s], min(key[s], k), key[s]);
                 }
                 if (SORTED && sorted) {
-                    uint32_t m = max(max(max(key[0], key[1]), max(key[2], key[3])), max(max(key[4], key[5]), max(key[6], key[7])));
-                    far16 = __reduce_max_sync(~0ull, m) >> 16;
+                    uint64_t all_m = ~0ull;
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) { cov_m[s] |= in_m[s]; all_m &= cov_m[s]; }
+                    if (all_m == ~0ull) {
+                        uint32_t m = max(max(max(key[0], key[1]), max(key[2], key[3])), max(max(key[4], key[5]), max(key[6], key[7])));
+                        far16 = __reduce_max_sync(~0ull, m) >> 16;
+                    }
                 }
             }
         }
