@@ -1,2 +1,3 @@
 bash tools/perf/ab.sh maze 3
-python -m pytest tests -m gpu -x -q -k "maze or Maze or occlusion or full_size or reference_gl" 2>&1 | tail -2
+bash tools/perf/ab.sh pickup_dr 1
+python -m pytest tests -m gpu -x -q 2>&1 | tail -2
