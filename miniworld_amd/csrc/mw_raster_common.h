@@ -562,6 +562,8 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 }
                 ++kp_ev;
                 const int *__restrict__ rr = reinterpret_cast<const int *>(rr_env + (size_t)p * MW_RASTER_REC);
+                // (the depth plane is asked for with the edges: behind the coverage test its scalar load would be waited for on its own)
+                const float za0 = __int_as_float(rr[10]), zdx = __int_as_float(rr[11]), zdy = __int_as_float(rr[12]);
                 // (coverage as wave masks in scalar registers, like pass A: one compare per sample and open edge, one select
                 // per sample — no per-lane flags, no branches around the samples)
                 uint64_t in_m[8];
@@ -580,7 +582,6 @@ __device__ inline void raster_tile_fmt(const TileCtx &cx, int tx, int ty, const 
                 for (int s = 0; s < 8; ++s) any_m |= in_m[s];
                 if (!any_m) continue;
                 ++kp_hit;
-                const float za0 = __int_as_float(rr[10]), zdx = __int_as_float(rr[11]), zdy = __int_as_float(rr[12]);
                 const uint32_t id = MESH ? (uint32_t)rr[9] : (uint32_t)p;           // the mesh kernel's keys carry draw ids
 #pragma unroll
                 for (int s = 0; s < 8; ++s) {
